@@ -1,0 +1,176 @@
+"""Dense feature extractor (EfficientNet encoder + UNet decoder), drop-in for
+the reference's ``modules/DenseFeatureExtractor.py`` (same class names,
+constructor arguments, attribute names and state_dict keys).
+
+Dense convolutions stay on PyTorch-ROCm / MIOpen (SURVEY.md section 8 row a3 and
+"next" row N1); what is done here on our own terms is the inference-time
+plan: in ``eval()`` every conv+BatchNorm pair of the decoder is folded once
+into a single biased convolution and the folded weights are cached, and the
+encoder keeps only the five activations the decoder reads instead of all
+sixteen.
+"""
+from __future__ import annotations
+
+import logging
+import sys
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .efficientnet import tf_efficientnet_b5_ap
+
+# skip-connection table: encoder-name fragment -> (feature_select, skip channels 3..0)
+# (reference modules/DenseFeatureExtractor.py:62-85)
+_SKIPS = {
+    "efficientnet-b5": ((4, 5, 6, 8, 11), (176, 64, 40, 24)),
+    "efficientnet-b1": ((4, 5, 6, 8, 11), (112, 40, 24, 16)),
+    "efficientnet-v2-s": ((2, 3, 4, 6, 9), (160, 64, 48, 24)),
+    "efficientnet-v2-m": ((2, 3, 4, 6, 9), (176, 80, 48, 24)),
+}
+
+
+class Encoder(nn.Module):
+    """Collects the activation after every child of the backbone, expanding the
+    children of ``blocks`` / ``features`` (reference :11-27).  ``keep`` limits
+    what is retained (indices into that list); None keeps everything."""
+
+    def __init__(self, backend: nn.Module, keep: Optional[tuple] = None):
+        super().__init__()
+        self.original_model = backend
+        self.keep = keep
+
+    def forward(self, x: torch.Tensor) -> List[Optional[torch.Tensor]]:
+        feats: List[Optional[torch.Tensor]] = [x]
+        cur = x
+
+        def push(t):
+            nonlocal cur
+            cur = t
+            idx = len(feats)
+            feats.append(t if self.keep is None or idx in self.keep else None)
+
+        for name, child in self.original_model._modules.items():
+            if name in ("blocks", "features"):
+                for sub in child._modules.values():
+                    push(sub(cur))
+            else:
+                push(child(cur))
+        return feats
+
+
+def _fold_conv_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d):
+    s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    w = conv.weight * s.view(-1, 1, 1, 1)
+    b0 = conv.bias if conv.bias is not None else torch.zeros_like(bn.running_mean)
+    return w, (b0 - bn.running_mean) * s + bn.bias
+
+
+class UpSampleWithSkip(nn.Module):
+    """bilinear(align_corners=True) resize to the skip's size, concat, then
+    2 x [conv3x3, BN, LeakyReLU(0.01)] (reference :30-47)."""
+
+    def __init__(self, input_features: int, output_features: int):
+        super().__init__()
+        self._net = nn.Sequential(
+            nn.Conv2d(input_features, output_features, kernel_size=3, stride=1, padding=1),
+            nn.BatchNorm2d(output_features),
+            nn.LeakyReLU(),
+            nn.Conv2d(output_features, output_features, kernel_size=3, stride=1, padding=1),
+            nn.BatchNorm2d(output_features),
+            nn.LeakyReLU())
+        self._folded = None
+
+    def train(self, mode: bool = True):
+        self._folded = None
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *a, **kw):
+        self._folded = None
+        return super()._load_from_state_dict(*a, **kw)
+
+    def forward(self, x, skip_features):
+        up = F.interpolate(x, size=skip_features.shape[-2:], mode="bilinear", align_corners=True)
+        f = torch.cat([up, skip_features], dim=1)
+        if self.training or torch.is_grad_enabled():
+            return self._net(f)
+        if self._folded is None or self._folded[0].device != f.device:
+            with torch.no_grad():
+                self._folded = (*_fold_conv_bn(self._net[0], self._net[1]), *_fold_conv_bn(self._net[3], self._net[4]))
+        w1, b1, w2, b2 = self._folded
+        f = F.leaky_relu(F.conv2d(f, w1, b1, padding=1), 0.01)
+        return F.leaky_relu(F.conv2d(f, w2, b2, padding=1), 0.01)
+
+
+class Decoder(nn.Module):
+    """UNet decoder (reference :50-118).  ``conv2`` is a 1x1 convolution with
+    padding=1 -- inherited quirk, kept."""
+
+    def __init__(self, num_features=2048, num_classes=1, bottleneck_features=2048, mode="features",
+                 encoder_name=None, do_final_upscale=False):
+        super().__init__()
+        f = int(num_features)
+        self.encoder_name = encoder_name
+        self.conv2 = nn.Conv2d(bottleneck_features, f, kernel_size=1, stride=1, padding=1)
+        for frag, (select, skips) in _SKIPS.items():
+            if frag in (encoder_name or ""):
+                self.feature_select = list(select)
+                break
+        else:
+            sys.exit("Error: encoder name not recognised when building decoder.")
+        self.up1 = UpSampleWithSkip(f // 1 + skips[0], f // 2)
+        self.up2 = UpSampleWithSkip(f // 2 + skips[1], f // 4)
+        self.up3 = UpSampleWithSkip(f // 4 + skips[2], f // 8)
+        self.up4 = UpSampleWithSkip(f // 8 + skips[3], f // 16)
+        self.final_upscale = UpSampleWithSkip(f // 16 + 3, f // 16) if do_final_upscale else None
+        self.mode = mode if mode is not None else "features"
+        self.conv3 = nn.Conv2d(f // 16, num_classes if self.mode == "features" else 1, kernel_size=3, stride=1, padding=1)
+
+    def forward(self, features):
+        b0, b1, b2, b3, b4 = (features[i] for i in self.feature_select)
+        x = self.conv2(b4)
+        for up, skip in ((self.up1, b3), (self.up2, b2), (self.up3, b1), (self.up4, b0)):
+            x = up(x, skip)
+        if self.final_upscale is not None:
+            x = self.final_upscale(x, features[0])
+        return self.conv3(x)
+
+
+class DenseFeatureExtractor(nn.Module):
+    """``args`` is the reference's config tree (see objcavit_amd.config).  Only
+    the EfficientNet-B5 backbone is available locally; the reference's other
+    encoder choices need torchvision / hub downloads (reference :141-168)."""
+
+    def __init__(self, args, backbone: Optional[nn.Module] = None):
+        super().__init__()
+        self.args = args
+        self.logger = logging.getLogger(__name__)
+        block = self.args[self.args.model.name]
+        self.n_bins = block.n_bins
+        self.num_decoded_channels = 128
+        self._encoder_params_module_list = []
+        self._non_encoder_params_module_list = []
+
+        name = block.encoder_name
+        if backbone is None:
+            if "efficientnet-b5" not in name:
+                sys.exit(f"Error: encoder '{name}' is not available in this build (efficientnet-b5 only).")
+            backbone = tf_efficientnet_b5_ap(pretrained=False)
+        # remove unused final layers, as the reference does (:152-156)
+        backbone.bn2 = nn.Identity()
+        backbone.act2 = nn.Identity()
+        backbone.global_pool = nn.Identity()
+        backbone.classifier = nn.Identity()
+        num_features = 2048 if "efficientnet-b5" in name else 1280
+
+        self.decoder = Decoder(num_classes=128, num_features=num_features, bottleneck_features=num_features,
+                               mode=block.get("mode"), encoder_name=name,
+                               do_final_upscale=block.get("do_final_upscale"))
+        keep = tuple(self.decoder.feature_select) + ((0,) if block.get("do_final_upscale") else ())
+        self.encoder = Encoder(backbone, keep=keep)
+        self._encoder_params_module_list.append(self.encoder)
+        self._non_encoder_params_module_list.append(self.decoder)
+
+    def forward(self, image):
+        return self.decoder(self.encoder(image))

@@ -1,0 +1,144 @@
+"""EfficientNet-B5 ("tf_efficientnet_b5_ap" layout) backbone, defined locally.
+
+The reference obtains this network with ``torch.hub.load('rwightman/
+gen-efficientnet-pytorch', 'tf_efficientnet_b5_ap', pretrained=True)``
+(modules/DenseFeatureExtractor.py:149) -- a run-time fetch of third-party
+source and weights.  Here the architecture is a local module whose child
+order (conv_stem, bn1, act1, blocks, conv_head, bn2, act2, global_pool,
+classifier) and parameter names follow that model family, so that
+
+* the reference's ``Encoder`` wrapper (modules/DenseFeatureExtractor.py:18-27)
+  collects the same 16 activations with feature_select = [4, 5, 6, 8, 11]
+  giving 24/40/64/176/2048 channels, and
+* a checkpoint of the reference (``...encoder.original_model.blocks.3.2.conv_dw
+  .weight`` etc.) loads by key.
+
+Dense convolutions run through PyTorch-ROCm (MIOpen); SURVEY.md section 8 keeps
+the encoder out of the hand-written-kernel list (row N1 "next").
+Architecture table: oracle/effnet_ref.py header (width x1.6, depth x2.2,
+TF "SAME" padding, BN eps 1e-3, swish, squeeze-excite 0.25 of block input).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+BN_EPS = 1e-3
+BN_MOMENTUM = 0.01
+
+# (kind, repeats, kernel, stride, expand, out_channels)
+B5_STAGES = (("ds", 3, 3, 1, 1, 24), ("ir", 5, 3, 2, 6, 40), ("ir", 5, 5, 2, 6, 64), ("ir", 7, 3, 2, 6, 128),
+             ("ir", 7, 5, 1, 6, 176), ("ir", 9, 5, 2, 6, 304), ("ir", 3, 3, 1, 6, 512))
+B5_STEM, B5_HEAD = 48, 2048
+
+
+class Conv2dSame(nn.Conv2d):
+    """Conv2d with TensorFlow 'SAME' padding computed from the input size."""
+
+    def __init__(self, cin, cout, k, stride=1, groups=1, bias=False):
+        super().__init__(cin, cout, k, stride=stride, padding=0, groups=groups, bias=bias)
+
+    def forward(self, x):
+        k, s = self.kernel_size[0], self.stride[0]
+        ih, iw = x.shape[-2:]
+        ph = max((math.ceil(ih / s) - 1) * s + k - ih, 0)
+        pw = max((math.ceil(iw / s) - 1) * s + k - iw, 0)
+        if ph == pw and ph % 2 == 0:          # symmetric: let the conv kernel pad
+            return F.conv2d(x, self.weight, self.bias, self.stride, ph // 2, 1, self.groups)
+        x = F.pad(x, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
+        return F.conv2d(x, self.weight, self.bias, self.stride, 0, 1, self.groups)
+
+
+class SqueezeExcite(nn.Module):
+    def __init__(self, chs, reduced):
+        super().__init__()
+        self.conv_reduce = nn.Conv2d(chs, reduced, 1, bias=True)
+        self.act1 = nn.SiLU()
+        self.conv_expand = nn.Conv2d(reduced, chs, 1, bias=True)
+
+    def forward(self, x):
+        s = x.mean((2, 3), keepdim=True)
+        s = self.conv_expand(self.act1(self.conv_reduce(s)))
+        return x * torch.sigmoid(s)
+
+
+def _bn(c):
+    return nn.BatchNorm2d(c, eps=BN_EPS, momentum=BN_MOMENTUM)
+
+
+class DepthwiseSeparableConv(nn.Module):
+    def __init__(self, cin, cout, k, stride):
+        super().__init__()
+        self.has_residual = stride == 1 and cin == cout
+        self.conv_dw = Conv2dSame(cin, cin, k, stride, groups=cin)
+        self.bn1 = _bn(cin)
+        self.act1 = nn.SiLU()
+        self.se = SqueezeExcite(cin, max(1, int(cin * 0.25)))
+        self.conv_pw = nn.Conv2d(cin, cout, 1, bias=False)
+        self.bn2 = _bn(cout)
+        self.act2 = nn.Identity()
+
+    def forward(self, x):
+        y = self.act1(self.bn1(self.conv_dw(x)))
+        y = self.act2(self.bn2(self.conv_pw(self.se(y))))
+        return y + x if self.has_residual else y
+
+
+class InvertedResidual(nn.Module):
+    def __init__(self, cin, cout, k, stride, expand):
+        super().__init__()
+        mid = cin * expand
+        self.has_residual = stride == 1 and cin == cout
+        self.conv_pw = nn.Conv2d(cin, mid, 1, bias=False)
+        self.bn1 = _bn(mid)
+        self.act1 = nn.SiLU()
+        self.conv_dw = Conv2dSame(mid, mid, k, stride, groups=mid)
+        self.bn2 = _bn(mid)
+        self.act2 = nn.SiLU()
+        self.se = SqueezeExcite(mid, max(1, int(cin * 0.25)))
+        self.conv_pwl = nn.Conv2d(mid, cout, 1, bias=False)
+        self.bn3 = _bn(cout)
+
+    def forward(self, x):
+        y = self.act1(self.bn1(self.conv_pw(x)))
+        y = self.act2(self.bn2(self.conv_dw(y)))
+        y = self.bn3(self.conv_pwl(self.se(y)))
+        return y + x if self.has_residual else y
+
+
+class GenEfficientNet(nn.Module):
+    def __init__(self, stages=B5_STAGES, stem=B5_STEM, head=B5_HEAD, num_classes=1000):
+        super().__init__()
+        self.conv_stem = Conv2dSame(3, stem, 3, stride=2)
+        self.bn1 = _bn(stem)
+        self.act1 = nn.SiLU()
+        blocks, cin = [], stem
+        for kind, reps, k, s, e, cout in stages:
+            stage = []
+            for r in range(reps):
+                stride = s if r == 0 else 1
+                stage.append(DepthwiseSeparableConv(cin, cout, k, stride) if kind == "ds"
+                             else InvertedResidual(cin, cout, k, stride, e))
+                cin = cout
+            blocks.append(nn.Sequential(*stage))
+        self.blocks = nn.Sequential(*blocks)
+        self.conv_head = nn.Conv2d(cin, head, 1, bias=False)
+        self.bn2 = _bn(head)
+        self.act2 = nn.SiLU()
+        self.global_pool = nn.AdaptiveAvgPool2d(1)
+        self.classifier = nn.Linear(head, num_classes)
+
+    def forward(self, x):
+        x = self.act1(self.bn1(self.conv_stem(x)))
+        x = self.act2(self.bn2(self.conv_head(self.blocks(x))))
+        return self.classifier(self.global_pool(x).flatten(1))
+
+
+def tf_efficientnet_b5_ap(pretrained: bool = False) -> GenEfficientNet:
+    """Local constructor standing in for the hub entry point of the same name.
+    There is no network here: ``pretrained`` weights must be loaded by the
+    caller from a state_dict / checkpoint."""
+    return GenEfficientNet()
