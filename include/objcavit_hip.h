@@ -1,0 +1,130 @@
+/* objcavit_hip.h -- C ABI of libobjcavit_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the forward depth-inference hot path of ObjCAViT.  The
+ * reference has no FFI of its own: the path sits behind Python
+ * nn.Module.forward() calls that reach ATen kernels.  Each entry point below
+ * replaces the ATen work behind the cited reference lines (paths relative to
+ * the reference tree) and is what a ctypes binding in the reference's modules
+ * would bind.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 (or uint8 for masks) unless
+ *     stated otherwise; tensors are dense row-major with the strides given;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - entry points only enqueue work: no allocation, no synchronisation, no
+ *     host<->device copies, so a caller may capture them into a hipGraph;
+ *     scratch memory is supplied by the caller (`*_workspace_bytes`);
+ *   - return 0 on success, a hipError_t (> 0) if a launch failed, -1 for a
+ *     rejected argument; ocv_last_error() returns the message (thread-local).
+ *   - arithmetic is fp32 end to end (v_mfma_f32_32x32x2_f32 for contractions).
+ */
+#ifndef OBJCAVIT_HIP_H
+#define OBJCAVIT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ocv_stream_t;
+
+#define OCV_ABI_VERSION 1
+int ocv_abi_version(void);
+const char* ocv_last_error(void);
+
+/* activation codes for ocv_linear_fwd */
+#define OCV_ACT_NONE 0
+#define OCV_ACT_RELU 1
+#define OCV_ACT_LEAKY_RELU 2 /* slope 0.01 (nn.LeakyReLU default) */
+
+/* out[z][m][n] = act( sum_k A[z][m][k] * W(n,k) + bias[n] )
+ * W(n,k) = W[z][n*ldw + k] if w_kn == 0 (nn.Linear layout, [N,K])
+ *        = W[z][k*ldw + n] if w_kn != 0 ([K,N] layout).
+ * batch strides (elements) may be 0 to share an operand across the batch.
+ * Replaces nn.Linear / nn.Sequential(Linear, LeakyReLU, ...) at
+ * modules/ObjCAViT.py:257-282,289,299-303,324-330,378 and
+ * modules/miniViT.py:16-20,33; also used for the in/out projections of
+ * nn.MultiheadAttention and linear1 of nn.TransformerEncoderLayer. */
+int ocv_linear_fwd(const float* A, int lda, long strideA, const float* W, int ldw, long strideW, int w_kn,
+                   const float* bias, float* out, int ldo, long strideO, int batch, int M, int N, int K, int act,
+                   ocv_stream_t stream);
+
+/* out[m][:] = LayerNorm( residual[m][:] + A[m][:] W^T + bias ) * gamma + beta,  N == E <= 128... exactly 128.
+ * zero_row_mask (uint8[M], nullable): rows with a non-zero entry are written as 0.0
+ * (nested-tensor fast path of nn.TransformerEncoder).
+ * Replaces out_proj + residual + norm1 and linear2 + residual + norm2 of
+ * nn.TransformerEncoderLayer (modules/ObjCAViT.py:155-161,169,188; modules/layers.py:8-9,23). */
+int ocv_linear_residual_layernorm_fwd(const float* A, int lda, const float* W, int ldw, const float* bias,
+                                      const float* residual, int ldres, const float* gamma, const float* beta,
+                                      float eps, const uint8_t* zero_row_mask, float* out, int ldo, int M, int N,
+                                      int K, ocv_stream_t stream);
+
+/* out[m][:] = LayerNorm(x[m][:] (+ residual[m][:])) * gamma + beta over E columns (biased variance).
+ * residual nullable.  Stand-alone form of the LayerNorm used above. */
+int ocv_layernorm_residual_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float eps,
+                               float* out, int rows, int E, ocv_stream_t stream);
+
+/* Attention core: ctx[b, i, h*d : (h+1)*d] = softmax_j( q_bih . k_bjh * scale + mask_bj ) v_bjh,  d == 32.
+ * q/k/v/ctx are addressed as ptr + b*batch_stride + i*seq_stride + h*32 (strides in elements), so packed
+ * [.., 3E] projections and seq-first (S x B x E) layouts need no copies.
+ * key_padding_mask: uint8 [B, Sk], non-zero = ignore key (nullable).  A query row whose keys are ALL masked
+ * yields NaN, as torch does. */
+int ocv_attention_fwd(const float* q, long q_bs, int q_ss, const float* k, long k_bs, int k_ss, const float* v,
+                      long v_bs, int v_ss, const uint8_t* key_padding_mask, float* ctx, long o_bs, int o_ss, int B,
+                      int H, int Sq, int Sk, float scale, ocv_stream_t stream);
+
+/* nn.MultiheadAttention(E, H, batch_first=True).forward(query, key, value, key_padding_mask, need_weights=False)
+ * (modules/ObjCAViT.py:163-164,195-207): packed in_proj_weight [3E,E] / in_proj_bias [3E], out_proj [E,E] + [E].
+ * q_src [B,Sq,E], k_src / v_src [B,Sk,E] dense; out [B,Sq,E].  E == 128, H == 4. */
+size_t ocv_mha_workspace_bytes(int B, int Sq, int Sk, int E);
+int ocv_mha_fwd(const float* q_src, const float* k_src, const float* v_src, const uint8_t* key_padding_mask,
+                const float* in_proj_w, const float* in_proj_b, const float* out_w, const float* out_b, float* out,
+                int B, int Sq, int Sk, int E, int H, void* workspace, size_t workspace_bytes, ocv_stream_t stream);
+
+/* One post-norm nn.TransformerEncoderLayer(E=128, H=4, FF, relu, eps) in eval mode on x [B,S,E] (dense):
+ *   x1 = LN1(x + MHA(x, x, x, mask));  out = LN2(x1 + W2 relu(W1 x1 + b1) + b2)
+ * (modules/ObjCAViT.py:155-161,169,188; modules/layers.py:8-9,23).  `out` may alias `x`.
+ * zero_padded_rows != 0: rows flagged in key_padding_mask are written as 0.0 in `out` (last layer of a masked
+ * encoder). */
+typedef struct {
+  const float *in_proj_w, *in_proj_b, *out_proj_w, *out_proj_b;
+  const float *norm1_w, *norm1_b, *linear1_w, *linear1_b, *linear2_w, *linear2_b, *norm2_w, *norm2_b;
+} ocv_encoder_layer_params;
+size_t ocv_encoder_layer_workspace_bytes(int B, int S, int E, int FF);
+int ocv_encoder_layer_fwd(const float* x, const ocv_encoder_layer_params* p, const uint8_t* key_padding_mask,
+                          int zero_padded_rows, float* out, int B, int S, int E, int H, int FF, float eps,
+                          void* workspace, size_t workspace_bytes, ocv_stream_t stream);
+
+/* Patch embedding: Conv2d(C -> E, kernel = stride = 16, no padding) on fmap [B,C,h,w] (NCHW), flattened to tokens,
+ * plus bias and positional embedding, written token-major:
+ *   out[b][s][e] = bias[e] + pos[b*pos_bs + s*E + e] + sum_{c,i,j} W[e][c][i][j] * fmap[b][c][16*ph+i][16*pw+j]
+ * with s = ph*(w/16) + pw.  pos_bs = 0 shares one [S,E] table across the batch; pos may be NULL.
+ * Replaces image_embedding_convPxP + flatten + pos add + permute (modules/ObjCAViT.py:287-288,333,362-364;
+ * modules/layers.py:11-12,17-22).  E == 128. */
+size_t ocv_patch_embed_workspace_bytes(int B, int C, int h, int w, int E);
+int ocv_patch_embed_fwd(const float* fmap, const float* W, const float* bias, const float* pos, long pos_bs,
+                        float* out, int B, int C, int h, int w, int E, void* workspace, size_t workspace_bytes,
+                        ocv_stream_t stream);
+
+/* PixelWiseDotProduct (modules/layers.py:31-36): ram[b][q][p] = sum_c feat[b][c][p] * queries[b][q][c].
+ * feat [B,C,P] (NCHW with P = h*w), queries addressed as ptr + b*q_bs + q*q_ld + c, ram [B,Q,P].  C == Q == 128. */
+int ocv_pixel_dot_fwd(const float* feat, const float* queries, long q_bs, int q_ld, float* ram, int B, int C, int Q,
+                      int P, ocv_stream_t stream);
+
+/* Fused bin head (modules/GraphBins.py:109-119 == modules/AdaBins.py:77-87 together with modules/layers.py:31-36):
+ *   logits[b][k][p] = bout[k] + sum_q Wout[k][q] * ( sum_c feat[b][c][p] * queries[b][q][c] )
+ *   depth[b][p]     = sum_k softmax_k(logits[b][:, p]) * centers[b][k]
+ * One pass over feat; the 128-channel range-attention maps and the 256-bin logits / probabilities never reach
+ * HBM.  The two contractions are associated as (Wout . queries[b]) . feat (workspace holds the folded
+ * [B,256,128] matrix).  C == Q == 128, n_bins == 256. */
+size_t ocv_bin_head_workspace_bytes(int B, int n_bins, int C);
+int ocv_bin_head_fwd(const float* feat, const float* queries, long q_bs, int q_ld, const float* Wout,
+                     const float* bout, const float* centers, float* depth, int B, int C, int Q, int n_bins, int P,
+                     void* workspace, size_t workspace_bytes, ocv_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OBJCAVIT_HIP_H */

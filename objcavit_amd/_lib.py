@@ -1,0 +1,98 @@
+"""ctypes binding of libobjcavit_hip.so (declarations: include/objcavit_hip.h).
+
+The library is the product: if it cannot be loaded the kernels raise -- there
+is no CPU or PyTorch fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libobjcavit_hip.so")
+
+_f32p = C.c_void_p      # device pointers travel as integers
+_u8p = C.c_void_p
+_stream = C.c_void_p
+
+
+class EncoderLayerParams(C.Structure):
+    """ocv_encoder_layer_params"""
+    _fields_ = [(n, C.c_void_p) for n in (
+        "in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "norm1_w", "norm1_b",
+        "linear1_w", "linear1_b", "linear2_w", "linear2_b", "norm2_w", "norm2_b")]
+
+
+# name -> (restype, argtypes); every symbol declared in include/objcavit_hip.h
+PROTOTYPES = {
+    "ocv_abi_version": (C.c_int, []),
+    "ocv_last_error": (C.c_char_p, []),
+    "ocv_linear_fwd": (C.c_int, [_f32p, C.c_int, C.c_long, _f32p, C.c_int, C.c_long, C.c_int, _f32p, _f32p, C.c_int,
+                                 C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
+    "ocv_linear_residual_layernorm_fwd": (C.c_int, [_f32p, C.c_int, _f32p, C.c_int, _f32p, _f32p, C.c_int, _f32p, _f32p,
+                                                    C.c_float, _u8p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
+    "ocv_layernorm_residual_fwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_float, _f32p, C.c_int, C.c_int, _stream]),
+    "ocv_attention_fwd": (C.c_int, [_f32p, C.c_long, C.c_int, _f32p, C.c_long, C.c_int, _f32p, C.c_long, C.c_int, _u8p,
+                                    _f32p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _stream]),
+    "ocv_mha_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ocv_mha_fwd": (C.c_int, [_f32p, _f32p, _f32p, _u8p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int,
+                              C.c_int, C.c_int, C.c_void_p, C.c_size_t, _stream]),
+    "ocv_encoder_layer_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ocv_encoder_layer_fwd": (C.c_int, [_f32p, C.POINTER(EncoderLayerParams), _u8p, C.c_int, _f32p, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_size_t, _stream]),
+    "ocv_patch_embed_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ocv_patch_embed_fwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_long, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_void_p, C.c_size_t, _stream]),
+    "ocv_pixel_dot_fwd": (C.c_int, [_f32p, _f32p, C.c_long, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
+    "ocv_bin_head_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "ocv_bin_head_fwd": (C.c_int, [_f32p, _f32p, C.c_long, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, _stream]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load(path: Optional[str] = None) -> C.CDLL:
+    """Load the library (once) and attach the prototypes.
+
+    ``import torch`` must come first: libobjcavit_hip.so needs libamdhip64.so.7
+    and has to share the HIP runtime instance PyTorch-ROCm already loaded
+    (same SONAME -> the dynamic loader reuses it), otherwise torch's streams
+    and device pointers would be foreign to our launches.
+    """
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    import torch  # noqa: F401  (loads torch/lib/libamdhip64.so first)
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise HipLibraryError(
+            f"{p} not found: build it with `python -m objcavit_amd.build` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback for the ObjCAViT hot path.")
+    try:
+        lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
+    except OSError as e:
+        raise HipLibraryError(f"cannot load {p}: {e}") from e
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{p} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ocv_abi_version() != 1:
+        raise HipLibraryError(f"ABI version mismatch: library {lib.ocv_abi_version()}, binding 1")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().ocv_last_error().decode(errors="replace")
+        raise HipLibraryError(f"{what} failed (rc={rc}): {msg}")

@@ -1,0 +1,211 @@
+// Fused AdaBins-style bin head and pixel-wise dot product for gfx950.
+//
+// bin head, per pixel p of image b (C = 128 channels, 256 bins):
+//   logits[k] = bout[k] + sum_c Wf[b][k][c] * feat[b][c][p],   Wf[b] = Wout . queries[b]   (256 x 128)
+//   depth     = sum_k softmax_k(logits) * centers[b][k]
+// The feature map is streamed from HBM exactly once (4 B x 128 per pixel in,
+// 4 B out); the 128-channel range-attention maps and the 256-bin logits and
+// probabilities (433 MB/img in the reference's un-fused form) never exist.
+//
+// Mapping: a workgroup = 4 wavefronts, persistent over 128-pixel tiles of one
+// image; Wf[b] (128 KiB) is staged ONCE per workgroup into LDS with rows padded
+// to 129 floats.  A wavefront owns 32 consecutive pixels: its B operand
+// (feat[c][p], lane = pixel, 128 B coalesced per half-wave per channel) is
+// loaded straight into 64 VGPRs -- every element is used by exactly one
+// wavefront, so LDS staging would buy nothing -- while the next tile's 64
+// loads are already in flight.  The 256 bins are walked in 8 tiles of 32:
+// 64 x v_mfma_f32_32x32x2_f32 per tile (A operand = one ds_read_b32 per
+// issue), then an online softmax update in registers.  A lane holds 16 bins of
+// the tile for its pixel, lane^32 the other 16: max / sum / weighted sum need
+// one wavefront shuffle (xor 32) per tile.
+#include "common.hpp"
+#include "../../include/objcavit_hip.h"
+
+namespace {
+
+constexpr int CH = 128;        // channels == queries
+constexpr int NB = 256;        // bins
+constexpr int WLD = CH + 1;
+constexpr int TP = 128;        // pixels per workgroup tile
+
+__device__ __forceinline__ void load_pixels(float (&bf)[CH / 2], const float* __restrict__ fb, long P, long pix, int hh,
+                                            bool ok) {
+  const float* src = fb + (long)hh * P + (ok ? pix : 0);
+#pragma unroll
+  for (int s = 0; s < CH / 2; ++s) bf[s] = ok ? src[(long)(2 * s) * P] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void bin_head_kernel(const float* __restrict__ feat, const float* __restrict__ Wf,
+                                                       const float* __restrict__ bout,
+                                                       const float* __restrict__ centers, float* __restrict__ depth,
+                                                       long P, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Wl = lds;                  // [256][129]
+  float* bl = Wl + NB * WLD;        // [256]
+  float* cl = bl + NB;              // [256]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.y;
+  const float* fb = feat + (long)b * CH * P;
+  const float* wb = Wf + (long)b * NB * CH;
+
+  for (int i = tid; i < NB * CH / 4; i += 256) {
+    const float4 t = ld4(wb + (long)i * 4);
+    const int k = (i * 4) / CH, c = (i * 4) % CH;
+    float* d = Wl + k * WLD + c;
+    d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+  }
+  bl[tid] = bout[tid];
+  cl[tid] = centers[(long)b * NB + tid];
+  __syncthreads();
+
+  float cur[CH / 2], nxt[CH / 2];
+  int tile = blockIdx.x;
+  if (tile < ntiles) {
+    const long pix = (long)tile * TP + wave * 32 + l31;
+    load_pixels(cur, fb, P, pix, hh, pix < P);
+  }
+  for (; tile < ntiles; tile += gridDim.x) {
+    const long pix = (long)tile * TP + wave * 32 + l31;
+    const int tn = tile + gridDim.x;
+    if (tn < ntiles) {
+      const long pn = (long)tn * TP + wave * 32 + l31;
+      load_pixels(nxt, fb, P, pn, hh, pn < P);
+    }
+
+    float m_run = -__builtin_inff(), l_half = 0.f, d_half = 0.f;
+#pragma unroll 1
+    for (int t = 0; t < NB / 32; ++t) {
+      f32x16 acc = {0};
+      const float* wrow = Wl + (t * 32 + l31) * WLD + hh;
+#pragma unroll
+      for (int s = 0; s < CH / 2; ++s) acc = mfma_32x32x2(wrow[2 * s], cur[s], acc);
+
+      float tmax = -__builtin_inff();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[r] += bl[t * 32 + acc_row(r, hh)];
+        tmax = fmaxf(tmax, acc[r]);
+      }
+      tmax = xor32_max(tmax);
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = fast_exp(m_run - m_new);
+      float ps = 0.f, ds = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pr = fast_exp(acc[r] - m_new);
+        ps += pr;
+        ds += pr * cl[t * 32 + acc_row(r, hh)];
+      }
+      l_half = l_half * alpha + ps;
+      d_half = d_half * alpha + ds;
+      m_run = m_new;
+    }
+    const float l = xor32_sum(l_half), d = xor32_sum(d_half);
+    if (hh == 0 && pix < P) depth[(long)b * P + pix] = d / l;
+
+    if (tn < ntiles) {
+#pragma unroll
+      for (int s = 0; s < CH / 2; ++s) cur[s] = nxt[s];
+    }
+  }
+}
+
+// ram[b][q][p] = sum_c queries[b][q][c] * feat[b][c][p]
+__global__ __launch_bounds__(256) void pixel_dot_kernel(const float* __restrict__ feat, const float* __restrict__ qm,
+                                                        long q_bs, int q_ld, float* __restrict__ ram, long P,
+                                                        int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Ql = lds;                  // [128][129]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.y;
+  const float* fb = feat + (long)b * CH * P;
+  const float* qb = qm + (long)b * q_bs;
+  float* rb = ram + (long)b * CH * P;
+
+  for (int i = tid; i < CH * CH; i += 256) {
+    const int q = i / CH, c = i % CH;
+    Ql[q * WLD + c] = qb[(long)q * q_ld + c];
+  }
+  __syncthreads();
+
+  float cur[CH / 2];
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long pix = (long)tile * TP + wave * 32 + l31;
+    load_pixels(cur, fb, P, pix, hh, pix < P);
+#pragma unroll 1
+    for (int t = 0; t < CH / 32; ++t) {
+      f32x16 acc = {0};
+      const float* qrow = Ql + (t * 32 + l31) * WLD + hh;
+#pragma unroll
+      for (int s = 0; s < CH / 2; ++s) acc = mfma_32x32x2(qrow[2 * s], cur[s], acc);
+      if (pix < P) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rb[(long)(t * 32 + acc_row(r, hh)) * P + pix] = acc[r];
+      }
+    }
+  }
+}
+
+int blocks_per_image(int B, int ntiles) {
+  // persistent grid: about one workgroup per CU (256), at least 1 and at most one per tile
+  int per = (256 + B - 1) / B;
+  if (per > ntiles) per = ntiles;
+  if (per < 1) per = 1;
+  return per;
+}
+
+}  // namespace
+
+extern "C" size_t ocv_bin_head_workspace_bytes(int B, int n_bins, int C) {
+  if (B < 1 || n_bins != NB || C != CH) return 0;
+  return (size_t)B * NB * CH * sizeof(float);
+}
+
+extern "C" int ocv_pixel_dot_fwd(const float* feat, const float* queries, long q_bs, int q_ld, float* ram, int B,
+                                 int C, int Q, int P, ocv_stream_t stream) {
+  OCV_CHECK_ARG(feat && queries && ram, "ocv_pixel_dot_fwd: null pointer");
+  OCV_CHECK_ARG(C == CH && Q == CH, "ocv_pixel_dot_fwd: C and Q must be %d (got %d, %d)", CH, C, Q);
+  OCV_CHECK_ARG(B >= 1 && B <= 65535 && P >= 1 && q_ld >= C, "ocv_pixel_dot_fwd: bad sizes");
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)pixel_dot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  const int ntiles = ocv_cdiv(P, TP);
+  int per = blocks_per_image(B, ntiles) * 2;      // 66 KiB LDS -> two workgroups per CU
+  if (per > ntiles) per = ntiles;
+  hipLaunchKernelGGL(pixel_dot_kernel, dim3(per, B), dim3(256), (size_t)CH * WLD * sizeof(float), (hipStream_t)stream,
+                     feat, queries, q_bs, q_ld, ram, (long)P, ntiles);
+  OCV_CHECK_LAUNCH("ocv_pixel_dot_fwd");
+  return 0;
+}
+
+extern "C" int ocv_bin_head_fwd(const float* feat, const float* queries, long q_bs, int q_ld, const float* Wout,
+                                const float* bout, const float* centers, float* depth, int B, int C, int Q, int n_bins,
+                                int P, void* workspace, size_t workspace_bytes, ocv_stream_t stream) {
+  OCV_CHECK_ARG(feat && queries && Wout && bout && centers && depth && workspace, "ocv_bin_head_fwd: null pointer");
+  OCV_CHECK_ARG(C == CH && Q == CH && n_bins == NB, "ocv_bin_head_fwd: needs C = Q = %d, n_bins = %d", CH, NB);
+  OCV_CHECK_ARG(B >= 1 && B <= 65535 && P >= 1 && q_ld >= C, "ocv_bin_head_fwd: bad sizes");
+  OCV_CHECK_ARG(workspace_bytes >= ocv_bin_head_workspace_bytes(B, n_bins, C) && ocv_aligned16(workspace),
+                "ocv_bin_head_fwd: workspace too small or misaligned");
+  float* Wf = (float*)workspace;
+  // Wf[b] (256 x 128) = Wout (256 x 128q) . queries[b] (128q x 128c): W operand given in [K, N] layout
+  int rc = ocv_linear_fwd(Wout, Q, 0, queries, q_ld, q_bs, 1, nullptr, Wf, CH, (long)NB * CH, B, NB, CH, Q, OCV_ACT_NONE,
+                          stream);
+  if (rc != 0) return rc;
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)bin_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  const int ntiles = ocv_cdiv(P, TP);
+  const int per = blocks_per_image(B, ntiles);
+  const size_t lds = (size_t)(NB * WLD + 2 * NB) * sizeof(float);
+  hipLaunchKernelGGL(bin_head_kernel, dim3(per, B), dim3(256), lds, (hipStream_t)stream, feat, Wf, bout, centers,
+                     depth, (long)P, ntiles);
+  OCV_CHECK_LAUNCH("ocv_bin_head_fwd");
+  return 0;
+}

@@ -1,0 +1,101 @@
+// Composite entry points of the C ABI (multi-head attention module and one
+// transformer encoder layer) plus error reporting.  Each composite only chains
+// the kernels of linear.hip / attention.hip on the caller's stream using the
+// caller's workspace: no allocation, no synchronisation.
+#include <stdarg.h>
+#include <stdio.h>
+#include <math.h>
+
+#include "common.hpp"
+#include "../../include/objcavit_hip.h"
+
+namespace {
+thread_local char g_err[512] = "";
+inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+}  // namespace
+
+void ocv_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int ocv_abi_version(void) { return OCV_ABI_VERSION; }
+extern "C" const char* ocv_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------
+// nn.MultiheadAttention forward (distinct q / k / v sources allowed)
+// workspace: qp [B*Sq, E] | kp [B*Sk, E] | vp [B*Sk, E] | ctx [B*Sq, E]
+// ---------------------------------------------------------------------------
+extern "C" size_t ocv_mha_workspace_bytes(int B, int Sq, int Sk, int E) {
+  if (B < 1 || Sq < 1 || Sk < 1 || E < 1) return 0;
+  const size_t q = align_up((size_t)B * Sq * E * sizeof(float)), k = align_up((size_t)B * Sk * E * sizeof(float));
+  return 2 * q + 2 * k;
+}
+
+extern "C" int ocv_mha_fwd(const float* q_src, const float* k_src, const float* v_src, const uint8_t* key_padding_mask,
+                           const float* in_proj_w, const float* in_proj_b, const float* out_w, const float* out_b,
+                           float* out, int B, int Sq, int Sk, int E, int H, void* workspace, size_t workspace_bytes,
+                           ocv_stream_t stream) {
+  OCV_CHECK_ARG(q_src && k_src && v_src && in_proj_w && in_proj_b && out_w && out_b && out && workspace,
+                "ocv_mha_fwd: null pointer");
+  OCV_CHECK_ARG(H >= 1 && E == H * 32, "ocv_mha_fwd: head dim must be 32 (E=%d, H=%d)", E, H);
+  OCV_CHECK_ARG(workspace_bytes >= ocv_mha_workspace_bytes(B, Sq, Sk, E), "ocv_mha_fwd: workspace too small");
+  const size_t qb = align_up((size_t)B * Sq * E * sizeof(float)), kb = align_up((size_t)B * Sk * E * sizeof(float));
+  char* ws = (char*)workspace;
+  float* qp = (float*)ws;
+  float* kp = (float*)(ws + qb);
+  float* vp = (float*)(ws + qb + kb);
+  float* ctx = (float*)(ws + qb + 2 * kb);
+  int rc;
+  if ((rc = ocv_linear_fwd(q_src, E, 0, in_proj_w, E, 0, 0, in_proj_b, qp, E, 0, 1, B * Sq, E, E, OCV_ACT_NONE, stream))) return rc;
+  if ((rc = ocv_linear_fwd(k_src, E, 0, in_proj_w + (size_t)E * E, E, 0, 0, in_proj_b + E, kp, E, 0, 1, B * Sk, E, E, OCV_ACT_NONE, stream))) return rc;
+  if ((rc = ocv_linear_fwd(v_src, E, 0, in_proj_w + (size_t)2 * E * E, E, 0, 0, in_proj_b + 2 * E, vp, E, 0, 1, B * Sk, E, E, OCV_ACT_NONE, stream))) return rc;
+  if ((rc = ocv_attention_fwd(qp, (long)Sq * E, E, kp, (long)Sk * E, E, vp, (long)Sk * E, E, key_padding_mask, ctx,
+                              (long)Sq * E, E, B, H, Sq, Sk, 1.0f / sqrtf(32.0f), stream))) return rc;
+  return ocv_linear_fwd(ctx, E, 0, out_w, E, 0, 0, out_b, out, E, 0, 1, B * Sq, E, E, OCV_ACT_NONE, stream);
+}
+
+// ---------------------------------------------------------------------------
+// one post-norm transformer encoder layer
+// workspace: qkv [M, 3E] | ctx [M, E] | x1 [M, E] | hid [M, FF]
+// ---------------------------------------------------------------------------
+extern "C" size_t ocv_encoder_layer_workspace_bytes(int B, int S, int E, int FF) {
+  if (B < 1 || S < 1 || E < 1 || FF < 1) return 0;
+  const size_t M = (size_t)B * S;
+  return align_up(M * 3 * E * sizeof(float)) + 2 * align_up(M * E * sizeof(float)) + align_up(M * FF * sizeof(float));
+}
+
+extern "C" int ocv_encoder_layer_fwd(const float* x, const ocv_encoder_layer_params* p,
+                                     const uint8_t* key_padding_mask, int zero_padded_rows, float* out, int B, int S,
+                                     int E, int H, int FF, float eps, void* workspace, size_t workspace_bytes,
+                                     ocv_stream_t stream) {
+  OCV_CHECK_ARG(x && p && out && workspace, "ocv_encoder_layer_fwd: null pointer");
+  OCV_CHECK_ARG(E == 128 && H == 4, "ocv_encoder_layer_fwd: built for E = 128, H = 4 (got %d, %d)", E, H);
+  OCV_CHECK_ARG(workspace_bytes >= ocv_encoder_layer_workspace_bytes(B, S, E, FF), "ocv_encoder_layer_fwd: workspace too small");
+  const int M = B * S;
+  char* ws = (char*)workspace;
+  float* qkv = (float*)ws;
+  ws += align_up((size_t)M * 3 * E * sizeof(float));
+  float* ctx = (float*)ws;
+  ws += align_up((size_t)M * E * sizeof(float));
+  float* x1 = (float*)ws;
+  ws += align_up((size_t)M * E * sizeof(float));
+  float* hid = (float*)ws;
+  int rc;
+  // packed QKV projection
+  if ((rc = ocv_linear_fwd(x, E, 0, p->in_proj_w, E, 0, 0, p->in_proj_b, qkv, 3 * E, 0, 1, M, 3 * E, E, OCV_ACT_NONE, stream))) return rc;
+  if ((rc = ocv_attention_fwd(qkv, (long)S * 3 * E, 3 * E, qkv + E, (long)S * 3 * E, 3 * E, qkv + 2 * E,
+                              (long)S * 3 * E, 3 * E, key_padding_mask, ctx, (long)S * E, E, B, H, S, S,
+                              1.0f / sqrtf(32.0f), stream))) return rc;
+  // x1 = LN1(x + ctx Wo^T + bo)
+  if ((rc = ocv_linear_residual_layernorm_fwd(ctx, E, p->out_proj_w, E, p->out_proj_b, x, E, p->norm1_w, p->norm1_b,
+                                              eps, nullptr, x1, E, M, E, E, stream))) return rc;
+  // hid = relu(x1 W1^T + b1)
+  if ((rc = ocv_linear_fwd(x1, E, 0, p->linear1_w, E, 0, 0, p->linear1_b, hid, FF, 0, 1, M, FF, E, OCV_ACT_RELU, stream))) return rc;
+  // out = LN2(x1 + hid W2^T + b2)
+  const uint8_t* zmask = (zero_padded_rows && key_padding_mask) ? key_padding_mask : nullptr;
+  return ocv_linear_residual_layernorm_fwd(hid, FF, p->linear2_w, FF, p->linear2_b, x1, E, p->norm2_w, p->norm2_b, eps,
+                                           zmask, out, E, M, E, FF, stream);
+}

@@ -1,0 +1,63 @@
+// Shared device helpers for the gfx950 (CDNA4 / MI355X) kernels.
+//
+// All matrix work uses the exact-fp32 matrix instruction
+// v_mfma_f32_32x32x2_f32 (64-lane wavefront, 32x32 output tile, K = 2 per
+// issue, 64 FLOP/clk/SIMD).  Operand and result lane maps (guide section 3):
+//   A operand: lane l supplies A[i = l & 31][k = l >> 5]        (one VGPR)
+//   B operand: lane l supplies B[k = l >> 5][j = l & 31]        (one VGPR)
+//   C/D      : 16 VGPRs; register r of lane l is
+//              D[row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][col = l & 31]
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define OCV_WAVE 64
+
+__device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// row of accumulator register r for lane-half hh (= lane >> 5)
+__device__ __forceinline__ constexpr int acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float xor32_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float xor32_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+
+// exp via the hardware exp2 (v_exp_f32): ~1 ulp, exp(-inf) == 0
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+void ocv_set_error(const char* fmt, ...);
+
+#define OCV_CHECK_ARG(cond, ...)        \
+  do {                                  \
+    if (!(cond)) {                      \
+      ocv_set_error(__VA_ARGS__);       \
+      return -1;                        \
+    }                                   \
+  } while (0)
+
+#define OCV_CHECK_LAUNCH(name)                                              \
+  do {                                                                      \
+    hipError_t e__ = hipGetLastError();                                     \
+    if (e__ != hipSuccess) {                                                \
+      ocv_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return (int)e__;                                                      \
+    }                                                                       \
+  } while (0)
+
+static inline bool ocv_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline int ocv_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,245 @@
+// Linear layers (+ fused residual/LayerNorm epilogue) and stand-alone LayerNorm
+// for gfx950.  fp32 in, fp32 accumulate, v_mfma_f32_32x32x2_f32.
+//
+// Tiling: one workgroup = 4 wavefronts = a 32 (rows) x 128 (columns) output
+// tile; wave w owns columns [32w, 32w+32).  K is walked in steps of 32 through
+// LDS (A tile 32x32, W tile 128x32, rows padded to 33 floats so that the
+// per-lane ds_read_b32 of an MFMA operand -- 32 consecutive rows, one column --
+// hits 32 distinct banks).  fp32 MFMA issues once per 64 cycles per SIMD, so
+// two 4-byte LDS reads per MFMA are far from the LDS limit; the kernel is
+// bound by the matrix pipe (157 TFLOP/s chip peak) or, for the tiny object-side
+// layers, by launch latency.
+#include "common.hpp"
+#include "../../include/objcavit_hip.h"
+
+namespace {
+
+constexpr int BM = 32, BN = 128, BK = 32, LDT = BK + 1;
+
+enum { EPI_NONE = 0, EPI_RELU = 1, EPI_LEAKY = 2, EPI_RES_LN = 3 };
+
+struct LinearArgs {
+  const float* A; int lda; long sA;
+  const float* W; int ldw; long sW;
+  const float* bias;
+  float* out; int ldo; long sO;
+  int M, N, K;
+  // EPI_RES_LN only
+  const float* res; int ldres;
+  const float* gamma; const float* beta; float eps;
+  const uint8_t* zero_mask;
+};
+
+template <int EPI, bool W_KN, bool VEC>
+__global__ __launch_bounds__(256) void linear_kernel(LinearArgs p) {
+  __shared__ float As[BM][LDT];
+  __shared__ float Ws[BN][LDT];
+  __shared__ float Cs[EPI == EPI_RES_LN ? BM : 1][EPI == EPI_RES_LN ? BN + 1 : 1];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const float* __restrict__ A = p.A + (long)blockIdx.z * p.sA;
+  const float* __restrict__ W = p.W + (long)blockIdx.z * p.sW;
+  float* __restrict__ out = p.out + (long)blockIdx.z * p.sO;
+  const int M = p.M, N = p.N, K = p.K;
+
+  f32x16 acc = {0};
+
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    // ---- A tile: thread -> (row tid/8, 4 consecutive k)
+    {
+      const int r = tid >> 3, kk = (tid & 7) * 4;
+      const int gm = m0 + r, gk = k0 + kk;
+      float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+      if (gm < M) {
+        const float* src = A + (long)gm * p.lda + gk;
+        if (VEC && gk + 3 < K) {
+          float4 t = ld4(src);
+          v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w;
+        } else {
+          if (gk + 0 < K) v0 = src[0];
+          if (gk + 1 < K) v1 = src[1];
+          if (gk + 2 < K) v2 = src[2];
+          if (gk + 3 < K) v3 = src[3];
+        }
+      }
+      As[r][kk + 0] = v0; As[r][kk + 1] = v1; As[r][kk + 2] = v2; As[r][kk + 3] = v3;
+    }
+    // ---- W tile (128 x 32)
+    if (!W_KN) {
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int r = pass * 32 + (tid >> 3), kk = (tid & 7) * 4;
+        const int gn = n0 + r, gk = k0 + kk;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        if (gn < N) {
+          const float* src = W + (long)gn * p.ldw + gk;
+          if (VEC && gk + 3 < K) {
+            float4 t = ld4(src);
+            v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w;
+          } else {
+            if (gk + 0 < K) v0 = src[0];
+            if (gk + 1 < K) v1 = src[1];
+            if (gk + 2 < K) v2 = src[2];
+            if (gk + 3 < K) v3 = src[3];
+          }
+        }
+        Ws[r][kk + 0] = v0; Ws[r][kk + 1] = v1; Ws[r][kk + 2] = v2; Ws[r][kk + 3] = v3;
+      }
+    } else {
+      // W stored [K, N]: thread -> (k = pass*8 + tid/32, 4 consecutive n)
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int kk = pass * 8 + (tid >> 5), nn = (tid & 31) * 4;
+        const int gk = k0 + kk, gn = n0 + nn;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        if (gk < K) {
+          const float* src = W + (long)gk * p.ldw + gn;
+          if (VEC && gn + 3 < N) {
+            float4 t = ld4(src);
+            v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w;
+          } else {
+            if (gn + 0 < N) v0 = src[0];
+            if (gn + 1 < N) v1 = src[1];
+            if (gn + 2 < N) v2 = src[2];
+            if (gn + 3 < N) v3 = src[3];
+          }
+        }
+        Ws[nn + 0][kk] = v0; Ws[nn + 1][kk] = v1; Ws[nn + 2][kk] = v2; Ws[nn + 3][kk] = v3;
+      }
+    }
+    __syncthreads();
+    const float* arow = &As[l31][hh];
+    const float* wrow = &Ws[wave * 32 + l31][hh];
+#pragma unroll
+    for (int s = 0; s < BK / 2; ++s) acc = mfma_32x32x2(arow[2 * s], wrow[2 * s], acc);
+    __syncthreads();
+  }
+
+  const int n = n0 + wave * 32 + l31;
+  const float bn = (p.bias != nullptr && n < N) ? p.bias[n] : 0.f;
+
+  if (EPI != EPI_RES_LN) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + acc_row(r, hh);
+      float v = acc[r] + bn;
+      if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+      if (EPI == EPI_LEAKY) v = v > 0.f ? v : 0.01f * v;
+      if (m < M && n < N) out[(long)m * p.ldo + n] = v;
+    }
+  } else {
+    // residual add, then LayerNorm over the 128 columns held by this workgroup
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = acc_row(r, hh), m = m0 + row;
+      float v = acc[r] + bn;
+      if (m < M) v += p.res[(long)m * p.ldres + n];
+      Cs[row][wave * 32 + l31] = v;
+    }
+    __syncthreads();
+    const float g0 = p.gamma[lane], g1 = p.gamma[lane + 64];
+    const float b0 = p.beta[lane], b1 = p.beta[lane + 64];
+#pragma unroll
+    for (int i = 0; i < BM / 4; ++i) {
+      const int row = wave * (BM / 4) + i, m = m0 + row;
+      const float x0 = Cs[row][lane], x1 = Cs[row][lane + 64];
+      const float mean = wave_sum(x0 + x1) * (1.0f / BN);
+      const float d0 = x0 - mean, d1 = x1 - mean;
+      const float var = wave_sum(d0 * d0 + d1 * d1) * (1.0f / BN);
+      const float rstd = 1.0f / sqrtf(var + p.eps);
+      if (m < M) {
+        const bool z = p.zero_mask != nullptr && p.zero_mask[m] != 0;
+        out[(long)m * p.ldo + lane] = z ? 0.f : d0 * rstd * g0 + b0;
+        out[(long)m * p.ldo + lane + 64] = z ? 0.f : d1 * rstd * g1 + b1;
+      }
+    }
+  }
+}
+
+// one wavefront per row
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        float* __restrict__ out, int rows, int E) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (long)row * E;
+  const float* rr = res ? res + (long)row * E : nullptr;
+  float s = 0.f;
+  for (int c = lane; c < E; c += 64) s += xr[c] + (rr ? rr[c] : 0.f);
+  const float mean = wave_sum(s) / (float)E;
+  float q = 0.f;
+  for (int c = lane; c < E; c += 64) {
+    const float d = xr[c] + (rr ? rr[c] : 0.f) - mean;
+    q += d * d;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + eps);
+  for (int c = lane; c < E; c += 64) {
+    const float d = xr[c] + (rr ? rr[c] : 0.f) - mean;
+    out[(long)row * E + c] = d * rstd * gamma[c] + beta[c];
+  }
+}
+
+template <int EPI>
+int launch_linear(const LinearArgs& a, int batch, bool w_kn, hipStream_t st) {
+  dim3 grid(ocv_cdiv(a.M, BM), ocv_cdiv(a.N, BN), batch), block(256);
+  const bool vecA = (a.lda % 4 == 0) && (a.sA % 4 == 0) && ocv_aligned16(a.A);
+  const bool vecW = (a.ldw % 4 == 0) && (a.sW % 4 == 0) && ocv_aligned16(a.W);
+  const bool vec = vecA && vecW && (w_kn || a.K % 4 == 0);
+  if (w_kn) {
+    if (vec) hipLaunchKernelGGL((linear_kernel<EPI, true, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((linear_kernel<EPI, true, false>), grid, block, 0, st, a);
+  } else {
+    if (vec) hipLaunchKernelGGL((linear_kernel<EPI, false, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((linear_kernel<EPI, false, false>), grid, block, 0, st, a);
+  }
+  OCV_CHECK_LAUNCH("ocv_linear");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int ocv_linear_fwd(const float* A, int lda, long strideA, const float* W, int ldw, long strideW, int w_kn,
+                              const float* bias, float* out, int ldo, long strideO, int batch, int M, int N, int K,
+                              int act, ocv_stream_t stream) {
+  OCV_CHECK_ARG(A && W && out, "ocv_linear_fwd: null pointer");
+  OCV_CHECK_ARG(batch >= 1 && M >= 0 && N >= 1 && K >= 1, "ocv_linear_fwd: bad sizes batch=%d M=%d N=%d K=%d", batch, M, N, K);
+  OCV_CHECK_ARG(lda >= K && ldo >= N && ldw >= (w_kn ? N : K), "ocv_linear_fwd: leading dimension too small");
+  OCV_CHECK_ARG(act >= 0 && act <= 2, "ocv_linear_fwd: unknown activation %d", act);
+  if (M == 0) return 0;
+  LinearArgs a{A, lda, strideA, W, ldw, strideW, bias, out, ldo, strideO, M, N, K, nullptr, 0, nullptr, nullptr, 0.f, nullptr};
+  hipStream_t st = (hipStream_t)stream;
+  switch (act) {
+    case OCV_ACT_RELU: return launch_linear<EPI_RELU>(a, batch, w_kn != 0, st);
+    case OCV_ACT_LEAKY_RELU: return launch_linear<EPI_LEAKY>(a, batch, w_kn != 0, st);
+    default: return launch_linear<EPI_NONE>(a, batch, w_kn != 0, st);
+  }
+}
+
+extern "C" int ocv_linear_residual_layernorm_fwd(const float* A, int lda, const float* W, int ldw, const float* bias,
+                                                 const float* residual, int ldres, const float* gamma,
+                                                 const float* beta, float eps, const uint8_t* zero_row_mask,
+                                                 float* out, int ldo, int M, int N, int K, ocv_stream_t stream) {
+  OCV_CHECK_ARG(A && W && residual && gamma && beta && out, "ocv_linear_residual_layernorm_fwd: null pointer");
+  OCV_CHECK_ARG(N == BN, "ocv_linear_residual_layernorm_fwd: N must be %d (got %d)", BN, N);
+  OCV_CHECK_ARG(M >= 0 && K >= 1 && lda >= K && ldw >= K && ldo >= N && ldres >= N,
+                "ocv_linear_residual_layernorm_fwd: bad sizes");
+  if (M == 0) return 0;
+  LinearArgs a{A, lda, 0, W, ldw, 0, bias, out, ldo, 0, M, N, K, residual, ldres, gamma, beta, eps, zero_row_mask};
+  return launch_linear<EPI_RES_LN>(a, 1, false, (hipStream_t)stream);
+}
+
+extern "C" int ocv_layernorm_residual_fwd(const float* x, const float* residual, const float* gamma,
+                                          const float* beta, float eps, float* out, int rows, int E,
+                                          ocv_stream_t stream) {
+  OCV_CHECK_ARG(x && gamma && beta && out, "ocv_layernorm_residual_fwd: null pointer");
+  OCV_CHECK_ARG(rows >= 0 && E >= 1, "ocv_layernorm_residual_fwd: bad sizes");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(layernorm_kernel, dim3(ocv_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, residual, gamma,
+                     beta, eps, out, rows, E);
+  OCV_CHECK_LAUNCH("ocv_layernorm_residual_fwd");
+  return 0;
+}

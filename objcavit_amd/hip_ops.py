@@ -1,0 +1,352 @@
+"""Tensor-level wrappers over the C ABI (include/objcavit_hip.h).
+
+PyTorch is used here for device memory, the current HIP stream and nothing
+else: every function validates its operands on the host (shape, dtype, device,
+contiguity -- a wrong shape must never reach a hand-written kernel), takes raw
+``data_ptr()`` values and enqueues our kernels on ``torch.cuda.current_stream()``.
+All of them raise if the tensors are not on a GPU or the library is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import EncoderLayerParams, check
+
+ACT_NONE, ACT_RELU, ACT_LEAKY_RELU = 0, 1, 2
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t: torch.Tensor, name: str, dtype=torch.float32, contiguous: bool = True) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor")
+    if t.device.type != "cuda":
+        raise _lib.HipLibraryError(f"{name} is on {t.device}: the ObjCAViT hot path runs only on a ROCm GPU "
+                                   "(there is no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if contiguous and not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+# ---------------------------------------------------------------------------
+# optional per-entry-point timing with HIP events on the launch stream
+# (bench.py turns this on to measure kernel durations inside the timed region)
+# ---------------------------------------------------------------------------
+class _Timing:
+    enabled = False
+    events: Dict[str, list] = {}
+
+
+def enable_timing(on: bool = True) -> None:
+    _Timing.enabled = on
+    _Timing.events = {}
+
+
+def timing_results() -> Dict[str, Tuple[int, float]]:
+    """name -> (launch count, mean milliseconds); synchronises the device."""
+    torch.cuda.synchronize()
+    return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in _Timing.events.items() if v}
+
+
+class timed:
+    """Brackets a C-ABI call with a pair of events on the current stream when timing is enabled."""
+
+    def __init__(self, name: str):
+        self.name = name
+
+    def __enter__(self):
+        if _Timing.enabled:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _Timing.enabled:
+            self.b.record()
+            _Timing.events.setdefault(self.name, []).append((self.a, self.b))
+        return False
+
+
+# ---------------------------------------------------------------------------
+# workspace: one growing byte buffer per (device, tag)
+# ---------------------------------------------------------------------------
+_WS: Dict[Tuple[int, str], torch.Tensor] = {}
+
+
+def workspace(nbytes: int, device: torch.device, tag: str = "default") -> torch.Tensor:
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("workspace would grow during graph capture: run one eager warm-up call first")
+        buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+# ---------------------------------------------------------------------------
+# linear / layernorm
+# ---------------------------------------------------------------------------
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(x @ weight.T + bias); x [..., K] contiguous, weight [N, K]."""
+    lib = _lib.load()
+    _req(x, "x"); _req(weight, "weight")
+    K = x.shape[-1]
+    N = weight.shape[0]
+    if weight.dim() != 2 or weight.shape[1] != K:
+        raise ValueError(f"linear: weight {tuple(weight.shape)} does not match x[..., {K}]")
+    if bias is not None:
+        _req(bias, "bias")
+        if bias.numel() != N:
+            raise ValueError("linear: bias size mismatch")
+    M = x.numel() // K
+    if out is None:
+        out = torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)
+    else:
+        _req(out, "out")
+        if out.numel() != M * N:
+            raise ValueError("linear: out size mismatch")
+    check(lib.ocv_linear_fwd(x.data_ptr(), K, 0, weight.data_ptr(), K, 0, 0, _ptr(bias), out.data_ptr(), N, 0, 1, M, N, K,
+                             act, _stream()), "ocv_linear_fwd")
+    return out
+
+
+def linear_residual_layernorm(a: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, residual: torch.Tensor,
+                              gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
+                              zero_row_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """LayerNorm(residual + a @ weight.T + bias) over the last dim (== 128)."""
+    lib = _lib.load()
+    for n, t in (("a", a), ("weight", weight), ("bias", bias), ("residual", residual), ("gamma", gamma), ("beta", beta)):
+        _req(t, n)
+    K, N = a.shape[-1], weight.shape[0]
+    M = a.numel() // K
+    if weight.shape != (N, K) or residual.shape[-1] != N or residual.numel() != M * N or gamma.numel() != N or beta.numel() != N:
+        raise ValueError("linear_residual_layernorm: shape mismatch")
+    if zero_row_mask is not None:
+        _req(zero_row_mask, "zero_row_mask", torch.uint8)
+        if zero_row_mask.numel() != M:
+            raise ValueError("zero_row_mask: one byte per row expected")
+    out = torch.empty_like(residual)
+    check(lib.ocv_linear_residual_layernorm_fwd(a.data_ptr(), K, weight.data_ptr(), K, bias.data_ptr(), residual.data_ptr(),
+                                                N, gamma.data_ptr(), beta.data_ptr(), eps, _ptr(zero_row_mask),
+                                                out.data_ptr(), N, M, N, K, _stream()),
+          "ocv_linear_residual_layernorm_fwd")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
+              residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    _req(x, "x"); _req(gamma, "gamma"); _req(beta, "beta")
+    E = x.shape[-1]
+    if gamma.numel() != E or beta.numel() != E:
+        raise ValueError("layernorm: parameter size mismatch")
+    if residual is not None:
+        _req(residual, "residual")
+        if residual.shape != x.shape:
+            raise ValueError("layernorm: residual shape mismatch")
+    out = torch.empty_like(x)
+    check(lib.ocv_layernorm_residual_fwd(x.data_ptr(), _ptr(residual), gamma.data_ptr(), beta.data_ptr(), eps,
+                                         out.data_ptr(), x.numel() // E, E, _stream()), "ocv_layernorm_residual_fwd")
+    return out
+
+
+# ---------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------
+def _mask_u8(mask: Optional[torch.Tensor], B: int, Sk: int) -> Optional[torch.Tensor]:
+    if mask is None:
+        return None
+    if mask.device.type != "cuda":
+        raise _lib.HipLibraryError("key_padding_mask must be on the GPU")
+    if mask.shape != (B, Sk):
+        raise ValueError(f"key_padding_mask: expected {(B, Sk)}, got {tuple(mask.shape)}")
+    if mask.dtype == torch.bool:
+        mask = mask.view(torch.uint8) if mask.is_contiguous() else mask.contiguous().view(torch.uint8)
+    elif mask.dtype != torch.uint8:
+        raise TypeError("key_padding_mask must be bool or uint8")
+    return mask.contiguous()
+
+
+def attention_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, key_padding_mask: Optional[torch.Tensor],
+                   n_heads: int) -> torch.Tensor:
+    """softmax(q k^T / sqrt(32) + mask) v per head; q [B,Sq,E], k / v [B,Sk,E] (last-dim-contiguous views allowed)."""
+    lib = _lib.load()
+    for n, t in (("q", q), ("k", k), ("v", v)):
+        _req(t, n, contiguous=False)
+        if t.dim() != 3 or t.stride(2) != 1:
+            raise ValueError(f"{n}: expected [B, S, E] with unit stride on E")
+    B, Sq, E = q.shape
+    Sk = k.shape[1]
+    if k.shape != (B, Sk, E) or v.shape != (B, Sk, E) or E != n_heads * 32:
+        raise ValueError("attention_core: shape mismatch (head dim must be 32)")
+    m = _mask_u8(key_padding_mask, B, Sk)
+    ctx = torch.empty(B, Sq, E, dtype=torch.float32, device=q.device)
+    check(lib.ocv_attention_fwd(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1),
+                                v.data_ptr(), v.stride(0), v.stride(1), _ptr(m), ctx.data_ptr(), Sq * E, E, B, n_heads,
+                                Sq, Sk, 1.0 / math.sqrt(32.0), _stream()), "ocv_attention_fwd")
+    return ctx
+
+
+def mha(q_src: torch.Tensor, k_src: torch.Tensor, v_src: torch.Tensor, in_proj_w: torch.Tensor, in_proj_b: torch.Tensor,
+        out_w: torch.Tensor, out_b: torch.Tensor, key_padding_mask: Optional[torch.Tensor] = None,
+        n_heads: int = 4) -> torch.Tensor:
+    """nn.MultiheadAttention(batch_first=True, need_weights=False) forward."""
+    lib = _lib.load()
+    for n, t in (("q_src", q_src), ("k_src", k_src), ("v_src", v_src), ("in_proj_weight", in_proj_w),
+                 ("in_proj_bias", in_proj_b), ("out_proj.weight", out_w), ("out_proj.bias", out_b)):
+        _req(t, n)
+    B, Sq, E = q_src.shape
+    Sk = k_src.shape[1]
+    if k_src.shape != (B, Sk, E) or v_src.shape != (B, Sk, E):
+        raise ValueError("mha: key / value shape mismatch")
+    if in_proj_w.shape != (3 * E, E) or in_proj_b.numel() != 3 * E or out_w.shape != (E, E) or out_b.numel() != E:
+        raise ValueError("mha: parameter shape mismatch")
+    m = _mask_u8(key_padding_mask, B, Sk)
+    nb = lib.ocv_mha_workspace_bytes(B, Sq, Sk, E)
+    ws = workspace(nb, q_src.device)
+    out = torch.empty(B, Sq, E, dtype=torch.float32, device=q_src.device)
+    with timed("mha_cross" if q_src.data_ptr() != k_src.data_ptr() else "mha_self"):
+      check(lib.ocv_mha_fwd(q_src.data_ptr(), k_src.data_ptr(), v_src.data_ptr(), _ptr(m), in_proj_w.data_ptr(),
+                            in_proj_b.data_ptr(), out_w.data_ptr(), out_b.data_ptr(), out.data_ptr(), B, Sq, Sk, E, n_heads,
+                            ws.data_ptr(), ws.numel(), _stream()), "ocv_mha_fwd")
+    return out
+
+
+_LAYER_FIELDS = (("in_proj_w", "self_attn.in_proj_weight"), ("in_proj_b", "self_attn.in_proj_bias"),
+                 ("out_proj_w", "self_attn.out_proj.weight"), ("out_proj_b", "self_attn.out_proj.bias"),
+                 ("norm1_w", "norm1.weight"), ("norm1_b", "norm1.bias"),
+                 ("linear1_w", "linear1.weight"), ("linear1_b", "linear1.bias"),
+                 ("linear2_w", "linear2.weight"), ("linear2_b", "linear2.bias"),
+                 ("norm2_w", "norm2.weight"), ("norm2_b", "norm2.bias"))
+
+
+def layer_params(layer: torch.nn.Module) -> Tuple[EncoderLayerParams, list]:
+    """Pointer table for one nn.TransformerEncoderLayer-shaped parameter holder.
+    Returns (struct, keep-alive list of tensors)."""
+    sd = dict(layer.named_parameters())
+    st = EncoderLayerParams()
+    keep = []
+    for field, key in _LAYER_FIELDS:
+        t = _req(sd[key].detach(), key)
+        keep.append(t)
+        setattr(st, field, t.data_ptr())
+    return st, keep
+
+
+def encoder_layer(x: torch.Tensor, params: EncoderLayerParams, key_padding_mask: Optional[torch.Tensor] = None,
+                  zero_padded_rows: bool = False, n_heads: int = 4, dim_ff: int = 1024, eps: float = 1e-5,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    _req(x, "x")
+    if x.dim() != 3:
+        raise ValueError("encoder_layer: x must be [B, S, E]")
+    B, S, E = x.shape
+    m = _mask_u8(key_padding_mask, B, S)
+    nb = lib.ocv_encoder_layer_workspace_bytes(B, S, E, dim_ff)
+    ws = workspace(nb, x.device)
+    if out is None:
+        out = torch.empty_like(x)
+    with timed("encoder_layer"):
+      check(lib.ocv_encoder_layer_fwd(x.data_ptr(), C.byref(params), _ptr(m), int(zero_padded_rows), out.data_ptr(), B, S, E,
+                                      n_heads, dim_ff, eps, ws.data_ptr(), ws.numel(), _stream()), "ocv_encoder_layer_fwd")
+    return out
+
+
+# ---------------------------------------------------------------------------
+# patch embedding / pixel-wise dot / bin head
+# ---------------------------------------------------------------------------
+def patch_embed(fmap: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                pos: Optional[torch.Tensor]) -> torch.Tensor:
+    """tokens [B, S, E] = conv16x16/16(fmap) flattened + bias + pos; pos is [S, E] or [B, S, E]."""
+    lib = _lib.load()
+    _req(fmap, "fmap"); _req(weight, "weight")
+    B, Cc, h, w = fmap.shape
+    E = weight.shape[0]
+    if weight.shape != (E, Cc, 16, 16):
+        raise ValueError(f"patch_embed: weight {tuple(weight.shape)} does not match fmap channels {Cc} / 16x16 patches")
+    gh, gw = h // 16, w // 16
+    S = gh * gw
+    if S < 1:
+        raise ValueError("patch_embed: feature map smaller than one patch")
+    pos_bs = 0
+    if pos is not None:
+        _req(pos, "pos")
+        if pos.shape == (S, E):
+            pos_bs = 0
+        elif pos.shape == (B, S, E):
+            pos_bs = S * E
+        else:
+            raise ValueError(f"patch_embed: pos must be {(S, E)} or {(B, S, E)}, got {tuple(pos.shape)}")
+    if bias is not None:
+        _req(bias, "bias")
+        if bias.numel() != E:
+            raise ValueError("patch_embed: bias size mismatch")
+    nb = lib.ocv_patch_embed_workspace_bytes(B, Cc, h, w, E)
+    if nb == 0:
+        raise ValueError(f"patch_embed: unsupported configuration B={B} C={Cc} h={h} w={w} E={E}")
+    ws = workspace(nb, fmap.device)
+    out = torch.empty(B, S, E, dtype=torch.float32, device=fmap.device)
+    with timed("patch_embed"):
+      check(lib.ocv_patch_embed_fwd(fmap.data_ptr(), weight.data_ptr(), _ptr(bias), _ptr(pos), pos_bs, out.data_ptr(), B, Cc,
+                                    h, w, E, ws.data_ptr(), ws.numel(), _stream()), "ocv_patch_embed_fwd")
+    return out
+
+
+def _check_queries(queries: torch.Tensor, B: int, Cc: int) -> None:
+    _req(queries, "queries", contiguous=False)
+    if queries.dim() != 3 or queries.shape[0] != B or queries.shape[2] != Cc or queries.stride(2) != 1:
+        raise ValueError("queries: expected [B, Q, C] with unit stride on C")
+
+
+def pixel_dot(feat: torch.Tensor, queries: torch.Tensor) -> torch.Tensor:
+    """PixelWiseDotProduct: [B,C,h,w] x [B,Q,C] -> [B,Q,h,w]."""
+    lib = _lib.load()
+    _req(feat, "feat")
+    B, Cc, h, w = feat.shape
+    _check_queries(queries, B, Cc)
+    Q = queries.shape[1]
+    ram = torch.empty(B, Q, h, w, dtype=torch.float32, device=feat.device)
+    with timed("pixel_dot"):
+      check(lib.ocv_pixel_dot_fwd(feat.data_ptr(), queries.data_ptr(), queries.stride(0), queries.stride(1), ram.data_ptr(), B,
+                                  Cc, Q, h * w, _stream()), "ocv_pixel_dot_fwd")
+    return ram
+
+
+def bin_head(feat: torch.Tensor, queries: torch.Tensor, w_out: torch.Tensor, b_out: torch.Tensor,
+             centers: torch.Tensor) -> torch.Tensor:
+    """depth [B,1,h,w] = sum_k softmax_k(conv1x1(pixel_dot(feat, queries)))_k * centers_k, fused."""
+    lib = _lib.load()
+    _req(feat, "feat"); _req(b_out, "b_out"); _req(centers, "centers")
+    B, Cc, h, w = feat.shape
+    _check_queries(queries, B, Cc)
+    Q = queries.shape[1]
+    w2 = _req(w_out.reshape(w_out.shape[0], -1), "w_out")
+    nbins = w2.shape[0]
+    if w2.shape != (nbins, Q) or b_out.numel() != nbins or centers.shape != (B, nbins):
+        raise ValueError("bin_head: parameter shape mismatch")
+    nb = lib.ocv_bin_head_workspace_bytes(B, nbins, Cc)
+    if nb == 0:
+        raise ValueError(f"bin_head: unsupported configuration C={Cc} Q={Q} n_bins={nbins}")
+    ws = workspace(nb, feat.device, "bin_head")
+    depth = torch.empty(B, 1, h, w, dtype=torch.float32, device=feat.device)
+    with timed("bin_head"):
+      check(lib.ocv_bin_head_fwd(feat.data_ptr(), queries.data_ptr(), queries.stride(0), queries.stride(1), w2.data_ptr(),
+                                 b_out.data_ptr(), centers.data_ptr(), depth.data_ptr(), B, Cc, Q, nbins, h * w, ws.data_ptr(),
+                                 ws.numel(), _stream()), "ocv_bin_head_fwd")
+    return depth

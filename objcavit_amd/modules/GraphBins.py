@@ -1,0 +1,118 @@
+"""Drop-in for the reference's ``modules/GraphBins.py`` (boundary A):
+``GraphBins(args).forward(image) -> ReturnType(depth_pred, bin_edges, detections)``.
+
+The reference builds three frozen, no-grad producers in its constructor --
+YOLOv7-seg, the WordNet phrase builder and CLIP (modules/GraphBins.py:33-35,
+90-103).  They are inputs to the hot path, not part of it (SURVEY.md section 8,
+rows N4 / out of scope), and none of their weights or sources exist offline,
+so here they are ONE injectable callable:
+
+    object_provider(image) -> (object_features: list[B] of N_i x 512 float,
+                               object_xywh_list: list[B] of N_i x 4 (or None),
+                               detections: B x 3 x H x W uint8 or None)
+
+``SyntheticObjectProvider`` (the default) produces the deterministic boxes and
+features the benchmark configurations use; a real detector + text encoder can
+be plugged in without touching the model.
+"""
+from __future__ import annotations
+
+import logging
+import sys
+from collections import namedtuple
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import hip_ops
+from .AdaBins import bin_edges_and_centers
+from .DenseFeatureExtractor import DenseFeatureExtractor
+from .ObjCAViT import ObjCAViT
+
+
+class SyntheticObjectProvider:
+    """Fixed number of objects per image; xywh uniform in the image (full-resolution pixels, the convention of
+    modules/Yolov7Wrapper.py:118-123); features zeros for ``control_obj_zeros_512``
+    (modules/LanguageEmbeddingWrapper.py:56-61) or N(0,1) * 10/sqrt(512) standing in for un-normalised CLIP text
+    features.  Everything is generated once per (batch, size) on the host and cached on the device, so a forward
+    contains no host->device traffic (hipGraph-friendly)."""
+
+    def __init__(self, n_objects: int = 16, language: str = "control_obj_zeros_512", seed: int = 42, dim: int = 512):
+        if language not in ("control_obj_zeros_512", "clip"):
+            sys.exit(f"Error: Language model {language} not recognised")
+        self.n, self.language, self.seed, self.dim = n_objects, language, seed, dim
+        self._cache = {}
+
+    def __call__(self, image: torch.Tensor):
+        B, _, H, W = image.shape
+        key = (B, H, W, image.device)
+        if key not in self._cache:
+            rs = np.random.RandomState(self.seed)
+            boxes = np.stack([rs.uniform(0, W, (B, self.n)), rs.uniform(0, H, (B, self.n)),
+                              rs.uniform(8, W / 2, (B, self.n)), rs.uniform(8, H / 2, (B, self.n))], axis=-1)
+            if self.language == "clip":
+                feats = rs.standard_normal((B, self.n, self.dim)) * (10.0 / np.sqrt(self.dim))
+            else:
+                feats = np.zeros((B, self.n, self.dim))
+            self._cache[key] = (torch.from_numpy(feats.astype(np.float32)).to(image.device),
+                                torch.from_numpy(boxes.astype(np.float32)).to(image.device))
+        feats, boxes = self._cache[key]
+        return [f for f in feats], [b for b in boxes], None
+
+
+class GraphBins(nn.Module):
+    def __init__(self, args, object_provider: Optional[Callable] = None, backbone: nn.Module = None):
+        super().__init__()
+        self.args = args
+        self.logger = logging.getLogger(__name__)
+        self._encoder_params_module_list = []
+        self._non_encoder_params_module_list = []
+        self._frozen_params_module_list = []
+        self.ReturnType = namedtuple('ReturnType', ['depth_pred', 'bin_edges', 'detections'])
+
+        self.dense_feature_extractor = DenseFeatureExtractor(self.args, backbone=backbone)
+        self._encoder_params_module_list.append(self.dense_feature_extractor.encoder)
+        self._non_encoder_params_module_list.append(self.dense_feature_extractor.decoder)
+
+        oc = self.args[self.args.model.name].objcavit
+        self.object_provider = object_provider or SyntheticObjectProvider(
+            16, oc.get("language_embedding_strategy") or "control_obj_zeros_512")
+
+        max_seq_len = 1200 if self.args[self.args.model.name].get('do_final_upscale') else 500
+        self.objcavit = ObjCAViT(self.args, n_query_channels=128, patch_size=16, im_feature_dim=128,
+                                 obj_feature_dim=512, embedding_dim=oc.embedding_dim,
+                                 dim_out=self.args.graphbins.n_bins, norm='linear', max_seq_len=max_seq_len)
+        self._non_encoder_params_module_list.append(self.objcavit)
+
+        self.conv_out = nn.Sequential(nn.Conv2d(oc.embedding_dim, self.args.graphbins.n_bins, kernel_size=1, stride=1, padding=0),
+                                      nn.Softmax(dim=1))
+        self._non_encoder_params_module_list.append(self.conv_out)
+
+    def get_encoder_params(self):
+        for m in self._encoder_params_module_list:
+            yield from m.parameters()
+
+    def get_non_encoder_params(self):
+        for m in self._non_encoder_params_module_list:
+            yield from m.parameters()
+
+    def get_frozen_params(self):
+        for m in self._frozen_params_module_list:
+            yield from m.parameters()
+
+    def forward(self, image, object_features: Optional[List[torch.Tensor]] = None,
+                object_xywh_list: Optional[List[Optional[torch.Tensor]]] = None):
+        dense_features = self.dense_feature_extractor(image)
+        detections = None
+        if object_features is None:
+            with torch.no_grad():
+                object_features, object_xywh_list, detections = self.object_provider(image)
+        object_features = [nf.float() for nf in object_features]
+        bin_widths_normed, feat, queries = self.objcavit.forward_parts(dense_features, object_features, object_xywh_list)
+        ds = self.args[self.args.basic.dataset]
+        bin_edges, centers = bin_edges_and_centers(bin_widths_normed, ds.min_depth, ds.max_depth)
+        conv = self.conv_out[0]
+        depth_pred = hip_ops.bin_head(feat, queries, conv.weight.detach(), conv.bias.detach(), centers)
+        return self.ReturnType(depth_pred=depth_pred, bin_edges=bin_edges, detections=detections)

@@ -1,0 +1,332 @@
+"""Drop-in for the reference's ``modules/ObjCAViT.py``: ``ObjCAViT``,
+``SelfAttnCrossAttn`` and ``GridRandomPositionalEmbeddings`` with the same
+constructor arguments, forward signatures, return values and state_dict keys
+(including the prototype-layer keys ``image_encoder_layers.*`` /
+``obj_encoder_layers.*`` of reference :155-161).
+
+What runs where
+---------------
+HIP (libobjcavit_hip.so): patch-embedding convolution fused with bias +
+  positional embedding + token layout, every transformer layer (packed QKV
+  projection, masked multi-head attention, out-proj + residual + LayerNorm,
+  FFN + residual + LayerNorm), both cross-attentions, every Linear (object
+  embedding, positional MLP, regressor) and the pixel-wise dot product.
+MIOpen through PyTorch-ROCm: the 3x3 convolution.
+PyTorch glue (a few KB of data): padding ragged object lists, bin-width
+  normalisation, grid_sample / roi-align positional strategies.
+
+Reference behaviours that are reproduced on purpose:
+Q1 key rows are FRONT-padded with 1e-4 while the mask is BACK-padded; Q2 the
+first cross-attention takes V from the IMAGE tokens; Q3 ``saca_2`` receives a
+B x S x E tensor; Q4 padded object rows leave the object encoder as exact
+zeros; Q6 the coordinate normalisation of ``grid_random``.
+"""
+from __future__ import annotations
+
+import math
+import sys
+from typing import List, Optional, Sequence, Tuple, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import hip_ops
+from .layers import HipEncoderStack, PatchTransformerEncoder, PixelWiseDotProduct  # noqa: F401
+from .miniViT import regress_bin_widths
+
+PAD_VALUE = 0.0001          # reference :183,194
+
+
+# ---------------------------------------------------------------------------
+# positional embeddings
+# ---------------------------------------------------------------------------
+def _ps_roi_align_1x1(grid: torch.Tensor, boxes: torch.Tensor, spatial_scale: float) -> torch.Tensor:
+    """Position-sensitive RoI-align with a 1x1 output on a 1 x C x H x W grid
+    (torchvision.ops.ps_roi_align(..., output_size=[1,1], sampling_ratio=-1)),
+    vectorised over boxes.  boxes K x 4 (x1,y1,x2,y2) -> K x C."""
+    C, H, W = grid.shape[1:]
+    K = boxes.shape[0]
+    b = boxes * spatial_scale - 0.5
+    x1, y1 = b[:, 0], b[:, 1]
+    rw = (b[:, 2] - x1).clamp(min=0.1)
+    rh = (b[:, 3] - y1).clamp(min=0.1)
+    gw = torch.ceil(rw).clamp(min=1)
+    gh = torch.ceil(rh).clamp(min=1)
+    nmax_y, nmax_x = int(gh.max().item()), int(gw.max().item())
+    iy = torch.arange(nmax_y, device=grid.device, dtype=grid.dtype)
+    ix = torch.arange(nmax_x, device=grid.device, dtype=grid.dtype)
+    yy = y1[:, None] + (iy[None, :] + 0.5) * (rh / gh)[:, None]          # K x ny
+    xx = x1[:, None] + (ix[None, :] + 0.5) * (rw / gw)[:, None]          # K x nx
+    vy = iy[None, :] < gh[:, None]
+    vx = ix[None, :] < gw[:, None]
+
+    def prep(v, size):
+        inside = (v >= -1.0) & (v <= size)
+        v = v.clamp(min=0.0)
+        lo = v.floor()
+        top = lo >= size - 1
+        lo = torch.where(top, torch.full_like(lo, size - 1), lo)
+        hi = torch.where(top, lo, lo + 1)
+        v = torch.where(top, lo, v)
+        frac = v - lo
+        return lo.long(), hi.long(), frac, inside
+
+    yl, yh, ly, oky = prep(yy, H)
+    xl, xh, lx, okx = prep(xx, W)
+    g = grid[0]                                                          # C x H x W
+
+    def gather(yi, xi):                                                  # -> K x ny x nx x C
+        return g[:, yi[:, :, None], xi[:, None, :]].permute(1, 2, 3, 0)
+
+    hy, hx = 1 - ly, 1 - lx
+    val = (gather(yl, xl) * (hy[:, :, None] * hx[:, None, :])[..., None]
+           + gather(yl, xh) * (hy[:, :, None] * lx[:, None, :])[..., None]
+           + gather(yh, xl) * (ly[:, :, None] * hx[:, None, :])[..., None]
+           + gather(yh, xh) * (ly[:, :, None] * lx[:, None, :])[..., None])
+    wgt = ((vy & oky)[:, :, None] & (vx & okx)[:, None, :]).to(grid.dtype)[..., None]
+    return (val * wgt).sum(dim=(1, 2)) / (gh * gw)[:, None]
+
+
+class GridRandomPositionalEmbeddings(nn.Module):
+    """One learnable vector per image patch (reference :18-147).  ``forward``
+    reproduces the reference's sampling literally, including its coordinate
+    normalisation."""
+
+    def __init__(self, args, embedding_dim, patch_size, mode="centre"):
+        super().__init__()
+        self.args = args
+        self.embedding_dim = embedding_dim
+        self.patch_size = patch_size
+        self.mode = mode
+        assert self.mode in ["centre", "roi_align"], "Error: unrecognised GridRandomPositionalEmbeddings mode."
+        ds = self.args[self.args.basic.dataset]
+        lengths = [math.ceil(d[0] / patch_size) * math.ceil(d[1] / patch_size)
+                   for d in (ds.dimensions_train, ds.dimensions_test)]
+        self.sequence_length = max(lengths)
+        self.positional_encodings = nn.Parameter(torch.rand(self.sequence_length, self.embedding_dim), requires_grad=True)
+
+    def forward(self, coords, image_features, input_coord_space="img", factor=2.0):
+        fh, fw = image_features.shape[2], image_features.shape[3]
+        gh, gw = math.ceil(fh / self.patch_size), math.ceil(fw / self.patch_size)
+        grid = self.positional_encodings[0:gh * gw, :].view(gh, gw, -1).permute(2, 0, 1).unsqueeze(0).contiguous()
+        if self.mode == "centre":
+            nc = coords.clone()
+            if input_coord_space == "img":
+                nc[:, 0] = ((nc[:, 0] / gh) * 2) - 1          # dim 1 of B x S x 2: tokens 0 and 1 (reference :95-96)
+                nc[:, 1] = ((nc[:, 1] / gw) * 2) - 1
+                nc = nc.unsqueeze(1)
+                s = F.grid_sample(grid.expand(nc.shape[0], -1, -1, -1), nc, mode="bilinear", padding_mode="zeros",
+                                  align_corners=False)
+                return s.squeeze(2).permute(0, 2, 1).contiguous()
+            nc[:, 0] = ((nc[:, 0] / (fh * factor)) * 2) - 1   # x over HEIGHT, y over WIDTH (reference :104-105)
+            nc[:, 1] = ((nc[:, 1] / (fw * factor)) * 2) - 1
+            s = F.grid_sample(grid, nc.view(1, 1, nc.shape[0], 2), mode="bilinear", padding_mode="zeros",
+                              align_corners=False)
+            return s.squeeze(2).squeeze(0).permute(1, 0).contiguous()
+        hw, hh = coords[..., 2] / 2, coords[..., 3] / 2
+        xyxy = torch.stack([coords[..., 0] - hw, coords[..., 1] - hh, coords[..., 0] + hw, coords[..., 1] + hh],
+                           dim=-1).clamp(min=0.0)
+        if input_coord_space == "img":
+            B, S = xyxy.shape[:2]
+            return _ps_roi_align_1x1(grid, xyxy.reshape(B * S, 4), 1 / self.patch_size).view(B, S, -1)
+        return _ps_roi_align_1x1(grid, xyxy, 1 / (self.patch_size * factor))
+
+
+def _mlp_hip(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+    """nn.Sequential(Linear, LeakyReLU, ..., Linear) through ocv_linear_fwd."""
+    lin = [m for m in seq if isinstance(m, nn.Linear)]
+    y = x.contiguous()
+    for i, m in enumerate(lin):
+        y = hip_ops.linear(y, m.weight.detach(), m.bias.detach(),
+                           hip_ops.ACT_LEAKY_RELU if i + 1 < len(lin) else hip_ops.ACT_NONE)
+    return y
+
+
+# ---------------------------------------------------------------------------
+# self-attention + cross-attention block
+# ---------------------------------------------------------------------------
+class SelfAttnCrossAttn(nn.Module):
+    def __init__(self, args, embedding_dim=128, num_heads=4, dim_feedforward=1024):
+        super().__init__()
+        self.args = args
+        self.image_encoder_layers = nn.TransformerEncoderLayer(embedding_dim, num_heads, dim_feedforward=dim_feedforward, batch_first=True)
+        self.image_transformer_encoder = nn.TransformerEncoder(self.image_encoder_layers, num_layers=4, enable_nested_tensor=False)
+        self._img_stack = HipEncoderStack(self.image_transformer_encoder)
+        self._obj_stack = None
+        if self.args.graphbins.objcavit.get("no_obj_sa") != True:  # noqa: E712  (config value may be None)
+            self.obj_encoder_layers = nn.TransformerEncoderLayer(embedding_dim, num_heads, dim_feedforward=dim_feedforward, batch_first=True)
+            self.obj_transformer_encoder = nn.TransformerEncoder(self.obj_encoder_layers, num_layers=4, enable_nested_tensor=False)
+            self._obj_stack = HipEncoderStack(self.obj_transformer_encoder)
+        self.cross_attn_obj_im = nn.MultiheadAttention(embed_dim=embedding_dim, num_heads=4, batch_first=True)
+        self.cross_attn_im_obj = nn.MultiheadAttention(embed_dim=embedding_dim, num_heads=4, batch_first=True)
+
+    @staticmethod
+    def _pad_objects(object_features, device) -> Tuple[torch.Tensor, torch.Tensor]:
+        """list of N_i x E (or a B x S x E tensor, iterated over its batch dim) ->
+        (B x Nmax x E padded with 1e-4, B x Nmax bool mask, True = padding)  (reference :180-183)."""
+        if isinstance(object_features, torch.Tensor):
+            B, N = object_features.shape[:2]
+            return object_features.contiguous(), torch.zeros(B, N, dtype=torch.bool, device=device)
+        counts = [int(o.shape[0]) for o in object_features]
+        nmax = max(counts)
+        if all(c == nmax for c in counts):
+            return torch.stack(list(object_features), dim=0), torch.zeros(len(counts), nmax, dtype=torch.bool, device=device)
+        feats = nn.utils.rnn.pad_sequence(list(object_features), batch_first=True, padding_value=PAD_VALUE)
+        mask = torch.arange(nmax, device=device)[None, :] >= torch.tensor(counts, device=device)[:, None]
+        return feats, mask
+
+    def forward(self, image_patch_embeddings, object_features, want_object_output: bool = True):
+        x = image_patch_embeddings.contiguous()
+        B, S, E = x.shape
+        att_img = self._img_stack(x)                                                      # reference :169
+        feats, mask = self._pad_objects(object_features, x.device)
+        if self._obj_stack is None:
+            att_obj = feats                                                               # :186
+        else:
+            att_obj = self._obj_stack(feats, mask)                                        # :188 (padded rows -> 0)
+        amt = S - att_obj.shape[1]                                                        # :192
+        if amt < 0:
+            raise ValueError(f"more objects per image ({att_obj.shape[1]}) than image tokens ({S})")
+        kpm = F.pad(mask, (0, amt), value=True)                                           # :193  mask padded at the BACK
+        att_obj_p = F.pad(att_obj, (0, 0, amt, 0), value=PAD_VALUE).contiguous()          # :194  rows padded at the FRONT
+        ca1 = self.cross_attn_obj_im
+        final_img = hip_ops.mha(att_img, att_obj_p, att_img, ca1.in_proj_weight.detach(), ca1.in_proj_bias.detach(),
+                                ca1.out_proj.weight.detach(), ca1.out_proj.bias.detach(), kpm, ca1.num_heads)   # :195-201
+        final_obj = None
+        if want_object_output:
+            ca2 = self.cross_attn_im_obj
+            final_obj = hip_ops.mha(att_obj_p, att_img, att_obj_p, ca2.in_proj_weight.detach(), ca2.in_proj_bias.detach(),
+                                    ca2.out_proj.weight.detach(), ca2.out_proj.bias.detach(), None, ca2.num_heads)  # :202-207
+        return final_img, final_obj
+
+
+# ---------------------------------------------------------------------------
+# ObjCAViT
+# ---------------------------------------------------------------------------
+_MLP_IN = {"learned": 2, "learned_bbox_wh": 4}
+
+
+class ObjCAViT(nn.Module):
+    def __init__(self, args, im_feature_dim=128, obj_feature_dim=512, n_query_channels=128, patch_size=16, dim_out=256,
+                 embedding_dim=128, num_heads=4, norm='linear', max_seq_len=50):
+        super().__init__()
+        self.args = args
+        self.norm = norm
+        self.n_query_channels = n_query_channels
+        self.patch_size = patch_size
+        self.half_patch_size = self.patch_size // 2
+        self.obj_feature_dim = obj_feature_dim
+        self.strategy = self.args[self.args.model.name].objcavit.positional_embedding_strategy
+
+        if self.strategy == "grid_random":
+            self.positional_encoder = GridRandomPositionalEmbeddings(args, embedding_dim=embedding_dim, patch_size=patch_size, mode="centre")
+        elif self.strategy == "grid_random_roi_align":
+            self.positional_encoder = GridRandomPositionalEmbeddings(args, embedding_dim=embedding_dim, patch_size=patch_size, mode="roi_align")
+        elif self.strategy in _MLP_IN:
+            widths = (_MLP_IN[self.strategy], 32, 64, 128, 256, embedding_dim)
+            layers: List[nn.Module] = []
+            for i in range(5):
+                layers.append(nn.Linear(widths[i], widths[i + 1], bias=True))
+                if i < 4:
+                    layers.append(nn.LeakyReLU())
+            self.positional_encoder = nn.Sequential(*layers)
+        else:
+            sys.exit("Error: ObjCAViT positional embedding strategy not recognised.")
+
+        self.image_embedding_convPxP = nn.Conv2d(im_feature_dim, embedding_dim, kernel_size=self.patch_size, stride=patch_size, padding=0)
+        self.obj_embedding_layer = nn.Linear(self.obj_feature_dim, embedding_dim)
+        self.saca_1 = SelfAttnCrossAttn(self.args, embedding_dim, num_heads, dim_feedforward=1024)
+        self.use_2_saca = self.args.graphbins.objcavit.get("use_2_saca") == True  # noqa: E712
+        if self.use_2_saca:
+            self.saca_2 = SelfAttnCrossAttn(self.args, embedding_dim, num_heads, dim_feedforward=1024)
+        self.dot_product_layer = PixelWiseDotProduct()
+        self.conv3x3 = nn.Conv2d(im_feature_dim, embedding_dim, kernel_size=3, stride=1, padding=1)
+        self.regressor = nn.Sequential(nn.Linear(embedding_dim, 256), nn.LeakyReLU(),
+                                       nn.Linear(256, 256), nn.LeakyReLU(),
+                                       nn.Linear(256, dim_out))
+        self._img_pos_cache = {}
+
+    # -- positional embeddings ------------------------------------------------
+    def _patch_coords(self, B: int, gh: int, gw: int, device) -> torch.Tensor:
+        """B x S x 4 patch centres (feature-map pixels) and sizes (reference :336-347)."""
+        xs = torch.arange(gw, device=device).view(1, -1).expand(gh, -1)
+        ys = torch.arange(gh, device=device).view(-1, 1).expand(-1, gw)
+        pc = (torch.stack([xs, ys], dim=0) * self.patch_size + self.half_patch_size).flatten(1)
+        pc = pc.expand(B, -1, -1).permute(0, 2, 1).float()
+        return torch.cat([pc, torch.ones_like(pc) * self.patch_size], dim=2)
+
+    def _object_pos(self, xywh: torch.Tensor, image_features: torch.Tensor) -> torch.Tensor:
+        if self.strategy == "grid_random":
+            return self.positional_encoder(xywh[:, 0:2], image_features, "obj")
+        if self.strategy == "grid_random_roi_align":
+            return self.positional_encoder(xywh[:, 0:4], image_features, "obj")
+        return _mlp_hip(self.positional_encoder, xywh[:, 0:_MLP_IN[self.strategy]])
+
+    def _image_pos(self, image_features: torch.Tensor, gh: int, gw: int) -> torch.Tensor:
+        """Positional embedding of the image tokens: [S, E] (shared by the batch) for the MLP strategies -- it
+        depends only on (gh, gw) and the weights, so in eval it is computed once and cached --
+        or [B, S, E] for the grid strategies."""
+        B = image_features.shape[0]
+        if self.strategy in _MLP_IN:
+            params = [p for p in self.positional_encoder.parameters()]
+            key = (gh, gw, image_features.device, tuple(p.data_ptr() for p in params), tuple(p._version for p in params))
+            hit = self._img_pos_cache.get("k") == key
+            if not hit:
+                pc = self._patch_coords(1, gh, gw, image_features.device)[0]
+                self._img_pos_cache = {"k": key, "v": _mlp_hip(self.positional_encoder, pc[:, 0:_MLP_IN[self.strategy]])}
+            return self._img_pos_cache["v"]
+        pc = self._patch_coords(B, gh, gw, image_features.device)
+        n = 2 if self.strategy == "grid_random" else 4
+        return self.positional_encoder(pc[..., 0:n], image_features, "img").contiguous()
+
+    # -- forward ---------------------------------------------------------------
+    def forward_parts(self, image_features, object_features, object_xywh_list):
+        """-> (bin_widths_normed, conv3x3 features, queries view B x n_query x E)."""
+        if self.training:
+            raise RuntimeError("the HIP path implements inference (eval mode) only")
+        dev = image_features.device
+        image_features = image_features.contiguous()
+        B = image_features.shape[0]
+        if len(object_features) != B or len(object_xywh_list) != B:
+            raise ValueError("object_features / object_xywh_list must have one entry per image")
+        # 1. objects: Linear(512 -> E) + positional embedding, all images in one launch (reference :311-330)
+        boxes = [torch.full((1, 4), -1.0, device=dev) if b is None else b.to(dev, torch.float32) for b in object_xywh_list]
+        counts = [int(f.shape[0]) for f in object_features]
+        for c, b in zip(counts, boxes):
+            if b.shape[0] != c:
+                raise ValueError("object_features and object_xywh_list disagree on the number of objects")
+        all_feat = torch.cat([f.to(dev, torch.float32) for f in object_features], dim=0)
+        all_box = torch.cat(boxes, dim=0)
+        if self.strategy.startswith("grid_random"):
+            pos = torch.cat([self._object_pos(b, image_features) for b in boxes], dim=0)
+        else:
+            pos = self._object_pos(all_box, image_features)
+        emb = hip_ops.linear(all_feat.contiguous(), self.obj_embedding_layer.weight.detach(),
+                             self.obj_embedding_layer.bias.detach()) + pos
+        objs = list(torch.split(emb, counts, dim=0))
+        for i in range(B):
+            object_features[i] = objs[i]                       # the reference overwrites the caller's list (:330)
+
+        # 2. image tokens: patch conv + bias + positional embedding, token-major (reference :333-364)
+        if self.patch_size != 16:
+            raise NotImplementedError("the patch-embedding kernel is built for 16x16 patches")
+        gh, gw = image_features.shape[2] // 16, image_features.shape[3] // 16
+        if gh * gw < self.n_query_channels + 1:
+            raise ValueError(f"need at least {self.n_query_channels + 1} patches, got {gh * gw}")
+        tok = hip_ops.patch_embed(image_features, self.image_embedding_convPxP.weight.detach(),
+                                  self.image_embedding_convPxP.bias.detach(), self._image_pos(image_features, gh, gw))
+
+        # 3. self-attention / cross-attention stacks (reference :366-368)
+        tok, obj = self.saca_1(tok, objs, want_object_output=self.use_2_saca)
+        if self.use_2_saca:
+            tok, obj = self.saca_2(tok, obj, want_object_output=False)
+
+        # 4. heads (reference :373-388)
+        feat = self.conv3x3(image_features)
+        y = regress_bin_widths(self.regressor, tok[:, 0, :], self.norm)
+        return y, feat, tok[:, 1:self.n_query_channels + 1, :]
+
+    def forward(self, image_features, object_features, object_xywh_list):
+        y, feat, queries = self.forward_parts(image_features, object_features, object_xywh_list)
+        return y, self.dot_product_layer(feat, queries)

@@ -1,0 +1,58 @@
+"""Drop-in for the reference's ``modules/miniViT.py`` (class ``mViT``): same
+constructor, forward signature, return values and state_dict keys; the
+patch-embedding convolution, the four transformer layers, the regressor and
+the pixel-wise dot product run as HIP kernels, the 3x3 convolution through
+MIOpen.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import hip_ops
+from .layers import PatchTransformerEncoder, PixelWiseDotProduct
+
+
+def regress_bin_widths(regressor: nn.Sequential, head: torch.Tensor, norm: str) -> torch.Tensor:
+    """regressor MLP (Linear, LeakyReLU, Linear, LeakyReLU, Linear) + normalisation
+    (reference modules/miniViT.py:33-42 == modules/ObjCAViT.py:378-388)."""
+    y = hip_ops.linear(head.contiguous(), regressor[0].weight.detach(), regressor[0].bias.detach(), hip_ops.ACT_LEAKY_RELU)
+    y = hip_ops.linear(y, regressor[2].weight.detach(), regressor[2].bias.detach(), hip_ops.ACT_LEAKY_RELU)
+    y = hip_ops.linear(y, regressor[4].weight.detach(), regressor[4].bias.detach(), hip_ops.ACT_NONE)
+    if norm == "linear":
+        y = torch.relu(y) + 0.1
+    elif norm == "softmax":
+        return torch.softmax(y, dim=1)
+    else:
+        y = torch.sigmoid(y)
+    return y / y.sum(dim=1, keepdim=True)
+
+
+class mViT(nn.Module):
+    def __init__(self, in_channels, n_query_channels=128, patch_size=16, dim_out=256,
+                 embedding_dim=128, num_heads=4, norm='linear', max_seq_len=500):
+        super().__init__()
+        self.norm = norm
+        self.n_query_channels = n_query_channels
+        self.patch_transformer = PatchTransformerEncoder(in_channels, patch_size, embedding_dim, num_heads, max_seq_len)
+        self.dot_product_layer = PixelWiseDotProduct()
+        self.conv3x3 = nn.Conv2d(in_channels, embedding_dim, kernel_size=3, stride=1, padding=1)
+        self.regressor = nn.Sequential(nn.Linear(embedding_dim, 256), nn.LeakyReLU(),
+                                       nn.Linear(256, 256), nn.LeakyReLU(),
+                                       nn.Linear(256, dim_out))
+
+    def forward_parts(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """-> (bin_widths_normed B x dim_out, conv3x3 features B x E x h x w, queries B x n_query x E (view)).
+        Used by AdaBins.forward so that the range-attention maps are never materialised."""
+        tok = self.patch_transformer.forward_batch_first(x)           # B x S x E
+        if tok.shape[1] < self.n_query_channels + 1:
+            raise ValueError(f"need at least {self.n_query_channels + 1} patches, got {tok.shape[1]}")
+        feat = self.conv3x3(x)
+        y = regress_bin_widths(self.regressor, tok[:, 0, :], self.norm)
+        return y, feat, tok[:, 1:self.n_query_channels + 1, :]
+
+    def forward(self, x):
+        y, feat, queries = self.forward_parts(x)
+        return y, self.dot_product_layer(feat, queries)

@@ -1,0 +1,96 @@
+"""-m "not gpu": host-side logic of the product package (no kernels run)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from objcavit_amd import _lib
+from objcavit_amd.config import AttrDict, load_yaml, make_args
+from util import load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_and_binding_declare_the_same_symbols():
+    hdr = open(os.path.join(ROOT, "include", "objcavit_hip.h")).read()
+    declared = set(re.findall(r"\b(ocv_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+
+
+def test_library_loads_and_exports_every_symbol():
+    """The C-ABI library must be present (built by __graft_entry__.build()) and export the whole header.
+    No compute call is made: there is no GPU here."""
+    if not os.path.exists(_lib.LIB_PATH):
+        from objcavit_amd.build import build
+        build()
+    lib = _lib.load()
+    for name in _lib.PROTOTYPES:
+        assert hasattr(lib, name), name
+    assert lib.ocv_abi_version() == 1
+    # argument validation runs on the host before any launch
+    assert lib.ocv_patch_embed_workspace_bytes(16, 128, 240, 320, 128) == 8 * 4800 * 128 * 4
+    assert lib.ocv_patch_embed_workspace_bytes(1, 128, 240, 320, 64) == 0
+    assert lib.ocv_bin_head_workspace_bytes(2, 256, 128) == 2 * 256 * 128 * 4
+    rc = lib.ocv_linear_fwd(None, 4, 0, None, 4, 0, 0, None, None, 4, 0, 1, 1, 1, 4, 0, None)
+    assert rc == -1 and b"null pointer" in lib.ocv_last_error()
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(_lib.HipLibraryError):
+        _lib.load(str(tmp_path / "nope.so"))
+
+
+def test_cpu_tensors_are_rejected_not_silently_computed():
+    from objcavit_amd import hip_ops
+    with pytest.raises(_lib.HipLibraryError):
+        hip_ops.linear(torch.zeros(4, 8), torch.zeros(3, 8))
+    from objcavit_amd.modules.miniViT import mViT
+    m = mViT(128).eval()
+    with pytest.raises(_lib.HipLibraryError):
+        m(torch.zeros(1, 128, 176, 192))
+
+
+def test_attrdict_and_make_args():
+    a = make_args(strategy="learned_bbox_wh", use_2_saca=True, dataset="kitti")
+    assert a.graphbins.objcavit.positional_embedding_strategy == "learned_bbox_wh"
+    assert a[a.model.name].objcavit.get("use_2_saca") is True
+    assert a.graphbins.objcavit.get("no_obj_sa") is None
+    assert a[a.basic.dataset].max_depth == 80
+    d = AttrDict(x={"y": [1, {"z": 2}]})
+    assert d.x.y[1].z == 2
+
+
+def test_reference_yaml_files_parse():
+    ref = "/root/reference/params/nyu_adabins_enet-b5.yaml"
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not present")
+    a = load_yaml(ref)
+    assert a.model.name == "adabins" and a.adabins.n_bins == 256 and "efficientnet-b5" in a.adabins.encoder_name
+
+
+@pytest.mark.parametrize("fixture,build", [
+    ("g1_mvit_mini", lambda: __import__("objcavit_amd.modules.miniViT", fromlist=["mViT"]).mViT(128)),
+    ("g2_saca_16_5", lambda: __import__("objcavit_amd.modules.ObjCAViT", fromlist=["x"]).SelfAttnCrossAttn(make_args(), 128, 4, 1024)),
+    ("g2_saca_16_5_nosa", lambda: __import__("objcavit_amd.modules.ObjCAViT", fromlist=["x"]).SelfAttnCrossAttn(make_args(no_obj_sa=True), 128, 4, 1024)),
+])
+def test_state_dict_keys_match_reference(fixture, build):
+    """Checkpoint interchange: the drop-in exposes exactly the reference's keys and shapes."""
+    meta, _ = load_golden(fixture)
+    sd = build().state_dict()
+    assert {k: list(v.shape) for k, v in sd.items()} == meta["shapes"]
+
+
+def test_full_model_state_dict_keys_match_reference():
+    from objcavit_amd.modules.AdaBins import AdaBins
+    from objcavit_amd.modules.ObjCAViT import ObjCAViT
+    meta, _ = load_golden("g5_adabins_mini")
+    sd = AdaBins(make_args(model="adabins")).state_dict()
+    assert {k: list(v.shape) for k, v in sd.items()} == meta["shapes"]
+    for tag, kw in (("learned", {}), ("bbox_wh_2saca", dict(strategy="learned_bbox_wh", use_2_saca=True)),
+                    ("grid_random", dict(strategy="grid_random"))):
+        meta, _ = load_golden(f"g3_objcavit_{tag}")
+        a = make_args(dimensions_train=[352, 384], dimensions_test=[352, 384], **kw)
+        sd = ObjCAViT(a, embedding_dim=128, max_seq_len=500).state_dict()
+        assert {k: list(v.shape) for k, v in sd.items()} == meta["shapes"], tag

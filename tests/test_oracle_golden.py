@@ -1,0 +1,117 @@
+"""-m "not gpu": the CPU oracle (oracle/restate.py) against the golden vectors
+that tests/golden/make_golden.py produced by running the reference's own
+modules.  These pin the oracle; the GPU tests then compare the HIP path with
+the oracle and with the same fixtures."""
+import numpy as np
+import pytest
+import torch
+
+import gen
+from oracle import restate
+from util import gains_of, load_golden, rel_dev, state_dict_from
+
+torch.set_grad_enabled(False)
+TOL = 3e-5
+
+
+@pytest.mark.parametrize("tag", ["mini", "nyu"])
+def test_g1_mvit(tag):
+    meta, z = load_golden(f"g1_mvit_{tag}")
+    sd = state_dict_from(meta["shapes"], meta["seed"], gains_of(meta))
+    x = gen.randn("x", (meta["B"], 128, meta["fh"], meta["fw"]), meta["seed"])
+    y, ram = restate.mvit_forward(x, sd)
+    tgt = restate.patch_transformer_encoder(x, sd, "patch_transformer.")
+    assert rel_dev(y, z["y"]) < TOL
+    assert rel_dev(ram.flatten(2)[:, :, torch.from_numpy(z["pix"])], z["ram_px"]) < TOL
+    assert rel_dev(tgt, z["tgt"]) < TOL
+    assert abs(float(y.sum(1).mean()) - 1.0) < 1e-5      # widths are normalised
+
+
+@pytest.mark.parametrize("tag", ["16_5", "1_1", "100_3", "16_5_nosa", "8_8_8"])
+def test_g2_saca(tag):
+    meta, z = load_golden(f"g2_saca_{tag}")
+    sd = state_dict_from(meta["shapes"], meta["seed"], gains_of(meta))
+    S, E = meta["S"], 128
+    tok = gen.randn("tok", (len(meta["counts"]), S, E), meta["seed"])
+    objs = [gen.randn(f"obj{i}", (n, E), meta["seed"]) for i, n in enumerate(meta["counts"])]
+    fi, fo, inter = restate.saca_forward(tok, objs, sd, "", no_obj_sa=meta["no_obj_sa"])
+    assert rel_dev(fi, z["final_img"]) < TOL
+    assert rel_dev(fo, z["final_obj"]) < TOL
+    if not meta["no_obj_sa"]:
+        # padded object rows leave the encoder as exact zeros
+        for b, n in enumerate(meta["counts"]):
+            assert float(inter["att_obj"][b, n:].abs().max() if n < inter["att_obj"].shape[1] else 0.0) == 0.0
+
+
+def test_q1_degenerate_cross_attention():
+    """with Nmax <= S/2 every image token receives the same vector."""
+    meta, z = load_golden("g2_saca_16_5")
+    fi = torch.from_numpy(z["final_img"])
+    assert float((fi - fi[:, :1]).abs().max()) < 1e-6
+    meta, z = load_golden("g2_saca_100_3")
+    fi = torch.from_numpy(z["final_img"])
+    assert float((fi[0] - fi[0, :1]).abs().max()) > 1e-3      # Nmax > S/2: real objects are attended
+
+
+def _objcavit_inputs(meta):
+    fh, fw, seed = meta["fh"], meta["fw"], meta["seed"]
+    H, W = 2 * fh, 2 * fw
+    x = gen.randn("x", (len(meta["counts"]), 128, fh, fw), seed)
+    feats, xywh = [], []
+    for i, n in enumerate(meta["counts"]):
+        k = 1 if n is None else n
+        feats.append(gen.randn(f"f{i}", (k, 512), seed, 10.0 / np.sqrt(512)))
+        xywh.append(None if n is None else gen.boxes(f"b{i}", n, seed, H, W))
+    return x, feats, xywh
+
+
+G3_TAGS = ["learned", "learned_nosa", "bbox_wh_2saca", "learned_2saca_eq", "grid_random", "learned_many",
+           "bbox_wh_2saca_many"]
+
+
+@pytest.mark.parametrize("tag", G3_TAGS)
+def test_g3_objcavit(tag):
+    meta, z = load_golden(f"g3_objcavit_{tag}")
+    sd = state_dict_from(meta["shapes"], meta["seed"], gains_of(meta))
+    x, feats, xywh = _objcavit_inputs(meta)
+    y, ram, inter = restate.objcavit_forward(x, feats, xywh, sd, "", return_intermediates=True, **meta["kw"])
+    assert rel_dev(y, z["y"]) < TOL
+    assert rel_dev(ram.flatten(2)[:, :, torch.from_numpy(z["pix"])], z["ram_px"]) < TOL
+    assert rel_dev(inter["saca1_img"], z["saca1_img"]) < TOL
+
+
+def test_g4_decoder_and_encoder_order():
+    from oracle import effnet_ref
+    meta, z = load_golden("g4_decoder")
+    sd_e = state_dict_from(meta["shapes_enc"], meta["seed"])
+    sd_d = state_dict_from(meta["shapes_dec"], meta["seed"])
+    x = gen.randn("img", (1, 3, 96, 128), meta["seed"])
+    feats = effnet_ref.encoder_features(x, sd_e, "original_model.")
+    assert [int(f.shape[1]) for f in feats] == meta["chans"]
+    assert np.allclose([float(feats[i].mean()) for i in (4, 5, 6, 8, 11)], z["skip_means"], rtol=1e-4, atol=1e-6)
+    out = restate.decoder_forward(feats, sd_d, "")
+    assert rel_dev(out, z["out"]) < TOL
+
+
+@pytest.mark.parametrize("tag", ["mini", "nyu"])
+def test_g5_adabins_config1(tag):
+    """BASELINE configs[0]: AdaBins enet-b5 NYU, CPU forward."""
+    meta, z = load_golden(f"g5_adabins_{tag}")
+    sd = state_dict_from(meta["shapes"], meta["seed"], gains_of(meta))
+    img = gen.randn("img", (1, 3, meta["H"], meta["W"]), meta["seed"])
+    depth, edges = restate.adabins_forward(img, sd, 0.001, 10)
+    assert meta["fields"] == ["depth_pred", "bin_edges"]
+    assert depth.shape == (1, 1, meta["H"] // 2, meta["W"] // 2) and edges.shape == (1, 257)
+    ref = torch.from_numpy(z["depth_px"])
+    got = depth.flatten()[torch.from_numpy(z["pix"])]
+    assert float(((got - ref).abs() / ref).max()) < 1e-4
+    assert rel_dev(edges, z["bin_edges"]) < TOL
+    assert abs(float(depth.min()) - float(z["depth_stats"][0])) < 1e-3
+
+
+def test_grid_sample_restatement_matches_torch():
+    rs = np.random.RandomState(0)
+    inp = torch.from_numpy(rs.standard_normal((2, 5, 7, 9)).astype(np.float32))
+    grid = torch.from_numpy(rs.uniform(-1.3, 1.3, (2, 3, 11, 2)).astype(np.float32))
+    ref = torch.nn.functional.grid_sample(inp, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+    assert rel_dev(restate.grid_sample_bilinear_zeros(inp, grid), ref) < 1e-6
