@@ -172,7 +172,7 @@ def main():
                                  alg_GFLOP=round(km[name]["flops"] / 1e9, 3), GBps=round(gbs, 1), TFLOPs=round(tfs, 2),
                                  frac_hbm=round(gbs / HBM_PEAK_GBS, 4), frac_mfma_f32=round(tfs / F32_MFMA_PEAK_TFLOPS, 4),
                                  total_ms_per_step=round(ms * cnt / a.steps, 4))
-        dom = max(kernels, key=lambda k: kernels[k]["total_ms_per_step"]) if kernels else None
+        dom = max(kernels, key=lambda k: kernels[k]["ms"]) if kernels else None     # longest single launch
         roofline = None
         if dom:
             k = kernels[dom]

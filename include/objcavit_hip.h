@@ -120,6 +120,13 @@ int ocv_pixel_dot_fwd(const float* feat, const float* queries, long q_bs, int q_
  * HBM.  The two contractions are associated as (Wout . queries[b]) . feat (workspace holds the folded
  * [B,256,128] matrix).  C == Q == 128, n_bins == 256. */
 size_t ocv_bin_head_workspace_bytes(int B, int n_bins, int C);
+/* The two stages of ocv_bin_head_fwd as separate calls (same arithmetic, lets a caller time the main kernel):
+ *   ocv_bin_head_fold_fwd   Wf[b] = Wout (n_bins x Q) . queries[b] (Q x C)            -> Wf [B, n_bins, C]
+ *   ocv_bin_head_folded_fwd depth[b][p] = sum_k softmax_k(bout + Wf[b] . feat[b][:, p]) * centers[b][k] */
+int ocv_bin_head_fold_fwd(const float* queries, long q_bs, int q_ld, const float* Wout, float* Wf, int B, int C, int Q,
+                          int n_bins, ocv_stream_t stream);
+int ocv_bin_head_folded_fwd(const float* feat, const float* Wf, const float* bout, const float* centers, float* depth,
+                            int B, int C, int n_bins, int P, ocv_stream_t stream);
 int ocv_bin_head_fwd(const float* feat, const float* queries, long q_bs, int q_ld, const float* Wout,
                      const float* bout, const float* centers, float* depth, int B, int C, int Q, int n_bins, int P,
                      void* workspace, size_t workspace_bytes, ocv_stream_t stream);

@@ -46,6 +46,8 @@ PROTOTYPES = {
                                       C.c_int, C.c_void_p, C.c_size_t, _stream]),
     "ocv_pixel_dot_fwd": (C.c_int, [_f32p, _f32p, C.c_long, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
     "ocv_bin_head_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "ocv_bin_head_fold_fwd": (C.c_int, [_f32p, C.c_long, C.c_int, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
+    "ocv_bin_head_folded_fwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
     "ocv_bin_head_fwd": (C.c_int, [_f32p, _f32p, C.c_long, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, _stream]),
 }

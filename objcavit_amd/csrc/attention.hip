@@ -175,14 +175,14 @@ extern "C" int ocv_attention_fwd(const float* q, long q_bs, int q_ss, const floa
   if (vec) {
     static bool attr_v = false;
     if (!attr_v) {
-      hipFuncSetAttribute((const void*)attention_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)attention_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_v = true;
     }
     hipLaunchKernelGGL((attention_kernel<true>), grid, block, lds, st, a);
   } else {
     static bool attr_s = false;
     if (!attr_s) {
-      hipFuncSetAttribute((const void*)attention_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)attention_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_s = true;
     }
     hipLaunchKernelGGL((attention_kernel<false>), grid, block, lds, st, a);

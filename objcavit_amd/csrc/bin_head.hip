@@ -171,7 +171,7 @@ extern "C" int ocv_pixel_dot_fwd(const float* feat, const float* queries, long q
   OCV_CHECK_ARG(B >= 1 && B <= 65535 && P >= 1 && q_ld >= C, "ocv_pixel_dot_fwd: bad sizes");
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute((const void*)pixel_dot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)pixel_dot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   const int ntiles = ocv_cdiv(P, TP);
@@ -183,22 +183,24 @@ extern "C" int ocv_pixel_dot_fwd(const float* feat, const float* queries, long q
   return 0;
 }
 
-extern "C" int ocv_bin_head_fwd(const float* feat, const float* queries, long q_bs, int q_ld, const float* Wout,
-                                const float* bout, const float* centers, float* depth, int B, int C, int Q, int n_bins,
-                                int P, void* workspace, size_t workspace_bytes, ocv_stream_t stream) {
-  OCV_CHECK_ARG(feat && queries && Wout && bout && centers && depth && workspace, "ocv_bin_head_fwd: null pointer");
-  OCV_CHECK_ARG(C == CH && Q == CH && n_bins == NB, "ocv_bin_head_fwd: needs C = Q = %d, n_bins = %d", CH, NB);
-  OCV_CHECK_ARG(B >= 1 && B <= 65535 && P >= 1 && q_ld >= C, "ocv_bin_head_fwd: bad sizes");
-  OCV_CHECK_ARG(workspace_bytes >= ocv_bin_head_workspace_bytes(B, n_bins, C) && ocv_aligned16(workspace),
-                "ocv_bin_head_fwd: workspace too small or misaligned");
-  float* Wf = (float*)workspace;
+extern "C" int ocv_bin_head_fold_fwd(const float* queries, long q_bs, int q_ld, const float* Wout, float* Wf, int B,
+                                     int C, int Q, int n_bins, ocv_stream_t stream) {
+  OCV_CHECK_ARG(queries && Wout && Wf, "ocv_bin_head_fold_fwd: null pointer");
+  OCV_CHECK_ARG(C == CH && Q == CH && n_bins == NB, "ocv_bin_head_fold_fwd: needs C = Q = %d, n_bins = %d", CH, NB);
+  OCV_CHECK_ARG(B >= 1 && B <= 65535 && q_ld >= C, "ocv_bin_head_fold_fwd: bad sizes");
   // Wf[b] (256 x 128) = Wout (256 x 128q) . queries[b] (128q x 128c): W operand given in [K, N] layout
-  int rc = ocv_linear_fwd(Wout, Q, 0, queries, q_ld, q_bs, 1, nullptr, Wf, CH, (long)NB * CH, B, NB, CH, Q, OCV_ACT_NONE,
-                          stream);
-  if (rc != 0) return rc;
+  return ocv_linear_fwd(Wout, Q, 0, queries, q_ld, q_bs, 1, nullptr, Wf, CH, (long)NB * CH, B, NB, CH, Q, OCV_ACT_NONE,
+                        stream);
+}
+
+extern "C" int ocv_bin_head_folded_fwd(const float* feat, const float* Wf, const float* bout, const float* centers,
+                                       float* depth, int B, int C, int n_bins, int P, ocv_stream_t stream) {
+  OCV_CHECK_ARG(feat && Wf && bout && centers && depth, "ocv_bin_head_folded_fwd: null pointer");
+  OCV_CHECK_ARG(C == CH && n_bins == NB, "ocv_bin_head_folded_fwd: needs C = %d, n_bins = %d", CH, NB);
+  OCV_CHECK_ARG(B >= 1 && B <= 65535 && P >= 1 && ocv_aligned16(Wf), "ocv_bin_head_folded_fwd: bad sizes / alignment");
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute((const void*)bin_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)bin_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   const int ntiles = ocv_cdiv(P, TP);
@@ -206,6 +208,19 @@ extern "C" int ocv_bin_head_fwd(const float* feat, const float* queries, long q_
   const size_t lds = (size_t)(NB * WLD + 2 * NB) * sizeof(float);
   hipLaunchKernelGGL(bin_head_kernel, dim3(per, B), dim3(256), lds, (hipStream_t)stream, feat, Wf, bout, centers,
                      depth, (long)P, ntiles);
-  OCV_CHECK_LAUNCH("ocv_bin_head_fwd");
+  OCV_CHECK_LAUNCH("ocv_bin_head_folded_fwd");
   return 0;
+}
+
+extern "C" int ocv_bin_head_fwd(const float* feat, const float* queries, long q_bs, int q_ld, const float* Wout,
+                                const float* bout, const float* centers, float* depth, int B, int C, int Q, int n_bins,
+                                int P, void* workspace, size_t workspace_bytes, ocv_stream_t stream) {
+  OCV_CHECK_ARG(feat && queries && Wout && bout && centers && depth && workspace, "ocv_bin_head_fwd: null pointer");
+  OCV_CHECK_ARG(workspace_bytes >= ocv_bin_head_workspace_bytes(B, n_bins, C) && workspace_bytes > 0 &&
+                    ocv_aligned16(workspace),
+                "ocv_bin_head_fwd: workspace too small or misaligned (or unsupported C / n_bins)");
+  float* Wf = (float*)workspace;
+  int rc = ocv_bin_head_fold_fwd(queries, q_bs, q_ld, Wout, Wf, B, C, Q, n_bins, stream);
+  if (rc != 0) return rc;
+  return ocv_bin_head_folded_fwd(feat, Wf, bout, centers, depth, B, C, n_bins, P, stream);
 }

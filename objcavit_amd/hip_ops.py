@@ -345,8 +345,10 @@ def bin_head(feat: torch.Tensor, queries: torch.Tensor, w_out: torch.Tensor, b_o
         raise ValueError(f"bin_head: unsupported configuration C={Cc} Q={Q} n_bins={nbins}")
     ws = workspace(nb, feat.device, "bin_head")
     depth = torch.empty(B, 1, h, w, dtype=torch.float32, device=feat.device)
-    with timed("bin_head"):
-      check(lib.ocv_bin_head_fwd(feat.data_ptr(), queries.data_ptr(), queries.stride(0), queries.stride(1), w2.data_ptr(),
-                                 b_out.data_ptr(), centers.data_ptr(), depth.data_ptr(), B, Cc, Q, nbins, h * w, ws.data_ptr(),
-                                 ws.numel(), _stream()), "ocv_bin_head_fwd")
+    wf = ws.view(torch.float32)
+    check(lib.ocv_bin_head_fold_fwd(queries.data_ptr(), queries.stride(0), queries.stride(1), w2.data_ptr(), wf.data_ptr(), B,
+                                    Cc, Q, nbins, _stream()), "ocv_bin_head_fold_fwd")
+    with timed("bin_head"):          # brackets exactly one launch of bin_head_kernel
+        check(lib.ocv_bin_head_folded_fwd(feat.data_ptr(), wf.data_ptr(), b_out.data_ptr(), centers.data_ptr(),
+                                          depth.data_ptr(), B, Cc, nbins, h * w, _stream()), "ocv_bin_head_folded_fwd")
     return depth

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output (gpurun_out/prof/...) into the small summaries committed under profiles/.
+
+    python profiles/summarize.py gpurun_out/prof r01
+
+kt/        : rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py ...
+pmc_fetch/ : rocprofv3 --kernel-trace --pmc FETCH_SIZE ...      (separate pass, no other trace domains)
+pmc_write/ : rocprofv3 --kernel-trace --pmc WRITE_SIZE ...
+Writes <tag>_kernel_stats.csv (rocprof's own per-kernel stats for the whole process, MIOpen's first-call
+solver search included), <tag>_step_breakdown.txt (the LAST bench step only, from the kernel trace) and
+<tag>_pmc.json (+ roofline_traffic.json, which bench.py reads for roofline.traffic).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+OURS = ("bin_head_kernel", "pixel_dot_kernel", "patch_embed_partial_kernel", "patch_embed_reduce_kernel",
+        "attention_kernel", "linear_kernel", "layernorm_kernel", "ffn_kernel", "cross_attn", "upsample_concat",
+        "depthwise", "ocv_")
+
+
+def short(name):
+    return name.replace("(anonymous namespace)::", "").replace("void ", "")[:110]
+
+
+def main(src, tag):
+    out = os.path.dirname(os.path.abspath(__file__))
+    ks = glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv"))
+    if ks:
+        shutil.copy(ks[0], os.path.join(out, f"{tag}_kernel_stats.csv"))
+    kt = glob.glob(os.path.join(src, "kt", "*", "*_kernel_trace.csv"))
+    if kt:
+        rows = list(csv.DictReader(open(kt[0])))
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+        idx = [i for i, r in enumerate(rows) if "bin_head_kernel" in r["Kernel_Name"]]
+        step = rows[idx[-2] + 1: idx[-1] + 1]
+        t0, t1 = int(step[0]["Start_Timestamp"]), int(step[-1]["End_Timestamp"])
+        agg = collections.defaultdict(lambda: [0, 0])
+        for r in step:
+            a = agg[short(r["Kernel_Name"])]
+            a[0] += 1
+            a[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        tot = sum(v[1] for v in agg.values())
+        ours = sum(v[1] for k, v in agg.items() if any(o in k for o in OURS))
+        with open(os.path.join(out, f"{tag}_step_breakdown.txt"), "w") as f:
+            f.write(f"# last bench step from {os.path.basename(kt[0])}: wall {(t1 - t0) / 1e6:.3f} ms, {len(step)} kernels, "
+                    f"sum of kernel time {tot / 1e6:.3f} ms, hand-written kernels {ours / 1e6:.3f} ms\n")
+            f.write(f"{'kernel':110s} {'n':>5s} {'total_ms':>9s} {'avg_us':>9s} {'pct':>6s}\n")
+            for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                f.write(f"{k:110s} {v[0]:5d} {v[1] / 1e6:9.3f} {v[1] / v[0] / 1e3:9.1f} {100 * v[1] / tot:6.2f}\n")
+    pmc = {}
+    for d, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        fs = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
+        if not fs:
+            continue
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(fs[0])):
+            if r["Counter_Name"] == cname and any(o in r["Kernel_Name"] for o in OURS):
+                agg[short(r["Kernel_Name"]).split("(")[0]].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            pmc.setdefault(k, {})[cname + "_KB_max"] = max(v)
+            pmc[k][cname + "_KB_mean"] = sum(v) / len(v)
+            pmc[k]["launches"] = len(v)
+    if pmc:
+        json.dump(pmc, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
+        traffic = {}
+        for key, name in (("bin_head", "bin_head_kernel"), ("patch_embed", "patch_embed_partial_kernel<true>")):
+            if name in pmc and "FETCH_SIZE_KB_max" in pmc[name] and "WRITE_SIZE_KB_max" in pmc[name]:
+                # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE tallies 128-B requests at 64 B -> x2; WRITE_SIZE exact
+                traffic[key] = int((2 * pmc[name]["FETCH_SIZE_KB_max"] + pmc[name]["WRITE_SIZE_KB_max"]) * 1024)
+        json.dump(traffic, open(os.path.join(out, "roofline_traffic.json"), "w"), indent=1, sort_keys=True)
+    print("wrote summaries to", out)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
