@@ -38,6 +38,7 @@ const char* ocv_last_error(void);
 #define OCV_ACT_NONE 0
 #define OCV_ACT_RELU 1
 #define OCV_ACT_LEAKY_RELU 2 /* slope 0.01 (nn.LeakyReLU default) */
+#define OCV_ACT_SILU 3       /* x * sigmoid(x); depthwise entry point only */
 
 /* out[z][m][n] = act( sum_k A[z][m][k] * W(n,k) + bias[n] )
  * W(n,k) = W[z][n*ldw + k] if w_kn == 0 (nn.Linear layout, [N,K])
@@ -101,17 +102,20 @@ int ocv_encoder_layer_fwd(const float* x, const ocv_encoder_layer_params* p, con
  * plus bias and positional embedding, written token-major:
  *   out[b][s][e] = bias[e] + pos[b*pos_bs + s*E + e] + sum_{c,i,j} W[e][c][i][j] * fmap[b][c][16*ph+i][16*pw+j]
  * with s = ph*(w/16) + pw.  pos_bs = 0 shares one [S,E] table across the batch; pos may be NULL.
+ * channels_last != 0: fmap is stored [B,h,w,C] (torch channels_last) and W in its channels_last storage order
+ * [E,16,16,C]; otherwise fmap is [B,C,h,w] and W [E,C,16,16].  (The same flag on the pixel-dot / bin-head entry
+ * points selects [B,P,C] vs [B,C,P] for feat; outputs are always NCHW.)
  * Replaces image_embedding_convPxP + flatten + pos add + permute (modules/ObjCAViT.py:287-288,333,362-364;
  * modules/layers.py:11-12,17-22).  E == 128. */
 size_t ocv_patch_embed_workspace_bytes(int B, int C, int h, int w, int E);
-int ocv_patch_embed_fwd(const float* fmap, const float* W, const float* bias, const float* pos, long pos_bs,
-                        float* out, int B, int C, int h, int w, int E, void* workspace, size_t workspace_bytes,
-                        ocv_stream_t stream);
+int ocv_patch_embed_fwd(const float* fmap, int channels_last, const float* W, const float* bias, const float* pos,
+                        long pos_bs, float* out, int B, int C, int h, int w, int E, void* workspace,
+                        size_t workspace_bytes, ocv_stream_t stream);
 
 /* PixelWiseDotProduct (modules/layers.py:31-36): ram[b][q][p] = sum_c feat[b][c][p] * queries[b][q][c].
  * feat [B,C,P] (NCHW with P = h*w), queries addressed as ptr + b*q_bs + q*q_ld + c, ram [B,Q,P].  C == Q == 128. */
-int ocv_pixel_dot_fwd(const float* feat, const float* queries, long q_bs, int q_ld, float* ram, int B, int C, int Q,
-                      int P, ocv_stream_t stream);
+int ocv_pixel_dot_fwd(const float* feat, int channels_last, const float* queries, long q_bs, int q_ld, float* ram,
+                      int B, int C, int Q, int P, ocv_stream_t stream);
 
 /* Fused bin head (modules/GraphBins.py:109-119 == modules/AdaBins.py:77-87 together with modules/layers.py:31-36):
  *   logits[b][k][p] = bout[k] + sum_q Wout[k][q] * ( sum_c feat[b][c][p] * queries[b][q][c] )
@@ -125,11 +129,19 @@ size_t ocv_bin_head_workspace_bytes(int B, int n_bins, int C);
  *   ocv_bin_head_folded_fwd depth[b][p] = sum_k softmax_k(bout + Wf[b] . feat[b][:, p]) * centers[b][k] */
 int ocv_bin_head_fold_fwd(const float* queries, long q_bs, int q_ld, const float* Wout, float* Wf, int B, int C, int Q,
                           int n_bins, ocv_stream_t stream);
-int ocv_bin_head_folded_fwd(const float* feat, const float* Wf, const float* bout, const float* centers, float* depth,
-                            int B, int C, int n_bins, int P, ocv_stream_t stream);
-int ocv_bin_head_fwd(const float* feat, const float* queries, long q_bs, int q_ld, const float* Wout,
+int ocv_bin_head_folded_fwd(const float* feat, int channels_last, const float* Wf, const float* bout,
+                            const float* centers, float* depth, int B, int C, int n_bins, int P, ocv_stream_t stream);
+int ocv_bin_head_fwd(const float* feat, int channels_last, const float* queries, long q_bs, int q_ld, const float* Wout,
                      const float* bout, const float* centers, float* depth, int B, int C, int Q, int n_bins, int P,
                      void* workspace, size_t workspace_bytes, ocv_stream_t stream);
+
+/* Depthwise k x k convolution (k in {3,5}, stride in {1,2}) with explicit top/left zero padding (bottom/right
+ * padding is implied by Ho/Wo -- covers TensorFlow "SAME"), per-channel bias (folded BatchNorm) and optional SiLU:
+ *   out[b][c][y][x] = act( bias[c] + sum_{i,j} w[c][i][j] * in[b][c][y*stride - pad_t + i][x*stride - pad_l + j] )
+ * in [B,C,H,W], w [C,k,k], out [B,C,Ho,Wo], NCHW fp32.  Replaces conv_dw + bn + act of the EfficientNet MBConv
+ * blocks that the reference runs through its hub backbone (modules/DenseFeatureExtractor.py:18-27,149). */
+int ocv_depthwise_conv_fwd(const float* in, const float* w, const float* bias, float* out, int B, int C, int H, int W,
+                           int k, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, ocv_stream_t stream);
 
 #ifdef __cplusplus
 }

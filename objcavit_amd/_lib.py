@@ -42,14 +42,15 @@ PROTOTYPES = {
     "ocv_encoder_layer_fwd": (C.c_int, [_f32p, C.POINTER(EncoderLayerParams), _u8p, C.c_int, _f32p, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_size_t, _stream]),
     "ocv_patch_embed_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
-    "ocv_patch_embed_fwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_long, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
+    "ocv_patch_embed_fwd": (C.c_int, [_f32p, C.c_int, _f32p, _f32p, _f32p, C.c_long, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_void_p, C.c_size_t, _stream]),
-    "ocv_pixel_dot_fwd": (C.c_int, [_f32p, _f32p, C.c_long, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
+    "ocv_pixel_dot_fwd": (C.c_int, [_f32p, C.c_int, _f32p, C.c_long, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
     "ocv_bin_head_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "ocv_bin_head_fold_fwd": (C.c_int, [_f32p, C.c_long, C.c_int, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
-    "ocv_bin_head_folded_fwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
-    "ocv_bin_head_fwd": (C.c_int, [_f32p, _f32p, C.c_long, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int,
+    "ocv_bin_head_folded_fwd": (C.c_int, [_f32p, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
+    "ocv_bin_head_fwd": (C.c_int, [_f32p, C.c_int, _f32p, C.c_long, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, _stream]),
+    "ocv_depthwise_conv_fwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p] + [C.c_int] * 11 + [_stream]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -28,13 +28,31 @@ constexpr int NB = 256;        // bins
 constexpr int WLD = CH + 1;
 constexpr int TP = 128;        // pixels per workgroup tile
 
+// B operand of one 32-pixel wavefront tile: 64 VGPRs, lane = (pixel l31, k-slot hh).
+// The K order of an MFMA chain is free as long as A and B agree, so it is chosen per layout:
+//   NCHW  feat[c][p]: step s, slot hh <-> channel 2s + hh   (128-B coalesced run per half-wave per channel)
+//   NHWC  feat[p][c]: step s, slot hh <-> channel 64hh + s  (each lane reads its pixel's 256 contiguous bytes)
+template <bool NHWC>
 __device__ __forceinline__ void load_pixels(float (&bf)[CH / 2], const float* __restrict__ fb, long P, long pix, int hh,
                                             bool ok) {
-  const float* src = fb + (long)hh * P + (ok ? pix : 0);
+  if (!NHWC) {
+    const float* src = fb + (long)hh * P + (ok ? pix : 0);
 #pragma unroll
-  for (int s = 0; s < CH / 2; ++s) bf[s] = ok ? src[(long)(2 * s) * P] : 0.f;
+    for (int s = 0; s < CH / 2; ++s) bf[s] = ok ? src[(long)(2 * s) * P] : 0.f;
+  } else {
+    const float* src = fb + (ok ? pix : 0) * CH + 64 * hh;
+#pragma unroll
+    for (int s = 0; s < CH / 8; ++s) {
+      const float4 t = ok ? ld4(src + 4 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bf[4 * s + 0] = t.x; bf[4 * s + 1] = t.y; bf[4 * s + 2] = t.z; bf[4 * s + 3] = t.w;
+    }
+  }
 }
+// LDS column of the A operand for (step s, slot hh) under the same K order
+template <bool NHWC>
+__device__ __forceinline__ constexpr int a_col(int s, int hh) { return NHWC ? 64 * hh + s : 2 * s + hh; }
 
+template <bool NHWC>
 __global__ __launch_bounds__(256) void bin_head_kernel(const float* __restrict__ feat, const float* __restrict__ Wf,
                                                        const float* __restrict__ bout,
                                                        const float* __restrict__ centers, float* __restrict__ depth,
@@ -64,23 +82,23 @@ __global__ __launch_bounds__(256) void bin_head_kernel(const float* __restrict__
   int tile = blockIdx.x;
   if (tile < ntiles) {
     const long pix = (long)tile * TP + wave * 32 + l31;
-    load_pixels(cur, fb, P, pix, hh, pix < P);
+    load_pixels<NHWC>(cur, fb, P, pix, hh, pix < P);
   }
   for (; tile < ntiles; tile += gridDim.x) {
     const long pix = (long)tile * TP + wave * 32 + l31;
     const int tn = tile + gridDim.x;
     if (tn < ntiles) {
       const long pn = (long)tn * TP + wave * 32 + l31;
-      load_pixels(nxt, fb, P, pn, hh, pn < P);
+      load_pixels<NHWC>(nxt, fb, P, pn, hh, pn < P);
     }
 
     float m_run = -__builtin_inff(), l_half = 0.f, d_half = 0.f;
 #pragma unroll 1
     for (int t = 0; t < NB / 32; ++t) {
       f32x16 acc = {0};
-      const float* wrow = Wl + (t * 32 + l31) * WLD + hh;
+      const float* wrow = Wl + (t * 32 + l31) * WLD + a_col<NHWC>(0, hh);
 #pragma unroll
-      for (int s = 0; s < CH / 2; ++s) acc = mfma_32x32x2(wrow[2 * s], cur[s], acc);
+      for (int s = 0; s < CH / 2; ++s) acc = mfma_32x32x2(wrow[a_col<NHWC>(s, 0)], cur[s], acc);
 
       float tmax = -__builtin_inff();
 #pragma unroll
@@ -113,6 +131,7 @@ __global__ __launch_bounds__(256) void bin_head_kernel(const float* __restrict__
 }
 
 // ram[b][q][p] = sum_c queries[b][q][c] * feat[b][c][p]
+template <bool NHWC>
 __global__ __launch_bounds__(256) void pixel_dot_kernel(const float* __restrict__ feat, const float* __restrict__ qm,
                                                         long q_bs, int q_ld, float* __restrict__ ram, long P,
                                                         int ntiles) {
@@ -134,13 +153,13 @@ __global__ __launch_bounds__(256) void pixel_dot_kernel(const float* __restrict_
   float cur[CH / 2];
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long pix = (long)tile * TP + wave * 32 + l31;
-    load_pixels(cur, fb, P, pix, hh, pix < P);
+    load_pixels<NHWC>(cur, fb, P, pix, hh, pix < P);
 #pragma unroll 1
     for (int t = 0; t < CH / 32; ++t) {
       f32x16 acc = {0};
-      const float* qrow = Ql + (t * 32 + l31) * WLD + hh;
+      const float* qrow = Ql + (t * 32 + l31) * WLD + a_col<NHWC>(0, hh);
 #pragma unroll
-      for (int s = 0; s < CH / 2; ++s) acc = mfma_32x32x2(qrow[2 * s], cur[s], acc);
+      for (int s = 0; s < CH / 2; ++s) acc = mfma_32x32x2(qrow[a_col<NHWC>(s, 0)], cur[s], acc);
       if (pix < P) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) rb[(long)(t * 32 + acc_row(r, hh)) * P + pix] = acc[r];
@@ -164,21 +183,28 @@ extern "C" size_t ocv_bin_head_workspace_bytes(int B, int n_bins, int C) {
   return (size_t)B * NB * CH * sizeof(float);
 }
 
-extern "C" int ocv_pixel_dot_fwd(const float* feat, const float* queries, long q_bs, int q_ld, float* ram, int B,
-                                 int C, int Q, int P, ocv_stream_t stream) {
+extern "C" int ocv_pixel_dot_fwd(const float* feat, int channels_last, const float* queries, long q_bs, int q_ld,
+                                 float* ram, int B, int C, int Q, int P, ocv_stream_t stream) {
   OCV_CHECK_ARG(feat && queries && ram, "ocv_pixel_dot_fwd: null pointer");
   OCV_CHECK_ARG(C == CH && Q == CH, "ocv_pixel_dot_fwd: C and Q must be %d (got %d, %d)", CH, C, Q);
   OCV_CHECK_ARG(B >= 1 && B <= 65535 && P >= 1 && q_ld >= C, "ocv_pixel_dot_fwd: bad sizes");
+  OCV_CHECK_ARG(!channels_last || ocv_aligned16(feat), "ocv_pixel_dot_fwd: channels_last map must be 16-byte aligned");
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)pixel_dot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)pixel_dot_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)pixel_dot_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   const int ntiles = ocv_cdiv(P, TP);
   int per = blocks_per_image(B, ntiles) * 2;      // 66 KiB LDS -> two workgroups per CU
   if (per > ntiles) per = ntiles;
-  hipLaunchKernelGGL(pixel_dot_kernel, dim3(per, B), dim3(256), (size_t)CH * WLD * sizeof(float), (hipStream_t)stream,
-                     feat, queries, q_bs, q_ld, ram, (long)P, ntiles);
+  const size_t lds = (size_t)CH * WLD * sizeof(float);
+  if (channels_last)
+    hipLaunchKernelGGL(pixel_dot_kernel<true>, dim3(per, B), dim3(256), lds, (hipStream_t)stream, feat, queries, q_bs,
+                       q_ld, ram, (long)P, ntiles);
+  else
+    hipLaunchKernelGGL(pixel_dot_kernel<false>, dim3(per, B), dim3(256), lds, (hipStream_t)stream, feat, queries, q_bs,
+                       q_ld, ram, (long)P, ntiles);
   OCV_CHECK_LAUNCH("ocv_pixel_dot_fwd");
   return 0;
 }
@@ -193,26 +219,33 @@ extern "C" int ocv_bin_head_fold_fwd(const float* queries, long q_bs, int q_ld, 
                         stream);
 }
 
-extern "C" int ocv_bin_head_folded_fwd(const float* feat, const float* Wf, const float* bout, const float* centers,
-                                       float* depth, int B, int C, int n_bins, int P, ocv_stream_t stream) {
+extern "C" int ocv_bin_head_folded_fwd(const float* feat, int channels_last, const float* Wf, const float* bout,
+                                       const float* centers, float* depth, int B, int C, int n_bins, int P,
+                                       ocv_stream_t stream) {
   OCV_CHECK_ARG(feat && Wf && bout && centers && depth, "ocv_bin_head_folded_fwd: null pointer");
   OCV_CHECK_ARG(C == CH && n_bins == NB, "ocv_bin_head_folded_fwd: needs C = %d, n_bins = %d", CH, NB);
   OCV_CHECK_ARG(B >= 1 && B <= 65535 && P >= 1 && ocv_aligned16(Wf), "ocv_bin_head_folded_fwd: bad sizes / alignment");
+  OCV_CHECK_ARG(!channels_last || ocv_aligned16(feat), "ocv_bin_head_folded_fwd: channels_last map must be 16-byte aligned");
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)bin_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)bin_head_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)bin_head_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   const int ntiles = ocv_cdiv(P, TP);
   const int per = blocks_per_image(B, ntiles);
   const size_t lds = (size_t)(NB * WLD + 2 * NB) * sizeof(float);
-  hipLaunchKernelGGL(bin_head_kernel, dim3(per, B), dim3(256), lds, (hipStream_t)stream, feat, Wf, bout, centers,
-                     depth, (long)P, ntiles);
+  if (channels_last)
+    hipLaunchKernelGGL(bin_head_kernel<true>, dim3(per, B), dim3(256), lds, (hipStream_t)stream, feat, Wf, bout,
+                       centers, depth, (long)P, ntiles);
+  else
+    hipLaunchKernelGGL(bin_head_kernel<false>, dim3(per, B), dim3(256), lds, (hipStream_t)stream, feat, Wf, bout,
+                       centers, depth, (long)P, ntiles);
   OCV_CHECK_LAUNCH("ocv_bin_head_folded_fwd");
   return 0;
 }
 
-extern "C" int ocv_bin_head_fwd(const float* feat, const float* queries, long q_bs, int q_ld, const float* Wout,
+extern "C" int ocv_bin_head_fwd(const float* feat, int channels_last, const float* queries, long q_bs, int q_ld, const float* Wout,
                                 const float* bout, const float* centers, float* depth, int B, int C, int Q, int n_bins,
                                 int P, void* workspace, size_t workspace_bytes, ocv_stream_t stream) {
   OCV_CHECK_ARG(feat && queries && Wout && bout && centers && depth && workspace, "ocv_bin_head_fwd: null pointer");
@@ -222,5 +255,5 @@ extern "C" int ocv_bin_head_fwd(const float* feat, const float* queries, long q_
   float* Wf = (float*)workspace;
   int rc = ocv_bin_head_fold_fwd(queries, q_bs, q_ld, Wout, Wf, B, C, Q, n_bins, stream);
   if (rc != 0) return rc;
-  return ocv_bin_head_folded_fwd(feat, Wf, bout, centers, depth, B, C, n_bins, P, stream);
+  return ocv_bin_head_folded_fwd(feat, channels_last, Wf, bout, centers, depth, B, C, n_bins, P, stream);
 }

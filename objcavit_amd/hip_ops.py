@@ -17,7 +17,7 @@ import torch
 from . import _lib
 from ._lib import EncoderLayerParams, check
 
-ACT_NONE, ACT_RELU, ACT_LEAKY_RELU = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_SILU = 0, 1, 2, 3
 
 
 def _stream() -> int:
@@ -271,15 +271,49 @@ def encoder_layer(x: torch.Tensor, params: EncoderLayerParams, key_padding_mask:
 # ---------------------------------------------------------------------------
 # patch embedding / pixel-wise dot / bin head
 # ---------------------------------------------------------------------------
+def _map4(t: torch.Tensor, name: str) -> Tuple[torch.Tensor, int]:
+    """[B, C, h, w] feature map that is dense either as NCHW or as NHWC (torch channels_last):
+    -> (tensor, channels_last flag).  Anything else is made NCHW-contiguous."""
+    _req(t, name, contiguous=False)
+    if t.dim() != 4:
+        raise ValueError(f"{name}: expected [B, C, h, w]")
+    if t.is_contiguous():
+        return t, 0
+    if t.is_contiguous(memory_format=torch.channels_last) and t.shape[1] % 64 == 0:
+        return t, 1
+    return t.contiguous(), 0
+
+
+_CL_WEIGHTS: Dict[Tuple[int, int], torch.Tensor] = {}
+
+
+def _weight_channels_last(w: torch.Tensor) -> torch.Tensor:
+    """conv weight [E, C, kh, kw] in channels_last storage order [E, kh, kw, C] (cached per parameter version)."""
+    if w.is_contiguous(memory_format=torch.channels_last) and not w.is_contiguous():
+        return w
+    key = (w.data_ptr(), w._version)
+    hit = _CL_WEIGHTS.get(key)
+    if hit is None or hit.shape != w.shape:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("weight re-layout during graph capture: run one eager warm-up call first")
+        _CL_WEIGHTS.clear()
+        hit = w.contiguous(memory_format=torch.channels_last)
+        _CL_WEIGHTS[key] = hit
+    return hit
+
+
 def patch_embed(fmap: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
                 pos: Optional[torch.Tensor]) -> torch.Tensor:
-    """tokens [B, S, E] = conv16x16/16(fmap) flattened + bias + pos; pos is [S, E] or [B, S, E]."""
+    """tokens [B, S, E] = conv16x16/16(fmap) flattened + bias + pos; pos is [S, E] or [B, S, E].
+    fmap may be NCHW-contiguous or channels_last."""
     lib = _lib.load()
-    _req(fmap, "fmap"); _req(weight, "weight")
+    fmap, cl = _map4(fmap, "fmap")
+    _req(weight, "weight", contiguous=False)
     B, Cc, h, w = fmap.shape
     E = weight.shape[0]
     if weight.shape != (E, Cc, 16, 16):
         raise ValueError(f"patch_embed: weight {tuple(weight.shape)} does not match fmap channels {Cc} / 16x16 patches")
+    weight = _weight_channels_last(weight) if cl else weight.contiguous()
     gh, gw = h // 16, w // 16
     S = gh * gw
     if S < 1:
@@ -303,8 +337,8 @@ def patch_embed(fmap: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.T
     ws = workspace(nb, fmap.device)
     out = torch.empty(B, S, E, dtype=torch.float32, device=fmap.device)
     with timed("patch_embed"):
-      check(lib.ocv_patch_embed_fwd(fmap.data_ptr(), weight.data_ptr(), _ptr(bias), _ptr(pos), pos_bs, out.data_ptr(), B, Cc,
-                                    h, w, E, ws.data_ptr(), ws.numel(), _stream()), "ocv_patch_embed_fwd")
+        check(lib.ocv_patch_embed_fwd(fmap.data_ptr(), cl, weight.data_ptr(), _ptr(bias), _ptr(pos), pos_bs, out.data_ptr(),
+                                      B, Cc, h, w, E, ws.data_ptr(), ws.numel(), _stream()), "ocv_patch_embed_fwd")
     return out
 
 
@@ -315,24 +349,26 @@ def _check_queries(queries: torch.Tensor, B: int, Cc: int) -> None:
 
 
 def pixel_dot(feat: torch.Tensor, queries: torch.Tensor) -> torch.Tensor:
-    """PixelWiseDotProduct: [B,C,h,w] x [B,Q,C] -> [B,Q,h,w]."""
+    """PixelWiseDotProduct: [B,C,h,w] (NCHW or channels_last) x [B,Q,C] -> [B,Q,h,w] (NCHW-contiguous)."""
     lib = _lib.load()
-    _req(feat, "feat")
+    feat, cl = _map4(feat, "feat")
     B, Cc, h, w = feat.shape
     _check_queries(queries, B, Cc)
     Q = queries.shape[1]
     ram = torch.empty(B, Q, h, w, dtype=torch.float32, device=feat.device)
     with timed("pixel_dot"):
-      check(lib.ocv_pixel_dot_fwd(feat.data_ptr(), queries.data_ptr(), queries.stride(0), queries.stride(1), ram.data_ptr(), B,
-                                  Cc, Q, h * w, _stream()), "ocv_pixel_dot_fwd")
+        check(lib.ocv_pixel_dot_fwd(feat.data_ptr(), cl, queries.data_ptr(), queries.stride(0), queries.stride(1),
+                                    ram.data_ptr(), B, Cc, Q, h * w, _stream()), "ocv_pixel_dot_fwd")
     return ram
 
 
 def bin_head(feat: torch.Tensor, queries: torch.Tensor, w_out: torch.Tensor, b_out: torch.Tensor,
              centers: torch.Tensor) -> torch.Tensor:
-    """depth [B,1,h,w] = sum_k softmax_k(conv1x1(pixel_dot(feat, queries)))_k * centers_k, fused."""
+    """depth [B,1,h,w] = sum_k softmax_k(conv1x1(pixel_dot(feat, queries)))_k * centers_k, fused.
+    feat may be NCHW-contiguous or channels_last."""
     lib = _lib.load()
-    _req(feat, "feat"); _req(b_out, "b_out"); _req(centers, "centers")
+    feat, cl = _map4(feat, "feat")
+    _req(b_out, "b_out"); _req(centers, "centers")
     B, Cc, h, w = feat.shape
     _check_queries(queries, B, Cc)
     Q = queries.shape[1]
@@ -349,6 +385,33 @@ def bin_head(feat: torch.Tensor, queries: torch.Tensor, w_out: torch.Tensor, b_o
     check(lib.ocv_bin_head_fold_fwd(queries.data_ptr(), queries.stride(0), queries.stride(1), w2.data_ptr(), wf.data_ptr(), B,
                                     Cc, Q, nbins, _stream()), "ocv_bin_head_fold_fwd")
     with timed("bin_head"):          # brackets exactly one launch of bin_head_kernel
-        check(lib.ocv_bin_head_folded_fwd(feat.data_ptr(), wf.data_ptr(), b_out.data_ptr(), centers.data_ptr(),
+        check(lib.ocv_bin_head_folded_fwd(feat.data_ptr(), cl, wf.data_ptr(), b_out.data_ptr(), centers.data_ptr(),
                                           depth.data_ptr(), B, Cc, nbins, h * w, _stream()), "ocv_bin_head_folded_fwd")
     return depth
+
+
+# ---------------------------------------------------------------------------
+# depthwise convolution (EfficientNet MBConv)
+# ---------------------------------------------------------------------------
+def depthwise_conv_same(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int,
+                        act: int = ACT_NONE) -> torch.Tensor:
+    """Depthwise k x k conv with TensorFlow 'SAME' padding, + bias (folded BN) + optional SiLU.
+    x [B,C,H,W] NCHW-contiguous, weight [C,1,k,k]."""
+    lib = _lib.load()
+    _req(x, "x"); _req(weight, "weight")
+    B, Cc, H, W = x.shape
+    k = weight.shape[-1]
+    if weight.shape != (Cc, 1, k, k):
+        raise ValueError(f"depthwise_conv_same: weight {tuple(weight.shape)} does not match {Cc} channels")
+    if bias is not None:
+        _req(bias, "bias")
+        if bias.numel() != Cc:
+            raise ValueError("depthwise_conv_same: bias size mismatch")
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    ph = max((Ho - 1) * stride + k - H, 0)
+    pw = max((Wo - 1) * stride + k - W, 0)
+    out = torch.empty(B, Cc, Ho, Wo, dtype=torch.float32, device=x.device)
+    with timed("depthwise"):
+        check(lib.ocv_depthwise_conv_fwd(x.data_ptr(), weight.data_ptr(), _ptr(bias), out.data_ptr(), B, Cc, H, W, k, stride,
+                                         ph // 2, pw // 2, Ho, Wo, act, _stream()), "ocv_depthwise_conv_fwd")
+    return out

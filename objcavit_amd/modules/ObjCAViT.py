@@ -286,7 +286,6 @@ class ObjCAViT(nn.Module):
         if self.training:
             raise RuntimeError("the HIP path implements inference (eval mode) only")
         dev = image_features.device
-        image_features = image_features.contiguous()
         B = image_features.shape[0]
         if len(object_features) != B or len(object_xywh_list) != B:
             raise ValueError("object_features / object_xywh_list must have one entry per image")
@@ -323,6 +322,9 @@ class ObjCAViT(nn.Module):
             tok, obj = self.saca_2(tok, obj, want_object_output=False)
 
         # 4. heads (reference :373-388)
+        if image_features.is_contiguous(memory_format=torch.channels_last) and not image_features.is_contiguous() \
+                and not self.conv3x3.weight.is_contiguous(memory_format=torch.channels_last):
+            self.conv3x3.to(memory_format=torch.channels_last)       # NHWC in -> NHWC MIOpen solver -> NHWC out
         feat = self.conv3x3(image_features)
         y = regress_bin_widths(self.regressor, tok[:, 0, :], self.norm)
         return y, feat, tok[:, 1:self.n_query_channels + 1, :]

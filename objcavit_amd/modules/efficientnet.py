@@ -13,8 +13,13 @@ classifier) and parameter names follow that model family, so that
 * a checkpoint of the reference (``...encoder.original_model.blocks.3.2.conv_dw
   .weight`` etc.) loads by key.
 
-Dense convolutions run through PyTorch-ROCm (MIOpen); SURVEY.md section 8 keeps
-the encoder out of the hand-written-kernel list (row N1 "next").
+Inference plan on the GPU (eval + no_grad): every
+BatchNorm is folded into the preceding convolution once and cached; the
+depthwise k x k stages (+ folded BN + SiLU) run as one hand-written HIP kernel
+(``ocv_depthwise_conv_fwd`` -- MIOpen falls back to a naive kernel for them on
+gfx950); pointwise / stem convolutions stay on MIOpen / hipBLASLt.  In
+training mode or on the CPU the plain PyTorch module graph runs (that is also
+what the golden generator wraps in the reference's ``Encoder``).
 Architecture table: oracle/effnet_ref.py header (width x1.6, depth x2.2,
 TF "SAME" padding, BN eps 1e-3, swish, squeeze-excite 0.25 of block input).
 """
@@ -25,6 +30,8 @@ import math
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from .. import hip_ops
 
 BN_EPS = 1e-3
 BN_MOMENTUM = 0.01
@@ -69,7 +76,45 @@ def _bn(c):
     return nn.BatchNorm2d(c, eps=BN_EPS, momentum=BN_MOMENTUM)
 
 
-class DepthwiseSeparableConv(nn.Module):
+def fold_bn(conv: nn.Conv2d, bn: nn.Module):
+    """(weight, bias) of conv followed by eval-mode BatchNorm (identity if ``bn`` is not a BatchNorm)."""
+    w = conv.weight.detach()
+    b = conv.bias.detach() if conv.bias is not None else None
+    if not isinstance(bn, nn.BatchNorm2d):
+        return w.contiguous(), b
+    s = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+    b0 = b if b is not None else torch.zeros_like(bn.running_mean)
+    return (w * s.view(-1, 1, 1, 1)).contiguous(), ((b0 - bn.running_mean) * s + bn.bias.detach()).contiguous()
+
+
+class _FoldedMixin:
+    """Caches BN-folded weights for the inference fast path; dropped on train() / load_state_dict / device moves."""
+
+    def _fast(self, x: torch.Tensor) -> bool:
+        return (not self.training) and (not torch.is_grad_enabled()) and x.device.type == "cuda"
+
+    def _folded(self, x: torch.Tensor):
+        c = self.__dict__.get("_fold_cache")
+        if c is None or c[0] != x.device:
+            with torch.no_grad():
+                c = (x.device, self._fold())
+            self.__dict__["_fold_cache"] = c
+        return c[1]
+
+    def train(self, mode: bool = True):
+        self.__dict__.pop("_fold_cache", None)
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *a, **kw):
+        self.__dict__.pop("_fold_cache", None)
+        return super()._load_from_state_dict(*a, **kw)
+
+    def _apply(self, fn, *a, **kw):
+        self.__dict__.pop("_fold_cache", None)
+        return super()._apply(fn, *a, **kw)
+
+
+class DepthwiseSeparableConv(_FoldedMixin, nn.Module):
     def __init__(self, cin, cout, k, stride):
         super().__init__()
         self.has_residual = stride == 1 and cin == cout
@@ -81,13 +126,21 @@ class DepthwiseSeparableConv(nn.Module):
         self.bn2 = _bn(cout)
         self.act2 = nn.Identity()
 
+    def _fold(self):
+        return fold_bn(self.conv_dw, self.bn1) + fold_bn(self.conv_pw, self.bn2)
+
     def forward(self, x):
+        if self._fast(x):
+            wd, bd, wp, bp = self._folded(x)
+            y = hip_ops.depthwise_conv_same(x.contiguous(), wd, bd, self.conv_dw.stride[0], hip_ops.ACT_SILU)
+            y = F.conv2d(self.se(y), wp, bp)
+            return y + x if self.has_residual else y
         y = self.act1(self.bn1(self.conv_dw(x)))
         y = self.act2(self.bn2(self.conv_pw(self.se(y))))
         return y + x if self.has_residual else y
 
 
-class InvertedResidual(nn.Module):
+class InvertedResidual(_FoldedMixin, nn.Module):
     def __init__(self, cin, cout, k, stride, expand):
         super().__init__()
         mid = cin * expand
@@ -102,7 +155,16 @@ class InvertedResidual(nn.Module):
         self.conv_pwl = nn.Conv2d(mid, cout, 1, bias=False)
         self.bn3 = _bn(cout)
 
+    def _fold(self):
+        return fold_bn(self.conv_pw, self.bn1) + fold_bn(self.conv_dw, self.bn2) + fold_bn(self.conv_pwl, self.bn3)
+
     def forward(self, x):
+        if self._fast(x):
+            we, be, wd, bd, wl, bl = self._folded(x)
+            y = F.silu(F.conv2d(x, we, be), inplace=True)
+            y = hip_ops.depthwise_conv_same(y, wd, bd, self.conv_dw.stride[0], hip_ops.ACT_SILU)
+            y = F.conv2d(self.se(y), wl, bl)
+            return y + x if self.has_residual else y
         y = self.act1(self.bn1(self.conv_pw(x)))
         y = self.act2(self.bn2(self.conv_dw(y)))
         y = self.bn3(self.conv_pwl(self.se(y)))

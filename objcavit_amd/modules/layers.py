@@ -79,4 +79,4 @@ class PixelWiseDotProduct(nn.Module):
         n, c, h, w = x.size()
         _, cout, ck = K.size()
         assert c == ck, "Number of channels in x and Embedding dimension (at dim 2) of K matrix must match"
-        return hip_ops.pixel_dot(x.contiguous(), K)
+        return hip_ops.pixel_dot(x, K)

@@ -49,6 +49,9 @@ class mViT(nn.Module):
         tok = self.patch_transformer.forward_batch_first(x)           # B x S x E
         if tok.shape[1] < self.n_query_channels + 1:
             raise ValueError(f"need at least {self.n_query_channels + 1} patches, got {tok.shape[1]}")
+        if x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous() \
+                and not self.conv3x3.weight.is_contiguous(memory_format=torch.channels_last):
+            self.conv3x3.to(memory_format=torch.channels_last)
         feat = self.conv3x3(x)
         y = regress_bin_widths(self.regressor, tok[:, 0, :], self.norm)
         return y, feat, tok[:, 1:self.n_query_channels + 1, :]

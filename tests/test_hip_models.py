@@ -142,3 +142,21 @@ def test_config2_full_size_properties():
     feats, boxes, _ = m.object_provider(img)
     solo = m(img[3:4], [feats[3]], [boxes[3]]).depth_pred
     assert max_rel(solo, d[3:4]) < 1e-4
+
+
+def test_encoder_fast_path_vs_oracle():
+    """EfficientNet-B5 encoder inference plan (folded BN, HIP depthwise kernel) vs the oracle's functional
+    restatement on identical weights: every one of the five skip activations."""
+    from oracle import effnet_ref
+    from objcavit_amd.modules.DenseFeatureExtractor import DenseFeatureExtractor
+    m = DenseFeatureExtractor(make_args()).eval()
+    sd = gen.load_into(m, 9)
+    img = gen.randn("img", (2, 3, 224, 288), 9)
+    ref = effnet_ref.encoder_features(img, sd, "encoder.original_model.")
+    feats = m.cuda().encoder(img.cuda())
+    for i in (4, 5, 6, 8, 11):
+        assert rel_dev(feats[i], ref[i]) < 1e-4, i
+    out = m.decoder(feats)
+    ref_out = restate.decoder_forward(ref, sd, "decoder.")
+    assert rel_dev(out, ref_out) < 1e-4
+    assert out.is_contiguous(memory_format=torch.channels_last)       # decoder runs NHWC on the GPU
