@@ -62,6 +62,15 @@ int ocv_linear_residual_layernorm_fwd(const float* A, int lda, const float* W, i
                                       float eps, const uint8_t* zero_row_mask, float* out, int ldo, int M, int N,
                                       int K, ocv_stream_t stream);
 
+/* Fused feed-forward block of a post-norm transformer layer, hidden activations never leave the chip:
+ *   out[m][:] = LayerNorm( x[m][:] + W2 relu(W1 x[m][:] + b1) + b2 ) * gamma + beta
+ * x / out [M, E] dense (out may alias x), w1 [FF, E], w2 [E, FF] (nn.Linear layout); E == 128, FF % 128 == 0.
+ * Replaces linear1 + ReLU + linear2 + residual + norm2 of nn.TransformerEncoderLayer
+ * (modules/ObjCAViT.py:155-161,169,188; modules/layers.py:8-9,23). */
+int ocv_ffn_residual_layernorm_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                                   const float* gamma, const float* beta, float eps, const uint8_t* zero_row_mask,
+                                   float* out, int M, int E, int FF, ocv_stream_t stream);
+
 /* out[m][:] = LayerNorm(x[m][:] (+ residual[m][:])) * gamma + beta over E columns (biased variance).
  * residual nullable.  Stand-alone form of the LayerNorm used above. */
 int ocv_layernorm_residual_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float eps,
@@ -78,11 +87,15 @@ int ocv_attention_fwd(const float* q, long q_bs, int q_ss, const float* k, long 
 
 /* nn.MultiheadAttention(E, H, batch_first=True).forward(query, key, value, key_padding_mask, need_weights=False)
  * (modules/ObjCAViT.py:163-164,195-207): packed in_proj_weight [3E,E] / in_proj_bias [3E], out_proj [E,E] + [E].
- * q_src [B,Sq,E], k_src / v_src [B,Sk,E] dense; out [B,Sq,E].  E == 128, H == 4. */
+ * q_src [B,Sq,E], k_src / v_src [B,Sk,E] dense; out [B,Sq,E].  E == 128, H == 4.
+ * kv_limit: 0, or a number of leading keys such that EVERY key j >= kv_limit is masked in every batch row (the
+ * caller knows it from the object counts: key_padding_mask is True for j >= n_b, so kv_limit = max_b n_b).  Keys
+ * beyond it are then neither projected nor scored -- identical result, since they carry zero probability. */
 size_t ocv_mha_workspace_bytes(int B, int Sq, int Sk, int E);
 int ocv_mha_fwd(const float* q_src, const float* k_src, const float* v_src, const uint8_t* key_padding_mask,
                 const float* in_proj_w, const float* in_proj_b, const float* out_w, const float* out_b, float* out,
-                int B, int Sq, int Sk, int E, int H, void* workspace, size_t workspace_bytes, ocv_stream_t stream);
+                int B, int Sq, int Sk, int kv_limit, int E, int H, void* workspace, size_t workspace_bytes,
+                ocv_stream_t stream);
 
 /* One post-norm nn.TransformerEncoderLayer(E=128, H=4, FF, relu, eps) in eval mode on x [B,S,E] (dense):
  *   x1 = LN1(x + MHA(x, x, x, mask));  out = LN2(x1 + W2 relu(W1 x1 + b1) + b2)

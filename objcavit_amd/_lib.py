@@ -37,7 +37,8 @@ PROTOTYPES = {
                                     _f32p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _stream]),
     "ocv_mha_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "ocv_mha_fwd": (C.c_int, [_f32p, _f32p, _f32p, _u8p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int,
-                              C.c_int, C.c_int, C.c_void_p, C.c_size_t, _stream]),
+                              C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, _stream]),
+    "ocv_ffn_residual_layernorm_fwd": (C.c_int, [_f32p] * 7 + [C.c_float, _u8p, _f32p, C.c_int, C.c_int, C.c_int, _stream]),
     "ocv_encoder_layer_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "ocv_encoder_layer_fwd": (C.c_int, [_f32p, C.POINTER(EncoderLayerParams), _u8p, C.c_int, _f32p, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_size_t, _stream]),

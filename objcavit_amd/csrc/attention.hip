@@ -36,6 +36,7 @@ struct AttnArgs {
   long q_bs, k_bs, v_bs, o_bs;
   int q_ss, k_ss, v_ss, o_ss;
   int Sq, Sk, kc;   // kc = chunk capacity (multiple of 32)
+  int mask_ld;
   float scale;
 };
 
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
     }
     for (int r = tid; r < nk; r += 256) {
       const int key = c0 + r;
-      const bool dead = key >= p.Sk || (p.mask != nullptr && p.mask[(long)b * p.Sk + key] != 0);
+      const bool dead = key >= p.Sk || (p.mask != nullptr && p.mask[(long)b * p.mask_ld + key] != 0);
       Ms[r] = dead ? NEG_INF : 0.f;
     }
     __syncthreads();
@@ -160,10 +161,17 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
 extern "C" int ocv_attention_fwd(const float* q, long q_bs, int q_ss, const float* k, long k_bs, int k_ss,
                                  const float* v, long v_bs, int v_ss, const uint8_t* key_padding_mask, float* ctx,
                                  long o_bs, int o_ss, int B, int H, int Sq, int Sk, float scale, ocv_stream_t stream) {
+  return ocv_attention_launch(q, q_bs, q_ss, k, k_bs, k_ss, v, v_bs, v_ss, key_padding_mask, Sk, ctx, o_bs, o_ss, B, H,
+                              Sq, Sk, scale, (hipStream_t)stream);
+}
+
+int ocv_attention_launch(const float* q, long q_bs, int q_ss, const float* k, long k_bs, int k_ss, const float* v,
+                         long v_bs, int v_ss, const uint8_t* key_padding_mask, int mask_ld, float* ctx, long o_bs,
+                         int o_ss, int B, int H, int Sq, int Sk, float scale, hipStream_t stream) {
   OCV_CHECK_ARG(q && k && v && ctx, "ocv_attention_fwd: null pointer");
   OCV_CHECK_ARG(B >= 1 && H >= 1 && Sq >= 1 && Sk >= 1, "ocv_attention_fwd: bad sizes B=%d H=%d Sq=%d Sk=%d", B, H, Sq, Sk);
   OCV_CHECK_ARG(B <= 65535 && H <= 65535, "ocv_attention_fwd: grid too large");
-  AttnArgs a{q, k, v, key_padding_mask, ctx, q_bs, k_bs, v_bs, o_bs, q_ss, k_ss, v_ss, o_ss, Sq, Sk, 0, scale};
+  AttnArgs a{q, k, v, key_padding_mask, ctx, q_bs, k_bs, v_bs, o_bs, q_ss, k_ss, v_ss, o_ss, Sq, Sk, 0, mask_ld, scale};
   a.kc = ((Sk + 31) / 32) * 32;
   if (a.kc > KC_MAX) a.kc = KC_MAX;
   const size_t lds = (size_t)a.kc * (HD + KLD + 1) * sizeof(float);
@@ -171,7 +179,7 @@ extern "C" int ocv_attention_fwd(const float* q, long q_bs, int q_ss, const floa
                    (k_bs % 4 == 0) && (v_bs % 4 == 0) && (o_bs % 4 == 0) && (k_ss % 4 == 0) && (v_ss % 4 == 0) &&
                    (o_ss % 4 == 0);
   dim3 grid(ocv_cdiv(Sq, 128), H, B), block(256);
-  hipStream_t st = (hipStream_t)stream;
+  hipStream_t st = stream;
   if (vec) {
     static bool attr_v = false;
     if (!attr_v) {

@@ -36,8 +36,8 @@ extern "C" size_t ocv_mha_workspace_bytes(int B, int Sq, int Sk, int E) {
 
 extern "C" int ocv_mha_fwd(const float* q_src, const float* k_src, const float* v_src, const uint8_t* key_padding_mask,
                            const float* in_proj_w, const float* in_proj_b, const float* out_w, const float* out_b,
-                           float* out, int B, int Sq, int Sk, int E, int H, void* workspace, size_t workspace_bytes,
-                           ocv_stream_t stream) {
+                           float* out, int B, int Sq, int Sk, int kv_limit, int E, int H, void* workspace,
+                           size_t workspace_bytes, ocv_stream_t stream) {
   OCV_CHECK_ARG(q_src && k_src && v_src && in_proj_w && in_proj_b && out_w && out_b && out && workspace,
                 "ocv_mha_fwd: null pointer");
   OCV_CHECK_ARG(H >= 1 && E == H * 32, "ocv_mha_fwd: head dim must be 32 (E=%d, H=%d)", E, H);
@@ -49,11 +49,15 @@ extern "C" int ocv_mha_fwd(const float* q_src, const float* k_src, const float* 
   float* vp = (float*)(ws + qb + kb);
   float* ctx = (float*)(ws + qb + 2 * kb);
   int rc;
+  OCV_CHECK_ARG(kv_limit >= 0, "ocv_mha_fwd: negative kv_limit");
+  OCV_CHECK_ARG(kv_limit == 0 || key_padding_mask != nullptr, "ocv_mha_fwd: kv_limit needs a key_padding_mask");
+  // keys >= kv_limit are all masked (caller's promise): project and score only the first Se keys of every batch row
+  const int Se = (kv_limit > 0 && kv_limit < Sk) ? kv_limit : Sk;
   if ((rc = ocv_linear_fwd(q_src, E, 0, in_proj_w, E, 0, 0, in_proj_b, qp, E, 0, 1, B * Sq, E, E, OCV_ACT_NONE, stream))) return rc;
-  if ((rc = ocv_linear_fwd(k_src, E, 0, in_proj_w + (size_t)E * E, E, 0, 0, in_proj_b + E, kp, E, 0, 1, B * Sk, E, E, OCV_ACT_NONE, stream))) return rc;
-  if ((rc = ocv_linear_fwd(v_src, E, 0, in_proj_w + (size_t)2 * E * E, E, 0, 0, in_proj_b + 2 * E, vp, E, 0, 1, B * Sk, E, E, OCV_ACT_NONE, stream))) return rc;
-  if ((rc = ocv_attention_fwd(qp, (long)Sq * E, E, kp, (long)Sk * E, E, vp, (long)Sk * E, E, key_padding_mask, ctx,
-                              (long)Sq * E, E, B, H, Sq, Sk, 1.0f / sqrtf(32.0f), stream))) return rc;
+  if ((rc = ocv_linear_fwd(k_src, E, (long)Sk * E, in_proj_w + (size_t)E * E, E, 0, 0, in_proj_b + E, kp, E, (long)Se * E, B, Se, E, E, OCV_ACT_NONE, stream))) return rc;
+  if ((rc = ocv_linear_fwd(v_src, E, (long)Sk * E, in_proj_w + (size_t)2 * E * E, E, 0, 0, in_proj_b + 2 * E, vp, E, (long)Se * E, B, Se, E, E, OCV_ACT_NONE, stream))) return rc;
+  if ((rc = ocv_attention_launch(qp, (long)Sq * E, E, kp, (long)Se * E, E, vp, (long)Se * E, E, key_padding_mask, Sk, ctx,
+                                 (long)Sq * E, E, B, H, Sq, Se, 1.0f / sqrtf(32.0f), (hipStream_t)stream))) return rc;
   return ocv_linear_fwd(ctx, E, 0, out_w, E, 0, 0, out_b, out, E, 0, 1, B * Sq, E, E, OCV_ACT_NONE, stream);
 }
 
@@ -92,10 +96,14 @@ extern "C" int ocv_encoder_layer_fwd(const float* x, const ocv_encoder_layer_par
   // x1 = LN1(x + ctx Wo^T + bo)
   if ((rc = ocv_linear_residual_layernorm_fwd(ctx, E, p->out_proj_w, E, p->out_proj_b, x, E, p->norm1_w, p->norm1_b,
                                               eps, nullptr, x1, E, M, E, E, stream))) return rc;
-  // hid = relu(x1 W1^T + b1)
-  if ((rc = ocv_linear_fwd(x1, E, 0, p->linear1_w, E, 0, 0, p->linear1_b, hid, FF, 0, 1, M, FF, E, OCV_ACT_RELU, stream))) return rc;
-  // out = LN2(x1 + hid W2^T + b2)
   const uint8_t* zmask = (zero_padded_rows && key_padding_mask) ? key_padding_mask : nullptr;
+  if (FF % 128 == 0) {
+    // out = LN2(x1 + W2 relu(W1 x1 + b1) + b2), hidden activations stay in LDS
+    return ocv_ffn_residual_layernorm_fwd(x1, p->linear1_w, p->linear1_b, p->linear2_w, p->linear2_b, p->norm2_w,
+                                          p->norm2_b, eps, zmask, out, M, E, FF, stream);
+  }
+  // generic hidden size: hid = relu(x1 W1^T + b1); out = LN2(x1 + hid W2^T + b2)
+  if ((rc = ocv_linear_fwd(x1, E, 0, p->linear1_w, E, 0, 0, p->linear1_b, hid, FF, 0, 1, M, FF, E, OCV_ACT_RELU, stream))) return rc;
   return ocv_linear_residual_layernorm_fwd(hid, FF, p->linear2_w, FF, p->linear2_b, x1, E, p->norm2_w, p->norm2_b, eps,
                                            zmask, out, E, M, E, FF, stream);
 }

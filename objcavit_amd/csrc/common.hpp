@@ -59,5 +59,10 @@ void ocv_set_error(const char* fmt, ...);
     }                                                                       \
   } while (0)
 
+// attention launch with an explicit row stride for the key-padding mask (mask[b * mask_ld + key])
+int ocv_attention_launch(const float* q, long q_bs, int q_ss, const float* k, long k_bs, int k_ss, const float* v,
+                         long v_bs, int v_ss, const uint8_t* key_padding_mask, int mask_ld, float* ctx, long o_bs,
+                         int o_ss, int B, int H, int Sq, int Sk, float scale, hipStream_t stream);
+
 static inline bool ocv_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline int ocv_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

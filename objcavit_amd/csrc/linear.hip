@@ -183,12 +183,197 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------
+// "streamed-weight" linear: the layer sizes of the transformer stack (K = 128,
+// 512, 1024; weights in nn.Linear [N, K] layout, everything 16-byte aligned).
+//
+// In out = A W^T every weight element is consumed by exactly ONE wavefront (the
+// one that owns its output column), so the weight operand is loaded straight
+// from L2 into VGPRs as float4 -- no LDS round trip; at 64 cycles per fp32 MFMA
+// one 16-byte load feeds 4 issues.  Only the activation rows, which all four
+// wavefronts share, are staged in LDS (32 x 128-float chunks, rows padded to
+// 132 floats so the ds_read_b128 of the A operand is conflict-free).
+// The K order inside a chunk is permuted so that both operands are 16-byte
+// vectors: MFMA step (t, e), k-slot hh  <->  k = 8 t + 4 hh + e.
+// ---------------------------------------------------------------------------
+constexpr int FM = 32, FKC = 128, FLD = FKC + 4;
+
+__device__ __forceinline__ void stage_rows(float (*Xs)[FLD], const float* __restrict__ src, int ld, int m0, int M,
+                                           int k0, int kc, int tid) {
+  const int row = tid >> 3;
+  const bool ok = m0 + row < M;
+#pragma unroll
+  for (int pass = 0; pass < FKC / 32; ++pass) {
+    const int c4 = (tid & 7) * 4 + 32 * pass;
+    if (c4 < kc) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) t = ld4(src + (long)(m0 + row) * ld + k0 + c4);
+      *reinterpret_cast<float4*>(&Xs[row][c4]) = t;
+    }
+  }
+}
+
+// 64 MFMAs (or fewer for a short chunk): acc += Xs[32 x kc] . Wregs^T
+__device__ __forceinline__ f32x16 chunk_mfma(f32x16 acc, const float (*Xs)[FLD], const float4 (&w)[FKC / 8], int kc,
+                                             int l31, int hh) {
+#pragma unroll
+  for (int t = 0; t < FKC / 8; ++t) {
+    if (8 * t < kc) {
+      const float4 a = *reinterpret_cast<const float4*>(&Xs[l31][8 * t + 4 * hh]);
+      acc = mfma_32x32x2(a.x, w[t].x, acc);
+      acc = mfma_32x32x2(a.y, w[t].y, acc);
+      acc = mfma_32x32x2(a.z, w[t].z, acc);
+      acc = mfma_32x32x2(a.w, w[t].w, acc);
+    }
+  }
+  return acc;
+}
+
+__device__ __forceinline__ void load_wregs(float4 (&w)[FKC / 8], const float* __restrict__ wrow, int kc) {
+#pragma unroll
+  for (int t = 0; t < FKC / 8; ++t)
+    w[t] = (8 * t < kc) ? ld4(wrow + 8 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// residual + LayerNorm over the 128 columns of a 32-row tile held in Cs (one wavefront per 8 rows)
+__device__ __forceinline__ void ln_rows(const float (*Cs)[BN + 1], const float* gamma, const float* beta, float eps,
+                                        const uint8_t* zero_mask, float* out, int ldo, int m0, int M, int lane, int wave) {
+  const float g0 = gamma[lane], g1 = gamma[lane + 64];
+  const float b0 = beta[lane], b1 = beta[lane + 64];
+#pragma unroll
+  for (int i = 0; i < FM / 4; ++i) {
+    const int row = wave * (FM / 4) + i, m = m0 + row;
+    const float x0 = Cs[row][lane], x1 = Cs[row][lane + 64];
+    const float mean = wave_sum(x0 + x1) * (1.0f / BN);
+    const float d0 = x0 - mean, d1 = x1 - mean;
+    const float var = wave_sum(d0 * d0 + d1 * d1) * (1.0f / BN);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (m < M) {
+      const bool z = zero_mask != nullptr && zero_mask[m] != 0;
+      out[(long)m * ldo + lane] = z ? 0.f : d0 * rstd * g0 + b0;
+      out[(long)m * ldo + lane + 64] = z ? 0.f : d1 * rstd * g1 + b1;
+    }
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void linear_stream_kernel(LinearArgs p) {
+  __shared__ __attribute__((aligned(16))) float Xs[FM][FLD];
+  __shared__ float Cs[EPI == EPI_RES_LN ? FM : 1][BN + 1];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int m0 = blockIdx.x * FM, n0 = blockIdx.y * BN;
+  const float* __restrict__ A = p.A + (long)blockIdx.z * p.sA;
+  const float* __restrict__ W = p.W + (long)blockIdx.z * p.sW;
+  float* __restrict__ out = p.out + (long)blockIdx.z * p.sO;
+  const int M = p.M, N = p.N, K = p.K;
+  const int n = n0 + wave * 32 + l31;
+  const float* wrow = W + (long)(n < N ? n : N - 1) * p.ldw + 4 * hh;
+
+  f32x16 acc = {0};
+  for (int k0 = 0; k0 < K; k0 += FKC) {
+    const int kc = min(FKC, K - k0);
+    float4 w[FKC / 8];
+    load_wregs(w, wrow + k0, kc);
+    __syncthreads();
+    stage_rows(Xs, A, p.lda, m0, M, k0, kc, tid);
+    __syncthreads();
+    acc = chunk_mfma(acc, Xs, w, kc, l31, hh);
+  }
+
+  const float bn = (p.bias != nullptr && n < N) ? p.bias[n] : 0.f;
+  if (EPI != EPI_RES_LN) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + acc_row(r, hh);
+      float v = acc[r] + bn;
+      if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+      if (EPI == EPI_LEAKY) v = v > 0.f ? v : 0.01f * v;
+      if (m < M && n < N) out[(long)m * p.ldo + n] = v;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = acc_row(r, hh), m = m0 + row;
+      float v = acc[r] + bn;
+      if (m < M) v += p.res[(long)m * p.ldres + n];
+      Cs[row][wave * 32 + l31] = v;
+    }
+    __syncthreads();
+    ln_rows(Cs, p.gamma, p.beta, p.eps, p.zero_mask, out, p.ldo, m0, M, lane, wave);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Fused feed-forward block of a post-norm transformer layer:
+//   out = LayerNorm( x + W2 relu(W1 x + b1) + b2 )        x: [M, 128], FF hidden units
+// One workgroup = 32 rows.  The hidden activations never leave the chip: they
+// are produced 128 units at a time into LDS (phase 1, 64 MFMAs per wavefront)
+// and immediately contracted with the matching 128-column slice of W2 into the
+// output accumulator (phase 2, 64 MFMAs).  W1 / W2 stream from L2 into VGPRs
+// (see above); the W2 slice is fetched while phase 1 multiplies.
+// Saves the [M, FF] round trip through HBM (19.7 MB at bs = 16) and two launches.
+// ---------------------------------------------------------------------------
+struct FFNArgs {
+  const float *x, *w1, *b1, *w2, *b2, *gamma, *beta;
+  float eps;
+  const uint8_t* zero_mask;
+  float* out;
+  int M, FF;
+};
+
+__global__ __launch_bounds__(256) void ffn_fused_kernel(FFNArgs p) {
+  __shared__ __attribute__((aligned(16))) float Xs[FM][FLD];
+  __shared__ __attribute__((aligned(16))) float Hs[FM][FLD];
+  __shared__ float Cs[FM][BN + 1];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int m0 = blockIdx.x * FM;
+  const int col = wave * 32 + l31;                 // hidden unit within a chunk (phase 1) / output column (phase 2)
+
+  stage_rows(Xs, p.x, BN, m0, p.M, 0, BN, tid);
+  f32x16 acc = {0};
+  float4 w1r[FKC / 8], w2r[FKC / 8];
+  load_wregs(w1r, p.w1 + (long)col * BN + 4 * hh, BN);
+  __syncthreads();
+
+  const int nchunk = p.FF / FKC;
+  for (int c = 0; c < nchunk; ++c) {
+    load_wregs(w2r, p.w2 + (long)col * p.FF + c * FKC + 4 * hh, FKC);        // in flight during phase 1
+    f32x16 h = {0};
+    h = chunk_mfma(h, Xs, w1r, BN, l31, hh);
+    const float b1 = p.b1[c * FKC + col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Hs[acc_row(r, hh)][col] = fmaxf(h[r] + b1, 0.f);
+    if (c + 1 < nchunk) load_wregs(w1r, p.w1 + (long)((c + 1) * FKC + col) * BN + 4 * hh, BN);   // next chunk's W1
+    __syncthreads();
+    acc = chunk_mfma(acc, Hs, w2r, FKC, l31, hh);
+    __syncthreads();
+  }
+
+  const float b2 = p.b2[col];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = acc_row(r, hh);
+    Cs[row][col] = acc[r] + b2 + Xs[row][col];      // residual = the layer input rows (zero beyond M)
+  }
+  __syncthreads();
+  ln_rows(Cs, p.gamma, p.beta, p.eps, p.zero_mask, p.out, BN, m0, p.M, lane, wave);
+}
+
 template <int EPI>
 int launch_linear(const LinearArgs& a, int batch, bool w_kn, hipStream_t st) {
   dim3 grid(ocv_cdiv(a.M, BM), ocv_cdiv(a.N, BN), batch), block(256);
   const bool vecA = (a.lda % 4 == 0) && (a.sA % 4 == 0) && ocv_aligned16(a.A);
   const bool vecW = (a.ldw % 4 == 0) && (a.sW % 4 == 0) && ocv_aligned16(a.W);
   const bool vec = vecA && vecW && (w_kn || a.K % 4 == 0);
+  if (!w_kn && vec && a.K % 8 == 0) {
+    hipLaunchKernelGGL((linear_stream_kernel<EPI>), grid, block, 0, st, a);
+    OCV_CHECK_LAUNCH("ocv_linear(stream)");
+    return 0;
+  }
   if (w_kn) {
     if (vec) hipLaunchKernelGGL((linear_kernel<EPI, true, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((linear_kernel<EPI, true, false>), grid, block, 0, st, a);
@@ -241,5 +426,20 @@ extern "C" int ocv_layernorm_residual_fwd(const float* x, const float* residual,
   hipLaunchKernelGGL(layernorm_kernel, dim3(ocv_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, residual, gamma,
                      beta, eps, out, rows, E);
   OCV_CHECK_LAUNCH("ocv_layernorm_residual_fwd");
+  return 0;
+}
+
+extern "C" int ocv_ffn_residual_layernorm_fwd(const float* x, const float* w1, const float* b1, const float* w2,
+                                              const float* b2, const float* gamma, const float* beta, float eps,
+                                              const uint8_t* zero_row_mask, float* out, int M, int E, int FF,
+                                              ocv_stream_t stream) {
+  OCV_CHECK_ARG(x && w1 && b1 && w2 && b2 && gamma && beta && out, "ocv_ffn_residual_layernorm_fwd: null pointer");
+  OCV_CHECK_ARG(E == BN && FF >= FKC && FF % FKC == 0, "ocv_ffn_residual_layernorm_fwd: needs E = %d and FF a multiple of %d (got %d, %d)", BN, FKC, E, FF);
+  OCV_CHECK_ARG(M >= 0, "ocv_ffn_residual_layernorm_fwd: bad M");
+  OCV_CHECK_ARG(ocv_aligned16(x) && ocv_aligned16(w1) && ocv_aligned16(w2), "ocv_ffn_residual_layernorm_fwd: x / w1 / w2 must be 16-byte aligned");
+  if (M == 0) return 0;
+  FFNArgs a{x, w1, b1, w2, b2, gamma, beta, eps, zero_row_mask, out, M, FF};
+  hipLaunchKernelGGL(ffn_fused_kernel, dim3(ocv_cdiv(M, FM)), dim3(256), 0, (hipStream_t)stream, a);
+  OCV_CHECK_LAUNCH("ocv_ffn_residual_layernorm_fwd");
   return 0;
 }

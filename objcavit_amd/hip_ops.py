@@ -149,6 +149,29 @@ def linear_residual_layernorm(a: torch.Tensor, weight: torch.Tensor, bias: torch
     return out
 
 
+def ffn_residual_layernorm(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor,
+                           gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
+                           zero_row_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """LayerNorm(x + W2 relu(W1 x + b1) + b2), fused (hidden activations stay on chip); x [..., 128]."""
+    lib = _lib.load()
+    for n, t in (("x", x), ("w1", w1), ("b1", b1), ("w2", w2), ("b2", b2), ("gamma", gamma), ("beta", beta)):
+        _req(t, n)
+    E = x.shape[-1]
+    FF = w1.shape[0]
+    M = x.numel() // E
+    if w1.shape != (FF, E) or w2.shape != (E, FF) or b1.numel() != FF or b2.numel() != E or gamma.numel() != E or beta.numel() != E:
+        raise ValueError("ffn_residual_layernorm: shape mismatch")
+    if zero_row_mask is not None:
+        _req(zero_row_mask, "zero_row_mask", torch.uint8)
+        if zero_row_mask.numel() != M:
+            raise ValueError("zero_row_mask: one byte per row expected")
+    out = torch.empty_like(x)
+    check(lib.ocv_ffn_residual_layernorm_fwd(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                             gamma.data_ptr(), beta.data_ptr(), eps, _ptr(zero_row_mask), out.data_ptr(), M, E,
+                                             FF, _stream()), "ocv_ffn_residual_layernorm_fwd")
+    return out
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
               residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = _lib.load()
@@ -205,8 +228,9 @@ def attention_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, key_paddin
 
 def mha(q_src: torch.Tensor, k_src: torch.Tensor, v_src: torch.Tensor, in_proj_w: torch.Tensor, in_proj_b: torch.Tensor,
         out_w: torch.Tensor, out_b: torch.Tensor, key_padding_mask: Optional[torch.Tensor] = None,
-        n_heads: int = 4) -> torch.Tensor:
-    """nn.MultiheadAttention(batch_first=True, need_weights=False) forward."""
+        n_heads: int = 4, kv_limit: int = 0) -> torch.Tensor:
+    """nn.MultiheadAttention(batch_first=True, need_weights=False) forward.
+    kv_limit > 0: the caller guarantees every key j >= kv_limit is masked in every row, so those keys are skipped."""
     lib = _lib.load()
     for n, t in (("q_src", q_src), ("k_src", k_src), ("v_src", v_src), ("in_proj_weight", in_proj_w),
                  ("in_proj_bias", in_proj_b), ("out_proj.weight", out_w), ("out_proj.bias", out_b)):
@@ -223,7 +247,7 @@ def mha(q_src: torch.Tensor, k_src: torch.Tensor, v_src: torch.Tensor, in_proj_w
     out = torch.empty(B, Sq, E, dtype=torch.float32, device=q_src.device)
     with timed("mha_cross" if q_src.data_ptr() != k_src.data_ptr() else "mha_self"):
       check(lib.ocv_mha_fwd(q_src.data_ptr(), k_src.data_ptr(), v_src.data_ptr(), _ptr(m), in_proj_w.data_ptr(),
-                            in_proj_b.data_ptr(), out_w.data_ptr(), out_b.data_ptr(), out.data_ptr(), B, Sq, Sk, E, n_heads,
+                            in_proj_b.data_ptr(), out_w.data_ptr(), out_b.data_ptr(), out.data_ptr(), B, Sq, Sk, int(kv_limit), E, n_heads,
                             ws.data_ptr(), ws.numel(), _stream()), "ocv_mha_fwd")
     return out
 

@@ -191,8 +191,11 @@ class SelfAttnCrossAttn(nn.Module):
         kpm = F.pad(mask, (0, amt), value=True)                                           # :193  mask padded at the BACK
         att_obj_p = F.pad(att_obj, (0, 0, amt, 0), value=PAD_VALUE).contiguous()          # :194  rows padded at the FRONT
         ca1 = self.cross_attn_obj_im
+        # every key at position >= Nmax is masked (mask is True beyond each image's object count, and was padded with
+        # True at the back): the kernel only projects / scores the first Nmax keys -- same result, ~10x less work
         final_img = hip_ops.mha(att_img, att_obj_p, att_img, ca1.in_proj_weight.detach(), ca1.in_proj_bias.detach(),
-                                ca1.out_proj.weight.detach(), ca1.out_proj.bias.detach(), kpm, ca1.num_heads)   # :195-201
+                                ca1.out_proj.weight.detach(), ca1.out_proj.bias.detach(), kpm, ca1.num_heads,
+                                kv_limit=int(mask.shape[1]))                                                  # :195-201
         final_obj = None
         if want_object_output:
             ca2 = self.cross_attn_im_obj

@@ -64,6 +64,21 @@ def test_linear_residual_layernorm(ops, M, K):
     assert float(got[dev(mask)].abs().max()) == 0.0 if mask.any() else True
 
 
+@pytest.mark.parametrize("M,FF", [(1, 128), (45, 1024), (300, 1024), (4800, 1024), (33, 256)])
+def test_ffn_residual_layernorm_fused(ops, M, FF):
+    x = rnd("x", (M, 128), 1)
+    w1, b1 = rnd("w1", (FF, 128), 2, 1 / math.sqrt(128)), rnd("b1", (FF,), 3, 0.1)
+    w2, b2 = rnd("w2", (128, FF), 4, 1 / math.sqrt(FF)), rnd("b2", (128,), 5, 0.1)
+    g, be = 1 + 0.1 * rnd("g", (128,), 6), rnd("be", (128,), 7)
+    ref = restate.layer_norm(x + torch.relu(x @ w1.T + b1) @ w2.T + b2, g, be)
+    got = ops.ffn_residual_layernorm(dev(x), dev(w1), dev(b1), dev(w2), dev(b2), dev(g), dev(be))
+    assert rel_dev(got, ref) < TOL
+    mask = (torch.arange(M) % 4 == 2)
+    got = ops.ffn_residual_layernorm(dev(x), dev(w1), dev(b1), dev(w2), dev(b2), dev(g), dev(be),
+                                     zero_row_mask=dev(mask.to(torch.uint8)))
+    assert rel_dev(got, ref.masked_fill(mask[:, None], 0.0)) < TOL
+
+
 @pytest.mark.parametrize("rows,E", [(1, 128), (301, 128), (17, 96), (9, 300)])
 def test_layernorm(ops, rows, E):
     x, r = rnd("x", (rows, E), 1, 3.0), rnd("r", (rows, E), 2)
@@ -135,6 +150,21 @@ def test_mha_module(ops, Sq, Sk, masked):
     ref = restate.multi_head_attention(qs, ks, vs, iw, ib, ow, ob, mask)
     got = ops.mha(dev(qs), dev(ks), dev(vs), dev(iw), dev(ib), dev(ow), dev(ob), None if mask is None else dev(mask))
     assert rel_dev(got, ref) < TOL
+
+
+@pytest.mark.parametrize("counts", [[16, 5], [1, 1], [100, 3], [32] * 4])
+def test_mha_kv_limit_skips_only_masked_keys(ops, counts):
+    """Cross-attention #1 layout: keys >= Nmax are all masked; kv_limit = Nmax must not change the result."""
+    B, S, E = len(counts), 132, 128
+    qs, ks = rnd("qs", (B, S, E), 1), rnd("ks", (B, S, E), 2)
+    iw, ib = rnd("iw", (3 * E, E), 4, 2 / math.sqrt(E)), rnd("ib", (3 * E,), 5, 0.1)
+    ow, ob = rnd("ow", (E, E), 6, 1 / math.sqrt(E)), rnd("ob", (E,), 7, 0.1)
+    mask = torch.arange(S)[None, :] >= torch.tensor(counts)[:, None]
+    ref = restate.multi_head_attention(qs, ks, qs, iw, ib, ow, ob, mask)
+    args = (dev(qs), dev(ks), dev(qs), dev(iw), dev(ib), dev(ow), dev(ob), dev(mask))
+    full = ops.mha(*args)
+    lim = ops.mha(*args, kv_limit=max(counts))
+    assert rel_dev(full, ref) < TOL and rel_dev(lim, ref) < TOL
 
 
 def _encoder_sd(seed, prefix="layers."):
@@ -243,7 +273,7 @@ def test_pixel_dot_and_bin_head_channels_last(ops, B, h, w):
     assert float(((got.cpu() - ref_depth).abs() / ref_depth).max()) < 1e-4
     # NCHW and NHWC paths agree to rounding
     got_nchw = ops.bin_head(dev(feat), qg, dev(wout), dev(bout), centers)
-    assert float(((got - got_nchw).abs() / got_nchw).max()) < 1e-5
+    assert float(((got - got_nchw).abs() / got_nchw).max()) < 1e-4      # different K order inside the MFMA chains
 
 
 # ------------------------------------------------------------------ depthwise convolution
