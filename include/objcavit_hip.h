@@ -38,7 +38,7 @@ const char* ocv_last_error(void);
 #define OCV_ACT_NONE 0
 #define OCV_ACT_RELU 1
 #define OCV_ACT_LEAKY_RELU 2 /* slope 0.01 (nn.LeakyReLU default) */
-#define OCV_ACT_SILU 3       /* x * sigmoid(x); depthwise entry point only */
+#define OCV_ACT_SILU 3       /* x * sigmoid(x); convolution entry points only */
 
 /* out[z][m][n] = act( sum_k A[z][m][k] * W(n,k) + bias[n] )
  * W(n,k) = W[z][n*ldw + k] if w_kn == 0 (nn.Linear layout, [N,K])
@@ -155,6 +155,20 @@ int ocv_bin_head_fwd(const float* feat, int channels_last, const float* queries,
  * blocks that the reference runs through its hub backbone (modules/DenseFeatureExtractor.py:18-27,149). */
 int ocv_depthwise_conv_fwd(const float* in, const float* w, const float* bias, float* out, int B, int C, int H, int W,
                            int k, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, ocv_stream_t stream);
+
+/* Convolution k x k (k in {1,3}), stride 1, zero "same" padding, on NHWC fp32 activations, computed as an implicit
+ * GEMM on the bf16 matrix cores with split-bf16 operands (x = hi + lo, 3 MFMAs per product, fp32 accumulate;
+ * ~1e-6 relative error, see csrc/conv_igemm.hip):
+ *   y[b][h][w][co] = act( bias[co] + sum_{ky,kx,ci} xcat[b][h+ky-k/2][w+kx-k/2][ci] * Wt[ky*k+kx][co][ci] ) (+ residual)
+ * xcat is x1 [B,H,W,C1] followed along channels by the optional x2 [B,H,W,C2] (virtual concat: the skip connection of
+ * UpSampleWithSkip, modules/DenseFeatureExtractor.py:44-47).  w_hi / w_lo: bf16 [k*k][Cout][Cp], Cp = C1+C2 rounded up
+ * to 32, zero padded, w_hi = bf16(W), w_lo = bf16(W - w_hi) (prepared once on the host).  C1, C2 multiples of 4; C1 a
+ * multiple of 32 when x2 is given.  residual (nullable) and y are [B,H,W,Cout].  act: OCV_ACT_*.
+ * Replaces the conv3x3 (+ folded BN + LeakyReLU) stages of the UNet decoder (modules/DenseFeatureExtractor.py:37-42,97)
+ * and ObjCAViT.conv3x3 / mViT.conv3x3 (modules/ObjCAViT.py:298,374; modules/miniViT.py:15,25). */
+int ocv_conv_nhwc_fwd(const float* x1, int C1, const float* x2, int C2, const void* w_hi, const void* w_lo,
+                      const float* bias, const float* residual, float* y, int B, int H, int W, int Cout, int ksize,
+                      int act, ocv_stream_t stream);
 
 #ifdef __cplusplus
 }

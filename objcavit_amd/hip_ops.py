@@ -439,3 +439,63 @@ def depthwise_conv_same(x: torch.Tensor, weight: torch.Tensor, bias: Optional[to
         check(lib.ocv_depthwise_conv_fwd(x.data_ptr(), weight.data_ptr(), _ptr(bias), out.data_ptr(), B, Cc, H, W, k, stride,
                                          ph // 2, pw // 2, Ho, Wo, act, _stream()), "ocv_depthwise_conv_fwd")
     return out
+
+
+# ---------------------------------------------------------------------------
+# split-bf16 implicit-GEMM convolution on NHWC activations
+# ---------------------------------------------------------------------------
+def prep_conv_weight(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[Cout, Cin, k, k] fp32 -> (w_hi, w_lo) bf16 [k*k, Cout, Cp] with Cp = Cin rounded up to 32 (zero padded),
+    w_hi = bf16(W), w_lo = bf16(W - w_hi).  Done once per weight version by the callers (cached there)."""
+    Cout, Cin, kh, kw = weight.shape
+    if kh != kw or kh not in (1, 3):
+        raise ValueError("prep_conv_weight: kernel must be 1x1 or 3x3")
+    w = weight.detach().float().permute(2, 3, 0, 1).reshape(kh * kw, Cout, Cin)
+    Cp = (Cin + 31) // 32 * 32
+    if Cp != Cin:
+        w = torch.nn.functional.pad(w, (0, Cp - Cin))
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    return hi.contiguous(), lo.contiguous()
+
+
+def _nhwc(t: torch.Tensor, name: str) -> torch.Tensor:
+    _req(t, name, contiguous=False)
+    if t.dim() != 4:
+        raise ValueError(f"{name}: expected a 4-D [B, C, H, W] tensor")
+    if not t.is_contiguous(memory_format=torch.channels_last):
+        t = t.contiguous(memory_format=torch.channels_last)
+    return t
+
+
+def conv_nhwc(x1: torch.Tensor, x2: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: torch.Tensor,
+              bias: Optional[torch.Tensor], ksize: int, act: int = ACT_NONE,
+              residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(conv_kxk(cat([x1, x2], 1)) + bias) (+ residual); logical shapes [B, C, H, W], storage channels_last."""
+    lib = _lib.load()
+    x1 = _nhwc(x1, "x1")
+    B, C1, H, W = x1.shape
+    C2 = 0
+    if x2 is not None:
+        x2 = _nhwc(x2, "x2")
+        if x2.shape[0] != B or x2.shape[2:] != x1.shape[2:]:
+            raise ValueError("conv_nhwc: x2 must match x1 in batch and spatial size")
+        C2 = x2.shape[1]
+    for n, t in (("w_hi", w_hi), ("w_lo", w_lo)):
+        _req(t, n, torch.bfloat16)
+    taps, Cout, Cp = w_hi.shape
+    if w_lo.shape != w_hi.shape or taps != ksize * ksize or Cp != (C1 + C2 + 31) // 32 * 32:
+        raise ValueError(f"conv_nhwc: weights {tuple(w_hi.shape)} do not match {C1}+{C2} input channels, k={ksize}")
+    if bias is not None:
+        _req(bias, "bias")
+        if bias.numel() != Cout:
+            raise ValueError("conv_nhwc: bias size mismatch")
+    y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x1.device, memory_format=torch.channels_last)
+    if residual is not None:
+        residual = _nhwc(residual, "residual")
+        if residual.shape != y.shape:
+            raise ValueError("conv_nhwc: residual shape mismatch")
+    with timed(f"conv{ksize}x{ksize}"):
+        check(lib.ocv_conv_nhwc_fwd(x1.data_ptr(), C1, _ptr(x2), C2, w_hi.data_ptr(), w_lo.data_ptr(), _ptr(bias),
+                                    _ptr(residual), y.data_ptr(), B, H, W, Cout, ksize, act, _stream()), "ocv_conv_nhwc_fwd")
+    return y

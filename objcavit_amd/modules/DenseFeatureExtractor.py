@@ -19,7 +19,50 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import hip_ops
 from .efficientnet import tf_efficientnet_b5_ap
+
+
+def split_bf16_convs_enabled() -> bool:
+    """3x3 convolutions of the decoder / heads: hand-written split-bf16 implicit GEMM (default) or MIOpen fp32
+    (OCV_CONV=miopen).  Both are checked against the CPU oracle by the parity tests."""
+    import os
+    return os.environ.get("OCV_CONV", "split_bf16") != "miopen"
+
+
+class SplitConv3x3:
+    """Inference-time plan for one 3x3 (or 1x1) convolution [+ folded BatchNorm]: weights split into bf16 hi/lo
+    once per parameter version, then ``ocv_conv_nhwc_fwd``."""
+
+    def __init__(self, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d] = None):
+        self.conv, self.bn = conv, bn
+        self._key = None
+        self._prep = None
+
+    def usable(self, c1: int, c2: int = 0) -> bool:
+        k = self.conv.kernel_size
+        return (split_bf16_convs_enabled() and k[0] == k[1] and k[0] in (1, 3) and self.conv.stride == (1, 1)
+                and self.conv.padding == (k[0] // 2, k[0] // 2) and self.conv.groups == 1 and self.conv.dilation == (1, 1)
+                and c1 % 4 == 0 and c2 % 4 == 0 and (c2 == 0 or c1 % 32 == 0))
+
+    def __call__(self, x1, x2=None, act=hip_ops.ACT_NONE):
+        ps = [self.conv.weight] + ([self.conv.bias] if self.conv.bias is not None else [])
+        if self.bn is not None:
+            ps += [self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if key != self._key:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("weight preparation during graph capture: run one eager warm-up call first")
+            with torch.no_grad():
+                if self.bn is not None:
+                    w, b = _fold_conv_bn(self.conv, self.bn)
+                else:
+                    w, b = self.conv.weight, self.conv.bias
+                hi, lo = hip_ops.prep_conv_weight(w)
+                self._prep = (hi, lo, None if b is None else b.detach().float().contiguous())
+            self._key = key
+        hi, lo, b = self._prep
+        return hip_ops.conv_nhwc(x1, x2, hi, lo, b, self.conv.kernel_size[0], act)
 
 # skip-connection table: encoder-name fragment -> (feature_select, skip channels 3..0)
 # (reference modules/DenseFeatureExtractor.py:62-85)
@@ -82,6 +125,8 @@ class UpSampleWithSkip(nn.Module):
             nn.LeakyReLU())
         self._folded = None
         self._folded_cl = False
+        self._split1 = SplitConv3x3(self._net[0], self._net[1])
+        self._split2 = SplitConv3x3(self._net[3], self._net[4])
 
     def train(self, mode: bool = True):
         self._folded = None
@@ -93,6 +138,11 @@ class UpSampleWithSkip(nn.Module):
 
     def forward(self, x, skip_features):
         up = F.interpolate(x, size=skip_features.shape[-2:], mode="bilinear", align_corners=True)
+        if (not self.training and not torch.is_grad_enabled() and up.device.type == "cuda"
+                and self._split1.usable(up.shape[1], skip_features.shape[1])):
+            # hand-written path: the channel concat is virtual (two A-operand sources), BN is folded, LeakyReLU fused
+            f = self._split1(up, skip_features, hip_ops.ACT_LEAKY_RELU)
+            return self._split2(f, None, hip_ops.ACT_LEAKY_RELU)
         f = torch.cat([up, skip_features], dim=1)
         if self.training or torch.is_grad_enabled():
             return self._net(f)
@@ -131,6 +181,7 @@ class Decoder(nn.Module):
         self.final_upscale = UpSampleWithSkip(f // 16 + 3, f // 16) if do_final_upscale else None
         self.mode = mode if mode is not None else "features"
         self.conv3 = nn.Conv2d(f // 16, num_classes if self.mode == "features" else 1, kernel_size=3, stride=1, padding=1)
+        self._split3 = SplitConv3x3(self.conv3)
 
     def forward(self, features):
         b0, b1, b2, b3, b4 = (features[i] for i in self.feature_select)
@@ -148,6 +199,8 @@ class Decoder(nn.Module):
             x = up(x, skip)
         if self.final_upscale is not None:
             x = self.final_upscale(x, features[0])
+        if x.device.type == "cuda" and not self.training and not torch.is_grad_enabled() and self._split3.usable(x.shape[1]):
+            return self._split3(x)
         return self.conv3(x)
 
 

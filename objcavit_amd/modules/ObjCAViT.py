@@ -325,12 +325,21 @@ class ObjCAViT(nn.Module):
             tok, obj = self.saca_2(tok, obj, want_object_output=False)
 
         # 4. heads (reference :373-388)
-        if image_features.is_contiguous(memory_format=torch.channels_last) and not image_features.is_contiguous() \
-                and not self.conv3x3.weight.is_contiguous(memory_format=torch.channels_last):
-            self.conv3x3.to(memory_format=torch.channels_last)       # NHWC in -> NHWC MIOpen solver -> NHWC out
-        feat = self.conv3x3(image_features)
+        feat = self._conv3x3_nhwc(image_features)
         y = regress_bin_widths(self.regressor, tok[:, 0, :], self.norm)
         return y, feat, tok[:, 1:self.n_query_channels + 1, :]
+
+    def _conv3x3_nhwc(self, x):
+        from .DenseFeatureExtractor import SplitConv3x3
+        plan = self.__dict__.get("_split3x3")
+        if plan is None:
+            plan = self.__dict__["_split3x3"] = SplitConv3x3(self.conv3x3)
+        if plan.usable(x.shape[1]):
+            return plan(x)                                            # split-bf16 implicit GEMM, NHWC in / out
+        if x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous() \
+                and not self.conv3x3.weight.is_contiguous(memory_format=torch.channels_last):
+            self.conv3x3.to(memory_format=torch.channels_last)       # NHWC in -> NHWC MIOpen solver -> NHWC out
+        return self.conv3x3(x)
 
     def forward(self, image_features, object_features, object_xywh_list):
         y, feat, queries = self.forward_parts(image_features, object_features, object_xywh_list)

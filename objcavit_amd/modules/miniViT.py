@@ -49,12 +49,21 @@ class mViT(nn.Module):
         tok = self.patch_transformer.forward_batch_first(x)           # B x S x E
         if tok.shape[1] < self.n_query_channels + 1:
             raise ValueError(f"need at least {self.n_query_channels + 1} patches, got {tok.shape[1]}")
+        feat = self._conv3x3_nhwc(x)
+        y = regress_bin_widths(self.regressor, tok[:, 0, :], self.norm)
+        return y, feat, tok[:, 1:self.n_query_channels + 1, :]
+
+    def _conv3x3_nhwc(self, x):
+        from .DenseFeatureExtractor import SplitConv3x3
+        plan = self.__dict__.get("_split3x3")
+        if plan is None:
+            plan = self.__dict__["_split3x3"] = SplitConv3x3(self.conv3x3)
+        if plan.usable(x.shape[1]):
+            return plan(x)                                            # split-bf16 implicit GEMM, NHWC in / out
         if x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous() \
                 and not self.conv3x3.weight.is_contiguous(memory_format=torch.channels_last):
             self.conv3x3.to(memory_format=torch.channels_last)
-        feat = self.conv3x3(x)
-        y = regress_bin_widths(self.regressor, tok[:, 0, :], self.norm)
-        return y, feat, tok[:, 1:self.n_query_channels + 1, :]
+        return self.conv3x3(x)
 
     def forward(self, x):
         y, feat, queries = self.forward_parts(x)

@@ -295,3 +295,44 @@ def test_depthwise_conv_same(ops, k, s, B, C, H, W, act):
     got = ops.depthwise_conv_same(dev(x), dev(w), dev(b), s, act)
     assert got.shape == ref.shape
     assert rel_dev(got, ref) < TOL
+
+
+# ------------------------------------------------------------------ split-bf16 implicit-GEMM convolution
+SPLIT_TOL = 2e-5     # hi+lo carries 16 bits, 3 of 4 partial products kept: ~1e-6 measured, bound stated in the kernel
+
+
+@pytest.mark.parametrize("B,H,W,C1,C2,Cout,k,act", [
+    (2, 30, 40, 64, 24, 128, 3, 2),       # concat, Cin = 88 (not a multiple of 32)
+    (1, 17, 23, 32, 0, 40, 3, 0),         # ragged M, Cout < tile
+    (3, 16, 16, 128, 0, 128, 3, 0),       # conv3x3 of the heads
+    (1, 240, 320, 128, 0, 128, 3, 0),     # full NYU head size
+    (2, 15, 20, 256, 176, 256, 3, 2),     # decoder-like
+    (2, 9, 11, 96, 0, 200, 1, 3),         # 1x1 + SiLU, two N tiles
+    (1, 5, 7, 4, 0, 8, 3, 1),             # tiny
+])
+def test_conv_nhwc_split_bf16(ops, B, H, W, C1, C2, Cout, k, act):
+    x1 = rnd("x1", (B, C1, H, W), 1)
+    x2 = rnd("x2", (B, C2, H, W), 2) if C2 else None
+    w, b = rnd("w", (Cout, C1 + C2, k, k), 3, 1 / math.sqrt((C1 + C2) * k * k)), rnd("b", (Cout,), 4, 0.2)
+    xin = x1 if x2 is None else torch.cat([x1, x2], 1)
+    ref = F.conv2d(xin.double(), w.double(), b.double(), padding=k // 2).float()
+    ref = [ref, torch.relu(ref), F.leaky_relu(ref, 0.01), F.silu(ref)][act]
+    hi, lo = ops.prep_conv_weight(dev(w))
+    cl = torch.channels_last
+    got = ops.conv_nhwc(dev(x1).contiguous(memory_format=cl), None if x2 is None else dev(x2).contiguous(memory_format=cl),
+                        hi, lo, dev(b), k, act)
+    assert got.shape == ref.shape and got.is_contiguous(memory_format=cl)
+    assert rel_dev(got, ref) < SPLIT_TOL
+    res = rnd("res", tuple(ref.shape), 5)
+    got = ops.conv_nhwc(dev(x1), None if x2 is None else dev(x2), hi, lo, dev(b), k, act, residual=dev(res))
+    assert rel_dev(got, ref + res) < SPLIT_TOL
+
+
+def test_conv_nhwc_split_bf16_error_is_small_for_large_dynamic_range(ops):
+    """Operands spanning 6 decades: the split representation keeps fp32's exponent range (unlike fp16)."""
+    x = rnd("x", (1, 64, 12, 12), 1) * torch.logspace(-3, 3, 64).view(1, 64, 1, 1)
+    w = rnd("w", (32, 64, 3, 3), 2, 0.05) / torch.logspace(-3, 3, 64).view(1, 64, 1, 1)
+    ref = F.conv2d(x.double(), w.double(), None, padding=1).float()
+    hi, lo = ops.prep_conv_weight(dev(w))
+    got = ops.conv_nhwc(dev(x), None, hi, lo, None, 3)
+    assert rel_dev(got, ref) < SPLIT_TOL
