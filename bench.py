@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="no hipGraph: one Python-dispatched launch per kernel")
     a = ap.parse_args()
 
     from objcavit_amd import dp, hip_ops
@@ -135,8 +136,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    run = model
+    if not a.eager:
+        from objcavit_amd.graph import GraphedGraphBins
+        run = GraphedGraphBins(model, img)          # capture = part of warm-up; img is the graph's static input
+        log("forward captured into a hipGraph")
     for i in range(a.warmup):
-        out = model(img)
+        out = run(img)
         torch.cuda.synchronize()
         log(f"warm-up step {i} done")
     barrier()
@@ -145,14 +151,24 @@ def main():
     records = []
     t0 = time.perf_counter()
     for step in range(a.steps):
-        out = model(img)
+        out = run(img)
         records.append(dp.per_image_metrics(out.depth_pred, gt, 0.001, 10.0, first_image_id=(step * world + rank) * B))
     table = dp.gather_records(torch.cat(records, 0), world)      # the one collective of the job
     barrier()
     dt = time.perf_counter() - t0
-    timing = hip_ops.timing_results()
-    hip_ops.enable_timing(False)
+    timing = hip_ops.timing_results()          # graph mode: only the eager bin-head launch carries events here
     log(f"timed region done: {dt / a.steps * 1e3:.1f} ms/step")
+    if not a.eager:
+        # durations of the other hand-written entry points: one eager pass right after the timed region
+        n_head = timing.get("bin_head", (0, 0.0))
+        hip_ops.enable_timing(True)
+        for _ in range(3):
+            model(img)
+        extra = hip_ops.timing_results()
+        timing = {k: (v[0] / 3 * a.steps, v[1]) for k, v in extra.items()}
+        if n_head[0]:
+            timing["bin_head"] = n_head
+    hip_ops.enable_timing(False)
 
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
@@ -193,6 +209,7 @@ def main():
             "value": round(world * a.steps * B / dt, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "launch": "eager" if a.eager else "hipGraph replay (+1 eager bin-head launch) per step",
             "config": {"workload": "BASELINE configs[2]: ObjCAViT enet-b5 NYU 480x640, emb_dim=128, learned pos-MLP, "
                                    f"{N_OBJ} objs/img with random 512-d text features, bs={B} per GPU, random-init weights",
                        "global_batch": world * B, "image": [H, W], "objects_per_image": N_OBJ, "parallelism": f"dp{world}"},

@@ -102,8 +102,10 @@ class GraphBins(nn.Module):
         for m in self._frozen_params_module_list:
             yield from m.parameters()
 
-    def forward(self, image, object_features: Optional[List[torch.Tensor]] = None,
-                object_xywh_list: Optional[List[Optional[torch.Tensor]]] = None):
+    def forward_until_head(self, image, object_features: Optional[List[torch.Tensor]] = None,
+                           object_xywh_list: Optional[List[Optional[torch.Tensor]]] = None):
+        """Everything up to the inputs of the fused bin head: (feat, queries, centers, bin_edges, detections).
+        Split out so that a hipGraph can capture it while the head kernel stays individually timeable."""
         dense_features = self.dense_feature_extractor(image)
         detections = None
         if object_features is None:
@@ -113,6 +115,14 @@ class GraphBins(nn.Module):
         bin_widths_normed, feat, queries = self.objcavit.forward_parts(dense_features, object_features, object_xywh_list)
         ds = self.args[self.args.basic.dataset]
         bin_edges, centers = bin_edges_and_centers(bin_widths_normed, ds.min_depth, ds.max_depth)
+        return feat, queries, centers, bin_edges, detections
+
+    def head(self, feat, queries, centers):
         conv = self.conv_out[0]
-        depth_pred = hip_ops.bin_head(feat, queries, conv.weight.detach(), conv.bias.detach(), centers)
+        return hip_ops.bin_head(feat, queries, conv.weight.detach(), conv.bias.detach(), centers)
+
+    def forward(self, image, object_features: Optional[List[torch.Tensor]] = None,
+                object_xywh_list: Optional[List[Optional[torch.Tensor]]] = None):
+        feat, queries, centers, bin_edges, detections = self.forward_until_head(image, object_features, object_xywh_list)
+        depth_pred = self.head(feat, queries, centers)
         return self.ReturnType(depth_pred=depth_pred, bin_edges=bin_edges, detections=detections)

