@@ -1,9 +1,10 @@
 """hipGraph replay of the forward (BASELINE config 5 asks for a "hipGraph-captured forward").
 
-After the conv / transformer kernels were replaced the eager forward became HOST-bound: ~740 launches per step
-cost ~70 ms of Python / dispatch time against ~50 ms of GPU time at bs = 16.  Every C-ABI entry point only
-enqueues on the caller's stream (no allocation, no sync), so the whole forward is capturable with
-``torch.cuda.CUDAGraph`` (= hipGraph on ROCm): one replay per step.
+Every C-ABI entry point only enqueues on the caller's stream (no allocation, no sync), so the whole forward
+(~740 launches at bs = 16) is capturable with ``torch.cuda.CUDAGraph`` (= hipGraph on ROCm): one replay per step.
+Measured on MI355X / ROCm 7.2 (bench.py --graph): replay 77 ms per step against 51 ms for eager dispatch, whose
+launches the GPU already executes back to back (profiles/r01b) -- graph replay pays a per-node cost here, so it is
+kept as an option for launch-bound small batches, not as the default.
 
 ``GraphedGraphBins`` captures ``GraphBins.forward_until_head`` (shapes fixed by the example image; object boxes /
 features come from the model's provider and are baked in as static device tensors) and runs the fused bin-head
@@ -29,8 +30,8 @@ class GraphedGraphBins:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
-            self.feat, self.queries, self.centers, self.bin_edges, self.detections = \\
-                model.forward_until_head(self.static_image)
+            parts = model.forward_until_head(self.static_image)
+        self.feat, self.queries, self.centers, self.bin_edges, self.detections = parts
         self.ReturnType = model.ReturnType
 
     @torch.no_grad()
