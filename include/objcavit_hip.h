@@ -39,6 +39,7 @@ const char* ocv_last_error(void);
 #define OCV_ACT_RELU 1
 #define OCV_ACT_LEAKY_RELU 2 /* slope 0.01 (nn.LeakyReLU default) */
 #define OCV_ACT_SILU 3       /* x * sigmoid(x); convolution entry points only */
+#define OCV_ACT_SIGMOID 4    /* ocv_pointwise_conv_nhwc_fwd only (squeeze-excite gate) */
 
 /* out[z][m][n] = act( sum_k A[z][m][k] * W(n,k) + bias[n] )
  * W(n,k) = W[z][n*ldw + k] if w_kn == 0 (nn.Linear layout, [N,K])
@@ -155,6 +156,31 @@ int ocv_bin_head_fwd(const float* feat, int channels_last, const float* queries,
  * blocks that the reference runs through its hub backbone (modules/DenseFeatureExtractor.py:18-27,149). */
 int ocv_depthwise_conv_fwd(const float* in, const float* w, const float* bias, float* out, int B, int C, int H, int W,
                            int k, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, ocv_stream_t stream);
+
+/* NHWC building blocks of the EfficientNet MBConv stages (exact fp32):
+ * pointwise (1x1) convolution as a row GEMM with everything around it fused:
+ *   y[m][co] = act( bias[co] + sum_ci x[m][ci] * gate[m / rows_per_image][ci] * W[co][ci] ) + residual[m][co]
+ * x [M, Cin] (= [B,H,W,Cin]), W [Cout, Cin], gate (nullable) [B, Cin] = squeeze-excite gate applied to the INPUT,
+ * residual (nullable) [M, Cout]; Cin a multiple of 8; act any OCV_ACT_*.  Replaces conv_pw / conv_pwl / conv_head
+ * + BatchNorm + SiLU + the SE multiply + the skip add of the hub backbone's blocks
+ * (modules/DenseFeatureExtractor.py:18-27,149) and the SE fully-connected layers (with M = B). */
+int ocv_pointwise_conv_nhwc_fwd(const float* x, const float* gate, int rows_per_image, const float* W,
+                                const float* bias, const float* residual, float* y, long M, int Cin, int Cout, int act,
+                                ocv_stream_t stream);
+/* depthwise k x k (k in {3,5}, stride in {1,2}) on NHWC: in [B,H,W,C], w [k*k][C], out [B,Ho,Wo,C]; C % 4 == 0.
+ * Padding / bias / act as ocv_depthwise_conv_fwd. */
+int ocv_depthwise_conv_nhwc_fwd(const float* in, const float* w, const float* bias, float* out, int B, int C, int H,
+                                int W, int k, int stride, int pad_t, int pad_l, int Ho, int Wo, int act,
+                                ocv_stream_t stream);
+/* squeeze: out[b][c] = mean over the P = H*W pixels of x [B,P,C]; two-stage, fixed summation order. */
+size_t ocv_channel_mean_workspace_bytes(int B, int C, long P);
+int ocv_channel_mean_nhwc_fwd(const float* x, float* out, int B, int C, long P, void* workspace, size_t workspace_bytes,
+                              ocv_stream_t stream);
+
+/* squeeze-excite gate: gate[b][c] = sigmoid( b2[c] + sum_r w2[c][r] * silu( b1[r] + sum_c' w1[r][c'] * mean[b][c'] ) );
+ * mean / gate [B, C], w1 [R, C], w2 [C, R], R <= 256. */
+int ocv_se_gate_fwd(const float* mean, const float* w1, const float* b1, const float* w2, const float* b2, float* gate,
+                    int B, int C, int R, ocv_stream_t stream);
 
 /* Convolution k x k (k in {1,3}), stride 1, zero "same" padding, on NHWC fp32 activations, computed as an implicit
  * GEMM on the bf16 matrix cores with split-bf16 operands (x = hi + lo, 3 MFMAs per product, fp32 accumulate;

@@ -52,6 +52,12 @@ PROTOTYPES = {
     "ocv_bin_head_fwd": (C.c_int, [_f32p, C.c_int, _f32p, C.c_long, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, _stream]),
     "ocv_depthwise_conv_fwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p] + [C.c_int] * 11 + [_stream]),
+    "ocv_pointwise_conv_nhwc_fwd": (C.c_int, [_f32p, _f32p, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_long, C.c_int, C.c_int,
+                                              C.c_int, _stream]),
+    "ocv_depthwise_conv_nhwc_fwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p] + [C.c_int] * 11 + [_stream]),
+    "ocv_channel_mean_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_long]),
+    "ocv_channel_mean_nhwc_fwd": (C.c_int, [_f32p, _f32p, C.c_int, C.c_int, C.c_long, C.c_void_p, C.c_size_t, _stream]),
+    "ocv_se_gate_fwd": (C.c_int, [_f32p] * 6 + [C.c_int] * 3 + [_stream]),
     "ocv_conv_nhwc_fwd": (C.c_int, [_f32p, C.c_int, _f32p, C.c_int, C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p] +
                           [C.c_int] * 6 + [_stream]),
 }

@@ -17,7 +17,7 @@ import torch
 from . import _lib
 from ._lib import EncoderLayerParams, check
 
-ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_SILU = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_SILU, ACT_SIGMOID = 0, 1, 2, 3, 4
 
 
 def _stream() -> int:
@@ -499,3 +499,99 @@ def conv_nhwc(x1: torch.Tensor, x2: Optional[torch.Tensor], w_hi: torch.Tensor, 
         check(lib.ocv_conv_nhwc_fwd(x1.data_ptr(), C1, _ptr(x2), C2, w_hi.data_ptr(), w_lo.data_ptr(), _ptr(bias),
                                     _ptr(residual), y.data_ptr(), B, H, W, Cout, ksize, act, _stream()), "ocv_conv_nhwc_fwd")
     return y
+
+
+# ---------------------------------------------------------------------------
+# NHWC encoder blocks (pointwise conv with fused gate / bias / act / residual, depthwise, squeeze)
+# ---------------------------------------------------------------------------
+def pointwise_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = ACT_NONE,
+                   gate: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """1x1 convolution on a channels_last [B, C, H, W] tensor (or a plain [M, C] matrix): act(x*gate @ W^T + b) + res.
+    weight [Cout, Cin] (or [Cout, Cin, 1, 1]); gate [B, Cin]."""
+    lib = _lib.load()
+    four = x.dim() == 4
+    if four:
+        x = _nhwc(x, "x")
+        B, Cin, H, Wd = x.shape
+        M, rpi = B * H * Wd, H * Wd
+    else:
+        _req(x, "x")
+        M, Cin = x.shape
+        B, rpi = M, 1
+    w2 = _req(weight.reshape(weight.shape[0], -1), "weight")
+    Cout = w2.shape[0]
+    if w2.shape[1] != Cin:
+        raise ValueError(f"pointwise_nhwc: weight {tuple(weight.shape)} does not match {Cin} input channels")
+    if bias is not None:
+        _req(bias, "bias")
+        if bias.numel() != Cout:
+            raise ValueError("pointwise_nhwc: bias size mismatch")
+    if gate is not None:
+        _req(gate, "gate")
+        if gate.shape != (B, Cin):
+            raise ValueError(f"pointwise_nhwc: gate must be {(B, Cin)}, got {tuple(gate.shape)}")
+    if four:
+        y = torch.empty(B, Cout, H, Wd, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    else:
+        y = torch.empty(M, Cout, dtype=torch.float32, device=x.device)
+    if residual is not None:
+        residual = _nhwc(residual, "residual") if four else _req(residual, "residual")
+        if residual.shape != y.shape:
+            raise ValueError("pointwise_nhwc: residual shape mismatch")
+    with timed("pointwise"):
+        check(lib.ocv_pointwise_conv_nhwc_fwd(x.data_ptr(), _ptr(gate), rpi, w2.data_ptr(), _ptr(bias), _ptr(residual),
+                                              y.data_ptr(), M, Cin, Cout, act, _stream()), "ocv_pointwise_conv_nhwc_fwd")
+    return y
+
+
+def depthwise_nhwc_same(x: torch.Tensor, weight_kkc: torch.Tensor, bias: Optional[torch.Tensor], k: int, stride: int,
+                        act: int = ACT_NONE) -> torch.Tensor:
+    """Depthwise k x k conv, TF 'SAME' padding, channels_last in / out.  weight_kkc: [k*k, C] (tap-major)."""
+    lib = _lib.load()
+    x = _nhwc(x, "x")
+    _req(weight_kkc, "weight")
+    B, Cc, H, W = x.shape
+    if weight_kkc.shape != (k * k, Cc):
+        raise ValueError(f"depthwise_nhwc_same: weight {tuple(weight_kkc.shape)} does not match k={k}, C={Cc}")
+    if bias is not None:
+        _req(bias, "bias")
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    ph = max((Ho - 1) * stride + k - H, 0)
+    pw = max((Wo - 1) * stride + k - W, 0)
+    out = torch.empty(B, Cc, Ho, Wo, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    with timed("depthwise"):
+        check(lib.ocv_depthwise_conv_nhwc_fwd(x.data_ptr(), weight_kkc.data_ptr(), _ptr(bias), out.data_ptr(), B, Cc, H, W,
+                                              k, stride, ph // 2, pw // 2, Ho, Wo, act, _stream()),
+              "ocv_depthwise_conv_nhwc_fwd")
+    return out
+
+
+def channel_mean_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """[B, C] = mean over H, W of a channels_last [B, C, H, W] tensor."""
+    lib = _lib.load()
+    x = _nhwc(x, "x")
+    B, Cc, H, W = x.shape
+    nb = lib.ocv_channel_mean_workspace_bytes(B, Cc, H * W)
+    if nb == 0:
+        raise ValueError("channel_mean_nhwc: unsupported shape")
+    ws = workspace(nb, x.device, "mean")
+    out = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
+    check(lib.ocv_channel_mean_nhwc_fwd(x.data_ptr(), out.data_ptr(), B, Cc, H * W, ws.data_ptr(), ws.numel(), _stream()),
+          "ocv_channel_mean_nhwc_fwd")
+    return out
+
+
+def se_gate(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
+    """Squeeze-excite gate [B, C] of a channels_last activation: sigmoid(W2 silu(W1 mean_hw(x) + b1) + b2)."""
+    lib = _lib.load()
+    m = channel_mean_nhwc(x)
+    B, Cc = m.shape
+    for n, t in (("w1", w1), ("b1", b1), ("w2", w2), ("b2", b2)):
+        _req(t, n)
+    R = w1.shape[0]
+    if w1.shape != (R, Cc) or w2.shape != (Cc, R) or b1.numel() != R or b2.numel() != Cc:
+        raise ValueError("se_gate: parameter shape mismatch")
+    gate = torch.empty_like(m)
+    check(lib.ocv_se_gate_fwd(m.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), gate.data_ptr(), B,
+                              Cc, R, _stream()), "ocv_se_gate_fwd")
+    return gate

@@ -87,6 +87,26 @@ def fold_bn(conv: nn.Conv2d, bn: nn.Module):
     return (w * s.view(-1, 1, 1, 1)).contiguous(), ((b0 - bn.running_mean) * s + bn.bias.detach()).contiguous()
 
 
+def _dw_tap_major(w: torch.Tensor) -> torch.Tensor:
+    """depthwise weight [C, 1, k, k] -> [k*k, C] (the NHWC kernel reads 4 channels of one tap per lane)."""
+    return w.flatten(1).t().contiguous()
+
+
+def _se_params(se: "SqueezeExcite"):
+    return (se.conv_reduce.weight.detach().flatten(1).contiguous(), se.conv_reduce.bias.detach().contiguous(),
+            se.conv_expand.weight.detach().flatten(1).contiguous(), se.conv_expand.bias.detach().contiguous())
+
+
+class Conv1x1(nn.Conv2d):
+    """1x1 convolution without bias (conv_head); on the GPU in eval mode it runs as the NHWC pointwise kernel."""
+
+    def forward(self, x):
+        if (not self.training) and (not torch.is_grad_enabled()) and x.device.type == "cuda" and self.bias is None \
+                and x.shape[1] % 8 == 0:
+            return hip_ops.pointwise_nhwc(x, self.weight.detach(), None, hip_ops.ACT_NONE)
+        return super().forward(x)
+
+
 class _FoldedMixin:
     """Caches BN-folded weights for the inference fast path; dropped on train() / load_state_dict / device moves."""
 
@@ -127,14 +147,18 @@ class DepthwiseSeparableConv(_FoldedMixin, nn.Module):
         self.act2 = nn.Identity()
 
     def _fold(self):
-        return fold_bn(self.conv_dw, self.bn1) + fold_bn(self.conv_pw, self.bn2)
+        wd, bd = fold_bn(self.conv_dw, self.bn1)
+        wp, bp = fold_bn(self.conv_pw, self.bn2)
+        return (_dw_tap_major(wd), bd, wp.flatten(1).contiguous(), bp) + _se_params(self.se)
 
     def forward(self, x):
         if self._fast(x):
-            wd, bd, wp, bp = self._folded(x)
-            y = hip_ops.depthwise_conv_same(x.contiguous(), wd, bd, self.conv_dw.stride[0], hip_ops.ACT_SILU)
-            y = F.conv2d(self.se(y), wp, bp)
-            return y + x if self.has_residual else y
+            # NHWC plan: depthwise+BN+SiLU -> squeeze-excite gate -> 1x1 (+BN) with the gate on its input + skip add
+            wd, bd, wp, bp, s1, sb1, s2, sb2 = self._folded(x)
+            k = self.conv_dw.kernel_size[0]
+            y = hip_ops.depthwise_nhwc_same(x, wd, bd, k, self.conv_dw.stride[0], hip_ops.ACT_SILU)
+            g = hip_ops.se_gate(y, s1, sb1, s2, sb2)
+            return hip_ops.pointwise_nhwc(y, wp, bp, hip_ops.ACT_NONE, gate=g, residual=x if self.has_residual else None)
         y = self.act1(self.bn1(self.conv_dw(x)))
         y = self.act2(self.bn2(self.conv_pw(self.se(y))))
         return y + x if self.has_residual else y
@@ -156,15 +180,21 @@ class InvertedResidual(_FoldedMixin, nn.Module):
         self.bn3 = _bn(cout)
 
     def _fold(self):
-        return fold_bn(self.conv_pw, self.bn1) + fold_bn(self.conv_dw, self.bn2) + fold_bn(self.conv_pwl, self.bn3)
+        we, be = fold_bn(self.conv_pw, self.bn1)
+        wd, bd = fold_bn(self.conv_dw, self.bn2)
+        wl, bl = fold_bn(self.conv_pwl, self.bn3)
+        return (we.flatten(1).contiguous(), be, _dw_tap_major(wd), bd, wl.flatten(1).contiguous(), bl) + _se_params(self.se)
 
     def forward(self, x):
         if self._fast(x):
-            we, be, wd, bd, wl, bl = self._folded(x)
-            y = F.silu(F.conv2d(x, we, be), inplace=True)
-            y = hip_ops.depthwise_conv_same(y, wd, bd, self.conv_dw.stride[0], hip_ops.ACT_SILU)
-            y = F.conv2d(self.se(y), wl, bl)
-            return y + x if self.has_residual else y
+            # NHWC plan, 6 launches: expand 1x1 (+BN+SiLU) -> depthwise (+BN+SiLU) -> squeeze (2) -> gate ->
+            # project 1x1 (+BN) with the gate applied to its input rows and the skip connection added in the epilogue
+            we, be, wd, bd, wl, bl, s1, sb1, s2, sb2 = self._folded(x)
+            k = self.conv_dw.kernel_size[0]
+            y = hip_ops.pointwise_nhwc(x, we, be, hip_ops.ACT_SILU)
+            y = hip_ops.depthwise_nhwc_same(y, wd, bd, k, self.conv_dw.stride[0], hip_ops.ACT_SILU)
+            g = hip_ops.se_gate(y, s1, sb1, s2, sb2)
+            return hip_ops.pointwise_nhwc(y, wl, bl, hip_ops.ACT_NONE, gate=g, residual=x if self.has_residual else None)
         y = self.act1(self.bn1(self.conv_pw(x)))
         y = self.act2(self.bn2(self.conv_dw(y)))
         y = self.bn3(self.conv_pwl(self.se(y)))
@@ -187,7 +217,7 @@ class GenEfficientNet(nn.Module):
                 cin = cout
             blocks.append(nn.Sequential(*stage))
         self.blocks = nn.Sequential(*blocks)
-        self.conv_head = nn.Conv2d(cin, head, 1, bias=False)
+        self.conv_head = Conv1x1(cin, head, 1, bias=False)
         self.bn2 = _bn(head)
         self.act2 = nn.SiLU()
         self.global_pool = nn.AdaptiveAvgPool2d(1)

@@ -336,3 +336,52 @@ def test_conv_nhwc_split_bf16_error_is_small_for_large_dynamic_range(ops):
     hi, lo = ops.prep_conv_weight(dev(w))
     got = ops.conv_nhwc(dev(x), None, hi, lo, None, 3)
     assert rel_dev(got, ref) < SPLIT_TOL
+
+
+# ------------------------------------------------------------------ NHWC encoder blocks
+@pytest.mark.parametrize("B,H,W,Cin,Cout,act,use_gate,use_res", [
+    (2, 30, 40, 24, 144, 3, False, False),      # expand + SiLU
+    (2, 30, 40, 144, 24, 0, True, True),        # project with SE gate + skip (Cout <= 32 -> 128-row tiles)
+    (1, 15, 20, 512, 2048, 0, False, False),    # conv_head
+    (3, 7, 9, 240, 40, 0, True, False),         # Cout <= 64 tile
+    (1, 5, 5, 3072, 512, 0, True, True),        # K > one chunk
+    (2, 4, 4, 48, 200, 4, False, False),        # sigmoid, ragged N
+])
+def test_pointwise_nhwc(ops, B, H, W, Cin, Cout, act, use_gate, use_res):
+    x, w, b = rnd("x", (B, Cin, H, W), 1), rnd("w", (Cout, Cin, 1, 1), 2, 1 / math.sqrt(Cin)), rnd("b", (Cout,), 3, 0.2)
+    gate = torch.sigmoid(rnd("g", (B, Cin), 4)) if use_gate else None
+    res = rnd("r", (B, Cout, H, W), 5) if use_res else None
+    xin = x if gate is None else x * gate[:, :, None, None]
+    ref = F.conv2d(xin, w, b)
+    ref = [ref, torch.relu(ref), F.leaky_relu(ref, 0.01), F.silu(ref), torch.sigmoid(ref)][act]
+    if res is not None:
+        ref = ref + res
+    cl = torch.channels_last
+    got = ops.pointwise_nhwc(dev(x).contiguous(memory_format=cl), dev(w), dev(b), act,
+                             gate=None if gate is None else dev(gate),
+                             residual=None if res is None else dev(res).contiguous(memory_format=cl))
+    assert got.shape == ref.shape and got.is_contiguous(memory_format=cl)
+    assert rel_dev(got, ref) < TOL
+
+
+@pytest.mark.parametrize("k,s", [(3, 1), (3, 2), (5, 1), (5, 2)])
+@pytest.mark.parametrize("B,C,H,W", [(2, 48, 60, 80), (1, 8, 15, 20), (3, 12, 33, 47), (1, 4, 1, 1), (2, 144, 30, 41)])
+def test_depthwise_nhwc_same(ops, k, s, B, C, H, W):
+    x, w, b = rnd("x", (B, C, H, W), 1), rnd("w", (C, 1, k, k), 2, 0.3), rnd("b", (C,), 3, 0.2)
+    ref = F.silu(F.conv2d(_same_pad(x, k, s), w, b, stride=s, groups=C))
+    wt = dev(w).flatten(1).t().contiguous()
+    got = ops.depthwise_nhwc_same(dev(x).contiguous(memory_format=torch.channels_last), wt, dev(b), k, s, 3)
+    assert got.shape == ref.shape and rel_dev(got, ref) < TOL
+
+
+@pytest.mark.parametrize("B,C,H,W,R", [(16, 144, 120, 160, 6), (2, 48, 240, 320, 12), (3, 3072, 15, 20, 128), (1, 8, 1, 3, 2)])
+def test_channel_mean_and_se_gate(ops, B, C, H, W, R):
+    x = rnd("x", (B, C, H, W), 1)
+    xg = dev(x).contiguous(memory_format=torch.channels_last)
+    assert rel_dev(ops.channel_mean_nhwc(xg), x.mean((2, 3))) < TOL
+    w1, b1 = rnd("w1", (R, C), 2, 1 / math.sqrt(C)), rnd("b1", (R,), 3, 0.3)
+    w2, b2 = rnd("w2", (C, R), 4, 1 / math.sqrt(R)), rnd("b2", (C,), 5, 0.3)
+    ref = torch.sigmoid(F.silu(x.mean((2, 3)) @ w1.T + b1) @ w2.T + b2)
+    assert rel_dev(ops.se_gate(xg, dev(w1), dev(b1), dev(w2), dev(b2)), ref) < TOL
+    # deterministic two-stage reduction
+    assert torch.equal(ops.channel_mean_nhwc(xg), ops.channel_mean_nhwc(xg))
