@@ -177,9 +177,9 @@ size_t ocv_channel_mean_workspace_bytes(int B, int C, long P);
 int ocv_channel_mean_nhwc_fwd(const float* x, float* out, int B, int C, long P, void* workspace, size_t workspace_bytes,
                               ocv_stream_t stream);
 
-/* squeeze-excite gate: gate[b][c] = sigmoid( b2[c] + sum_r w2[c][r] * silu( b1[r] + sum_c' w1[r][c'] * mean[b][c'] ) );
- * mean / gate [B, C], w1 [R, C], w2 [C, R], R <= 256. */
-int ocv_se_gate_fwd(const float* mean, const float* w1, const float* b1, const float* w2, const float* b2, float* gate,
+/* squeeze-excite gate: gate[b][c] = sigmoid( b2[c] + sum_r w2t[r][c] * silu( b1[r] + sum_c' w1[r][c'] * mean[b][c'] ) );
+ * mean / gate [B, C], w1 [R, C] (conv_reduce), w2t [R, C] (conv_expand weight TRANSPOSED), R <= 256. */
+int ocv_se_gate_fwd(const float* mean, const float* w1, const float* b1, const float* w2t, const float* b2, float* gate,
                     int B, int C, int R, ocv_stream_t stream);
 
 /* Convolution k x k (k in {1,3}), stride 1, zero "same" padding, on NHWC fp32 activations, computed as an implicit

@@ -239,15 +239,16 @@ __global__ __launch_bounds__(256) void channel_mean_finish_kernel(const float* _
   out[i] = s * inv;
 }
 
-// squeeze-excite gate: gate[b][c] = sigmoid( b2[c] + sum_r W2[c][r] * silu( b1[r] + sum_c' W1[r][c'] * mean[b][c'] ) )
-// one workgroup per image; R <= 256 hidden units live in LDS.
+// squeeze-excite gate: gate[b][c] = sigmoid( b2[c] + sum_r W2t[r][c] * silu( b1[r] + sum_c' W1[r][c'] * mean[b][c'] ) )
+// grid (ceil(C / 256), B): every workgroup recomputes the R <= 256 hidden units of its image (one wavefront per unit,
+// coalesced rows of W1; R*C MACs, negligible) and then produces 256 gate channels with coalesced reads of W2^T.
 __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ mean, const float* __restrict__ w1,
-                                                      const float* __restrict__ b1, const float* __restrict__ w2,
+                                                      const float* __restrict__ b1, const float* __restrict__ w2t,
                                                       const float* __restrict__ b2, float* __restrict__ gate, int C,
                                                       int R) {
   __shared__ float hid[256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long b = blockIdx.x;
+  const long b = blockIdx.y;
   const float* mb = mean + b * C;
   for (int r = wave; r < R; r += 4) {
     const float* wr = w1 + (long)r * C;
@@ -260,10 +261,10 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const float* wc = w2 + (long)c * R;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < C) {
     float s = b2[c];
-    for (int r = 0; r < R; ++r) s = fmaf(wc[r], hid[r], s);
+    for (int r = 0; r < R; ++r) s = fmaf(w2t[(long)r * C + c], hid[r], s);
     gate[b * C + c] = 1.0f / (1.0f + fast_exp(-s));
   }
 }
@@ -333,11 +334,12 @@ extern "C" int ocv_channel_mean_nhwc_fwd(const float* x, float* out, int B, int 
   return 0;
 }
 
-extern "C" int ocv_se_gate_fwd(const float* mean, const float* w1, const float* b1, const float* w2, const float* b2,
+extern "C" int ocv_se_gate_fwd(const float* mean, const float* w1, const float* b1, const float* w2t, const float* b2,
                                float* gate, int B, int C, int R, ocv_stream_t stream) {
-  OCV_CHECK_ARG(mean && w1 && b1 && w2 && b2 && gate, "ocv_se_gate_fwd: null pointer");
-  OCV_CHECK_ARG(B >= 1 && C >= 1 && R >= 1 && R <= 256, "ocv_se_gate_fwd: bad sizes (R <= 256)");
-  hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, mean, w1, b1, w2, b2, gate, C, R);
+  OCV_CHECK_ARG(mean && w1 && b1 && w2t && b2 && gate, "ocv_se_gate_fwd: null pointer");
+  OCV_CHECK_ARG(B >= 1 && B <= 65535 && C >= 1 && R >= 1 && R <= 256, "ocv_se_gate_fwd: bad sizes (R <= 256)");
+  hipLaunchKernelGGL(se_gate_kernel, dim3(ocv_cdiv(C, 256), B), dim3(256), 0, (hipStream_t)stream, mean, w1, b1, w2t, b2,
+                     gate, C, R);
   OCV_CHECK_LAUNCH("ocv_se_gate_fwd");
   return 0;
 }

@@ -308,28 +308,31 @@ def _map4(t: torch.Tensor, name: str) -> Tuple[torch.Tensor, int]:
     return t.contiguous(), 0
 
 
-_CL_WEIGHTS: Dict[Tuple[int, int], torch.Tensor] = {}
+class ChannelsLastWeight:
+    """Per-owner cache of a conv weight in channels_last storage order [E, kh, kw, C].  Owned by the module that owns
+    the parameter (so the key (data_ptr, version) cannot alias another, already freed tensor)."""
 
+    def __init__(self):
+        self._key = None
+        self._val = None
 
-def _weight_channels_last(w: torch.Tensor) -> torch.Tensor:
-    """conv weight [E, C, kh, kw] in channels_last storage order [E, kh, kw, C] (cached per parameter version)."""
-    if w.is_contiguous(memory_format=torch.channels_last) and not w.is_contiguous():
-        return w
-    key = (w.data_ptr(), w._version)
-    hit = _CL_WEIGHTS.get(key)
-    if hit is None or hit.shape != w.shape:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("weight re-layout during graph capture: run one eager warm-up call first")
-        _CL_WEIGHTS.clear()
-        hit = w.contiguous(memory_format=torch.channels_last)
-        _CL_WEIGHTS[key] = hit
-    return hit
+    def get(self, w: torch.Tensor) -> torch.Tensor:
+        if w.is_contiguous(memory_format=torch.channels_last) and not w.is_contiguous():
+            return w
+        key = (w.data_ptr(), w._version, tuple(w.shape))
+        if key != self._key:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("weight re-layout during graph capture: run one eager warm-up call first")
+            self._val = w.detach().contiguous(memory_format=torch.channels_last)
+            self._key = key
+        return self._val
 
 
 def patch_embed(fmap: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
-                pos: Optional[torch.Tensor]) -> torch.Tensor:
+                pos: Optional[torch.Tensor], cl_cache: Optional[ChannelsLastWeight] = None) -> torch.Tensor:
     """tokens [B, S, E] = conv16x16/16(fmap) flattened + bias + pos; pos is [S, E] or [B, S, E].
-    fmap may be NCHW-contiguous or channels_last."""
+    fmap may be NCHW-contiguous or channels_last (then the weight is consumed in channels_last order; pass the
+    owner's ``cl_cache`` to avoid re-laying it out on every call)."""
     lib = _lib.load()
     fmap, cl = _map4(fmap, "fmap")
     _req(weight, "weight", contiguous=False)
@@ -337,7 +340,10 @@ def patch_embed(fmap: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.T
     E = weight.shape[0]
     if weight.shape != (E, Cc, 16, 16):
         raise ValueError(f"patch_embed: weight {tuple(weight.shape)} does not match fmap channels {Cc} / 16x16 patches")
-    weight = _weight_channels_last(weight) if cl else weight.contiguous()
+    if cl:
+        weight = cl_cache.get(weight) if cl_cache is not None else weight.contiguous(memory_format=torch.channels_last)
+    else:
+        weight = weight.contiguous()
     gh, gw = h // 16, w // 16
     S = gh * gw
     if S < 1:
@@ -581,17 +587,18 @@ def channel_mean_nhwc(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def se_gate(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
-    """Squeeze-excite gate [B, C] of a channels_last activation: sigmoid(W2 silu(W1 mean_hw(x) + b1) + b2)."""
+def se_gate(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2t: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
+    """Squeeze-excite gate [B, C] of a channels_last activation: sigmoid(W2 silu(W1 mean_hw(x) + b1) + b2).
+    w1 [R, C]; w2t [R, C] = W2 transposed (coalesced over channels)."""
     lib = _lib.load()
     m = channel_mean_nhwc(x)
     B, Cc = m.shape
-    for n, t in (("w1", w1), ("b1", b1), ("w2", w2), ("b2", b2)):
+    for n, t in (("w1", w1), ("b1", b1), ("w2t", w2t), ("b2", b2)):
         _req(t, n)
     R = w1.shape[0]
-    if w1.shape != (R, Cc) or w2.shape != (Cc, R) or b1.numel() != R or b2.numel() != Cc:
+    if w1.shape != (R, Cc) or w2t.shape != (R, Cc) or b1.numel() != R or b2.numel() != Cc:
         raise ValueError("se_gate: parameter shape mismatch")
     gate = torch.empty_like(m)
-    check(lib.ocv_se_gate_fwd(m.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), gate.data_ptr(), B,
+    check(lib.ocv_se_gate_fwd(m.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), gate.data_ptr(), B,
                               Cc, R, _stream()), "ocv_se_gate_fwd")
     return gate

@@ -94,7 +94,7 @@ def _dw_tap_major(w: torch.Tensor) -> torch.Tensor:
 
 def _se_params(se: "SqueezeExcite"):
     return (se.conv_reduce.weight.detach().flatten(1).contiguous(), se.conv_reduce.bias.detach().contiguous(),
-            se.conv_expand.weight.detach().flatten(1).contiguous(), se.conv_expand.bias.detach().contiguous())
+            se.conv_expand.weight.detach().flatten(1).t().contiguous(), se.conv_expand.bias.detach().contiguous())
 
 
 class Conv1x1(nn.Conv2d):

@@ -56,6 +56,7 @@ class PatchTransformerEncoder(nn.Module):
         self.embedding_convPxP = nn.Conv2d(in_channels, embedding_dim, kernel_size=patch_size, stride=patch_size, padding=0)
         self.positional_encodings = nn.Parameter(torch.rand(max_seq_len, embedding_dim), requires_grad=True)
         self._stack = HipEncoderStack(self.transformer_encoder)
+        self._w_cl = hip_ops.ChannelsLastWeight()
 
     def forward_batch_first(self, x: torch.Tensor) -> torch.Tensor:
         """B x S x E tokens (the layout the kernels work in)."""
@@ -65,7 +66,7 @@ class PatchTransformerEncoder(nn.Module):
         if S > self.positional_encodings.shape[0]:
             raise ValueError(f"sequence length {S} exceeds max_seq_len {self.positional_encodings.shape[0]}")
         tok = hip_ops.patch_embed(x, self.embedding_convPxP.weight.detach(), self.embedding_convPxP.bias.detach(),
-                                  self.positional_encodings.detach()[:S])
+                                  self.positional_encodings.detach()[:S], cl_cache=self._w_cl)
         return self._stack(tok)
 
     def forward(self, x):

@@ -382,6 +382,6 @@ def test_channel_mean_and_se_gate(ops, B, C, H, W, R):
     w1, b1 = rnd("w1", (R, C), 2, 1 / math.sqrt(C)), rnd("b1", (R,), 3, 0.3)
     w2, b2 = rnd("w2", (C, R), 4, 1 / math.sqrt(R)), rnd("b2", (C,), 5, 0.3)
     ref = torch.sigmoid(F.silu(x.mean((2, 3)) @ w1.T + b1) @ w2.T + b2)
-    assert rel_dev(ops.se_gate(xg, dev(w1), dev(b1), dev(w2), dev(b2)), ref) < TOL
+    assert rel_dev(ops.se_gate(xg, dev(w1), dev(b1), dev(w2).t().contiguous(), dev(b2)), ref) < TOL
     # deterministic two-stage reduction
     assert torch.equal(ops.channel_mean_nhwc(xg), ops.channel_mean_nhwc(xg))
