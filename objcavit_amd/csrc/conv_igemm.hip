@@ -53,8 +53,19 @@ struct ConvArgs {
   int mtiles, ntiles;
 };
 
-__device__ __forceinline__ void split4(const float4 v, __bf16* hi, __bf16* lo) {
-  const float f[4] = {v.x, v.y, v.z, v.w};
+// Global loads whose completion is counted BY HAND.  hipcc's own s_waitcnt insertion cannot express "wait for the
+// older of two in-flight register stages" across the loop back-edge (it emitted vmcnt(5..0), draining the younger
+// stage too), so the loads are issued from inline asm -- invisible to that pass -- and each stage is retired by an
+// explicit counted s_waitcnt whose asm statement takes the stage's registers as in/out operands: every consumer
+// is data-dependent on the wait and cannot be scheduled above it.
+__device__ __forceinline__ f32x4 gload16_async(const void* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+__device__ __forceinline__ void split4(const f32x4 v, __bf16* hi, __bf16* lo) {
+  const float f[4] = {v[0], v[1], v[2], v[3]};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const __bf16 h = (__bf16)f[i];
@@ -102,10 +113,12 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
   const int cchunks = p.Cp / CBK;
   const int nsteps = taps * cchunks;
 
-  float4 ra[4];
-  uint4 rbh, rbl;
+  // Two register stages: the global loads of K step s+2 are issued while step s is multiplied and step s+1's loads
+  // are still in flight, so every load has two full steps (>= 2 x 1536 matrix-pipe cycles) to land before it is
+  // converted and written to LDS -- one step of cover was not enough under load (27 % -> see DESIGN.md).
+  struct Stage { f32x4 ra[4]; f32x4 rbh, rbl; unsigned ok; };
 
-  auto issue_loads = [&](int step) {
+  auto issue_loads = [&](int step, Stage& st) {
     const int tap = step / cchunks, c0 = (step - tap * cchunks) * CBK;
     const int ky = tap / p.ks, kx = tap - ky * p.ks;
     const int iy = ay + ky - pad, ix = ax + kx - pad;
@@ -115,21 +128,40 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
     int cend;
     if (c0 < p.C1) { src = p.x1 + pix * p.C1 + c0; cend = p.C1 - c0; }
     else { src = p.x2 + pix * p.C2 + (c0 - p.C1); cend = p.Cin - c0; }
+    // Unconditional loads (out-of-image taps / channel tails read a safe address and are zeroed by a select):
+    // a load inside an exec-masked branch makes hipcc fall back to s_waitcnt vmcnt(0), which would drain the
+    // younger stage's loads as well and undo the two-step prefetch.
+    // The zeroing select is deferred to write_lds (stage.ok): touching the loaded registers here would make the
+    // compiler wait for the load at once.
+    st.ok = 0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int c = acol + 4 * e;
-      ra[e] = (inb && c + 4 <= cend) ? ld4(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool ok = inb && c + 4 <= cend;
+      st.ra[e] = gload16_async(ok ? src + c : p.x1);
+      st.ok |= ok ? (1u << e) : 0u;
     }
     const long woff = ((long)tap * p.Cout + bn) * p.Cp + c0 + bcol;
-    rbh = *reinterpret_cast<const uint4*>(p.whi + woff);
-    rbl = *reinterpret_cast<const uint4*>(p.wlo + woff);
+    st.rbh = gload16_async(p.whi + woff);
+    st.rbl = gload16_async(p.wlo + woff);
   };
+  // retire a stage: N = number of YOUNGER loads that may stay in flight (6 = the other stage, 0 = none)
+#define OCV_RETIRE(st, N)                                                                                              \
+  asm volatile("s_waitcnt vmcnt(" #N ")"                                                                               \
+               : "+v"(st.ra[0]), "+v"(st.ra[1]), "+v"(st.ra[2]), "+v"(st.ra[3]), "+v"(st.rbh), "+v"(st.rbl)           \
+               :                                                                                                       \
+               : "memory")
 
-  auto write_lds = [&](int buf) {
+  auto write_lds = [&](int buf, Stage& st) {
     unsigned char* base = lds + buf * BUF_BYTES;
     __bf16 hi[16], lo[16];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) split4(ra[e], hi + 4 * e, lo + 4 * e);
+    for (int e = 0; e < 4; ++e) {
+      const bool ok = (st.ok >> e) & 1u;
+      const f32x4 t = st.ra[e];
+      const f32x4 z = {ok ? t[0] : 0.f, ok ? t[1] : 0.f, ok ? t[2] : 0.f, ok ? t[3] : 0.f};
+      split4(z, hi + 4 * e, lo + 4 * e);
+    }
     unsigned char* ah = base + arow * ROWB + acol * 2;
     unsigned char* al = ah + A_BYTES;
     *reinterpret_cast<bf16x8*>(ah) = *reinterpret_cast<bf16x8*>(hi);
@@ -137,8 +169,8 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
     *reinterpret_cast<bf16x8*>(al) = *reinterpret_cast<bf16x8*>(lo);
     *reinterpret_cast<bf16x8*>(al + 16) = *reinterpret_cast<bf16x8*>(lo + 8);
     unsigned char* bh = base + 2 * A_BYTES + brow * ROWB + bcol * 2;
-    *reinterpret_cast<uint4*>(bh) = rbh;
-    *reinterpret_cast<uint4*>(bh + B_BYTES) = rbl;
+    *reinterpret_cast<f32x4*>(bh) = st.rbh;
+    *reinterpret_cast<f32x4*>(bh + B_BYTES) = st.rbl;
   };
 
   f32x16 acc[2][2];
@@ -147,15 +179,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0};
 
-  issue_loads(0);
-  write_lds(0);
-  __syncthreads();
-
-  for (int step = 0; step < nsteps; ++step) {
-    const int buf = step & 1;
-    const bool more = step + 1 < nsteps;
-    if (more) issue_loads(step + 1);
-
+  auto compute = [&](int buf) {
     const unsigned char* base = lds + buf * BUF_BYTES;
     const unsigned char* pa = base + (wm * 64 + l31) * ROWB + hh * 16;
     const unsigned char* pb = base + 2 * A_BYTES + (wn * 64 + l31) * ROWB + hh * 16;
@@ -178,9 +202,37 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
-    if (more) write_lds(buf ^ 1);
+  };
+
+  Stage s0, s1;
+  issue_loads(0, s0);
+  OCV_RETIRE(s0, 0);
+  write_lds(0, s0);
+  __syncthreads();
+  if (nsteps > 1) issue_loads(1, s1);
+
+  for (int step = 0; step < nsteps; step += 2) {
+    // even step: multiply buffer 0; step+1 is in flight in s1; fetch step+2 into s0
+    const bool more2 = step + 2 < nsteps;
+    if (more2) issue_loads(step + 2, s0);
+    compute(0);
+    if (step + 1 < nsteps) {
+      if (more2) OCV_RETIRE(s1, 6); else OCV_RETIRE(s1, 0);
+      write_lds(1, s1);
+    }
+    __syncthreads();
+    if (step + 1 >= nsteps) break;
+    // odd step: multiply buffer 1; step+2 is in flight in s0; fetch step+3 into s1
+    const bool more3 = step + 3 < nsteps;
+    if (more3) issue_loads(step + 3, s1);
+    compute(1);
+    if (more2) {
+      if (more3) OCV_RETIRE(s0, 6); else OCV_RETIRE(s0, 0);
+      write_lds(0, s0);
+    }
     __syncthreads();
   }
+#undef OCV_RETIRE
 
   // ---- epilogue: bias, activation, optional residual, NHWC store (128-byte runs per half-wave)
 #pragma unroll
