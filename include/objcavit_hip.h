@@ -178,9 +178,10 @@ int ocv_channel_mean_nhwc_fwd(const float* x, float* out, int B, int C, long P, 
                               ocv_stream_t stream);
 
 /* squeeze-excite gate: gate[b][c] = sigmoid( b2[c] + sum_r w2t[r][c] * silu( b1[r] + sum_c' w1[r][c'] * mean[b][c'] ) );
- * mean / gate [B, C], w1 [R, C] (conv_reduce), w2t [R, C] (conv_expand weight TRANSPOSED), R <= 256. */
+ * mean / gate [B, C], w1 [R, C] (conv_reduce), w2t [R, C] (conv_expand weight TRANSPOSED), R <= 256;
+ * hidden_ws: caller scratch of B*R floats. */
 int ocv_se_gate_fwd(const float* mean, const float* w1, const float* b1, const float* w2t, const float* b2, float* gate,
-                    int B, int C, int R, ocv_stream_t stream);
+                    float* hidden_ws, int B, int C, int R, ocv_stream_t stream);
 
 /* Convolution k x k (k in {1,3}), stride 1, zero "same" padding, on NHWC fp32 activations, computed as an implicit
  * GEMM on the bf16 matrix cores with split-bf16 operands (x = hi + lo, 3 MFMAs per product, fp32 accumulate;

@@ -10,7 +10,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libobjcavit_hip.so")
+LIB_PATH = os.environ.get("OCV_LIB_PATH") or os.path.join(_HERE, "lib", "libobjcavit_hip.so")   # env: diagnostic builds
 
 _f32p = C.c_void_p      # device pointers travel as integers
 _u8p = C.c_void_p
@@ -57,7 +57,7 @@ PROTOTYPES = {
     "ocv_depthwise_conv_nhwc_fwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p] + [C.c_int] * 11 + [_stream]),
     "ocv_channel_mean_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_long]),
     "ocv_channel_mean_nhwc_fwd": (C.c_int, [_f32p, _f32p, C.c_int, C.c_int, C.c_long, C.c_void_p, C.c_size_t, _stream]),
-    "ocv_se_gate_fwd": (C.c_int, [_f32p] * 6 + [C.c_int] * 3 + [_stream]),
+    "ocv_se_gate_fwd": (C.c_int, [_f32p] * 7 + [C.c_int] * 3 + [_stream]),
     "ocv_conv_nhwc_fwd": (C.c_int, [_f32p, C.c_int, _f32p, C.c_int, C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p] +
                           [C.c_int] * 6 + [_stream]),
 }

@@ -44,7 +44,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src in SOURCES:
         obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
         cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-c",
-               os.path.join(CSRC, src), "-o", obj]
+               os.path.join(CSRC, src), "-o", obj] + os.environ.get("OCV_EXTRA_HIPCC_FLAGS", "").split()
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -23,15 +23,21 @@
 // and split into hi/lo in registers on its way to LDS.  Weights are split once
 // on the host into two bf16 arrays laid out [tap][Cout][Cin rounded up to 32].
 //
-// Tile: 256 pixels x 128 channels per workgroup of 8 wavefronts (4 x 2, each
-// 64 x 64 = 2 x 2 accumulators of 32x32); K advances 32 channels of one tap per
-// step through a double-buffered LDS image (A_hi, A_lo, B_hi, B_lo; rows padded
-// to 80 bytes so the 16-byte fragment reads of 16 consecutive rows land in 16
-// different bank slots).  Per step and wavefront: 16 ds_read_b128, 24 MFMAs;
-// the next step's global loads are issued before the MFMAs and converted /
-// written to the other buffer after them; one barrier per step.
-// Workgroup ids are remapped so that the N-tiles of one pixel tile run on the
-// same XCD and share its A rows in that XCD's L2.
+// Tile: 256 pixels x 128 channels per workgroup; K advances 32 channels of one tap per step (channel chunk outer,
+// tap inner: the nine taps of a chunk re-read the same L2-resident lines) through a double-buffered LDS image
+// (A_hi, A_lo, B_hi, B_lo; rows padded to 80 bytes so the 16-byte fragment reads of 16 consecutive rows land in
+// 16 different bank slots).
+//
+// The 8 wavefronts are SPECIALISED (first version: every wavefront did everything; PMC: 8.5 VALU instructions per
+// MFMA, matrix pipe 32 % busy -- the address / bounds / fp32->hi,lo conversion work of a step ran in lock-step on
+// all waves between two barriers and could not overlap the MFMAs):
+//   waves 0-3  CONSUMERS: 2 x 2 over the tile, 128 x 64 outputs each (8 accumulators); per step 24 ds_read_b128 and
+//              48 MFMAs, nothing else.
+//   waves 4-7  PRODUCERS: gather the next A chunk (4 rows x 32 B per lane, out-of-image taps read a zero page, no
+//              selects), split it into hi/lo, fetch the pre-split weight chunk, write the other LDS buffer.  Loads
+//              run two steps ahead in two register stages retired by hand-counted s_waitcnt (inline-asm loads).
+// One consumer and one producer wave share each SIMD: matrix pipe and VALU run side by side; one barrier per step.
+// Workgroup ids are remapped so that the N-tiles of one pixel tile run on the same XCD and share its L2.
 #include "common.hpp"
 #include "../../include/objcavit_hip.h"
 
@@ -60,7 +66,11 @@ struct ConvArgs {
 // is data-dependent on the wait and cannot be scheduled above it.
 __device__ __forceinline__ f32x4 gload16_async(const void* p) {
   f32x4 v;
+#ifdef OCV_ABL_NOLOAD
+  asm volatile("v_mov_b32 %0, 0" : "=v"(v) : "v"(p));
+#else
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+#endif
   return v;
 }
 
@@ -74,12 +84,23 @@ __device__ __forceinline__ void split4(const f32x4 v, __bf16* hi, __bf16* lo) {
   }
 }
 
+__device__ __attribute__((aligned(256))) float ocv_zero_page[64];      // zero-initialised: source of padded taps
+
+// Diagnostic build only (-DOCV_STAMPS): per-phase cycle sums of workgroup 0 (s_memtime), never in the product build.
+#ifdef OCV_STAMPS
+__device__ unsigned long long ocv_conv_stamps[16];
+#define STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
+#define STAMP_ADD(slot, t0, t1) do { if (blockIdx.x == 0 && lane == 0) stamp_acc[slot] += (t1) - (t0); } while (0)
+#else
+#define STAMP(var)
+#define STAMP_ADD(slot, t0, t1)
+#endif
+
 __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
 
   // ---- XCD-aware, bijective workgroup -> tile map: consecutive tiles (N fastest) share an XCD
   const int nwg = p.mtiles * p.ntiles;
@@ -91,173 +112,237 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
   const int mt = wg / p.ntiles, nt = wg - mt * p.ntiles;
   const long m0 = (long)mt * CBM;
   const int n0 = nt * CBN;
+  const int taps = p.ks * p.ks, pad = p.ks >> 1;
+  const int nsteps = taps * (p.Cp / CBK);
 
-  // ---- A-gather role: thread -> (row = tid / 2, 16 channels at (tid & 1) * 16)
-  const int arow = tid >> 1, acol = (tid & 1) * 16;
-  const long am = m0 + arow;
-  const bool avalid = am < p.M;
-  int ay = 0, ax = 0;
-  long apix = 0;
-  if (avalid) {
-    const long hw = (long)p.H * p.W;
-    const long b = am / hw, rem = am - b * hw;
-    ay = (int)(rem / p.W);
-    ax = (int)(rem - (long)ay * p.W);
-    apix = am;                            // NHWC pixel index == m
-  }
-  const int pad = p.ks >> 1;
-  // ---- B role: thread -> (n = tid / 4, 8 channels at (tid & 3) * 8)
-  const int brow = tid >> 2, bcol = (tid & 3) * 8;
-  const int bn = min(n0 + brow, p.Cout - 1);
-  const int taps = p.ks * p.ks;
-  const int cchunks = p.Cp / CBK;
-  const int nsteps = taps * cchunks;
-
-  // Two register stages: the global loads of K step s+2 are issued while step s is multiplied and step s+1's loads
-  // are still in flight, so every load has two full steps (>= 2 x 1536 matrix-pipe cycles) to land before it is
-  // converted and written to LDS -- one step of cover was not enough under load (27 % -> see DESIGN.md).
-  struct Stage { f32x4 ra[4]; f32x4 rbh, rbl; unsigned ok; };
-
-  auto issue_loads = [&](int step, Stage& st) {
-    const int tap = step / cchunks, c0 = (step - tap * cchunks) * CBK;
-    const int ky = tap / p.ks, kx = tap - ky * p.ks;
-    const int iy = ay + ky - pad, ix = ax + kx - pad;
-    const bool inb = avalid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-    const long pix = apix + (long)(ky - pad) * p.W + (kx - pad);
-    const float* src;
-    int cend;
-    if (c0 < p.C1) { src = p.x1 + pix * p.C1 + c0; cend = p.C1 - c0; }
-    else { src = p.x2 + pix * p.C2 + (c0 - p.C1); cend = p.Cin - c0; }
-    // Unconditional loads (out-of-image taps / channel tails read a safe address and are zeroed by a select):
-    // a load inside an exec-masked branch makes hipcc fall back to s_waitcnt vmcnt(0), which would drain the
-    // younger stage's loads as well and undo the two-step prefetch.
-    // The zeroing select is deferred to write_lds (stage.ok): touching the loaded registers here would make the
-    // compiler wait for the load at once.
-    st.ok = 0;
+  if (wave < 4) {
+    // =========================== CONSUMERS ===========================
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[4][2];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = acol + 4 * e;
-      const bool ok = inb && c + 4 <= cend;
-      st.ra[e] = gload16_async(ok ? src + c : p.x1);
-      st.ok |= ok ? (1u << e) : 0u;
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0};
+
+#ifdef OCV_STAMPS
+    unsigned long long stamp_acc[4] = {0, 0, 0, 0};
+#endif
+    __syncthreads();                                   // buffer 0 written by the producers' prologue
+    for (int step = 0; step < nsteps; ++step) {
+      STAMP(tc0);
+      const unsigned char* base = lds + (step & 1) * BUF_BYTES;
+      const unsigned char* pa = base + (wm * 128 + l31) * ROWB + hh * 16;
+      const unsigned char* pb = base + 2 * A_BYTES + (wn * 64 + l31) * ROWB + hh * 16;
+      // all 24 fragment reads of the step are issued up front: the second k-slice's reads return while the first
+      // slice's 24 MFMAs run (the only matrix-pipe wave of this SIMD would otherwise sit through their latency)
+      bf16x8 ah[2][4], al[2][4], bh[2][2], bl[2][2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          bh[kk][j] = *reinterpret_cast<const bf16x8*>(pb + j * 32 * ROWB + kk * 32);
+          bl[kk][j] = *reinterpret_cast<const bf16x8*>(pb + B_BYTES + j * 32 * ROWB + kk * 32);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          ah[kk][i] = *reinterpret_cast<const bf16x8*>(pa + i * 32 * ROWB + kk * 32);
+          al[kk][i] = *reinterpret_cast<const bf16x8*>(pa + A_BYTES + i * 32 * ROWB + kk * 32);
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk][i], bh[kk][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk][i], bl[kk][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kk][i], bh[kk][j], acc[i][j], 0, 0, 0);
+          }
+      STAMP(tc1);
+      __syncthreads();
+      STAMP(tc2);
+      STAMP_ADD(0, tc0, tc1);       // consumer: reads + MFMAs
+      STAMP_ADD(1, tc1, tc2);       // consumer: barrier wait
     }
-    const long woff = ((long)tap * p.Cout + bn) * p.Cp + c0 + bcol;
-    st.rbh = gload16_async(p.whi + woff);
-    st.rbl = gload16_async(p.wlo + woff);
+#ifdef OCV_STAMPS
+    if (blockIdx.x == 0 && tid == 0) { ocv_conv_stamps[0] = stamp_acc[0]; ocv_conv_stamps[1] = stamp_acc[1]; ocv_conv_stamps[7] = nsteps; }
+#endif
+
+    // ---- epilogue: bias, activation, optional residual, NHWC store (128-byte runs per half-wave)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + l31;
+      const bool nok = n < p.Cout;
+      const float bv = (p.bias != nullptr && nok) ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long m = m0 + wm * 128 + i * 32 + acc_row(r, hh);
+          if (nok && m < p.M) {
+            float v = acc[i][j][r] + bv;
+            if (p.act == OCV_ACT_LEAKY_RELU) v = v > 0.f ? v : 0.01f * v;
+            else if (p.act == OCV_ACT_SILU) v = v / (1.0f + fast_exp(-v));
+            else if (p.act == OCV_ACT_RELU) v = fmaxf(v, 0.f);
+            if (p.res != nullptr) v += p.res[m * p.Cout + n];
+            p.y[m * p.Cout + n] = v;
+          }
+        }
+    }
+    return;
+  }
+
+  // =========================== PRODUCERS ===========================
+  // All per-lane address work is hoisted out of the K loop (measured with s_memtime stamps: the first version
+  // spent 2200 of a step's 3600 producer cycles on 64-bit index arithmetic, divisions and bounds tests):
+  //   * per row: byte offsets of the pixel in both source tensors (32-bit; tensors are < 4 GiB, checked on the
+  //     host) and a 9-bit mask of the taps that fall inside the image;
+  //   * per step: one scalar byte offset for (tap shift, channel chunk); tap / chunk counters advance
+  //     incrementally (loads are issued strictly in step order), no division.
+  const int pt = tid - 256;                            // 0..255
+  // A role: 4 lanes per row (32 B = 8 channels each); rows (pt >> 2) + 64 i, i = 0..3
+  const int apart = (pt & 3) * 8;
+  unsigned rb1[4], rb2[4], tapmask[4];
+  {
+    const long hw = (long)p.H * p.W;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long am = m0 + (pt >> 2) + 64 * i;
+      const bool valid = am < p.M;
+      const long rem = valid ? am % hw : 0;
+      const int y = (int)(rem / p.W), x = (int)(rem - (long)y * p.W);
+      unsigned mask = 0;
+      for (int t = 0; t < taps; ++t) {
+        const int dy = t / p.ks - pad, dx = t % p.ks - pad;
+        if (valid && (unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W) mask |= 1u << t;
+      }
+      tapmask[i] = mask;
+      const long pix = valid ? am : 0;
+      rb1[i] = (unsigned)((pix * p.C1 + apart) * 4);
+      rb2[i] = (unsigned)((pix * p.C2 + apart) * 4);
+    }
+  }
+  // B role: 2 lanes per weight row (16 channels = 32 B each, hi and lo)
+  const int brow = pt >> 1, bcol = (pt & 1) * 16;
+  const int bn = min(n0 + brow, p.Cout - 1);
+  const unsigned wrow = (unsigned)(((long)bn * p.Cp + bcol) * 2);       // byte offset inside one tap's [Cout][Cp] slab
+  const unsigned wtap = (unsigned)((long)p.Cout * p.Cp * 2);             // bytes per tap slab
+
+  struct Stage { f32x4 a[8]; f32x4 bh[2], bl[2]; };
+
+  int nx_tap = 0, nx_c0 = 0;                                             // (tap, chunk) of the next step to issue
+  auto issue_loads = [&](Stage& st) {
+    const int tap = nx_tap, c0 = nx_c0;
+    if (++nx_tap == taps) { nx_tap = 0; nx_c0 += CBK; }
+    const int ky = tap / p.ks, kx = tap - ky * p.ks;                     // scalar, ks in {1, 3}
+    const bool first = c0 < p.C1;
+    const char* tbase = (const char*)(first ? p.x1 : p.x2);
+    const int tc = first ? p.C1 : p.C2;
+    const int cin = first ? c0 : c0 - p.C1;                              // chunk start inside the source tensor
+    // scalar byte offset of this (tap, chunk): (dy*W + dx) pixels and cin channels
+    const int soff = (((ky - pad) * p.W + (kx - pad)) * tc + cin) * 4;
+    const bool cok0 = cin + apart + 4 <= tc, cok1 = cin + apart + 8 <= tc;   // channel tail of a partial chunk
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool inb = (tapmask[i] >> tap) & 1u;
+      const unsigned off = (first ? rb1[i] : rb2[i]) + (unsigned)soff;
+      const char* src = tbase + off;
+      st.a[2 * i + 0] = gload16_async((inb && cok0) ? (const void*)src : (const void*)ocv_zero_page);
+      st.a[2 * i + 1] = gload16_async((inb && cok1) ? (const void*)(src + 16) : (const void*)ocv_zero_page);
+    }
+    const unsigned woff = (unsigned)tap * wtap + wrow + (unsigned)c0 * 2;
+    st.bh[0] = gload16_async((const char*)p.whi + woff);
+    st.bh[1] = gload16_async((const char*)p.whi + woff + 16);
+    st.bl[0] = gload16_async((const char*)p.wlo + woff);
+    st.bl[1] = gload16_async((const char*)p.wlo + woff + 16);
   };
-  // retire a stage: N = number of YOUNGER loads that may stay in flight (6 = the other stage, 0 = none)
-#define OCV_RETIRE(st, N)                                                                                              \
-  asm volatile("s_waitcnt vmcnt(" #N ")"                                                                               \
-               : "+v"(st.ra[0]), "+v"(st.ra[1]), "+v"(st.ra[2]), "+v"(st.ra[3]), "+v"(st.rbh), "+v"(st.rbl)           \
-               :                                                                                                       \
+  // retire a stage: N = number of YOUNGER loads that may stay in flight (12 = the other stage, 0 = none)
+#define OCV_RETIRE(st, N)                                                                                             \
+  asm volatile("s_waitcnt vmcnt(" #N ")"                                                                              \
+               : "+v"(st.a[0]), "+v"(st.a[1]), "+v"(st.a[2]), "+v"(st.a[3]), "+v"(st.a[4]), "+v"(st.a[5]),           \
+                 "+v"(st.a[6]), "+v"(st.a[7]), "+v"(st.bh[0]), "+v"(st.bh[1]), "+v"(st.bl[0]), "+v"(st.bl[1])        \
+               :                                                                                                      \
                : "memory")
 
   auto write_lds = [&](int buf, Stage& st) {
+#ifdef OCV_ABL_NOWRITE
+    asm volatile("" :: "v"(st.a[0]), "v"(st.a[7]), "v"(st.bh[0]), "v"(st.bl[1]));
+    return;
+#endif
     unsigned char* base = lds + buf * BUF_BYTES;
-    __bf16 hi[16], lo[16];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const bool ok = (st.ok >> e) & 1u;
-      const f32x4 t = st.ra[e];
-      const f32x4 z = {ok ? t[0] : 0.f, ok ? t[1] : 0.f, ok ? t[2] : 0.f, ok ? t[3] : 0.f};
-      split4(z, hi + 4 * e, lo + 4 * e);
+    for (int i = 0; i < 4; ++i) {
+      __bf16 hi[8], lo[8];
+#ifdef OCV_ABL_NOCONVERT
+      *reinterpret_cast<f32x4*>(hi) = st.a[2 * i + 0];
+      *reinterpret_cast<f32x4*>(lo) = st.a[2 * i + 1];
+#else
+      split4(st.a[2 * i + 0], hi, lo);
+      split4(st.a[2 * i + 1], hi + 4, lo + 4);
+#endif
+      unsigned char* ah = base + ((pt >> 2) + 64 * i) * ROWB + apart * 2;
+      *reinterpret_cast<bf16x8*>(ah) = *reinterpret_cast<bf16x8*>(hi);
+      *reinterpret_cast<bf16x8*>(ah + A_BYTES) = *reinterpret_cast<bf16x8*>(lo);
     }
-    unsigned char* ah = base + arow * ROWB + acol * 2;
-    unsigned char* al = ah + A_BYTES;
-    *reinterpret_cast<bf16x8*>(ah) = *reinterpret_cast<bf16x8*>(hi);
-    *reinterpret_cast<bf16x8*>(ah + 16) = *reinterpret_cast<bf16x8*>(hi + 8);
-    *reinterpret_cast<bf16x8*>(al) = *reinterpret_cast<bf16x8*>(lo);
-    *reinterpret_cast<bf16x8*>(al + 16) = *reinterpret_cast<bf16x8*>(lo + 8);
     unsigned char* bh = base + 2 * A_BYTES + brow * ROWB + bcol * 2;
-    *reinterpret_cast<f32x4*>(bh) = st.rbh;
-    *reinterpret_cast<f32x4*>(bh + B_BYTES) = st.rbl;
+    *reinterpret_cast<f32x4*>(bh) = st.bh[0];
+    *reinterpret_cast<f32x4*>(bh + 16) = st.bh[1];
+    *reinterpret_cast<f32x4*>(bh + B_BYTES) = st.bl[0];
+    *reinterpret_cast<f32x4*>(bh + B_BYTES + 16) = st.bl[1];
   };
 
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0};
-
-  auto compute = [&](int buf) {
-    const unsigned char* base = lds + buf * BUF_BYTES;
-    const unsigned char* pa = base + (wm * 64 + l31) * ROWB + hh * 16;
-    const unsigned char* pb = base + 2 * A_BYTES + (wn * 64 + l31) * ROWB + hh * 16;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        ah[i] = *reinterpret_cast<const bf16x8*>(pa + i * 32 * ROWB + kk * 32);
-        al[i] = *reinterpret_cast<const bf16x8*>(pa + A_BYTES + i * 32 * ROWB + kk * 32);
-        bh[i] = *reinterpret_cast<const bf16x8*>(pb + i * 32 * ROWB + kk * 32);
-        bl[i] = *reinterpret_cast<const bf16x8*>(pb + B_BYTES + i * 32 * ROWB + kk * 32);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-        }
-    }
-  };
-
+#ifdef OCV_STAMPS
+  unsigned long long stamp_acc[4] = {0, 0, 0, 0};
+#endif
   Stage s0, s1;
-  issue_loads(0, s0);
+  issue_loads(s0);
   OCV_RETIRE(s0, 0);
   write_lds(0, s0);
   __syncthreads();
-  if (nsteps > 1) issue_loads(1, s1);
+  if (nsteps > 1) issue_loads(s1);
 
   for (int step = 0; step < nsteps; step += 2) {
-    // even step: multiply buffer 0; step+1 is in flight in s1; fetch step+2 into s0
+    // even step (consumers multiply buffer 0): step+1 is in flight in s1; fetch step+2 into s0
     const bool more2 = step + 2 < nsteps;
-    if (more2) issue_loads(step + 2, s0);
-    compute(0);
+    STAMP(tp0);
+    if (more2) issue_loads(s0);
+    STAMP(tp1);
     if (step + 1 < nsteps) {
-      if (more2) OCV_RETIRE(s1, 6); else OCV_RETIRE(s1, 0);
-      write_lds(1, s1);
+      if (more2) OCV_RETIRE(s1, 12); else OCV_RETIRE(s1, 0);
     }
+    STAMP(tp2);
+    if (step + 1 < nsteps) write_lds(1, s1);
+    STAMP(tp3);
     __syncthreads();
+    STAMP(tp4);
+    STAMP_ADD(0, tp0, tp1);         // producer: address math + load issue
+    STAMP_ADD(1, tp1, tp2);         // producer: wait for the older stage
+    STAMP_ADD(2, tp2, tp3);         // producer: convert + LDS write
+    STAMP_ADD(3, tp3, tp4);         // producer: barrier wait
     if (step + 1 >= nsteps) break;
-    // odd step: multiply buffer 1; step+2 is in flight in s0; fetch step+3 into s1
+    // odd step (consumers multiply buffer 1): step+2 is in flight in s0; fetch step+3 into s1
     const bool more3 = step + 3 < nsteps;
-    if (more3) issue_loads(step + 3, s1);
-    compute(1);
+    if (more3) issue_loads(s1);
     if (more2) {
-      if (more3) OCV_RETIRE(s0, 6); else OCV_RETIRE(s0, 0);
+      if (more3) OCV_RETIRE(s0, 12); else OCV_RETIRE(s0, 0);
       write_lds(0, s0);
     }
     __syncthreads();
   }
 #undef OCV_RETIRE
-
-  // ---- epilogue: bias, activation, optional residual, NHWC store (128-byte runs per half-wave)
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + l31;
-    const bool nok = n < p.Cout;
-    const float bv = (p.bias != nullptr && nok) ? p.bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long m = m0 + wm * 64 + i * 32 + acc_row(r, hh);
-        if (nok && m < p.M) {
-          float v = acc[i][j][r] + bv;
-          if (p.act == OCV_ACT_LEAKY_RELU) v = v > 0.f ? v : 0.01f * v;
-          else if (p.act == OCV_ACT_SILU) v = v / (1.0f + fast_exp(-v));
-          else if (p.act == OCV_ACT_RELU) v = fmaxf(v, 0.f);
-          if (p.res != nullptr) v += p.res[m * p.Cout + n];
-          p.y[m * p.Cout + n] = v;
-        }
-      }
-  }
+#ifdef OCV_STAMPS
+  if (blockIdx.x == 0 && tid == 256) { for (int i = 0; i < 4; ++i) ocv_conv_stamps[2 + i] = stamp_acc[i]; }
+#endif
 }
 
 }  // namespace
+
+#ifdef OCV_STAMPS
+extern "C" int ocv_conv_read_stamps(unsigned long long* out16) {
+  return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(ocv_conv_stamps), 16 * sizeof(unsigned long long));
+}
+#endif
 
 extern "C" int ocv_conv_nhwc_fwd(const float* x1, int C1, const float* x2, int C2, const void* w_hi, const void* w_lo,
                                  const float* bias, const float* residual, float* y, int B, int H, int W, int Cout,
@@ -270,6 +355,9 @@ extern "C" int ocv_conv_nhwc_fwd(const float* x1, int C1, const float* x2, int C
   OCV_CHECK_ARG(act >= 0 && act <= 3, "ocv_conv_nhwc_fwd: unknown activation %d", act);
   OCV_CHECK_ARG(ocv_aligned16(x1) && ocv_aligned16(x2) && ocv_aligned16(w_hi) && ocv_aligned16(w_lo),
                 "ocv_conv_nhwc_fwd: operands must be 16-byte aligned");
+  OCV_CHECK_ARG((long)B * H * W * C1 * 4 < (1L << 32) && (long)B * H * W * (x2 ? C2 : 0) * 4 < (1L << 32) &&
+                    9L * Cout * (C1 + C2 + 32) * 2 < (1L << 32),
+                "ocv_conv_nhwc_fwd: each operand must be smaller than 4 GiB (32-bit byte offsets inside the kernel)");
   ConvArgs a;
   a.x1 = x1; a.x2 = x2; a.whi = (const __bf16*)w_hi; a.wlo = (const __bf16*)w_lo;
   a.bias = bias; a.res = residual; a.y = y;

@@ -112,6 +112,74 @@ __global__ __launch_bounds__(256) void pointwise_kernel(PWArgs p) {
   }
 }
 
+// Small-K variant (K <= 128, the HBM-bound expand / DS-project layers: 24 -> 144 at 240 x 320 moves 826 MB for
+// 8 GFLOP).  A workgroup stages 128 rows ONCE, each wavefront keeps its own 32 rows and walks ALL column tiles
+// itself (weights re-fetched per tile from L2, K/8 float4 per lane), so the activation rows are read from HBM
+// exactly once whatever Cout is, and there are 4x fewer, 4x longer workgroups than with one 32 x 128 tile each
+// (that form ran at 1.7 TB/s, dispatch- and latency-bound).
+__global__ __launch_bounds__(256) void pointwise_smallk_kernel(PWArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float Xs[];      // [128][XLD]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const long m0 = (long)blockIdx.x * 128;
+  const int K = p.K;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (tid >> 3) + 32 * i;
+    const long m = m0 + row;
+    const bool ok = m < p.M;
+    const float* src = p.x + m * K;
+    const float* gsrc = (p.gate != nullptr && ok) ? p.gate + (m / p.rows_per_image) * K : nullptr;
+#pragma unroll
+    for (int j = 0; j < KC / 32; ++j) {
+      const int c4 = (tid & 7) * 4 + 32 * j;
+      if (c4 < K) {
+        float4 t = ok ? ld4(src + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gsrc != nullptr) {
+          const float4 g = ld4(gsrc + c4);
+          t.x *= g.x; t.y *= g.y; t.z *= g.z; t.w *= g.w;
+        }
+        *reinterpret_cast<float4*>(&Xs[row * XLD + c4]) = t;
+      }
+    }
+  }
+  __syncthreads();
+  const float* xrow = Xs + (wave * 32 + l31) * XLD + 4 * hh;
+  float4 a[KC / 8];
+#pragma unroll
+  for (int t = 0; t < KC / 8; ++t)
+    a[t] = (8 * t < K) ? *reinterpret_cast<const float4*>(xrow + 8 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+  const int ntiles = (p.N + 31) >> 5;
+  for (int nt = 0; nt < ntiles; ++nt) {
+    const int n = nt * 32 + l31;
+    const float* wrow = p.W + (long)(n < p.N ? n : p.N - 1) * K + 4 * hh;
+    f32x16 acc = {0};
+#pragma unroll
+    for (int t = 0; t < KC / 8; ++t) {
+      if (8 * t < K) {
+        const float4 w = ld4(wrow + 8 * t);
+        acc = mfma_32x32x2(a[t].x, w.x, acc);
+        acc = mfma_32x32x2(a[t].y, w.y, acc);
+        acc = mfma_32x32x2(a[t].z, w.z, acc);
+        acc = mfma_32x32x2(a[t].w, w.w, acc);
+      }
+    }
+    if (n < p.N) {
+      const float bv = p.bias != nullptr ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = m0 + wave * 32 + acc_row(r, hh);
+        if (m < p.M) {
+          float v = apply_act(acc[r] + bv, p.act);
+          if (p.res != nullptr) v += p.res[m * p.N + n];
+          p.y[m * p.N + n] = v;
+        }
+      }
+    }
+  }
+}
+
 template <int WN>
 int launch_pw(const PWArgs& a, hipStream_t st) {
   constexpr int RM = 128 / WN;
@@ -239,34 +307,55 @@ __global__ __launch_bounds__(256) void channel_mean_finish_kernel(const float* _
   out[i] = s * inv;
 }
 
-// squeeze-excite gate: gate[b][c] = sigmoid( b2[c] + sum_r W2t[r][c] * silu( b1[r] + sum_c' W1[r][c'] * mean[b][c'] ) )
-// grid (ceil(C / 256), B): every workgroup recomputes the R <= 256 hidden units of its image (one wavefront per unit,
-// coalesced rows of W1; R*C MACs, negligible) and then produces 256 gate channels with coalesced reads of W2^T.
-__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ mean, const float* __restrict__ w1,
-                                                      const float* __restrict__ b1, const float* __restrict__ w2t,
-                                                      const float* __restrict__ b2, float* __restrict__ gate, int C,
-                                                      int R) {
-  __shared__ float hid[256];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// squeeze-excite gate, two tiny launches (both latency-bound; every loop is unrolled for independent loads):
+//   hid[b][r]  = silu( b1[r] + sum_c W1[r][c] * mean[b][c] )          one wavefront per (r, b), coalesced over c
+//   gate[b][c] = sigmoid( b2[c] + sum_r W2t[r][c] * hid[b][r] )       one lane per (c, b), coalesced over c
+__global__ __launch_bounds__(256) void se_hidden_kernel(const float* __restrict__ mean, const float* __restrict__ w1,
+                                                        const float* __restrict__ b1, float* __restrict__ hid, int C,
+                                                        int R) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
   const long b = blockIdx.y;
   const float* mb = mean + b * C;
-  for (int r = wave; r < R; r += 4) {
-    const float* wr = w1 + (long)r * C;
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s = fmaf(wr[c], mb[c], s);
-    s = wave_sum(s);
-    if (lane == 0) {
-      const float v = s + b1[r];
-      hid[r] = v / (1.0f + fast_exp(-v));
-    }
+  const float* wr = w1 + (long)r * C;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int c = lane;
+  for (; c + 192 < C; c += 256) {
+    s0 = fmaf(wr[c], mb[c], s0);
+    s1 = fmaf(wr[c + 64], mb[c + 64], s1);
+    s2 = fmaf(wr[c + 128], mb[c + 128], s2);
+    s3 = fmaf(wr[c + 192], mb[c + 192], s3);
   }
+  for (; c < C; c += 64) s0 = fmaf(wr[c], mb[c], s0);
+  const float s = wave_sum((s0 + s1) + (s2 + s3));
+  if (lane == 0) {
+    const float v = s + b1[r];
+    hid[b * R + r] = v / (1.0f + fast_exp(-v));
+  }
+}
+
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ hid, const float* __restrict__ w2t,
+                                                      const float* __restrict__ b2, float* __restrict__ gate, int C,
+                                                      int R) {
+  __shared__ float hs[256];
+  const long b = blockIdx.y;
+  if (threadIdx.x < R) hs[threadIdx.x] = hid[b * R + threadIdx.x];
   __syncthreads();
   const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c < C) {
-    float s = b2[c];
-    for (int r = 0; r < R; ++r) s = fmaf(w2t[(long)r * C + c], hid[r], s);
-    gate[b * C + c] = 1.0f / (1.0f + fast_exp(-s));
+  if (c >= C) return;
+  const float* w = w2t + c;
+  float s0 = b2[c], s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = 0;
+  for (; r + 3 < R; r += 4) {
+    s0 = fmaf(w[(long)r * C], hs[r], s0);
+    s1 = fmaf(w[(long)(r + 1) * C], hs[r + 1], s1);
+    s2 = fmaf(w[(long)(r + 2) * C], hs[r + 2], s2);
+    s3 = fmaf(w[(long)(r + 3) * C], hs[r + 3], s3);
   }
+  for (; r < R; ++r) s0 = fmaf(w[(long)r * C], hs[r], s0);
+  const float s = (s0 + s1) + (s2 + s3);
+  gate[b * C + c] = 1.0f / (1.0f + fast_exp(-s));
 }
 
 int mean_splits(int B, int C, long P) {
@@ -289,6 +378,16 @@ extern "C" int ocv_pointwise_conv_nhwc_fwd(const float* x, const float* gate, in
   if (M == 0) return 0;
   PWArgs a{x, gate, W, bias, residual, y, M, Cin, Cout, rows_per_image > 0 ? rows_per_image : 1, act};
   hipStream_t st = (hipStream_t)stream;
+  if (Cin <= KC && M >= 4096) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)pointwise_smallk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr = true;
+    }
+    hipLaunchKernelGGL(pointwise_smallk_kernel, dim3((unsigned)((M + 127) / 128)), dim3(256), (size_t)128 * XLD * sizeof(float), st, a);
+    OCV_CHECK_LAUNCH("ocv_pointwise_conv_nhwc_fwd(small K)");
+    return 0;
+  }
   if (Cout <= 32) return launch_pw<1>(a, st);
   if (Cout <= 64) return launch_pw<2>(a, st);
   return launch_pw<4>(a, st);
@@ -335,10 +434,12 @@ extern "C" int ocv_channel_mean_nhwc_fwd(const float* x, float* out, int B, int 
 }
 
 extern "C" int ocv_se_gate_fwd(const float* mean, const float* w1, const float* b1, const float* w2t, const float* b2,
-                               float* gate, int B, int C, int R, ocv_stream_t stream) {
-  OCV_CHECK_ARG(mean && w1 && b1 && w2t && b2 && gate, "ocv_se_gate_fwd: null pointer");
+                               float* gate, float* hidden_ws, int B, int C, int R, ocv_stream_t stream) {
+  OCV_CHECK_ARG(mean && w1 && b1 && w2t && b2 && gate && hidden_ws, "ocv_se_gate_fwd: null pointer");
   OCV_CHECK_ARG(B >= 1 && B <= 65535 && C >= 1 && R >= 1 && R <= 256, "ocv_se_gate_fwd: bad sizes (R <= 256)");
-  hipLaunchKernelGGL(se_gate_kernel, dim3(ocv_cdiv(C, 256), B), dim3(256), 0, (hipStream_t)stream, mean, w1, b1, w2t, b2,
+  hipLaunchKernelGGL(se_hidden_kernel, dim3(ocv_cdiv(R, 4), B), dim3(256), 0, (hipStream_t)stream, mean, w1, b1, hidden_ws, C, R);
+  OCV_CHECK_LAUNCH("ocv_se_gate_fwd(hidden)");
+  hipLaunchKernelGGL(se_gate_kernel, dim3(ocv_cdiv(C, 256), B), dim3(256), 0, (hipStream_t)stream, hidden_ws, w2t, b2,
                      gate, C, R);
   OCV_CHECK_LAUNCH("ocv_se_gate_fwd");
   return 0;

@@ -599,6 +599,7 @@ def se_gate(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2t: torch.Tens
     if w1.shape != (R, Cc) or w2t.shape != (R, Cc) or b1.numel() != R or b2.numel() != Cc:
         raise ValueError("se_gate: parameter shape mismatch")
     gate = torch.empty_like(m)
-    check(lib.ocv_se_gate_fwd(m.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), gate.data_ptr(), B,
-                              Cc, R, _stream()), "ocv_se_gate_fwd")
+    hid = workspace(B * R * 4, x.device, "se_hidden")
+    check(lib.ocv_se_gate_fwd(m.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), gate.data_ptr(),
+                              hid.data_ptr(), B, Cc, R, _stream()), "ocv_se_gate_fwd")
     return gate
