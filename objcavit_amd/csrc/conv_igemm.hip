@@ -34,8 +34,7 @@
 //   waves 0-3  CONSUMERS: 2 x 2 over the tile, 128 x 64 outputs each (8 accumulators); per step 24 ds_read_b128 and
 //              48 MFMAs, nothing else.
 //   waves 4-7  PRODUCERS: gather the next A chunk (4 rows x 32 B per lane, out-of-image taps read a zero page, no
-//              selects), split it into hi/lo, fetch the pre-split weight chunk, write the other LDS buffer.  Loads
-//              run two steps ahead in two register stages retired by hand-counted s_waitcnt (inline-asm loads).
+//              selects), split it into hi/lo, fetch the pre-split weight chunk, write the other LDS buffer.
 // One consumer and one producer wave share each SIMD: matrix pipe and VALU run side by side; one barrier per step.
 // Workgroup ids are remapped so that the N-tiles of one pixel tile run on the same XCD and share its L2.
 #include "common.hpp"
@@ -59,20 +58,11 @@ struct ConvArgs {
   int mtiles, ntiles;
 };
 
-// Global loads whose completion is counted BY HAND.  hipcc's own s_waitcnt insertion cannot express "wait for the
-// older of two in-flight register stages" across the loop back-edge (it emitted vmcnt(5..0), draining the younger
-// stage too), so the loads are issued from inline asm -- invisible to that pass -- and each stage is retired by an
-// explicit counted s_waitcnt whose asm statement takes the stage's registers as in/out operands: every consumer
-// is data-dependent on the wait and cannot be scheduled above it.
-__device__ __forceinline__ f32x4 gload16_async(const void* p) {
-  f32x4 v;
-#ifdef OCV_ABL_NOLOAD
-  asm volatile("v_mov_b32 %0, 0" : "=v"(v) : "v"(p));
-#else
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-#endif
-  return v;
-}
+// 16-byte global load (compiler-visible: hipcc tracks it and inserts the s_waitcnt before the first use).
+// An earlier version issued these from inline asm with hand-counted waits to keep two register stages in flight;
+// the register allocator is free to COPY such a destination register before the load has landed (it did, at the loop
+// back-edge), which reads stale data -- a silent, history-dependent corruption.  Never hide an in-flight load.
+__device__ __forceinline__ f32x4 gload16(const void* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 __device__ __forceinline__ void split4(const f32x4 v, __bf16* hi, __bf16* lo) {
   const float f[4] = {v[0], v[1], v[2], v[3]};
@@ -248,23 +238,15 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
       const bool inb = (tapmask[i] >> tap) & 1u;
       const unsigned off = (first ? rb1[i] : rb2[i]) + (unsigned)soff;
       const char* src = tbase + off;
-      st.a[2 * i + 0] = gload16_async((inb && cok0) ? (const void*)src : (const void*)ocv_zero_page);
-      st.a[2 * i + 1] = gload16_async((inb && cok1) ? (const void*)(src + 16) : (const void*)ocv_zero_page);
+      st.a[2 * i + 0] = gload16((inb && cok0) ? (const void*)src : (const void*)ocv_zero_page);
+      st.a[2 * i + 1] = gload16((inb && cok1) ? (const void*)(src + 16) : (const void*)ocv_zero_page);
     }
     const unsigned woff = (unsigned)tap * wtap + wrow + (unsigned)c0 * 2;
-    st.bh[0] = gload16_async((const char*)p.whi + woff);
-    st.bh[1] = gload16_async((const char*)p.whi + woff + 16);
-    st.bl[0] = gload16_async((const char*)p.wlo + woff);
-    st.bl[1] = gload16_async((const char*)p.wlo + woff + 16);
+    st.bh[0] = gload16((const char*)p.whi + woff);
+    st.bh[1] = gload16((const char*)p.whi + woff + 16);
+    st.bl[0] = gload16((const char*)p.wlo + woff);
+    st.bl[1] = gload16((const char*)p.wlo + woff + 16);
   };
-  // retire a stage: N = number of YOUNGER loads that may stay in flight (12 = the other stage, 0 = none)
-#define OCV_RETIRE(st, N)                                                                                             \
-  asm volatile("s_waitcnt vmcnt(" #N ")"                                                                              \
-               : "+v"(st.a[0]), "+v"(st.a[1]), "+v"(st.a[2]), "+v"(st.a[3]), "+v"(st.a[4]), "+v"(st.a[5]),           \
-                 "+v"(st.a[6]), "+v"(st.a[7]), "+v"(st.bh[0]), "+v"(st.bh[1]), "+v"(st.bl[0]), "+v"(st.bl[1])        \
-               :                                                                                                      \
-               : "memory")
-
   auto write_lds = [&](int buf, Stage& st) {
 #ifdef OCV_ABL_NOWRITE
     asm volatile("" :: "v"(st.a[0]), "v"(st.a[7]), "v"(st.bh[0]), "v"(st.bl[1]));
@@ -292,48 +274,19 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
     *reinterpret_cast<f32x4*>(bh + B_BYTES + 16) = st.bl[1];
   };
 
-#ifdef OCV_STAMPS
-  unsigned long long stamp_acc[4] = {0, 0, 0, 0};
-#endif
-  Stage s0, s1;
-  issue_loads(s0);
-  OCV_RETIRE(s0, 0);
-  write_lds(0, s0);
+  // One register stage: the loads of step s+1 are issued at the top of step s and converted / written to the other
+  // LDS buffer in the same step, while the consumers multiply the current buffer; one barrier per step.
+  Stage st;
+  issue_loads(st);
+  write_lds(0, st);
   __syncthreads();
-  if (nsteps > 1) issue_loads(s1);
-
-  for (int step = 0; step < nsteps; step += 2) {
-    // even step (consumers multiply buffer 0): step+1 is in flight in s1; fetch step+2 into s0
-    const bool more2 = step + 2 < nsteps;
-    STAMP(tp0);
-    if (more2) issue_loads(s0);
-    STAMP(tp1);
+  for (int step = 0; step < nsteps; ++step) {
     if (step + 1 < nsteps) {
-      if (more2) OCV_RETIRE(s1, 12); else OCV_RETIRE(s1, 0);
-    }
-    STAMP(tp2);
-    if (step + 1 < nsteps) write_lds(1, s1);
-    STAMP(tp3);
-    __syncthreads();
-    STAMP(tp4);
-    STAMP_ADD(0, tp0, tp1);         // producer: address math + load issue
-    STAMP_ADD(1, tp1, tp2);         // producer: wait for the older stage
-    STAMP_ADD(2, tp2, tp3);         // producer: convert + LDS write
-    STAMP_ADD(3, tp3, tp4);         // producer: barrier wait
-    if (step + 1 >= nsteps) break;
-    // odd step (consumers multiply buffer 1): step+2 is in flight in s0; fetch step+3 into s1
-    const bool more3 = step + 3 < nsteps;
-    if (more3) issue_loads(s1);
-    if (more2) {
-      if (more3) OCV_RETIRE(s0, 12); else OCV_RETIRE(s0, 0);
-      write_lds(0, s0);
+      issue_loads(st);
+      write_lds((step + 1) & 1, st);
     }
     __syncthreads();
   }
-#undef OCV_RETIRE
-#ifdef OCV_STAMPS
-  if (blockIdx.x == 0 && tid == 256) { for (int i = 0; i < 4; ++i) ocv_conv_stamps[2 + i] = stamp_acc[i]; }
-#endif
 }
 
 }  // namespace
