@@ -184,21 +184,30 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
   }
 
   // =========================== PRODUCERS ===========================
-  // All per-lane address work is hoisted out of the K loop (measured with s_memtime stamps: the first version
-  // spent 2200 of a step's 3600 producer cycles on 64-bit index arithmetic, divisions and bounds tests):
-  //   * per row: byte offsets of the pixel in both source tensors (32-bit; tensors are < 4 GiB, checked on the
-  //     host) and a 9-bit mask of the taps that fall inside the image;
-  //   * per step: one scalar byte offset for (tap shift, channel chunk); tap / chunk counters advance
-  //     incrementally (loads are issued strictly in step order), no division.
-  const int pt = tid - 256;                            // 0..255
-  // A role: 4 lanes per row (32 B = 8 channels each); rows (pt >> 2) + 64 i, i = 0..3
-  const int apart = (pt & 3) * 8;
-  unsigned rb1[4], rb2[4], tapmask[4];
+  // Two producer groups (waves 4-5 and 6-7) ALTERNATE: group g owns the K steps t = g, g+2, g+4, ...  A step's data
+  // may only be written to LDS during the interval before it is consumed (its buffer is being read in the one before
+  // that), so with a single group the global-load latency sat on the critical path of every step (1.8 us per step
+  // against 0.8 us of MFMAs).  Each group now has TWO intervals per step it owns:
+  //     interval t-1 (after writing step t):  issue the loads of step t+2          (>= one interval to land)
+  //     interval t   ("convert" interval)   :  wait, split fp32 -> bf16 hi/lo into registers
+  //     interval t+1 ("write" interval)     :  ds_write step t+2, then issue step t+4 ...
+  // while the other group does the same shifted by one interval.  Every wave has at most one stage of loads in
+  // flight and all loads are ordinary, compiler-visible loads (see gload16): exact s_waitcnt, no stale registers.
+  //
+  // All per-lane address work is hoisted out of the K loop (s_memtime stamps showed 2200 of 3600 producer cycles per
+  // step in 64-bit index arithmetic, divisions and bounds tests): per row the byte offsets of the pixel in both source
+  // tensors (32-bit; operands < 4 GiB, checked on the host) and a 9-bit mask of in-image taps; per step one scalar
+  // byte offset for (tap shift, channel chunk); tap / chunk counters advance incrementally.
+  const int g = (wave - 4) >> 1;                       // producer group
+  const int gt = tid - 256 - 128 * g;                  // 0..127 inside the group
+  // A role: 4 lanes per row (32 B = 8 channels each); rows (gt >> 2) + 32 i, i = 0..7
+  const int apart = (gt & 3) * 8;
+  unsigned rb1[8], rb2[8], tapmask[8];
   {
     const long hw = (long)p.H * p.W;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const long am = m0 + (pt >> 2) + 64 * i;
+    for (int i = 0; i < 8; ++i) {
+      const long am = m0 + (gt >> 2) + 32 * i;
       const bool valid = am < p.M;
       const long rem = valid ? am % hw : 0;
       const int y = (int)(rem / p.W), x = (int)(rem - (long)y * p.W);
@@ -213,28 +222,32 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
       rb2[i] = (unsigned)((pix * p.C2 + apart) * 4);
     }
   }
-  // B role: 2 lanes per weight row (16 channels = 32 B each, hi and lo)
-  const int brow = pt >> 1, bcol = (pt & 1) * 16;
-  const int bn = min(n0 + brow, p.Cout - 1);
-  const unsigned wrow = (unsigned)(((long)bn * p.Cp + bcol) * 2);       // byte offset inside one tap's [Cout][Cp] slab
+  // B role: one weight row per lane (32 channels: 64 B of hi, 64 B of lo)
+  const int bn = min(n0 + gt, p.Cout - 1);
+  const unsigned wrow = (unsigned)((long)bn * p.Cp * 2);                 // byte offset inside one tap's [Cout][Cp] slab
   const unsigned wtap = (unsigned)((long)p.Cout * p.Cp * 2);             // bytes per tap slab
 
-  struct Stage { f32x4 a[8]; f32x4 bh[2], bl[2]; };
+  struct Raw { f32x4 a[16]; f32x4 bh[4], bl[4]; };                       // one step as loaded
+  struct Cvt { bf16x8 ahi[8], alo[8]; };                                 // its A part, split
 
-  int nx_tap = 0, nx_c0 = 0;                                             // (tap, chunk) of the next step to issue
-  auto issue_loads = [&](Stage& st) {
+  int nx_tap = g % taps, nx_c0 = (g / taps) * CBK;                       // (tap, chunk) of this group's next step
+  auto advance = [&]() {                                                 // += 2 steps
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+      if (++nx_tap == taps) { nx_tap = 0; nx_c0 += CBK; }
+  };
+  auto issue_loads = [&](Raw& st) {
     const int tap = nx_tap, c0 = nx_c0;
-    if (++nx_tap == taps) { nx_tap = 0; nx_c0 += CBK; }
+    advance();
     const int ky = tap / p.ks, kx = tap - ky * p.ks;                     // scalar, ks in {1, 3}
     const bool first = c0 < p.C1;
     const char* tbase = (const char*)(first ? p.x1 : p.x2);
     const int tc = first ? p.C1 : p.C2;
     const int cin = first ? c0 : c0 - p.C1;                              // chunk start inside the source tensor
-    // scalar byte offset of this (tap, chunk): (dy*W + dx) pixels and cin channels
-    const int soff = (((ky - pad) * p.W + (kx - pad)) * tc + cin) * 4;
+    const int soff = (((ky - pad) * p.W + (kx - pad)) * tc + cin) * 4;   // scalar byte offset of (tap, chunk)
     const bool cok0 = cin + apart + 4 <= tc, cok1 = cin + apart + 8 <= tc;   // channel tail of a partial chunk
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
       const bool inb = (tapmask[i] >> tap) & 1u;
       const unsigned off = (first ? rb1[i] : rb2[i]) + (unsigned)soff;
       const char* src = tbase + off;
@@ -242,48 +255,56 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
       st.a[2 * i + 1] = gload16((inb && cok1) ? (const void*)(src + 16) : (const void*)ocv_zero_page);
     }
     const unsigned woff = (unsigned)tap * wtap + wrow + (unsigned)c0 * 2;
-    st.bh[0] = gload16((const char*)p.whi + woff);
-    st.bh[1] = gload16((const char*)p.whi + woff + 16);
-    st.bl[0] = gload16((const char*)p.wlo + woff);
-    st.bl[1] = gload16((const char*)p.wlo + woff + 16);
-  };
-  auto write_lds = [&](int buf, Stage& st) {
-#ifdef OCV_ABL_NOWRITE
-    asm volatile("" :: "v"(st.a[0]), "v"(st.a[7]), "v"(st.bh[0]), "v"(st.bl[1]));
-    return;
-#endif
-    unsigned char* base = lds + buf * BUF_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int e = 0; e < 4; ++e) {
+      st.bh[e] = gload16((const char*)p.whi + woff + 16 * e);
+      st.bl[e] = gload16((const char*)p.wlo + woff + 16 * e);
+    }
+  };
+  auto convert = [&](const Raw& st, Cvt& cv) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
       __bf16 hi[8], lo[8];
-#ifdef OCV_ABL_NOCONVERT
-      *reinterpret_cast<f32x4*>(hi) = st.a[2 * i + 0];
-      *reinterpret_cast<f32x4*>(lo) = st.a[2 * i + 1];
-#else
       split4(st.a[2 * i + 0], hi, lo);
       split4(st.a[2 * i + 1], hi + 4, lo + 4);
-#endif
-      unsigned char* ah = base + ((pt >> 2) + 64 * i) * ROWB + apart * 2;
-      *reinterpret_cast<bf16x8*>(ah) = *reinterpret_cast<bf16x8*>(hi);
-      *reinterpret_cast<bf16x8*>(ah + A_BYTES) = *reinterpret_cast<bf16x8*>(lo);
+      cv.ahi[i] = *reinterpret_cast<bf16x8*>(hi);
+      cv.alo[i] = *reinterpret_cast<bf16x8*>(lo);
     }
-    unsigned char* bh = base + 2 * A_BYTES + brow * ROWB + bcol * 2;
-    *reinterpret_cast<f32x4*>(bh) = st.bh[0];
-    *reinterpret_cast<f32x4*>(bh + 16) = st.bh[1];
-    *reinterpret_cast<f32x4*>(bh + B_BYTES) = st.bl[0];
-    *reinterpret_cast<f32x4*>(bh + B_BYTES + 16) = st.bl[1];
+  };
+  auto write_lds = [&](int buf, const Raw& st, const Cvt& cv) {
+    unsigned char* base = lds + buf * BUF_BYTES;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      unsigned char* ah = base + ((gt >> 2) + 32 * i) * ROWB + apart * 2;
+      *reinterpret_cast<bf16x8*>(ah) = cv.ahi[i];
+      *reinterpret_cast<bf16x8*>(ah + A_BYTES) = cv.alo[i];
+    }
+    unsigned char* bh = base + 2 * A_BYTES + gt * ROWB;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      *reinterpret_cast<f32x4*>(bh + 16 * e) = st.bh[e];
+      *reinterpret_cast<f32x4*>(bh + B_BYTES + 16 * e) = st.bl[e];
+    }
   };
 
-  // One register stage: the loads of step s+1 are issued at the top of step s and converted / written to the other
-  // LDS buffer in the same step, while the consumers multiply the current buffer; one barrier per step.
-  Stage st;
-  issue_loads(st);
-  write_lds(0, st);
+  Raw raw;
+  Cvt cvt;
+  // prologue: group g fills buffer g with step g (nobody reads yet); group 0 also starts the loads of step 2
+  if (g < nsteps) {
+    issue_loads(raw);
+    convert(raw, cvt);
+    write_lds(g, raw, cvt);
+  }
+  if (g == 0 && 2 < nsteps) issue_loads(raw);
   __syncthreads();
-  for (int step = 0; step < nsteps; ++step) {
-    if (step + 1 < nsteps) {
-      issue_loads(st);
-      write_lds((step + 1) & 1, st);
+  for (int t = 0; t < nsteps; ++t) {                   // interval t: the consumers multiply buffer t & 1
+    if ((t & 1) == g) {
+      // convert interval: the loads of step t+2 (issued one interval ago) land and are split; B stays as loaded
+      if (t + 2 < nsteps) convert(raw, cvt);
+    } else {
+      // write interval: step t+1 goes to buffer (t+1) & 1 (free since the last barrier), then fetch step t+3
+      if (t + 1 >= 2 && t + 1 < nsteps) write_lds((t + 1) & 1, raw, cvt);
+      if (t + 3 < nsteps) issue_loads(raw);
     }
     __syncthreads();
   }

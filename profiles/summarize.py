@@ -19,8 +19,9 @@ import shutil
 import sys
 
 OURS = ("bin_head_kernel", "pixel_dot_kernel", "patch_embed_partial_kernel", "patch_embed_reduce_kernel",
-        "attention_kernel", "linear_kernel", "layernorm_kernel", "ffn_kernel", "cross_attn", "upsample_concat",
-        "depthwise", "ocv_")
+        "attention_kernel", "linear_kernel", "linear_stream_kernel", "layernorm_kernel", "ffn_fused_kernel",
+        "conv_igemm_kernel", "pointwise_kernel", "pointwise_smallk_kernel", "depthwise_kernel", "depthwise_nhwc_kernel",
+        "channel_sum_kernel", "channel_mean_finish_kernel", "se_hidden_kernel", "se_gate_kernel")
 
 
 def short(name):
@@ -68,8 +69,11 @@ def main(src, tag):
     if pmc:
         json.dump(pmc, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
         traffic = {}
-        for key, name in (("bin_head", "bin_head_kernel"), ("patch_embed", "patch_embed_partial_kernel<true>")):
-            if name in pmc and "FETCH_SIZE_KB_max" in pmc[name] and "WRITE_SIZE_KB_max" in pmc[name]:
+        for key, prefix in (("bin_head", "bin_head_kernel"), ("patch_embed", "patch_embed_partial_kernel"),
+                            ("conv3x3", "conv_igemm_kernel")):
+            names = [n for n in pmc if n.startswith(prefix) and "FETCH_SIZE_KB_max" in pmc[n] and "WRITE_SIZE_KB_max" in pmc[n]]
+            if names:
+                name = names[0]
                 # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE tallies 128-B requests at 64 B -> x2; WRITE_SIZE exact
                 traffic[key] = int((2 * pmc[name]["FETCH_SIZE_KB_max"] + pmc[name]["WRITE_SIZE_KB_max"]) * 1024)
         json.dump(traffic, open(os.path.join(out, "roofline_traffic.json"), "w"), indent=1, sort_keys=True)

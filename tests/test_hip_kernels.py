@@ -385,3 +385,21 @@ def test_channel_mean_and_se_gate(ops, B, C, H, W, R):
     assert rel_dev(ops.se_gate(xg, dev(w1), dev(b1), dev(w2).t().contiguous(), dev(b2)), ref) < TOL
     # deterministic two-stage reduction
     assert torch.equal(ops.channel_mean_nhwc(xg), ops.channel_mean_nhwc(xg))
+
+
+def test_conv_nhwc_does_not_depend_on_stale_memory(ops):
+    """Regression: an earlier pipeline read load-destination registers before the loads had landed and only looked
+    right when registers / LDS / recycled allocations happened to hold the same data.  Poison the caching allocator
+    with NaN, then require the FIRST run on freshly recycled memory to be correct."""
+    B, H, W, C1, C2, Cout = 4, 120, 160, 256, 24, 128
+    cl = torch.channels_last
+    x1, x2 = dev(rnd("x1", (B, C1, H, W), 1)).contiguous(memory_format=cl), dev(rnd("x2", (B, C2, H, W), 2)).contiguous(memory_format=cl)
+    w, b = dev(rnd("w", (Cout, C1 + C2, 3, 3), 3, 0.02)), dev(rnd("b", (Cout,), 4, 0.2))
+    hi, lo = ops.prep_conv_weight(w)
+    ref = F.leaky_relu(F.conv2d(torch.cat([x1, x2], 1), w, b, padding=1), 0.01)
+    for _ in range(2):
+        poison = torch.full((1 << 30,), float("nan"), device="cuda")      # 4 GiB of NaN back into the allocator
+        del poison
+        y = ops.conv_nhwc(x1, x2, hi, lo, b, 3, 2)
+        assert bool(torch.isfinite(y).all())
+        assert rel_dev(y, ref) < 1e-4
