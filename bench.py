@@ -36,6 +36,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16, dense (the split-bf16 convolutions issue 3 of these per product)
 
 H, W, BATCH, N_OBJ = 480, 640, 16, 32
 E, S, P, NBINS = 128, 300, 240 * 320, 256
@@ -182,7 +183,21 @@ def main():
         assert table.shape[0] == world * a.steps * B
         km = kernel_model(B)
         kernels = {}
+        convs = []
         for name, (cnt, ms) in timing.items():
+            if name.startswith("conv3x3|") or name.startswith("conv1x1|"):
+                k = 3 if name.startswith("conv3x3") else 1
+                b_, h_, w_, ci, co = (int(v) for v in name.split("|")[1].split(","))
+                m_ = b_ * h_ * w_
+                flops = 2.0 * m_ * co * ci * k * k                      # algorithmic (fp32-equivalent) FLOPs
+                byts = m_ * ci * 4 + m_ * co * 4 + k * k * co * ci * 4   # read input once, write output once, weights
+                convs.append(dict(shape=f"B{b_} {h_}x{w_} {ci}->{co} k{k}", launches_per_step=cnt / a.steps, ms=round(ms, 4),
+                                  alg_GFLOP=round(flops / 1e9, 1), alg_MB=round(byts / 1e6, 1),
+                                  alg_TFLOPs=round(flops / (ms * 1e-3) / 1e12, 1),
+                                  issued_bf16_TFLOPs=round(3 * flops / (ms * 1e-3) / 1e12, 1),
+                                  frac_bf16_mfma=round(3 * flops / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+                                  GBps=round(byts / (ms * 1e-3) / 1e9, 1)))
+                continue
             if name not in km:
                 continue
             gbs = km[name]["bytes"] / (ms * 1e-3) / 1e9
@@ -193,7 +208,20 @@ def main():
                                  total_ms_per_step=round(ms * cnt / a.steps, 4))
         dom = max(kernels, key=lambda k: kernels[k]["ms"]) if kernels else None     # longest single launch
         roofline = None
-        if dom:
+        conv_dom = max(convs, key=lambda c: c["ms"]) if convs else None
+        if conv_dom and (dom is None or conv_dom["ms"] > kernels[dom]["ms"]):
+            # dominant hand-written kernel = the split-bf16 implicit-GEMM convolution (conv_igemm_kernel): matrix-pipe
+            # bound (AI >> ridge); achieved = ISSUED bf16 FLOPs (3 MFMAs per product) / duration vs the dense bf16 peak
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get("conv3x3")
+            roofline = dict(kernel="conv_igemm_kernel " + conv_dom["shape"], bound="mfma", achieved=conv_dom["issued_bf16_TFLOPs"],
+                            peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=conv_dom["frac_bf16_mfma"], traffic=traffic,
+                            algorithmic_fp32_TFLOPs=conv_dom["alg_TFLOPs"],
+                            x_over_fp32_mfma_peak=round(conv_dom["alg_TFLOPs"] / F32_MFMA_PEAK_TFLOPS, 2),
+                            ms=conv_dom["ms"], alg_MB=conv_dom["alg_MB"])
+        elif dom:
             k = kernels[dom]
             # fp32 contraction kernels sit above the ridge point (157.3 TF / 8 TB/s = 19.7 flop/B): matrix-pipe bound
             ai = km[dom]["flops"] / km[dom]["bytes"]
@@ -216,7 +244,7 @@ def main():
             "config": {"workload": "BASELINE configs[2]: ObjCAViT enet-b5 NYU 480x640, emb_dim=128, learned pos-MLP, "
                                    f"{N_OBJ} objs/img with random 512-d text features, bs={B} per GPU, random-init weights",
                        "global_batch": world * B, "image": [H, W], "objects_per_image": N_OBJ, "parallelism": f"dp{world}"},
-            "roofline": roofline, "kernels": kernels,
+            "roofline": roofline, "kernels": kernels, "convs": convs,
             "metrics_gathered": dp.summarise(table),
         }
         if world == 1 and not a.no_cpu_baseline:

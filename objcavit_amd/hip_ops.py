@@ -501,7 +501,7 @@ def conv_nhwc(x1: torch.Tensor, x2: Optional[torch.Tensor], w_hi: torch.Tensor, 
         residual = _nhwc(residual, "residual")
         if residual.shape != y.shape:
             raise ValueError("conv_nhwc: residual shape mismatch")
-    with timed(f"conv{ksize}x{ksize}"):
+    with timed(f"conv{ksize}x{ksize}|{B},{H},{W},{C1 + C2},{Cout}"):
         check(lib.ocv_conv_nhwc_fwd(x1.data_ptr(), C1, _ptr(x2), C2, w_hi.data_ptr(), w_lo.data_ptr(), _ptr(bias),
                                     _ptr(residual), y.data_ptr(), B, H, W, Cout, ksize, act, _stream()), "ocv_conv_nhwc_fwd")
     return y

@@ -16,4 +16,4 @@ fn = lib.ocv_conv_read_stamps; fn.restype = ctypes.c_int
 print("rc", fn(out))
 v = list(out)
 n = max(v[7], 1)
-print(f"steps {v[7]}; consumer: compute {v[0]/n:.0f} cyc/step, barrier {v[1]/n:.0f}; producer (even steps only, x2): issue {2*v[2]/n:.0f}, wait {2*v[3]/n:.0f}, convert+write {2*v[4]/n:.0f}, barrier {2*v[5]/n:.0f}")
+print(f"steps {v[7]}; consumer: compute {v[0]/n:.0f} ticks/step, barrier wait {v[1]/n:.0f} ticks/step")
