@@ -197,6 +197,20 @@ int ocv_conv_nhwc_fwd(const float* x1, int C1, const float* x2, int C2, const vo
                       const float* bias, const float* residual, float* y, int B, int H, int W, int Cout, int ksize,
                       int act, ocv_stream_t stream);
 
+/* The same convolution on an input that is ALREADY split: x_hi / x_lo bf16 [B,H,W,Cin] (Cin a multiple of 8), as
+ * produced by ocv_upsample_concat_split_fwd or by a previous convolution's y_hi / y_lo.  Outputs: y (fp32, nullable)
+ * and / or y_hi, y_lo (bf16 split of the same values, nullable pair).  No fp32->bf16 work per tap in the kernel. */
+int ocv_conv_nhwc_split_fwd(const void* x_hi, const void* x_lo, int Cin, const void* w_hi, const void* w_lo,
+                            const float* bias, const float* residual, float* y, void* y_hi, void* y_lo, int B, int H,
+                            int W, int Cout, int ksize, int act, ocv_stream_t stream);
+
+/* Bilinear resize of x [B,h,w,C1] (NHWC fp32) to H x W with align_corners = True, concatenated along channels with
+ * skip [B,H,W,C2] (nullable, then C2 = 0), written as the split-bf16 pair out_hi / out_lo [B,H,W,C1+C2]
+ * (hi = bf16(v), lo = bf16(v - hi)).  Replaces F.interpolate + torch.cat of UpSampleWithSkip.forward
+ * (modules/DenseFeatureExtractor.py:44-47) and feeds ocv_conv_nhwc_split_fwd. */
+int ocv_upsample_concat_split_fwd(const float* x, int h, int w, int C1, const float* skip, int C2, void* out_hi,
+                                  void* out_lo, int B, int H, int W, ocv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,7 +50,9 @@ constexpr int A_BYTES = CBM * ROWB, B_BYTES = CBN * ROWB;
 constexpr int BUF_BYTES = 2 * A_BYTES + 2 * B_BYTES;      // 61440
 
 struct ConvArgs {
-  const float* x1; const float* x2;     // NHWC; x2 (nullable) is concatenated after x1's channels
+  const float* x1; const float* x2;     // NHWC fp32; x2 (nullable) is concatenated after x1's channels
+  const __bf16* xhi; const __bf16* xlo; // OR the input already split (hi, lo), NHWC bf16 [.., Cin]  (IN_SPLIT kernel)
+  __bf16* yhi; __bf16* ylo;             // optional split copy of the output (for the next convolution)
   const __bf16* whi; const __bf16* wlo; // [taps][Cout][Cp]
   const float* bias; const float* res; float* y;
   int C1, C2, Cin, Cp, Cout, H, W, ks, act;
@@ -86,6 +88,7 @@ __device__ unsigned long long ocv_conv_stamps[16];
 #define STAMP_ADD(slot, t0, t1)
 #endif
 
+template <bool IN_SPLIT>
 __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
@@ -176,7 +179,12 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
             else if (p.act == OCV_ACT_SILU) v = v / (1.0f + fast_exp(-v));
             else if (p.act == OCV_ACT_RELU) v = fmaxf(v, 0.f);
             if (p.res != nullptr) v += p.res[m * p.Cout + n];
-            p.y[m * p.Cout + n] = v;
+            if (p.y != nullptr) p.y[m * p.Cout + n] = v;
+            if (p.yhi != nullptr) {                      // pre-split copy for the next convolution's A operand
+              const __bf16 hb = (__bf16)v;
+              p.yhi[m * p.Cout + n] = hb;
+              p.ylo[m * p.Cout + n] = (__bf16)(v - (float)hb);
+            }
           }
         }
     }
@@ -218,7 +226,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
       }
       tapmask[i] = mask;
       const long pix = valid ? am : 0;
-      rb1[i] = (unsigned)((pix * p.C1 + apart) * 4);
+      rb1[i] = IN_SPLIT ? (unsigned)((pix * p.Cin + apart) * 2) : (unsigned)((pix * p.C1 + apart) * 4);
       rb2[i] = (unsigned)((pix * p.C2 + apart) * 4);
     }
   }
@@ -240,6 +248,18 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
     const int tap = nx_tap, c0 = nx_c0;
     advance();
     const int ky = tap / p.ks, kx = tap - ky * p.ks;                     // scalar, ks in {1, 3}
+    if (IN_SPLIT) {
+      // pre-split input: 8 channels = 16 B of hi and 16 B of lo per lane and row, no conversion later
+      const int soff = (((ky - pad) * p.W + (kx - pad)) * p.Cin + c0) * 2;
+      const bool cok = c0 + apart + 8 <= p.Cin;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bool ok = ((tapmask[i] >> tap) & 1u) && cok;
+        const unsigned off = rb1[i] + (unsigned)soff;
+        st.a[2 * i + 0] = gload16(ok ? (const void*)((const char*)p.xhi + off) : (const void*)ocv_zero_page);
+        st.a[2 * i + 1] = gload16(ok ? (const void*)((const char*)p.xlo + off) : (const void*)ocv_zero_page);
+      }
+    } else {
     const bool first = c0 < p.C1;
     const char* tbase = (const char*)(first ? p.x1 : p.x2);
     const int tc = first ? p.C1 : p.C2;
@@ -254,6 +274,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
       st.a[2 * i + 0] = gload16((inb && cok0) ? (const void*)src : (const void*)ocv_zero_page);
       st.a[2 * i + 1] = gload16((inb && cok1) ? (const void*)(src + 16) : (const void*)ocv_zero_page);
     }
+    }
     const unsigned woff = (unsigned)tap * wtap + wrow + (unsigned)c0 * 2;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -264,6 +285,11 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
   auto convert = [&](const Raw& st, Cvt& cv) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
+      if (IN_SPLIT) {
+        cv.ahi[i] = __builtin_bit_cast(bf16x8, st.a[2 * i + 0]);
+        cv.alo[i] = __builtin_bit_cast(bf16x8, st.a[2 * i + 1]);
+        continue;
+      }
       __bf16 hi[8], lo[8];
       split4(st.a[2 * i + 0], hi, lo);
       split4(st.a[2 * i + 1], hi + 4, lo + 4);
@@ -318,6 +344,41 @@ extern "C" int ocv_conv_read_stamps(unsigned long long* out16) {
 }
 #endif
 
+namespace {
+int launch_conv(ConvArgs& a, int B, bool in_split, hipStream_t st) {
+  a.Cp = (a.Cin + CBK - 1) / CBK * CBK;
+  a.M = (long)B * a.H * a.W;
+  a.mtiles = ocv_cdiv(a.M, CBM); a.ntiles = ocv_cdiv(a.Cout, CBN);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  if (in_split) hipLaunchKernelGGL(conv_igemm_kernel<true>, dim3(a.mtiles * a.ntiles), dim3(512), 2 * BUF_BYTES, st, a);
+  else hipLaunchKernelGGL(conv_igemm_kernel<false>, dim3(a.mtiles * a.ntiles), dim3(512), 2 * BUF_BYTES, st, a);
+  OCV_CHECK_LAUNCH("ocv_conv_nhwc");
+  return 0;
+}
+}  // namespace
+
+extern "C" int ocv_conv_nhwc_split_fwd(const void* x_hi, const void* x_lo, int Cin, const void* w_hi, const void* w_lo,
+                                       const float* bias, const float* residual, float* y, void* y_hi, void* y_lo,
+                                       int B, int H, int W, int Cout, int ksize, int act, ocv_stream_t stream) {
+  OCV_CHECK_ARG(x_hi && x_lo && w_hi && w_lo && (y || (y_hi && y_lo)), "ocv_conv_nhwc_split_fwd: null pointer");
+  OCV_CHECK_ARG((y_hi == nullptr) == (y_lo == nullptr), "ocv_conv_nhwc_split_fwd: y_hi and y_lo go together");
+  OCV_CHECK_ARG(ksize == 1 || ksize == 3, "ocv_conv_nhwc_split_fwd: kernel size must be 1 or 3 (got %d)", ksize);
+  OCV_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && Cout >= 1 && Cin >= 8 && Cin % 8 == 0, "ocv_conv_nhwc_split_fwd: bad sizes (Cin must be a multiple of 8)");
+  OCV_CHECK_ARG(act >= 0 && act <= 3, "ocv_conv_nhwc_split_fwd: unknown activation %d", act);
+  OCV_CHECK_ARG(ocv_aligned16(x_hi) && ocv_aligned16(x_lo) && ocv_aligned16(w_hi) && ocv_aligned16(w_lo), "ocv_conv_nhwc_split_fwd: operands must be 16-byte aligned");
+  OCV_CHECK_ARG((long)B * H * W * Cin * 2 < (1L << 32) && 9L * Cout * (Cin + 32) * 2 < (1L << 32), "ocv_conv_nhwc_split_fwd: each operand must be smaller than 4 GiB");
+  ConvArgs a{};
+  a.xhi = (const __bf16*)x_hi; a.xlo = (const __bf16*)x_lo; a.yhi = (__bf16*)y_hi; a.ylo = (__bf16*)y_lo;
+  a.whi = (const __bf16*)w_hi; a.wlo = (const __bf16*)w_lo; a.bias = bias; a.res = residual; a.y = y;
+  a.C1 = Cin; a.C2 = 0; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.ks = ksize; a.act = act;
+  return launch_conv(a, B, true, (hipStream_t)stream);
+}
+
 extern "C" int ocv_conv_nhwc_fwd(const float* x1, int C1, const float* x2, int C2, const void* w_hi, const void* w_lo,
                                  const float* bias, const float* residual, float* y, int B, int H, int W, int Cout,
                                  int ksize, int act, ocv_stream_t stream) {
@@ -332,19 +393,10 @@ extern "C" int ocv_conv_nhwc_fwd(const float* x1, int C1, const float* x2, int C
   OCV_CHECK_ARG((long)B * H * W * C1 * 4 < (1L << 32) && (long)B * H * W * (x2 ? C2 : 0) * 4 < (1L << 32) &&
                     9L * Cout * (C1 + C2 + 32) * 2 < (1L << 32),
                 "ocv_conv_nhwc_fwd: each operand must be smaller than 4 GiB (32-bit byte offsets inside the kernel)");
-  ConvArgs a;
+  ConvArgs a{};
   a.x1 = x1; a.x2 = x2; a.whi = (const __bf16*)w_hi; a.wlo = (const __bf16*)w_lo;
   a.bias = bias; a.res = residual; a.y = y;
-  a.C1 = C1; a.C2 = x2 ? C2 : 0; a.Cin = a.C1 + a.C2; a.Cp = (a.Cin + CBK - 1) / CBK * CBK;
+  a.C1 = C1; a.C2 = x2 ? C2 : 0; a.Cin = a.C1 + a.C2;
   a.Cout = Cout; a.H = H; a.W = W; a.ks = ksize; a.act = act;
-  a.M = (long)B * H * W;
-  a.mtiles = ocv_cdiv(a.M, CBM); a.ntiles = ocv_cdiv(Cout, CBN);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
-  hipLaunchKernelGGL(conv_igemm_kernel, dim3(a.mtiles * a.ntiles), dim3(512), 2 * BUF_BYTES, (hipStream_t)stream, a);
-  OCV_CHECK_LAUNCH("ocv_conv_nhwc_fwd");
-  return 0;
+  return launch_conv(a, B, false, (hipStream_t)stream);
 }

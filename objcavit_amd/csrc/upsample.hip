@@ -1,0 +1,86 @@
+// Bilinear resize (align_corners = True) + channel concat with the skip connection + fp32 -> split-bf16, one pass,
+// NHWC, for the UNet decoder on gfx950 (UpSampleWithSkip.forward, modules/DenseFeatureExtractor.py:44-47:
+// F.interpolate(x, size=skip.size, mode='bilinear', align_corners=True); torch.cat([up_x, skip], dim=1)).
+//
+// Output format = what the split-bf16 convolution consumes directly (csrc/conv_igemm.hip): two bf16 NHWC tensors
+// hi = bf16(v), lo = bf16(v - hi) of the concatenated activation [B, H, W, C1 + C2].  Producing the split ONCE here
+// (and in the convolution epilogues) instead of inside every convolution removes 5 VALU operations per element from
+// each of the 9 taps x N-tiles that re-read the element -- the limiter of the first convolution kernel -- and the
+// resized tensor and the concatenated tensor are never materialised in fp32.
+// HBM-bound: reads C1 x 4 B x (h w / H W, through L2) + C2 x 4 B, writes (C1 + C2) x 4 B per output pixel; a lane owns
+// 4 consecutive channels of one output pixel (16-byte loads, 8-byte stores).
+// Arithmetic follows ATen's upsample_bilinear2d (scale = (in-1)/(out-1), src = scale*dst, lambda1 = src - floor(src),
+// out = h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)) so the fp32 value before splitting matches torch to rounding.
+#include "common.hpp"
+#include "../../include/objcavit_hip.h"
+
+namespace {
+
+struct UpArgs {
+  const float *x, *skip;
+  unsigned short *hi, *lo;      // bf16 bit patterns
+  int h, w, H, W, C1, C2;
+  float sh, sw;
+  long total;                   // B * H * W * (C1 + C2) / 4
+};
+
+__device__ __forceinline__ void store_split4(unsigned short* hi, unsigned short* lo, long off, float4 v) {
+  const float f[4] = {v.x, v.y, v.z, v.w};
+  unsigned short h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const __bf16 hb = (__bf16)f[i];
+    const __bf16 lb = (__bf16)(f[i] - (float)hb);
+    h[i] = __builtin_bit_cast(unsigned short, hb);
+    l[i] = __builtin_bit_cast(unsigned short, lb);
+  }
+  *reinterpret_cast<uint2*>(hi + off) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+  *reinterpret_cast<uint2*>(lo + off) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+}
+
+__global__ __launch_bounds__(256) void upsample_concat_split_kernel(UpArgs p) {
+  const int C = p.C1 + p.C2, c4n = C >> 2;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < p.total; idx += (long)gridDim.x * 256) {
+    const int c = (int)(idx % c4n) * 4;
+    long t = idx / c4n;
+    const int X = (int)(t % p.W);
+    t /= p.W;
+    const int Y = (int)(t % p.H);
+    const long b = t / p.H;
+    float4 v;
+    if (c < p.C1) {
+      const float sy = p.sh * Y, sx = p.sw * X;
+      const int y0 = (int)sy, x0 = (int)sx;
+      const int y1 = y0 + (y0 < p.h - 1 ? 1 : 0), x1 = x0 + (x0 < p.w - 1 ? 1 : 0);
+      const float h1 = sy - (float)y0, h0 = 1.0f - h1, w1 = sx - (float)x0, w0 = 1.0f - w1;
+      const float* base = p.x + b * (long)p.h * p.w * p.C1 + c;
+      const float4 v00 = ld4(base + ((long)y0 * p.w + x0) * p.C1), v01 = ld4(base + ((long)y0 * p.w + x1) * p.C1);
+      const float4 v10 = ld4(base + ((long)y1 * p.w + x0) * p.C1), v11 = ld4(base + ((long)y1 * p.w + x1) * p.C1);
+      v.x = h0 * (w0 * v00.x + w1 * v01.x) + h1 * (w0 * v10.x + w1 * v11.x);
+      v.y = h0 * (w0 * v00.y + w1 * v01.y) + h1 * (w0 * v10.y + w1 * v11.y);
+      v.z = h0 * (w0 * v00.z + w1 * v01.z) + h1 * (w0 * v10.z + w1 * v11.z);
+      v.w = h0 * (w0 * v00.w + w1 * v01.w) + h1 * (w0 * v10.w + w1 * v11.w);
+    } else {
+      v = ld4(p.skip + ((b * p.H + Y) * (long)p.W + X) * p.C2 + (c - p.C1));
+    }
+    store_split4(p.hi, p.lo, ((b * p.H + Y) * (long)p.W + X) * C + c, v);
+  }
+}
+
+}  // namespace
+
+extern "C" int ocv_upsample_concat_split_fwd(const float* x, int h, int w, int C1, const float* skip, int C2, void* out_hi,
+                                             void* out_lo, int B, int H, int W, ocv_stream_t stream) {
+  OCV_CHECK_ARG(x && out_hi && out_lo, "ocv_upsample_concat_split_fwd: null pointer");
+  OCV_CHECK_ARG(B >= 1 && h >= 1 && w >= 1 && H >= 1 && W >= 1 && C1 >= 4 && C1 % 4 == 0, "ocv_upsample_concat_split_fwd: bad sizes (C1 must be a multiple of 4)");
+  OCV_CHECK_ARG(skip == nullptr ? C2 == 0 : (C2 >= 4 && C2 % 4 == 0), "ocv_upsample_concat_split_fwd: C2 must be a multiple of 4 (0 without a skip tensor)");
+  OCV_CHECK_ARG(ocv_aligned16(x) && ocv_aligned16(skip) && ocv_aligned16(out_hi) && ocv_aligned16(out_lo), "ocv_upsample_concat_split_fwd: operands must be 16-byte aligned");
+  UpArgs a{x, skip, (unsigned short*)out_hi, (unsigned short*)out_lo, h, w, H, W, C1, C2,
+           H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f,
+           (long)B * H * W * ((C1 + C2) / 4)};
+  long blocks = (a.total + 255) / 256;
+  if (blocks > 256L * 64) blocks = 256L * 64;
+  hipLaunchKernelGGL(upsample_concat_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  OCV_CHECK_LAUNCH("ocv_upsample_concat_split_fwd");
+  return 0;
+}

@@ -603,3 +603,78 @@ def se_gate(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2t: torch.Tens
     check(lib.ocv_se_gate_fwd(m.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), gate.data_ptr(),
                               hid.data_ptr(), B, Cc, R, _stream()), "ocv_se_gate_fwd")
     return gate
+
+
+# ---------------------------------------------------------------------------
+# split-bf16 activations between our convolutions
+# ---------------------------------------------------------------------------
+class SplitAct:
+    """An activation held as two bf16 channels_last tensors hi = bf16(v), lo = bf16(v - hi), logical shape
+    [B, C, H, W].  Produced by ``upsample_concat_split`` / ``conv_nhwc_split(..., out_split=True)``, consumed by
+    ``conv_nhwc_split`` with no per-tap conversion work."""
+    __slots__ = ("hi", "lo")
+
+    def __init__(self, hi: torch.Tensor, lo: torch.Tensor):
+        self.hi, self.lo = hi, lo
+
+    @property
+    def shape(self):
+        return self.hi.shape
+
+    def float(self) -> torch.Tensor:
+        return self.hi.float() + self.lo.float()
+
+
+def upsample_concat_split(x: torch.Tensor, skip: Optional[torch.Tensor], size: Tuple[int, int]) -> SplitAct:
+    """split(cat([bilinear_resize(x, size, align_corners=True), skip], dim=1)); x / skip channels_last fp32."""
+    lib = _lib.load()
+    x = _nhwc(x, "x")
+    B, C1, h, w = x.shape
+    H, W = int(size[0]), int(size[1])
+    C2 = 0
+    if skip is not None:
+        skip = _nhwc(skip, "skip")
+        if skip.shape[0] != B or tuple(skip.shape[2:]) != (H, W):
+            raise ValueError("upsample_concat_split: skip must be [B, C2, H, W] at the target size")
+        C2 = skip.shape[1]
+    hi = torch.empty(B, C1 + C2, H, W, dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    lo = torch.empty_like(hi)
+    with timed("upsample_concat_split"):
+        check(lib.ocv_upsample_concat_split_fwd(x.data_ptr(), h, w, C1, _ptr(skip), C2, hi.data_ptr(), lo.data_ptr(), B, H, W,
+                                                _stream()), "ocv_upsample_concat_split_fwd")
+    return SplitAct(hi, lo)
+
+
+def conv_nhwc_split(x: SplitAct, w_hi: torch.Tensor, w_lo: torch.Tensor, bias: Optional[torch.Tensor], ksize: int,
+                    act: int = ACT_NONE, out_fp32: bool = True, out_split: bool = False):
+    """Split-bf16 convolution on a pre-split input.  Returns fp32 tensor, SplitAct, or (fp32, SplitAct)."""
+    lib = _lib.load()
+    if not (out_fp32 or out_split):
+        raise ValueError("conv_nhwc_split: nothing to output")
+    for n, t in (("x.hi", x.hi), ("x.lo", x.lo)):
+        _req(t, n, torch.bfloat16, contiguous=False)
+        if t.dim() != 4 or not t.is_contiguous(memory_format=torch.channels_last):
+            raise ValueError(f"{n}: expected a channels_last [B, C, H, W] bf16 tensor")
+    B, Cin, H, W = x.hi.shape
+    if x.lo.shape != x.hi.shape:
+        raise ValueError("conv_nhwc_split: hi / lo shape mismatch")
+    for n, t in (("w_hi", w_hi), ("w_lo", w_lo)):
+        _req(t, n, torch.bfloat16)
+    taps, Cout, Cp = w_hi.shape
+    if w_lo.shape != w_hi.shape or taps != ksize * ksize or Cp != (Cin + 31) // 32 * 32:
+        raise ValueError(f"conv_nhwc_split: weights {tuple(w_hi.shape)} do not match {Cin} input channels, k={ksize}")
+    if bias is not None:
+        _req(bias, "bias")
+        if bias.numel() != Cout:
+            raise ValueError("conv_nhwc_split: bias size mismatch")
+    cl = torch.channels_last
+    y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.hi.device, memory_format=cl) if out_fp32 else None
+    yh = torch.empty(B, Cout, H, W, dtype=torch.bfloat16, device=x.hi.device, memory_format=cl) if out_split else None
+    yl = torch.empty_like(yh) if out_split else None
+    with timed(f"conv{ksize}x{ksize}|{B},{H},{W},{Cin},{Cout}"):
+        check(lib.ocv_conv_nhwc_split_fwd(x.hi.data_ptr(), x.lo.data_ptr(), Cin, w_hi.data_ptr(), w_lo.data_ptr(), _ptr(bias),
+                                          None, _ptr(y), _ptr(yh), _ptr(yl), B, H, W, Cout, ksize, act, _stream()),
+              "ocv_conv_nhwc_split_fwd")
+    if out_fp32 and out_split:
+        return y, SplitAct(yh, yl)
+    return y if out_fp32 else SplitAct(yh, yl)

@@ -46,6 +46,11 @@ class SplitConv3x3:
                 and c1 % 4 == 0 and c2 % 4 == 0 and (c2 == 0 or c1 % 32 == 0))
 
     def __call__(self, x1, x2=None, act=hip_ops.ACT_NONE):
+        self._ensure_prepared()
+        hi, lo, b = self._prep
+        return hip_ops.conv_nhwc(x1, x2, hi, lo, b, self.conv.kernel_size[0], act)
+
+    def _ensure_prepared(self):
         ps = [self.conv.weight] + ([self.conv.bias] if self.conv.bias is not None else [])
         if self.bn is not None:
             ps += [self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
@@ -61,8 +66,12 @@ class SplitConv3x3:
                 hi, lo = hip_ops.prep_conv_weight(w)
                 self._prep = (hi, lo, None if b is None else b.detach().float().contiguous())
             self._key = key
+
+    def run_split(self, x: "hip_ops.SplitAct", act=hip_ops.ACT_NONE, out_fp32=True, out_split=False):
+        """Same convolution on a pre-split activation (no per-tap fp32 -> bf16 work in the kernel)."""
+        self._ensure_prepared()
         hi, lo, b = self._prep
-        return hip_ops.conv_nhwc(x1, x2, hi, lo, b, self.conv.kernel_size[0], act)
+        return hip_ops.conv_nhwc_split(x, hi, lo, b, self.conv.kernel_size[0], act, out_fp32=out_fp32, out_split=out_split)
 
 # skip-connection table: encoder-name fragment -> (feature_select, skip channels 3..0)
 # (reference modules/DenseFeatureExtractor.py:62-85)
@@ -136,7 +145,21 @@ class UpSampleWithSkip(nn.Module):
         self._folded = None
         return super()._load_from_state_dict(*a, **kw)
 
+    def forward_split(self, x, skip_features, out_fp32=True, out_split=False):
+        """GPU inference plan: resize + concat + fp32->split-bf16 in ONE pass, then both 3x3 convolutions on
+        pre-split activations; the second one hands the next stage fp32 (for its resize) and / or the split pair."""
+        cat = hip_ops.upsample_concat_split(x, skip_features, skip_features.shape[-2:])
+        f = self._split1.run_split(cat, hip_ops.ACT_LEAKY_RELU, out_fp32=False, out_split=True)
+        return self._split2.run_split(f, hip_ops.ACT_LEAKY_RELU, out_fp32=out_fp32, out_split=out_split)
+
+    def split_ready(self, x, skip_features) -> bool:
+        c1, c2 = x.shape[1], skip_features.shape[1]
+        return (not self.training and not torch.is_grad_enabled() and x.device.type == "cuda" and split_bf16_convs_enabled()
+                and self._split1.usable(c1, c2) and (c1 + c2) % 8 == 0 and self._net[0].out_channels % 8 == 0)
+
     def forward(self, x, skip_features):
+        if self.split_ready(x, skip_features):
+            return self.forward_split(x, skip_features)
         up = F.interpolate(x, size=skip_features.shape[-2:], mode="bilinear", align_corners=True)
         if (not self.training and not torch.is_grad_enabled() and up.device.type == "cuda"
                 and self._split1.usable(up.shape[1], skip_features.shape[1])):
@@ -195,7 +218,18 @@ class Decoder(nn.Module):
                 self.conv2.to(memory_format=cl)
                 self.conv3.to(memory_format=cl)
         x = self.conv2(b4)
-        for up, skip in ((self.up1, b3), (self.up2, b2), (self.up3, b1), (self.up4, b0)):
+        stages = ((self.up1, b3), (self.up2, b2), (self.up3, b1), (self.up4, b0))
+        if (self.final_upscale is None and all(up.split_ready(x, skip) for up, skip in stages[:1])
+                and self._split3.usable(self.conv3.in_channels) and self.conv3.in_channels % 8 == 0):
+            # all-split pipeline: the last stage hands conv3 its input pre-split; conv3 returns the fp32 feature map
+            # (patch embedding reads it) AND its split copy, which rides along for the heads' 3x3 convolution
+            for up, skip in stages[:-1]:
+                x = up.forward_split(x, skip)
+            xs = self.up4.forward_split(x, b0, out_fp32=False, out_split=True)
+            out, out_split = self._split3.run_split(xs, hip_ops.ACT_NONE, out_fp32=True, out_split=True)
+            out._ocv_split = out_split
+            return out
+        for up, skip in stages:
             x = up(x, skip)
         if self.final_upscale is not None:
             x = self.final_upscale(x, features[0])

@@ -337,6 +337,9 @@ class ObjCAViT(nn.Module):
         if plan is None:
             plan = self.__dict__["_split3x3"] = SplitConv3x3(self.conv3x3)
         if plan.usable(x.shape[1]):
+            pre = getattr(x, "_ocv_split", None)                      # the decoder's conv3 leaves its split copy here
+            if pre is not None and tuple(pre.shape) == tuple(x.shape):
+                return plan.run_split(pre)
             return plan(x)                                            # split-bf16 implicit GEMM, NHWC in / out
         if x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous() \
                 and not self.conv3x3.weight.is_contiguous(memory_format=torch.channels_last):

@@ -403,3 +403,37 @@ def test_conv_nhwc_does_not_depend_on_stale_memory(ops):
         y = ops.conv_nhwc(x1, x2, hi, lo, b, 3, 2)
         assert bool(torch.isfinite(y).all())
         assert rel_dev(y, ref) < 1e-4
+
+
+# ------------------------------------------------------------------ split activations between convolutions
+@pytest.mark.parametrize("B,h,w,H,W,C1,C2", [(2, 17, 22, 30, 40, 64, 24), (1, 30, 40, 60, 80, 32, 0), (3, 5, 7, 11, 13, 8, 4),
+                                             (1, 120, 160, 240, 320, 16, 8)])
+def test_upsample_concat_split(ops, B, h, w, H, W, C1, C2):
+    x = rnd("x", (B, C1, h, w), 1)
+    skip = rnd("s", (B, C2, H, W), 2) if C2 else None
+    ref = F.interpolate(x, size=[H, W], mode="bilinear", align_corners=True)
+    if skip is not None:
+        ref = torch.cat([ref, skip], 1)
+    got = ops.upsample_concat_split(dev(x), None if skip is None else dev(skip), (H, W))
+    assert got.hi.dtype == torch.bfloat16 and got.hi.is_contiguous(memory_format=torch.channels_last)
+    assert rel_dev(got.float(), ref) < 1e-5            # hi + lo carries 16 bits: 2^-17 relative per element
+    assert rel_dev(got.hi.float(), ref) < 5e-3         # hi alone is plain bf16
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,act", [(2, 30, 40, 88, 128, 3, 2), (1, 17, 23, 32, 40, 3, 0), (1, 60, 80, 256, 256, 3, 2),
+                                                  (2, 9, 11, 96, 200, 1, 3)])
+def test_conv_nhwc_split_in_and_out(ops, B, H, W, Cin, Cout, k, act):
+    x = rnd("x", (B, Cin, H, W), 1)
+    w, b = rnd("w", (Cout, Cin, k, k), 3, 1 / math.sqrt(Cin * k * k)), rnd("b", (Cout,), 4, 0.2)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=k // 2).float()
+    ref = [ref, torch.relu(ref), F.leaky_relu(ref, 0.01), F.silu(ref)][act]
+    hi, lo = ops.prep_conv_weight(dev(w))
+    xs = ops.upsample_concat_split(dev(x), None, (H, W))          # identity resize = plain split
+    y, ys = ops.conv_nhwc_split(xs, hi, lo, dev(b), k, act, out_fp32=True, out_split=True)
+    assert rel_dev(y, ref) < SPLIT_TOL
+    assert rel_dev(ys.float(), y) < 1e-5
+    y2 = ops.conv_nhwc_split(xs, hi, lo, dev(b), k, act, out_fp32=True, out_split=False)
+    assert torch.equal(y, y2)
+    # and it agrees with the fp32-input kernel to rounding
+    y3 = ops.conv_nhwc(dev(x), None, hi, lo, dev(b), k, act)
+    assert rel_dev(y, y3) < 1e-5
