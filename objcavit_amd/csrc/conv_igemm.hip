@@ -37,6 +37,8 @@
 //              selects), split it into hi/lo, fetch the pre-split weight chunk, write the other LDS buffer.
 // One consumer and one producer wave share each SIMD: matrix pipe and VALU run side by side; one barrier per step.
 // Workgroup ids are remapped so that the N-tiles of one pixel tile run on the same XCD and share its L2.
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "../../include/objcavit_hip.h"
 
@@ -64,7 +66,11 @@ struct ConvArgs {
 // An earlier version issued these from inline asm with hand-counted waits to keep two register stages in flight;
 // the register allocator is free to COPY such a destination register before the load has landed (it did, at the loop
 // back-edge), which reads stale data -- a silent, history-dependent corruption.  Never hide an in-flight load.
+#ifdef OCV_ABL_NOLOAD
+__device__ __forceinline__ f32x4 gload16(const void* p) { const float v = (float)(((unsigned long)p >> 4) & 1); return f32x4{v, v, v, v}; }
+#else
 __device__ __forceinline__ f32x4 gload16(const void* p) { return *reinterpret_cast<const f32x4*>(p); }
+#endif
 
 __device__ __forceinline__ void split4(const f32x4 v, __bf16* hi, __bf16* lo) {
   const float f[4] = {v[0], v[1], v[2], v[3]};
@@ -255,7 +261,11 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const bool ok = ((tapmask[i] >> tap) & 1u) && cok;
+#ifdef OCV_ABL_SMALLFOOT
+        const unsigned off = (rb1[i] + (unsigned)soff) & 0x3FF0u;          // diagnostic: every load hits a 16 KB window
+#else
         const unsigned off = rb1[i] + (unsigned)soff;
+#endif
         st.a[2 * i + 0] = gload16(ok ? (const void*)((const char*)p.xhi + off) : (const void*)ocv_zero_page);
         st.a[2 * i + 1] = gload16(ok ? (const void*)((const char*)p.xlo + off) : (const void*)ocv_zero_page);
       }
@@ -275,7 +285,11 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
       st.a[2 * i + 1] = gload16((inb && cok1) ? (const void*)(src + 16) : (const void*)ocv_zero_page);
     }
     }
+#ifdef OCV_ABL_SMALLFOOT
+    const unsigned woff = ((unsigned)tap * wtap + wrow + (unsigned)c0 * 2) & 0x3FF0u;
+#else
     const unsigned woff = (unsigned)tap * wtap + wrow + (unsigned)c0 * 2;
+#endif
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       st.bh[e] = gload16((const char*)p.whi + woff + 16 * e);
@@ -298,6 +312,10 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
     }
   };
   auto write_lds = [&](int buf, const Raw& st, const Cvt& cv) {
+#ifdef OCV_ABL_NOWRITE
+    asm volatile("" :: "v"(cv.ahi[0]), "v"(cv.alo[7]), "v"(st.bh[0]), "v"(st.bl[3]), "v"(cv.ahi[3]), "v"(cv.alo[2]));
+    return;
+#endif
     unsigned char* base = lds + buf * BUF_BYTES;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -323,17 +341,38 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
   }
   if (g == 0 && 2 < nsteps) issue_loads(raw);
   __syncthreads();
+#ifdef OCV_STAMPS
+  unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
+#endif
   for (int t = 0; t < nsteps; ++t) {                   // interval t: the consumers multiply buffer t & 1
+    STAMP(tp0);
     if ((t & 1) == g) {
       // convert interval: the loads of step t+2 (issued one interval ago) land and are split; B stays as loaded
       if (t + 2 < nsteps) convert(raw, cvt);
+#ifdef OCV_STAMPS
+      asm volatile("" :: "v"(cvt.ahi[0]), "v"(cvt.alo[7]), "v"(raw.bl[3]));
+#endif
+      STAMP(tp1);
+      STAMP_ADD(0, tp0, tp1);                          // wait for loads + convert
+      __syncthreads();
+      STAMP(tp2);
+      STAMP_ADD(1, tp1, tp2);                          // barrier wait (convert interval)
     } else {
       // write interval: step t+1 goes to buffer (t+1) & 1 (free since the last barrier), then fetch step t+3
       if (t + 1 >= 2 && t + 1 < nsteps) write_lds((t + 1) & 1, raw, cvt);
+      STAMP(tp1);
       if (t + 3 < nsteps) issue_loads(raw);
+      STAMP(tp2);
+      STAMP_ADD(2, tp0, tp1);                          // LDS writes
+      STAMP_ADD(3, tp1, tp2);                          // address math + load issue
+      __syncthreads();
+      STAMP(tp3);
+      STAMP_ADD(4, tp2, tp3);                          // barrier wait (write interval)
     }
-    __syncthreads();
   }
+#ifdef OCV_STAMPS
+  if (blockIdx.x == 0 && tid == 256) { for (int i = 0; i < 5; ++i) ocv_conv_stamps[2 + i] = stamp_acc[i]; }
+#endif
 }
 
 }  // namespace
@@ -343,6 +382,202 @@ extern "C" int ocv_conv_read_stamps(unsigned long long* out16) {
   return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(ocv_conv_stamps), 16 * sizeof(unsigned long long));
 }
 #endif
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Pre-split input, LDS-DMA variant.  With the activation already stored as (hi, lo) bf16 the A and B tiles are pure
+// copies, so the producers move them global -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write: the
+// ablation of the register-staged kernel put 25 % of its time in the ds_write_b128 path).  An LDS-DMA instruction
+// writes wave-uniform base + lane x 16 B, i.e. rows cannot be padded; bank conflicts are avoided instead by an XOR
+// swizzle of the 16-byte chunk index with (row >> 2) & 3, applied on the SOURCE side (each lane fetches the logical
+// chunk that belongs at its linear LDS slot) and on the fragment reads.
+// ---------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int DROW = 64;                                        // bytes per LDS row (32 bf16), unpadded
+constexpr int DA = CBM * DROW, DB = CBN * DROW;                 // 16384, 8192
+constexpr int DBUF = 2 * DA + 2 * DB;                           // 49152 per buffer
+constexpr int DNBUF = 3;                                         // 3 x 48 KiB: the DMA runs two K steps ahead
+
+__global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+
+  const int nwg = p.mtiles * p.ntiles;
+  int wg = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int mt = wg / p.ntiles, nt = wg - mt * p.ntiles;
+  const long m0 = (long)mt * CBM;
+  const int n0 = nt * CBN;
+  const int taps = p.ks * p.ks, pad = p.ks >> 1;
+  const int nsteps = taps * (p.Cp / CBK);
+
+  if (wave < 4) {
+    // =========================== CONSUMERS ===========================
+    const int wm = wave >> 1, wn = wave & 1;
+    const int sw = (l31 >> 2) & 3;                                // swizzle key of this lane's rows
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0};
+
+    __syncthreads();
+    for (int step = 0; step < nsteps; ++step) {
+      const unsigned char* base = lds + (step % DNBUF) * DBUF;
+      const unsigned char* pa = base + (wm * 128 + l31) * DROW;
+      const unsigned char* pb = base + 2 * DA + (wn * 64 + l31) * DROW;
+      bf16x8 ah[2][4], al[2][4], bh[2][2], bl[2][2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int co = (((kk * 2 + hh) ^ sw) * 16);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          bh[kk][j] = *reinterpret_cast<const bf16x8*>(pb + j * 32 * DROW + co);
+          bl[kk][j] = *reinterpret_cast<const bf16x8*>(pb + DB + j * 32 * DROW + co);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          ah[kk][i] = *reinterpret_cast<const bf16x8*>(pa + i * 32 * DROW + co);
+          al[kk][i] = *reinterpret_cast<const bf16x8*>(pa + DA + i * 32 * DROW + co);
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk][i], bh[kk][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk][i], bl[kk][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kk][i], bh[kk][j], acc[i][j], 0, 0, 0);
+          }
+      __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + l31;
+      const bool nok = n < p.Cout;
+      const float bv = (p.bias != nullptr && nok) ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long m = m0 + wm * 128 + i * 32 + acc_row(r, hh);
+          if (nok && m < p.M) {
+            float v = acc[i][j][r] + bv;
+            if (p.act == OCV_ACT_LEAKY_RELU) v = v > 0.f ? v : 0.01f * v;
+            else if (p.act == OCV_ACT_SILU) v = v / (1.0f + fast_exp(-v));
+            else if (p.act == OCV_ACT_RELU) v = fmaxf(v, 0.f);
+            if (p.res != nullptr) v += p.res[m * p.Cout + n];
+            if (p.y != nullptr) p.y[m * p.Cout + n] = v;
+            if (p.yhi != nullptr) {
+              const __bf16 hb = (__bf16)v;
+              p.yhi[m * p.Cout + n] = hb;
+              p.ylo[m * p.Cout + n] = (__bf16)(v - (float)hb);
+            }
+          }
+        }
+    }
+    return;
+  }
+
+  // =========================== PRODUCERS (LDS-DMA issuers) ===========================
+  // wave pw moves A rows [64 pw, 64 pw + 64) (hi and lo: 8 x 1 KiB pieces) and B rows [32 pw, 32 pw + 32) (4 pieces).
+  // Lane L of a piece lands at piece base + 16 L  =  row L >> 2, stored chunk L & 3, which must hold LOGICAL chunk
+  // (L & 3) ^ ((row >> 2) & 3) = (L & 3) ^ ((L >> 4) & 3)  (piece bases are multiples of 16 rows).
+  const int pw = wave - 4;
+  const int lrow = lane >> 2;
+  const int lchunk = (lane & 3) ^ ((lane >> 4) & 3);               // logical 16-byte chunk (8 channels) this lane fetches
+  unsigned rbA[4], tapmask[4];
+  {
+    const long hw = (long)p.H * p.W;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long am = m0 + 64 * pw + 16 * i + lrow;
+      const bool valid = am < p.M;
+      const long rem = valid ? am % hw : 0;
+      const int y = (int)(rem / p.W), x = (int)(rem - (long)y * p.W);
+      unsigned mask = 0;
+      for (int t = 0; t < taps; ++t) {
+        const int dy = t / p.ks - pad, dx = t % p.ks - pad;
+        if (valid && (unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W) mask |= 1u << t;
+      }
+      tapmask[i] = mask;
+      rbA[i] = (unsigned)(((valid ? am : 0) * p.Cin + lchunk * 8) * 2);
+    }
+  }
+  unsigned rbB[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int bn = min(n0 + 32 * pw + 16 * i + lrow, p.Cout - 1);
+    rbB[i] = (unsigned)(((long)bn * p.Cp + lchunk * 8) * 2);
+  }
+  const unsigned wtap = (unsigned)((long)p.Cout * p.Cp * 2);
+
+  int nx_tap = 0, nx_c0 = 0;
+  auto issue_dma = [&](int buf) {
+    const int tap = nx_tap, c0 = nx_c0;
+    if (++nx_tap == taps) { nx_tap = 0; nx_c0 += CBK; }
+    const int ky = tap / p.ks, kx = tap - ky * p.ks;
+    const int soff = (((ky - pad) * p.W + (kx - pad)) * p.Cin + c0) * 2;
+    const bool cok = c0 + lchunk * 8 + 8 <= p.Cin;
+    unsigned char* base = lds + buf * DBUF;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = ((tapmask[i] >> tap) & 1u) && cok;
+      const unsigned off = rbA[i] + (unsigned)soff;
+      const void* sh = ok ? (const void*)((const char*)p.xhi + off) : (const void*)ocv_zero_page;
+      const void* sl = ok ? (const void*)((const char*)p.xlo + off) : (const void*)ocv_zero_page;
+      unsigned char* dst = base + (64 * pw + 16 * i) * DROW;
+      __builtin_amdgcn_global_load_lds((gptr_t)sh, (lptr_t)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)sl, (lptr_t)(dst + DA), 16, 0, 0);
+    }
+    const unsigned woff = (unsigned)tap * wtap + (unsigned)c0 * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      unsigned char* dst = base + 2 * DA + (32 * pw + 16 * i) * DROW;
+      __builtin_amdgcn_global_load_lds((gptr_t)((const char*)p.whi + woff + rbB[i]), (lptr_t)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)((const char*)p.wlo + woff + rbB[i]), (lptr_t)(dst + DB), 16, 0, 0);
+    }
+  };
+
+  // Three LDS buffers, DMA two K steps ahead: in interval t (consumers on buffer t % 3) the producers issue step t+2
+  // into buffer (t+2) % 3 -- last read in interval t-1, free since the previous barrier -- and then only wait for step
+  // t+1, issued a whole interval earlier: a COUNTED s_waitcnt vmcnt(12) (this wave's 12 newest pieces may stay in
+  // flight) followed by a raw s_barrier; __syncthreads() would emit vmcnt(0) and drain the young pieces too.  An
+  // LDS-DMA has no register destination, so hand-counting it carries none of the register-copy hazard described at
+  // gload16().
+#define OCV_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+  issue_dma(0);
+  if (nsteps > 1) {
+    issue_dma(1);
+    OCV_WAIT_VM(12);
+  } else {
+    OCV_WAIT_VM(0);
+  }
+  __builtin_amdgcn_s_barrier();
+  for (int t = 0; t < nsteps; ++t) {
+    if (t + 2 < nsteps) {
+      issue_dma((t + 2) % DNBUF);
+      OCV_WAIT_VM(12);                                 // step t+1 has landed, step t+2 may still be in flight
+    } else {
+      OCV_WAIT_VM(0);
+    }
+    __builtin_amdgcn_s_barrier();
+  }
+#undef OCV_WAIT_VM
+}
+
+}  // namespace
 
 namespace {
 int launch_conv(ConvArgs& a, int B, bool in_split, hipStream_t st) {
@@ -355,7 +590,15 @@ int launch_conv(ConvArgs& a, int B, bool in_split, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  if (in_split) hipLaunchKernelGGL(conv_igemm_kernel<true>, dim3(a.mtiles * a.ntiles), dim3(512), 2 * BUF_BYTES, st, a);
+  static const bool use_dma = getenv("OCV_CONV_NO_DMA") == nullptr;
+  if (in_split && use_dma) {
+    static bool attr2 = false;
+    if (!attr2) {
+      (void)hipFuncSetAttribute((const void*)conv_split_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr2 = true;
+    }
+    hipLaunchKernelGGL(conv_split_dma_kernel, dim3(a.mtiles * a.ntiles), dim3(512), DNBUF * DBUF, st, a);
+  } else if (in_split) hipLaunchKernelGGL(conv_igemm_kernel<true>, dim3(a.mtiles * a.ntiles), dim3(512), 2 * BUF_BYTES, st, a);
   else hipLaunchKernelGGL(conv_igemm_kernel<false>, dim3(a.mtiles * a.ntiles), dim3(512), 2 * BUF_BYTES, st, a);
   OCV_CHECK_LAUNCH("ocv_conv_nhwc");
   return 0;
