@@ -167,6 +167,15 @@ int ocv_depthwise_conv_fwd(const float* in, const float* w, const float* bias, f
 int ocv_pointwise_conv_nhwc_fwd(const float* x, const float* gate, int rows_per_image, const float* W,
                                 const float* bias, const float* residual, float* y, long M, int Cin, int Cout, int act,
                                 ocv_stream_t stream);
+
+/* The same contraction on the bf16 matrix cores at fp32-level accuracy (split-bf16: every product is formed as
+ * hi*hi + hi*lo + lo*hi with fp32 accumulation, relative error of a product <= 2^-17): identical contract, except that
+ * the (static) weights arrive pre-split: w_hi = bf16(W), w_lo = bf16(W - w_hi), both [Cout, Kp] bf16 with rows
+ * zero-padded to Kp = ceil16(Cin).  The exact-fp32 entry point above is MFMA-bound from stage 4 of the encoder on
+ * (47 TFLOP/s of 157); this one is the encoder's default. */
+int ocv_pointwise_conv_nhwc_split_fwd(const float* x, const float* gate, int rows_per_image, const void* w_hi,
+                                      const void* w_lo, int Kp, const float* bias, const float* residual, float* y,
+                                      long M, int Cin, int Cout, int act, ocv_stream_t stream);
 /* depthwise k x k (k in {3,5}, stride in {1,2}) on NHWC: in [B,H,W,C], w [k*k][C], out [B,Ho,Wo,C]; C % 4 == 0.
  * Padding / bias / act as ocv_depthwise_conv_fwd. */
 int ocv_depthwise_conv_nhwc_fwd(const float* in, const float* w, const float* bias, float* out, int B, int C, int H,

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libobjcavit_hip.so")
-SOURCES = ("capi.hip", "linear.hip", "attention.hip", "patch_embed.hip", "bin_head.hip", "depthwise.hip", "conv_igemm.hip", "encoder_nhwc.hip", "upsample.hip")
+SOURCES = ("capi.hip", "linear.hip", "attention.hip", "patch_embed.hip", "bin_head.hip", "depthwise.hip", "conv_igemm.hip", "encoder_nhwc.hip", "upsample.hip", "pointwise_split.hip")
 ARCH = "gfx950"
 
 
@@ -39,6 +39,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
+    if os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)            # a failed rebuild must not leave a stale library behind
     objs = []
     procs = []
     for src in SOURCES:

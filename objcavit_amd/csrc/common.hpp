@@ -35,6 +35,11 @@ __device__ __forceinline__ float xor32_sum(float v) { return v + __shfl_xor(v, 3
 // exp via the hardware exp2 (v_exp_f32): ~1 ulp, exp(-inf) == 0
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
+// SiLU / sigmoid with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division (a ~12-instruction
+// sequence): the expand convolutions apply SiLU to every output and were VALU-bound on it.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
+__device__ __forceinline__ float fast_silu(float x) { return x * fast_sigmoid(x); }
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // ---------------------------------------------------------------------------

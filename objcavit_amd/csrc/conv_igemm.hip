@@ -182,7 +182,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
           if (nok && m < p.M) {
             float v = acc[i][j][r] + bv;
             if (p.act == OCV_ACT_LEAKY_RELU) v = v > 0.f ? v : 0.01f * v;
-            else if (p.act == OCV_ACT_SILU) v = v / (1.0f + fast_exp(-v));
+            else if (p.act == OCV_ACT_SILU) v = fast_silu(v);
             else if (p.act == OCV_ACT_RELU) v = fmaxf(v, 0.f);
             if (p.res != nullptr) v += p.res[m * p.Cout + n];
             if (p.y != nullptr) p.y[m * p.Cout + n] = v;
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
           if (nok && m < p.M) {
             float v = acc[i][j][r] + bv;
             if (p.act == OCV_ACT_LEAKY_RELU) v = v > 0.f ? v : 0.01f * v;
-            else if (p.act == OCV_ACT_SILU) v = v / (1.0f + fast_exp(-v));
+            else if (p.act == OCV_ACT_SILU) v = fast_silu(v);
             else if (p.act == OCV_ACT_RELU) v = fmaxf(v, 0.f);
             if (p.res != nullptr) v += p.res[m * p.Cout + n];
             if (p.y != nullptr) p.y[m * p.Cout + n] = v;

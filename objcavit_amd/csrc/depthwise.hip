@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void depthwise_kernel(DWArgs p) {
     }
     if (p.act == 3) {
 #pragma unroll
-      for (int o = 0; o < 4; ++o) acc[o] = acc[o] / (1.0f + fast_exp(-acc[o]));      // SiLU
+      for (int o = 0; o < 4; ++o) acc[o] = fast_silu(acc[o]);
     }
     float* op = p.out + (plane * p.Ho + oy) * (long)p.Wo + ox;
     if (ox + 3 < p.Wo && (p.Wo & 3) == 0) {

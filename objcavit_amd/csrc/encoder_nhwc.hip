@@ -25,8 +25,8 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
     case OCV_ACT_RELU: return fmaxf(v, 0.f);
     case OCV_ACT_LEAKY_RELU: return v > 0.f ? v : 0.01f * v;
-    case OCV_ACT_SILU: return v / (1.0f + fast_exp(-v));
-    case OCV_ACT_SIGMOID: return 1.0f / (1.0f + fast_exp(-v));
+    case OCV_ACT_SILU: return fast_silu(v);
+    case OCV_ACT_SIGMOID: return fast_sigmoid(v);
     default: return v;
   }
 }
@@ -113,50 +113,47 @@ __global__ __launch_bounds__(256) void pointwise_kernel(PWArgs p) {
 }
 
 // Small-K variant (K <= 128, the HBM-bound expand / DS-project layers: 24 -> 144 at 240 x 320 moves 826 MB for
-// 8 GFLOP).  A workgroup stages 128 rows ONCE, each wavefront keeps its own 32 rows and walks ALL column tiles
-// itself (weights re-fetched per tile from L2, K/8 float4 per lane), so the activation rows are read from HBM
-// exactly once whatever Cout is, and there are 4x fewer, 4x longer workgroups than with one 32 x 128 tile each
-// (that form ran at 1.7 TB/s, dispatch- and latency-bound).
+// 8 GFLOP).  Each wavefront owns 32 rows, keeps them (x gate) in VGPRs in MFMA A-operand order -- lane (l31, hh)
+// holds floats 8t + 4hh .. +3 of row l31, one 16-byte global load per t, every 32-byte sector fetched exactly once
+// -- and walks ALL column tiles itself (weights re-fetched per tile from L2, K/8 float4 per lane), so activation
+// rows are read from HBM exactly once whatever Cout is.  No LDS and no barrier: occupancy is bound by VGPRs only
+// (the earlier LDS-staged form held 67 KB per workgroup = 2 wavefronts per SIMD and ran at 1.5 TB/s).
+// KT = ceil(K / 8) rounded up to 4 / 8 / 16 sizes the register array.
+template <int KT>
 __global__ __launch_bounds__(256) void pointwise_smallk_kernel(PWArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float Xs[];      // [128][XLD]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
   const long m0 = (long)blockIdx.x * 128;
   const int K = p.K;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (tid >> 3) + 32 * i;
-    const long m = m0 + row;
+  float4 a[KT];
+  {
+    const long m = m0 + wave * 32 + l31;
     const bool ok = m < p.M;
-    const float* src = p.x + m * K;
-    const float* gsrc = (p.gate != nullptr && ok) ? p.gate + (m / p.rows_per_image) * K : nullptr;
+    const float* src = p.x + (ok ? m : 0) * K + 4 * hh;
+    const float* gsrc = p.gate != nullptr ? p.gate + ((ok ? m : 0) / p.rows_per_image) * K + 4 * hh : nullptr;
 #pragma unroll
-    for (int j = 0; j < KC / 32; ++j) {
-      const int c4 = (tid & 7) * 4 + 32 * j;
-      if (c4 < K) {
-        float4 t = ok ? ld4(src + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < KT; ++t) {
+      a[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (8 * t < K && ok) {
+        a[t] = ld4(src + 8 * t);
         if (gsrc != nullptr) {
-          const float4 g = ld4(gsrc + c4);
-          t.x *= g.x; t.y *= g.y; t.z *= g.z; t.w *= g.w;
+          const float4 g = ld4(gsrc + 8 * t);
+          a[t].x *= g.x; a[t].y *= g.y; a[t].z *= g.z; a[t].w *= g.w;
         }
-        *reinterpret_cast<float4*>(&Xs[row * XLD + c4]) = t;
       }
     }
   }
-  __syncthreads();
-  const float* xrow = Xs + (wave * 32 + l31) * XLD + 4 * hh;
-  float4 a[KC / 8];
-#pragma unroll
-  for (int t = 0; t < KC / 8; ++t)
-    a[t] = (8 * t < K) ? *reinterpret_cast<const float4*>(xrow + 8 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
 
-  const int ntiles = (p.N + 31) >> 5;
-  for (int nt = 0; nt < ntiles; ++nt) {
+  // blockIdx.y splits the column tiles when there are too few 128-row workgroups to fill the chip (small M, wide N)
+  const int ntiles_all = (p.N + 31) >> 5;
+  const int per_y = (ntiles_all + gridDim.y - 1) / gridDim.y;
+  const int nt_lo = blockIdx.y * per_y, ntiles = min(ntiles_all, nt_lo + per_y);
+  for (int nt = nt_lo; nt < ntiles; ++nt) {
     const int n = nt * 32 + l31;
     const float* wrow = p.W + (long)(n < p.N ? n : p.N - 1) * K + 4 * hh;
     f32x16 acc = {0};
 #pragma unroll
-    for (int t = 0; t < KC / 8; ++t) {
+    for (int t = 0; t < KT; ++t) {
       if (8 * t < K) {
         const float4 w = ld4(wrow + 8 * t);
         acc = mfma_32x32x2(a[t].x, w.x, acc);
@@ -331,7 +328,7 @@ __global__ __launch_bounds__(256) void se_hidden_kernel(const float* __restrict_
   const float s = wave_sum((s0 + s1) + (s2 + s3));
   if (lane == 0) {
     const float v = s + b1[r];
-    hid[b * R + r] = v / (1.0f + fast_exp(-v));
+    hid[b * R + r] = fast_silu(v);
   }
 }
 
@@ -355,7 +352,7 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
   }
   for (; r < R; ++r) s0 = fmaf(w[(long)r * C], hs[r], s0);
   const float s = (s0 + s1) + (s2 + s3);
-  gate[b * C + c] = 1.0f / (1.0f + fast_exp(-s));
+  gate[b * C + c] = fast_sigmoid(s);
 }
 
 int mean_splits(int B, int C, long P) {
@@ -379,12 +376,14 @@ extern "C" int ocv_pointwise_conv_nhwc_fwd(const float* x, const float* gate, in
   PWArgs a{x, gate, W, bias, residual, y, M, Cin, Cout, rows_per_image > 0 ? rows_per_image : 1, act};
   hipStream_t st = (hipStream_t)stream;
   if (Cin <= KC && M >= 4096) {
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute((const void*)pointwise_smallk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr = true;
-    }
-    hipLaunchKernelGGL(pointwise_smallk_kernel, dim3((unsigned)((M + 127) / 128)), dim3(256), (size_t)128 * XLD * sizeof(float), st, a);
+    const long mblocks = (M + 127) / 128;
+    int ysplit = 1;
+    const int ntl = (Cout + 31) / 32;
+    while (mblocks * ysplit < 768 && ysplit * 2 <= ntl) ysplit *= 2;
+    const dim3 grid((unsigned)mblocks, ysplit);
+    if (Cin <= 32) hipLaunchKernelGGL(pointwise_smallk_kernel<4>, grid, dim3(256), 0, st, a);
+    else if (Cin <= 64) hipLaunchKernelGGL(pointwise_smallk_kernel<8>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(pointwise_smallk_kernel<16>, grid, dim3(256), 0, st, a);
     OCV_CHECK_LAUNCH("ocv_pointwise_conv_nhwc_fwd(small K)");
     return 0;
   }

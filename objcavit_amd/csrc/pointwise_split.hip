@@ -1,0 +1,469 @@
+// Pointwise (1x1) convolution of the EfficientNet-B5 MBConv stages on the bf16 matrix cores with fp32-level accuracy
+// (row N1 of SURVEY.md section 8; the reference runs conv_pw / conv_pwl / conv_head through its hub backbone,
+// modules/DenseFeatureExtractor.py:18-27,149).
+//
+//   y[m][co] = act( bias[co] + sum_ci x[m][ci] * gate[m / rows_per_image][ci] * W[co][ci] ) + residual[m][co]
+//
+// Same contract as ocv_pointwise_conv_nhwc_fwd (csrc/encoder_nhwc.hip) except that the weights arrive pre-split:
+// W = w_hi + w_lo with w_hi = bf16(W), w_lo = bf16(W - w_hi), rows zero-padded to Kp = ceil16(Cin).  The activation
+// rows are split the same way on the fly and every product is formed as hi*hi + hi*lo + lo*hi on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation (the dropped lo*lo term is 2^-18 relative): 3 x 32 cycles per
+// 32 x 32 x 16 block against 8 x 64 cycles for v_mfma_f32_32x32x2_f32.  That is what the exact-fp32 kernels were
+// bound by from stage 4 of the encoder on (19200 x 1056 -> 176: 47 TFLOP/s = 30 % of the fp32 MFMA peak, 7 GFLOP
+// against 98 MB of traffic); with the split form every layer is back under its HBM / latency bound.
+//
+// Two kernels:
+//   pw_rows_kernel<KS>       Cin <= 128: a wavefront keeps its 32 rows (x gate), already split, in VGPRs in A-operand
+//                            order and walks the output-channel tiles; weights stream from L1/L2 straight into the B
+//                            operand.  No LDS, no barrier; rows are read from HBM exactly once.
+//   pw_tile_kernel<WN,WK,RT> any Cin: workgroup tile (32 RT) rows x (32 WN) channels, WK wavefront groups split every
+//                            64 WK-wide K slab between them (more wavefronts in flight for the small-M late stages,
+//                            summed through LDS in a fixed order at the end).  Rows are staged through LDS as split
+//                            bf16 (converted ONCE per workgroup), double buffered, one barrier per slab; next slab's
+//                            global loads (rows and weights) are issued before the current slab's MFMAs.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.hpp"
+#include "../../include/objcavit_hip.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct PSArgs {
+  const float *x, *gate, *bias, *res;
+  const __bf16 *whi, *wlo;          // [N][Kp]
+  float* y;
+  long M;
+  int K, Kp, N, rows_per_image, act;
+  int nbx, nby, col_major;          // tile kernel: row blocks, channel blocks, traversal order
+};
+
+__device__ __forceinline__ float act_fn(float v, int act) {
+  switch (act) {
+    case OCV_ACT_RELU: return fmaxf(v, 0.f);
+    case OCV_ACT_LEAKY_RELU: return v > 0.f ? v : 0.01f * v;
+    case OCV_ACT_SILU: return fast_silu(v);
+    case OCV_ACT_SIGMOID: return fast_sigmoid(v);
+    default: return v;
+  }
+}
+
+// 8 consecutive floats (two 16-byte vectors) -> bf16 hi / lo octets
+__device__ __forceinline__ void split8(const float4 u, const float4 v, bf16x8& hi, bf16x8& lo) {
+  const float f[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 h = (__bf16)f[i];
+    hi[i] = h;
+    lo[i] = (__bf16)(f[i] - (float)h);
+  }
+}
+
+__device__ __forceinline__ float4 mul4(float4 a, const float4 g) {
+  a.x *= g.x; a.y *= g.y; a.z *= g.z; a.w *= g.w;
+  return a;
+}
+
+// Diagnostic builds only (-DPW_ABL_*): knock out one stream at a time to find what bounds a kernel.
+#ifdef PW_ABL_NOW
+__device__ __forceinline__ bf16x8 ldb8(const __bf16* p) { const __bf16 v = (__bf16)(float)(((unsigned long)p >> 4) & 3); return bf16x8{v, v, v, v, v, v, v, v}; }
+#else
+__device__ __forceinline__ bf16x8 ldb8(const __bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+#endif
+#ifdef PW_ABL_NOA
+__device__ __forceinline__ float4 lda4(const float* p) { const float v = (float)(((unsigned long)p >> 4) & 3); return make_float4(v, v, v, v); }
+#else
+__device__ __forceinline__ float4 lda4(const float* p) { return ld4(p); }
+#endif
+#ifdef PW_ABL_NOGATE
+__device__ __forceinline__ float4 ldg4(const float* p) { const float v = (float)(((unsigned long)p >> 4) & 3); return make_float4(v, v, v, v); }
+#else
+__device__ __forceinline__ float4 ldg4(const float* p) { return ld4(p); }
+#endif
+
+__device__ __forceinline__ f32x16 mfma3(const bf16x8 ah, const bf16x8 al, const bf16x8 bh, const bf16x8 bl, f32x16 acc) {
+#ifdef PW_ABL_NOMFMA
+  acc[0] += (float)ah[0] + (float)al[1] + (float)bh[2] + (float)bl[3];
+#else
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+#endif
+  return acc;
+}
+
+// bias + activation + residual + store of one 32 x 32 accumulator tile whose first row is m_base
+__device__ __forceinline__ void store_tile(const PSArgs& p, const f32x16& acc, long m_base, int n, int hh) {
+  if (n >= p.N) return;
+  const float bv = p.bias != nullptr ? p.bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const long m = m_base + acc_row(r, hh);
+    if (m < p.M) {
+      float v = act_fn(acc[r] + bv, p.act);
+      if (p.res != nullptr) v += p.res[m * p.N + n];
+      p.y[m * p.N + n] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Cin <= 128: rows resident in registers.  KS = 16-wide K steps held (2 / 4 / 8).
+// ---------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(256) void pw_rows_kernel(PSArgs p) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const long m_base = (long)blockIdx.x * 128 + wave * 32;
+  const int K = p.K;
+  bf16x8 ahi[KS], alo[KS];
+  {
+    const long m = m_base + l31;
+    const bool ok = m < p.M;
+    const float* src = p.x + (ok ? m : 0) * K + 8 * hh;
+    const float* gsrc = p.gate != nullptr ? p.gate + ((ok ? m : 0) / p.rows_per_image) * K + 8 * hh : nullptr;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = u;
+      if (ok && 16 * s + 8 * hh < K) {
+        u = lda4(src + 16 * s);
+        v = lda4(src + 16 * s + 4);
+        if (gsrc != nullptr) {
+          u = mul4(u, ldg4(gsrc + 16 * s));
+          v = mul4(v, ldg4(gsrc + 16 * s + 4));
+        }
+      }
+      split8(u, v, ahi[s], alo[s]);
+    }
+  }
+  // blockIdx.y splits the channel tiles when there are too few 128-row workgroups to fill the chip
+  const int ntiles_all = (p.N + 31) >> 5;
+  const int per_y = (ntiles_all + gridDim.y - 1) / gridDim.y;
+  const int nt_lo = blockIdx.y * per_y, nt_hi = min(ntiles_all, nt_lo + per_y);
+  for (int nt = nt_lo; nt < nt_hi; ++nt) {
+    const int n = nt * 32 + l31;
+    const long woff = (long)(n < p.N ? n : p.N - 1) * p.Kp + 8 * hh;
+    f32x16 acc = {0};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (16 * s < p.Kp) acc = mfma3(ahi[s], alo[s], ldb8(p.whi + woff + 16 * s), ldb8(p.wlo + woff + 16 * s), acc);
+    }
+    store_tile(p, acc, m_base, n, hh);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// general tile kernel
+// ---------------------------------------------------------------------------
+constexpr int LROW = 144;            // bytes per LDS row: 64 bf16 + 16 pad (conflict-free ds_read_b128 across rows)
+
+template <int WN, int WK, int RT>
+__global__ __launch_bounds__(64 * WN * WK) void pw_tile_kernel(PSArgs p) {
+  constexpr int NT = 64 * WN * WK;             // threads
+  constexpr int ROWS = 32 * RT;
+  constexpr int KI = 64 * WK;                  // K slab per iteration
+  constexpr int OCT = (ROWS * 8 * WK) / NT;    // float octets staged per thread and slab (= 4 RT / WN)
+  constexpr int PART = ROWS * LROW;            // one (group, hi|lo) plane
+  constexpr int BUF = WK * 2 * PART;
+  static_assert(OCT >= 1 && OCT * NT == ROWS * 8 * WK, "staging map");
+  extern __shared__ __attribute__((aligned(16))) char lds[];    // 2 x BUF
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int wn = wave % WN, g = wave / WN;
+  // XCD-aware, bijective workgroup -> tile map: hardware deals consecutive workgroup ids round-robin to the 8 XCDs
+  // (each with its own 4 MB L2); give every XCD a CONTIGUOUS run of tiles in the order the host chose (channel-block
+  // major when the whole weight matrix would not fit an L2, so an XCD keeps one weight slice resident and streams
+  // rows; row-block major otherwise, so its rows are read once and all of W stays resident).
+  int bx, by;
+  {
+    const int nwg = gridDim.x;
+    int wg = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    if (p.col_major) { by = wg / p.nbx; bx = wg % p.nbx; }
+    else { bx = wg / p.nby; by = wg % p.nby; }
+  }
+  const long m0 = (long)bx * ROWS;
+  const int n = by * (32 * WN) + wn * 32 + l31;
+  const long woff = (long)(n < p.N ? n : p.N - 1) * p.Kp + 64 * g + 8 * hh;
+  const int K = p.K, Kp = p.Kp;
+  const int nit = (Kp + KI - 1) / KI;
+
+  // staging map: octet o -> (row, group, j): 8 floats at k = it * KI + 64 group + 8 j of row m0 + row
+  const float* asrc[OCT];
+  const float* gsrc[OCT];
+  int akoff[OCT], ldst[OCT];
+#pragma unroll
+  for (int i = 0; i < OCT; ++i) {
+    const int o = tid + i * NT;
+    const int row = o / (8 * WK), oc = o % (8 * WK);
+    const long m = m0 + row;
+    const bool ok = m < p.M;
+    akoff[i] = ok ? 8 * oc : (1 << 30);                        // rows past M never pass the k < K test
+    asrc[i] = p.x + (ok ? m : 0) * K + 8 * oc;
+    gsrc[i] = p.gate != nullptr ? p.gate + ((ok ? m : 0) / p.rows_per_image) * K + 8 * oc : nullptr;
+    ldst[i] = ((oc >> 3) * 2) * PART + row * LROW + (oc & 7) * 16;
+  }
+  float4 ra[OCT][2];
+  bf16x8 wh[4], wl[4], whn[4], wln[4];
+  auto load_a = [&](int it) {
+#pragma unroll
+    for (int i = 0; i < OCT; ++i) {
+      const int k = it * KI + akoff[i];
+      ra[i][0] = ra[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < K && k >= 0) {
+        ra[i][0] = lda4(asrc[i] + it * KI);
+        ra[i][1] = lda4(asrc[i] + it * KI + 4);
+        if (gsrc[i] != nullptr) {
+          ra[i][0] = mul4(ra[i][0], ldg4(gsrc[i] + it * KI));
+          ra[i][1] = mul4(ra[i][1], ldg4(gsrc[i] + it * KI + 4));
+        }
+      }
+    }
+  };
+  auto store_a = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < OCT; ++i) {
+      bf16x8 h, l;
+      split8(ra[i][0], ra[i][1], h, l);
+      char* d = lds + buf * BUF + ldst[i];
+      *reinterpret_cast<bf16x8*>(d) = h;
+      *reinterpret_cast<bf16x8*>(d + PART) = l;
+    }
+  };
+  auto load_w = [&](int it, bf16x8 (&h)[4], bf16x8 (&l)[4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int k = it * KI + 64 * g + 16 * s;
+      if (k < Kp) {
+        h[s] = ldb8(p.whi + woff + it * KI + 16 * s);
+        l[s] = ldb8(p.wlo + woff + it * KI + 16 * s);
+      }
+    }
+  };
+
+  f32x16 acc[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x16{0};
+
+  load_a(0);
+  load_w(0, wh, wl);
+  store_a(0);
+  __syncthreads();
+  for (int it = 0; it < nit; ++it) {
+    const bool more = it + 1 < nit;
+    if (more) {
+      load_a(it + 1);
+      load_w(it + 1, whn, wln);
+    }
+    const char* base = lds + (it & 1) * BUF + (g * 2) * PART + l31 * LROW + hh * 16;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (it * KI + 64 * g + 16 * s < Kp) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(base + rt * 32 * LROW + s * 32);
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(base + PART + rt * 32 * LROW + s * 32);
+          acc[rt] = mfma3(ah, al, wh[s], wl[s], acc[rt]);
+        }
+      }
+    }
+    if (more) {
+      store_a((it + 1) & 1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) { wh[s] = whn[s]; wl[s] = wln[s]; }
+    }
+    __syncthreads();
+  }
+
+  // K groups 1.. hand their partial tiles to group 0 through LDS ([group - 1][wn][rt][reg][lane], fixed order)
+  if (WK > 1) {
+    float* red = reinterpret_cast<float*>(lds);
+    if (g > 0) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((((g - 1) * WN + wn) * RT + rt) * 16 + r) * 64 + lane] = acc[rt][r];
+    }
+    __syncthreads();
+    if (g > 0) return;
+#pragma unroll
+    for (int gg = 1; gg < WK; ++gg)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rt][r] += red[((((gg - 1) * WN + wn) * RT + rt) * 16 + r) * 64 + lane];
+  }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) store_tile(p, acc[rt], m0 + rt * 32, n, hh);
+}
+
+template <int WN, int WK, int RT>
+int launch_tile(const PSArgs& a, hipStream_t st) {
+  constexpr int ROWS = 32 * RT;
+  constexpr size_t LDS = (size_t)2 * WK * 2 * ROWS * LROW;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)pw_tile_kernel<WN, WK, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  PSArgs b = a;
+  b.nbx = (int)((a.M + ROWS - 1) / ROWS);
+  b.nby = ocv_cdiv(a.N, 32 * WN);
+  b.col_major = (long)a.N * a.Kp * 4 > (3L << 20);
+  hipLaunchKernelGGL((pw_tile_kernel<WN, WK, RT>), dim3((unsigned)((long)b.nbx * b.nby)), dim3(64 * WN * WK), LDS, st, b);
+  OCV_CHECK_LAUNCH("ocv_pointwise_conv_nhwc_split_fwd");
+  return 0;
+}
+
+template <int WN>
+int launch_tile_wn(const PSArgs& a, int wk, int rt, hipStream_t st) {
+  if (rt == 2) return wk >= 2 ? launch_tile<WN, 2, 2>(a, st) : launch_tile<WN, 1, 2>(a, st);
+  if constexpr (WN <= 2) {
+    if (wk >= 4) return launch_tile<WN, 4, 1>(a, st);
+  }
+  if (wk >= 2) return launch_tile<WN, 2, 1>(a, st);
+  return launch_tile<WN, 1, 1>(a, st);
+}
+
+// ---------------------------------------------------------------------------
+// few output channels (<= 128), many rows: K-streaming rows kernel.  A wavefront owns 32 rows and ALL output channels
+// (NTL accumulator tiles), reads its rows straight from HBM in A-operand order (lane = (row, 8 consecutive floats) --
+// every 32-byte sector is fetched exactly once), splits them in registers and streams the matching weight columns from
+// L1/L2.  No LDS, no barrier, nothing shared between wavefronts: the memory system sees one long independent stream
+// per wavefront, which is what the HBM-bound project layers (240 -> 40 at 120 x 160: 393 MB, 6 GFLOP) want.
+// ---------------------------------------------------------------------------
+template <int NTL, int U>
+__global__ __launch_bounds__(256) void pw_stream_kernel(PSArgs p) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const long m_base = (long)blockIdx.x * 128 + wave * 32;
+  const int K = p.K, nsteps = p.Kp >> 4;
+  const long m = m_base + l31;
+  const bool ok = m < p.M;
+  const float* src = p.x + (ok ? m : 0) * K + 8 * hh;
+  const float* gsrc = p.gate != nullptr ? p.gate + ((ok ? m : 0) / p.rows_per_image) * K + 8 * hh : nullptr;
+  const int klim = ok ? K - 8 * hh : 0;        // this lane's octet of step s is in range iff 16 s < klim
+  long woff[NTL];
+#pragma unroll
+  for (int j = 0; j < NTL; ++j) woff[j] = (long)min(32 * j + l31, p.N - 1) * p.Kp + 8 * hh;
+  f32x16 acc[NTL];
+#pragma unroll
+  for (int j = 0; j < NTL; ++j) acc[j] = f32x16{0};
+
+  for (int s0 = 0; s0 < nsteps; s0 += U) {
+    float4 ra[U][2];
+    bf16x8 wh[U][NTL], wl[U][NTL];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int s = s0 + u;
+      ra[u][0] = ra[u][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (16 * s < klim) {
+        ra[u][0] = lda4(src + 16 * s);
+        ra[u][1] = lda4(src + 16 * s + 4);
+      }
+      if (s < nsteps) {
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+          wh[u][j] = ldb8(p.whi + woff[j] + 16 * s);
+          wl[u][j] = ldb8(p.wlo + woff[j] + 16 * s);
+        }
+      }
+    }
+    if (gsrc != nullptr) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int s = s0 + u;
+        if (16 * s < klim) {
+          ra[u][0] = mul4(ra[u][0], ldg4(gsrc + 16 * s));
+          ra[u][1] = mul4(ra[u][1], ldg4(gsrc + 16 * s + 4));
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (s0 + u < nsteps) {
+        bf16x8 ah, al;
+        split8(ra[u][0], ra[u][1], ah, al);
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) acc[j] = mfma3(ah, al, wh[u][j], wl[u][j], acc[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NTL; ++j) store_tile(p, acc[j], m_base, 32 * j + l31, hh);
+}
+
+// diagnostic override of the tile shape: OCV_PW_CFG="wn,wk,rt" (0 = heuristic); "stream" / "tile" force a kernel family
+struct PwCfg { int wn = 0, wk = 0, rt = 0, family = 0; };
+const PwCfg& pw_cfg() {
+  static PwCfg c = [] {
+    PwCfg v;
+    const char* e = getenv("OCV_PW_CFG");
+    if (e != nullptr) {
+      if (strcmp(e, "stream") == 0) v.family = 1;
+      else if (strcmp(e, "tile") == 0) v.family = 2;
+      else if (sscanf(e, "%d,%d,%d", &v.wn, &v.wk, &v.rt) == 3) v.family = 2;
+    }
+    return v;
+  }();
+  return c;
+}
+
+}  // namespace
+
+extern "C" int ocv_pointwise_conv_nhwc_split_fwd(const float* x, const float* gate, int rows_per_image, const void* w_hi,
+                                                 const void* w_lo, int Kp, const float* bias, const float* residual,
+                                                 float* y, long M, int Cin, int Cout, int act, ocv_stream_t stream) {
+  OCV_CHECK_ARG(x && w_hi && w_lo && y, "ocv_pointwise_conv_nhwc_split_fwd: null pointer");
+  OCV_CHECK_ARG(M >= 0 && Cin >= 8 && Cin % 8 == 0 && Cout >= 1, "ocv_pointwise_conv_nhwc_split_fwd: Cin must be a positive multiple of 8 (got M=%ld Cin=%d Cout=%d)", M, Cin, Cout);
+  OCV_CHECK_ARG(Kp == (Cin + 15) / 16 * 16, "ocv_pointwise_conv_nhwc_split_fwd: weight rows must be padded to Kp = ceil16(Cin) = %d (got %d)", (Cin + 15) / 16 * 16, Kp);
+  OCV_CHECK_ARG(gate == nullptr || rows_per_image >= 1, "ocv_pointwise_conv_nhwc_split_fwd: gate needs rows_per_image");
+  OCV_CHECK_ARG(act >= 0 && act <= OCV_ACT_SIGMOID, "ocv_pointwise_conv_nhwc_split_fwd: unknown activation %d", act);
+  OCV_CHECK_ARG(ocv_aligned16(x) && ocv_aligned16(w_hi) && ocv_aligned16(w_lo) && ocv_aligned16(gate),
+                "ocv_pointwise_conv_nhwc_split_fwd: x / w_hi / w_lo / gate must be 16-byte aligned");
+  if (M == 0) return 0;
+  PSArgs a{x, gate, bias, residual, (const __bf16*)w_hi, (const __bf16*)w_lo, y, M, Cin, Kp, Cout,
+           rows_per_image > 0 ? rows_per_image : 1, act};
+  hipStream_t st = (hipStream_t)stream;
+  const PwCfg& cfg = pw_cfg();
+  if (cfg.family == 0 && Cin <= 128 && M >= 4096) {
+    const long mblocks = (M + 127) / 128;
+    int ysplit = 1;
+    const int ntl = (Cout + 31) / 32;
+    while (mblocks * ysplit < 768 && ysplit * 2 <= ntl) ysplit *= 2;
+    const dim3 grid((unsigned)mblocks, ysplit);
+    if (Cin <= 32) hipLaunchKernelGGL(pw_rows_kernel<2>, grid, dim3(256), 0, st, a);
+    else if (Cin <= 64) hipLaunchKernelGGL(pw_rows_kernel<4>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(pw_rows_kernel<8>, grid, dim3(256), 0, st, a);
+    OCV_CHECK_LAUNCH("ocv_pointwise_conv_nhwc_split_fwd(rows)");
+    return 0;
+  }
+  if (cfg.family != 2 && Cout <= 128 && (M >= 65536 || cfg.family == 1)) {
+    const dim3 grid((unsigned)((M + 127) / 128));
+    if (Cout <= 32) hipLaunchKernelGGL((pw_stream_kernel<1, 4>), grid, dim3(256), 0, st, a);
+    else if (Cout <= 64) hipLaunchKernelGGL((pw_stream_kernel<2, 4>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((pw_stream_kernel<4, 2>), grid, dim3(256), 0, st, a);
+    OCV_CHECK_LAUNCH("ocv_pointwise_conv_nhwc_split_fwd(stream)");
+    return 0;
+  }
+  // tile shape: 128 channels wide unless there are fewer; two row tiles per wavefront (half the weight traffic) when
+  // that still leaves >= 512 workgroups; then K groups until the launch has a few thousand wavefronts
+  int wn = Cout > 64 ? 4 : (Cout > 32 ? 2 : 1);
+  if (cfg.wn) wn = cfg.wn;
+  const long nby = ocv_cdiv(Cout, 32 * wn);
+  int rt = ((M + 63) / 64) * nby >= 512 ? 2 : 1;
+  if (cfg.rt) rt = cfg.rt;
+  const long waves = ((M + 32 * rt - 1) / (32 * rt)) * nby * wn;
+  int wk = 1;
+  while (wk < 4 && wn * wk * 2 <= 8 && waves * wk < 4096 && Kp >= 256 * wk) wk *= 2;
+  if (cfg.wk) wk = cfg.wk;
+  if (rt == 2 && wk > 2) wk = 2;
+  if (wn == 4) return launch_tile_wn<4>(a, wk, rt, st);
+  if (wn == 2) return launch_tile_wn<2>(a, wk, rt, st);
+  return launch_tile_wn<1>(a, wk, rt, st);
+}

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, Optional, Sequence, Tuple
 
 import torch
@@ -510,10 +511,33 @@ def conv_nhwc(x1: torch.Tensor, x2: Optional[torch.Tensor], w_hi: torch.Tensor, 
 # ---------------------------------------------------------------------------
 # NHWC encoder blocks (pointwise conv with fused gate / bias / act / residual, depthwise, squeeze)
 # ---------------------------------------------------------------------------
-def pointwise_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = ACT_NONE,
+class SplitWeight:
+    """A static [Cout, Cin] matrix pre-split for the bf16x3 kernels: hi = bf16(W), lo = bf16(W - hi), rows zero-padded
+    to Kp = ceil16(Cin).  Built once per weight version by the callers (cached next to their BN-folded weights)."""
+
+    def __init__(self, weight: torch.Tensor):
+        w = weight.detach().float().reshape(weight.shape[0], -1)
+        self.cout, self.cin = w.shape
+        self.kp = (self.cin + 15) // 16 * 16
+        if self.kp != self.cin:
+            w = torch.nn.functional.pad(w, (0, self.kp - self.cin))
+        self.hi = w.to(torch.bfloat16).contiguous()
+        self.lo = (w - self.hi.float()).to(torch.bfloat16).contiguous()
+
+
+def pointwise_weight(weight: torch.Tensor):
+    """What the encoder hands to pointwise_nhwc: the split form (default) or, with OCV_PW=fp32 in the environment, the
+    fp32 matrix itself (exact v_mfma_f32_32x32x2_f32 path, ~3x slower from stage 4 on)."""
+    if os.environ.get("OCV_PW", "split") == "fp32":
+        return weight.detach().reshape(weight.shape[0], -1).contiguous()
+    return SplitWeight(weight)
+
+
+def pointwise_nhwc(x: torch.Tensor, weight, bias: Optional[torch.Tensor], act: int = ACT_NONE,
                    gate: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """1x1 convolution on a channels_last [B, C, H, W] tensor (or a plain [M, C] matrix): act(x*gate @ W^T + b) + res.
-    weight [Cout, Cin] (or [Cout, Cin, 1, 1]); gate [B, Cin]."""
+    weight: fp32 [Cout, Cin] (or [Cout, Cin, 1, 1]) -> exact fp32 kernel; a SplitWeight -> split-bf16 kernel.
+    gate [B, Cin]."""
     lib = _lib.load()
     four = x.dim() == 4
     if four:
@@ -524,10 +548,16 @@ def pointwise_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.T
         _req(x, "x")
         M, Cin = x.shape
         B, rpi = M, 1
-    w2 = _req(weight.reshape(weight.shape[0], -1), "weight")
-    Cout = w2.shape[0]
-    if w2.shape[1] != Cin:
-        raise ValueError(f"pointwise_nhwc: weight {tuple(weight.shape)} does not match {Cin} input channels")
+    split = isinstance(weight, SplitWeight)
+    if split:
+        _req(weight.hi, "weight.hi", torch.bfloat16)
+        _req(weight.lo, "weight.lo", torch.bfloat16)
+        Cout, wcin = weight.cout, weight.cin
+    else:
+        w2 = _req(weight.reshape(weight.shape[0], -1), "weight")
+        Cout, wcin = w2.shape
+    if wcin != Cin:
+        raise ValueError(f"pointwise_nhwc: weight with {wcin} input channels does not match {Cin} input channels")
     if bias is not None:
         _req(bias, "bias")
         if bias.numel() != Cout:
@@ -544,9 +574,15 @@ def pointwise_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.T
         residual = _nhwc(residual, "residual") if four else _req(residual, "residual")
         if residual.shape != y.shape:
             raise ValueError("pointwise_nhwc: residual shape mismatch")
-    with timed("pointwise"):
-        check(lib.ocv_pointwise_conv_nhwc_fwd(x.data_ptr(), _ptr(gate), rpi, w2.data_ptr(), _ptr(bias), _ptr(residual),
-                                              y.data_ptr(), M, Cin, Cout, act, _stream()), "ocv_pointwise_conv_nhwc_fwd")
+    with timed(f"pointwise|{M},{Cin},{Cout}"):
+        if split:
+            check(lib.ocv_pointwise_conv_nhwc_split_fwd(x.data_ptr(), _ptr(gate), rpi, weight.hi.data_ptr(),
+                                                        weight.lo.data_ptr(), weight.kp, _ptr(bias), _ptr(residual),
+                                                        y.data_ptr(), M, Cin, Cout, act, _stream()),
+                  "ocv_pointwise_conv_nhwc_split_fwd")
+        else:
+            check(lib.ocv_pointwise_conv_nhwc_fwd(x.data_ptr(), _ptr(gate), rpi, w2.data_ptr(), _ptr(bias), _ptr(residual),
+                                                  y.data_ptr(), M, Cin, Cout, act, _stream()), "ocv_pointwise_conv_nhwc_fwd")
     return y
 
 
@@ -565,7 +601,7 @@ def depthwise_nhwc_same(x: torch.Tensor, weight_kkc: torch.Tensor, bias: Optiona
     ph = max((Ho - 1) * stride + k - H, 0)
     pw = max((Wo - 1) * stride + k - W, 0)
     out = torch.empty(B, Cc, Ho, Wo, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    with timed("depthwise"):
+    with timed(f"depthwise|{B},{H},{W},{Cc},k{k}s{stride}"):
         check(lib.ocv_depthwise_conv_nhwc_fwd(x.data_ptr(), weight_kkc.data_ptr(), _ptr(bias), out.data_ptr(), B, Cc, H, W,
                                               k, stride, ph // 2, pw // 2, Ho, Wo, act, _stream()),
               "ocv_depthwise_conv_nhwc_fwd")

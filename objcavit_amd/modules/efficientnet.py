@@ -103,7 +103,12 @@ class Conv1x1(nn.Conv2d):
     def forward(self, x):
         if (not self.training) and (not torch.is_grad_enabled()) and x.device.type == "cuda" and self.bias is None \
                 and x.shape[1] % 8 == 0:
-            return hip_ops.pointwise_nhwc(x, self.weight.detach(), None, hip_ops.ACT_NONE)
+            c = self.__dict__.get("_pw_cache")
+            key = (x.device, self.weight._version, self.weight.data_ptr())
+            if c is None or c[0] != key:
+                c = (key, hip_ops.pointwise_weight(self.weight))
+                self.__dict__["_pw_cache"] = c
+            return hip_ops.pointwise_nhwc(x, c[1], None, hip_ops.ACT_NONE)
         return super().forward(x)
 
 
@@ -149,7 +154,7 @@ class DepthwiseSeparableConv(_FoldedMixin, nn.Module):
     def _fold(self):
         wd, bd = fold_bn(self.conv_dw, self.bn1)
         wp, bp = fold_bn(self.conv_pw, self.bn2)
-        return (_dw_tap_major(wd), bd, wp.flatten(1).contiguous(), bp) + _se_params(self.se)
+        return (_dw_tap_major(wd), bd, hip_ops.pointwise_weight(wp), bp) + _se_params(self.se)
 
     def forward(self, x):
         if self._fast(x):
@@ -183,7 +188,7 @@ class InvertedResidual(_FoldedMixin, nn.Module):
         we, be = fold_bn(self.conv_pw, self.bn1)
         wd, bd = fold_bn(self.conv_dw, self.bn2)
         wl, bl = fold_bn(self.conv_pwl, self.bn3)
-        return (we.flatten(1).contiguous(), be, _dw_tap_major(wd), bd, wl.flatten(1).contiguous(), bl) + _se_params(self.se)
+        return (hip_ops.pointwise_weight(we), be, _dw_tap_major(wd), bd, hip_ops.pointwise_weight(wl), bl) + _se_params(self.se)
 
     def forward(self, x):
         if self._fast(x):

@@ -364,6 +364,62 @@ def test_pointwise_nhwc(ops, B, H, W, Cin, Cout, act, use_gate, use_res):
     assert rel_dev(got, ref) < TOL
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,act,use_gate,use_res", [
+    (2, 60, 80, 24, 144, 3, False, False),      # rows kernel (M >= 4096, Cin <= 32), Kp = 32 > Cin
+    (2, 60, 80, 48, 24, 0, True, False),        # rows kernel, Cin <= 64, gate, one ragged channel tile
+    (1, 64, 80, 40, 240, 3, False, False),      # rows kernel, Cin % 16 == 8
+    (3, 40, 40, 128, 768, 3, False, False),     # rows kernel, Cin = 128, channel tiles split over blockIdx.y
+    (2, 33, 67, 64, 200, 4, True, True),        # rows kernel, ragged M and N, sigmoid
+    (2, 30, 40, 144, 24, 0, True, True),        # tile kernel WN=1
+    (1, 8, 8, 512, 24, 0, True, True),          # tile kernel WN=1, 4 K groups
+    (3, 7, 9, 240, 40, 0, True, False),         # tile kernel WN=2, ragged rows
+    (1, 15, 20, 1824, 304, 0, True, True),      # tile kernel WN=2, 4 K groups, K not a multiple of the slab
+    (1, 5, 5, 3072, 512, 0, True, True),        # tile kernel WN=4, 2 K groups
+    (1, 15, 20, 512, 2048, 0, False, False),    # conv_head
+    (3, 7, 9, 40, 72, 3, False, False),         # tile kernel, Cin % 16 == 8, small M
+    (2, 4, 4, 136, 200, 4, False, False),       # Kp = 144, sigmoid, ragged N
+    (2, 30, 40, 176, 1056, 3, False, False),    # stage-5 expand
+    (4, 120, 160, 240, 40, 0, True, True),      # tile kernel, many rows
+])
+def test_pointwise_nhwc_split(ops, B, H, W, Cin, Cout, act, use_gate, use_res):
+    x, w, b = rnd("x", (B, Cin, H, W), 1), rnd("w", (Cout, Cin, 1, 1), 2, 1 / math.sqrt(Cin)), rnd("b", (Cout,), 3, 0.2)
+    gate = torch.sigmoid(rnd("g", (B, Cin), 4)) if use_gate else None
+    res = rnd("r", (B, Cout, H, W), 5) if use_res else None
+    xin = x if gate is None else x * gate[:, :, None, None]
+    ref = F.conv2d(xin, w, b)
+    ref = [ref, torch.relu(ref), F.leaky_relu(ref, 0.01), F.silu(ref), torch.sigmoid(ref)][act]
+    if res is not None:
+        ref = ref + res
+    cl = torch.channels_last
+    sw = ops.SplitWeight(dev(w))
+    assert sw.kp == (Cin + 15) // 16 * 16 and sw.hi.shape == (Cout, sw.kp)
+    xg = dev(x).contiguous(memory_format=cl)
+    kw = dict(gate=None if gate is None else dev(gate), residual=None if res is None else dev(res).contiguous(memory_format=cl))
+    got = ops.pointwise_nhwc(xg, sw, dev(b), act, **kw)
+    assert got.shape == ref.shape and got.is_contiguous(memory_format=cl)
+    assert rel_dev(got, ref) < SPLIT_TOL
+    assert torch.equal(got, ops.pointwise_nhwc(xg, sw, dev(b), act, **kw))      # fixed-order K-group reduction
+
+
+def test_pointwise_nhwc_split_two_row_tiles(ops):
+    """16 x 120 x 160 rows: the launch takes the two-row-tiles-per-wavefront shape (RT = 2)."""
+    B, H, W, Cin, Cout = 16, 120, 160, 240, 40
+    x = torch.randn(B, Cin, H, W, generator=torch.Generator().manual_seed(1))
+    w, b = rnd("w", (Cout, Cin, 1, 1), 2, 1 / math.sqrt(Cin)), rnd("b", (Cout,), 3, 0.2)
+    ref = F.conv2d(x, w, b)
+    got = ops.pointwise_nhwc(dev(x).contiguous(memory_format=torch.channels_last), ops.SplitWeight(dev(w)), dev(b), 0)
+    assert rel_dev(got, ref) < SPLIT_TOL
+
+
+def test_pointwise_nhwc_split_keeps_fp32_range(ops):
+    """Channels spanning 6 decades: the split form keeps fp32's exponent range and ~16 mantissa bits."""
+    x = rnd("x", (2, 64, 12, 12), 1) * torch.logspace(-3, 3, 64).view(1, 64, 1, 1)
+    w = rnd("w", (96, 64, 1, 1), 2, 0.05) / torch.logspace(-3, 3, 64).view(1, 64, 1, 1)
+    ref = F.conv2d(x.double(), w.double()).float()
+    got = ops.pointwise_nhwc(dev(x).contiguous(memory_format=torch.channels_last), ops.SplitWeight(dev(w)), None, 0)
+    assert rel_dev(got, ref) < SPLIT_TOL
+
+
 @pytest.mark.parametrize("k,s", [(3, 1), (3, 2), (5, 1), (5, 2)])
 @pytest.mark.parametrize("B,C,H,W", [(2, 48, 60, 80), (1, 8, 15, 20), (3, 12, 33, 47), (1, 4, 1, 1), (2, 144, 30, 41)])
 def test_depthwise_nhwc_same(ops, k, s, B, C, H, W):
