@@ -176,6 +176,12 @@ int ocv_pointwise_conv_nhwc_fwd(const float* x, const float* gate, int rows_per_
 int ocv_pointwise_conv_nhwc_split_fwd(const float* x, const float* gate, int rows_per_image, const void* w_hi,
                                       const void* w_lo, int Kp, const float* bias, const float* residual, float* y,
                                       long M, int Cin, int Cout, int act, ocv_stream_t stream);
+/* Stem convolution: dense 3x3 (Cin * 9 <= 32, Cout <= 64), any stride, explicit top/left zero padding (bottom/right
+ * implied by Ho/Wo: TensorFlow "SAME"), + bias (folded BatchNorm) + activation; reads the NCHW image x [B,Cin,H,W] and
+ * writes the NHWC activation y [B,Ho,Wo,Cout]; w [Cout][Cin*3*3] (PyTorch's weight, flattened).  Exact fp32.  Replaces
+ * conv_stem + bn1 + act1 of the hub backbone (modules/DenseFeatureExtractor.py:18-27). */
+int ocv_stem_conv_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W, int Cout,
+                      int k, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, ocv_stream_t stream);
 /* depthwise k x k (k in {3,5}, stride in {1,2}) on NHWC: in [B,H,W,C], w [k*k][C], out [B,Ho,Wo,C]; C % 4 == 0.
  * Padding / bias / act as ocv_depthwise_conv_fwd. */
 int ocv_depthwise_conv_nhwc_fwd(const float* in, const float* w, const float* bias, float* out, int B, int C, int H,

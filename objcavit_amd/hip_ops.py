@@ -586,6 +586,31 @@ def pointwise_nhwc(x: torch.Tensor, weight, bias: Optional[torch.Tensor], act: i
     return y
 
 
+def stem_conv_same(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int,
+                   act: int = ACT_NONE) -> torch.Tensor:
+    """Dense 3x3 convolution with TF 'SAME' padding of an NCHW image, + bias + act; returns a channels_last tensor.
+    weight [Cout, Cin, 3, 3] with Cin * 9 <= 32, Cout <= 64."""
+    lib = _lib.load()
+    _req(x, "x")
+    _req(weight, "weight")
+    if x.dim() != 4 or weight.dim() != 4 or weight.shape[1] != x.shape[1] or weight.shape[2] != weight.shape[3]:
+        raise ValueError("stem_conv_same: expected x [B, Cin, H, W] and weight [Cout, Cin, k, k]")
+    B, Cin, H, W = x.shape
+    Cout, k = weight.shape[0], weight.shape[2]
+    if bias is not None:
+        _req(bias, "bias")
+        if bias.numel() != Cout:
+            raise ValueError("stem_conv_same: bias size mismatch")
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    ph = max((Ho - 1) * stride + k - H, 0)
+    pw = max((Wo - 1) * stride + k - W, 0)
+    out = torch.empty(B, Cout, Ho, Wo, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    with timed("stem_conv"):
+        check(lib.ocv_stem_conv_fwd(x.data_ptr(), weight.data_ptr(), _ptr(bias), out.data_ptr(), B, Cin, H, W, Cout, k,
+                                    stride, ph // 2, pw // 2, Ho, Wo, act, _stream()), "ocv_stem_conv_fwd")
+    return out
+
+
 def depthwise_nhwc_same(x: torch.Tensor, weight_kkc: torch.Tensor, bias: Optional[torch.Tensor], k: int, stride: int,
                         act: int = ACT_NONE) -> torch.Tensor:
     """Depthwise k x k conv, TF 'SAME' padding, channels_last in / out.  weight_kkc: [k*k, C] (tap-major)."""

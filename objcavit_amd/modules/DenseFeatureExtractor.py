@@ -101,15 +101,49 @@ class Encoder(nn.Module):
             nonlocal cur
             cur = t
             idx = len(feats)
-            feats.append(t if self.keep is None or idx in self.keep else None)
+            feats.append(t if t is not None and (self.keep is None or idx in self.keep) else None)
 
+        skip = self._fused_stem(x, push)
         for name, child in self.original_model._modules.items():
+            if name in skip:
+                continue
             if name in ("blocks", "features"):
                 for sub in child._modules.values():
                     push(sub(cur))
             else:
                 push(child(cur))
         return feats
+
+
+def _encoder_fused_stem(self, x, push):
+    """conv_stem + bn1 + act1 as ONE launch (csrc/stem.hip) on the inference fast path, when the caller does not keep
+    the two intermediate activations.  Returns the child names that were consumed."""
+    m = self.original_model
+    names = list(m._modules)[:3]
+    if names != ["conv_stem", "bn1", "act1"] or self.keep is None or 1 in self.keep or 2 in self.keep:
+        return ()
+    conv, bn, act = m.conv_stem, m.bn1, m.act1
+    if not (x.device.type == "cuda" and not torch.is_grad_enabled() and not m.training and isinstance(conv, nn.Conv2d)
+            and isinstance(bn, nn.BatchNorm2d) and isinstance(act, nn.SiLU) and conv.kernel_size == (3, 3)
+            and conv.groups == 1 and conv.in_channels * 9 <= 32 and conv.out_channels <= 64
+            and conv.padding == (0, 0) and conv.stride[0] == conv.stride[1] and x.dtype == torch.float32):
+        return ()
+    key = (x.device, conv.weight._version, conv.weight.data_ptr(), bn.weight._version, bn.bias._version,
+           bn.running_mean._version, bn.running_var._version)
+    c = self.__dict__.get("_stem_cache")
+    if c is None or c[0] != key:
+        with torch.no_grad():
+            w, b = _fold_conv_bn(conv, bn)
+            c = (key, w.float().contiguous(), b.float().contiguous())
+        self.__dict__["_stem_cache"] = c
+    y = hip_ops.stem_conv_same(x.contiguous(), c[1], c[2], conv.stride[0], hip_ops.ACT_SILU)
+    push(None)
+    push(None)
+    push(y)
+    return ("conv_stem", "bn1", "act1")
+
+
+Encoder._fused_stem = _encoder_fused_stem
 
 
 def _fold_conv_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d):

@@ -21,7 +21,8 @@ import sys
 OURS = ("bin_head_kernel", "pixel_dot_kernel", "patch_embed_partial_kernel", "patch_embed_reduce_kernel",
         "attention_kernel", "linear_kernel", "linear_stream_kernel", "layernorm_kernel", "ffn_fused_kernel",
         "conv_igemm_kernel", "pointwise_kernel", "pointwise_smallk_kernel", "depthwise_kernel", "depthwise_nhwc_kernel",
-        "channel_sum_kernel", "channel_mean_finish_kernel", "se_hidden_kernel", "se_gate_kernel")
+        "channel_sum_kernel", "channel_mean_finish_kernel", "se_hidden_kernel", "se_gate_kernel",
+        "conv_split_dma_kernel", "upsample_concat_split_kernel", "pw_rows_kernel", "pw_tile_kernel", "pw_stream_kernel")
 
 
 def short(name):

@@ -420,6 +420,22 @@ def test_pointwise_nhwc_split_keeps_fp32_range(ops):
     assert rel_dev(got, ref) < SPLIT_TOL
 
 
+@pytest.mark.parametrize("B,Cin,H,W,Cout,stride,act", [
+    (2, 3, 96, 128, 48, 2, 3),       # the B5 stem shape family: SAME padding 0/1 (even sizes)
+    (1, 3, 33, 47, 48, 2, 3),        # odd sizes: padding 1/1, ragged last pixel tile
+    (3, 3, 17, 20, 24, 1, 0),        # stride 1, symmetric padding, <= 32 channels, no activation
+    (2, 1, 9, 9, 64, 2, 1),          # single input plane, 64 channels, ReLU
+    (1, 2, 5, 4, 7, 3, 2),           # stride 3, ragged channel tile, LeakyReLU
+])
+def test_stem_conv_same(ops, B, Cin, H, W, Cout, stride, act):
+    x, w, b = rnd("x", (B, Cin, H, W), 1), rnd("w", (Cout, Cin, 3, 3), 2, 0.3), rnd("b", (Cout,), 3, 0.2)
+    ref = F.conv2d(_same_pad(x, 3, stride), w, b, stride=stride)
+    ref = [ref, torch.relu(ref), F.leaky_relu(ref, 0.01), F.silu(ref)][act]
+    got = ops.stem_conv_same(dev(x), dev(w), dev(b), stride, act)
+    assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert rel_dev(got, ref) < TOL
+
+
 @pytest.mark.parametrize("k,s", [(3, 1), (3, 2), (5, 1), (5, 2)])
 @pytest.mark.parametrize("B,C,H,W", [(2, 48, 60, 80), (1, 8, 15, 20), (3, 12, 33, 47), (1, 4, 1, 1), (2, 144, 30, 41)])
 def test_depthwise_nhwc_same(ops, k, s, B, C, H, W):
