@@ -170,12 +170,16 @@ int ocv_pointwise_conv_nhwc_fwd(const float* x, const float* gate, int rows_per_
 
 /* The same contraction on the bf16 matrix cores at fp32-level accuracy (split-bf16: every product is formed as
  * hi*hi + hi*lo + lo*hi with fp32 accumulation, relative error of a product <= 2^-17): identical contract, except that
- * the (static) weights arrive pre-split: w_hi = bf16(W), w_lo = bf16(W - w_hi), both [Cout, Kp] bf16 with rows
- * zero-padded to Kp = ceil16(Cin).  The exact-fp32 entry point above is MFMA-bound from stage 4 of the encoder on
- * (47 TFLOP/s of 157); this one is the encoder's default. */
-int ocv_pointwise_conv_nhwc_split_fwd(const float* x, const float* gate, int rows_per_image, const void* w_hi,
-                                      const void* w_lo, int Kp, const float* bias, const float* residual, float* y,
-                                      long M, int Cin, int Cout, int act, ocv_stream_t stream);
+ * the (static) weights arrive pre-split AND packed in matrix-core operand order, so that a wavefront's weight load is
+ * one contiguous 1 KB run.  With w_hi = bf16(W), w_lo = bf16(W - w_hi), both zero-padded to [ceil32(Cout)][Kp],
+ * Kp = ceil16(Cin):
+ *   w_packed[(((jt * (Kp/16) + s) * 2 + part) * 64 + lane) * 8 + e] = w_part[32 jt + (lane & 31)][16 s + 8 (lane >> 5) + e]
+ * (part 0 = hi, 1 = lo; bf16; ocv_pointwise_packed_weight_elems() elements).  The exact-fp32 entry point above is
+ * MFMA-bound from stage 4 of the encoder on (47 TFLOP/s of 157); this one is the encoder's default. */
+size_t ocv_pointwise_packed_weight_elems(int Cin, int Cout);
+int ocv_pointwise_conv_nhwc_split_fwd(const float* x, const float* gate, int rows_per_image, const void* w_packed,
+                                      const float* bias, const float* residual, float* y, long M, int Cin, int Cout,
+                                      int act, ocv_stream_t stream);
 /* Stem convolution: dense 3x3 (Cin * 9 <= 32, Cout <= 64), any stride, explicit top/left zero padding (bottom/right
  * implied by Ho/Wo: TensorFlow "SAME"), + bias (folded BatchNorm) + activation; reads the NCHW image x [B,Cin,H,W] and
  * writes the NHWC activation y [B,Ho,Wo,Cout]; w [Cout][Cin*3*3] (PyTorch's weight, flattened).  Exact fp32.  Replaces

@@ -12,15 +12,18 @@
 // bound by from stage 4 of the encoder on (19200 x 1056 -> 176: 47 TFLOP/s = 30 % of the fp32 MFMA peak, 7 GFLOP
 // against 98 MB of traffic); with the split form every layer is back under its HBM / latency bound.
 //
-// Two kernels:
-//   pw_rows_kernel<KS>       Cin <= 128: a wavefront keeps its 32 rows (x gate), already split, in VGPRs in A-operand
-//                            order and walks the output-channel tiles; weights stream from L1/L2 straight into the B
-//                            operand.  No LDS, no barrier; rows are read from HBM exactly once.
-//   pw_tile_kernel<WN,WK,RT> any Cin: workgroup tile (32 RT) rows x (32 WN) channels, WK wavefront groups split every
-//                            64 WK-wide K slab between them (more wavefronts in flight for the small-M late stages,
-//                            summed through LDS in a fixed order at the end).  Rows are staged through LDS as split
-//                            bf16 (converted ONCE per workgroup), double buffered, one barrier per slab; next slab's
-//                            global loads (rows and weights) are issued before the current slab's MFMAs.
+// Three kernels (dispatch and the measurements behind it: ocv_pointwise_conv_nhwc_split_fwd at the end of this file):
+//   pw_rows_kernel<KS>       Cin <= 128, very many rows: a wavefront keeps its 32 rows (x gate), already split, in
+//                            VGPRs in A-operand order and walks the output-channel tiles.  No LDS, no barrier; rows
+//                            are read from HBM exactly once.
+//   pw_stream_kernel<NTL,U>  <= 32 output channels, very many rows: a wavefront streams K for its 32 rows, U steps of
+//                            loads in flight; nothing shared between wavefronts.
+//   pw_tile_kernel<WN,WK,RT> everything else: workgroup tile (32 RT) rows x (32 WN) channels, WK wavefront groups
+//                            split every 64 WK-wide K slab between them (summed through LDS in a fixed order at the
+//                            end).  Rows are staged through LDS as split bf16 (converted ONCE per workgroup, coalesced
+//                            256-byte row segments), double buffered, one barrier per slab; the next slab's global
+//                            loads (rows and weights) are issued before the current slab's MFMAs.
+// In all three the weights are read straight from L2 into the B operand as contiguous 1 KB fragments (w_frag below).
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -34,7 +37,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct PSArgs {
   const float *x, *gate, *bias, *res;
-  const __bf16 *whi, *wlo;          // [N][Kp]
+  const __bf16* wp;                 // packed B-operand fragments, see w_frag()
   float* y;
   long M;
   int K, Kp, N, rows_per_image, act;
@@ -83,6 +86,16 @@ __device__ __forceinline__ float4 ldg4(const float* p) { const float v = (float)
 #else
 __device__ __forceinline__ float4 ldg4(const float* p) { return ld4(p); }
 #endif
+
+// Weight layout ("packed", built once on the host side of the C ABI): the B operand of v_mfma_f32_32x32x16_bf16 for
+// channel tile jt (32 channels) and K step s (16 inputs) is ONE contiguous 1 KB fragment -- lane l = 32 hh + l31
+// holds W[32 jt + l31][16 s + 8 hh .. + 7] -- hi fragment first, lo fragment right behind it:
+//   wp[((jt * nsteps + s) * 2 + part) * 512 + lane * 8 + e]
+// so a wavefront's weight load touches 8 consecutive cache lines instead of 32 scattered ones (with row-major [N][K]
+// weights the per-line tag work of those loads, not bandwidth, was the largest single cost of the tile kernel).
+__device__ __forceinline__ const __bf16* w_frag(const PSArgs& p, int jt, int s, int lane) {
+  return p.wp + (((long)jt * (p.Kp >> 4) + s) * 2) * 512 + lane * 8;
+}
 
 __device__ __forceinline__ f32x16 mfma3(const bf16x8 ah, const bf16x8 al, const bf16x8 bh, const bf16x8 bl, f32x16 acc) {
 #ifdef PW_ABL_NOMFMA
@@ -145,11 +158,11 @@ __global__ __launch_bounds__(256) void pw_rows_kernel(PSArgs p) {
   const int nt_lo = blockIdx.y * per_y, nt_hi = min(ntiles_all, nt_lo + per_y);
   for (int nt = nt_lo; nt < nt_hi; ++nt) {
     const int n = nt * 32 + l31;
-    const long woff = (long)(n < p.N ? n : p.N - 1) * p.Kp + 8 * hh;
+    const __bf16* wf = w_frag(p, nt, 0, lane);
     f32x16 acc = {0};
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      if (16 * s < p.Kp) acc = mfma3(ahi[s], alo[s], ldb8(p.whi + woff + 16 * s), ldb8(p.wlo + woff + 16 * s), acc);
+      if (16 * s < p.Kp) acc = mfma3(ahi[s], alo[s], ldb8(wf + s * 1024), ldb8(wf + s * 1024 + 512), acc);
     }
     store_tile(p, acc, m_base, n, hh);
   }
@@ -189,7 +202,8 @@ __global__ __launch_bounds__(64 * WN * WK) void pw_tile_kernel(PSArgs p) {
   }
   const long m0 = (long)bx * ROWS;
   const int n = by * (32 * WN) + wn * 32 + l31;
-  const long woff = (long)(n < p.N ? n : p.N - 1) * p.Kp + 64 * g + 8 * hh;
+  const int ntl_all = (p.N + 31) >> 5;
+  const __bf16* wf = w_frag(p, min(by * WN + wn, ntl_all - 1), 4 * g, lane);      // + (it * KI / 16 + s) * 1024
   const int K = p.K, Kp = p.Kp;
   const int nit = (Kp + KI - 1) / KI;
 
@@ -240,8 +254,8 @@ __global__ __launch_bounds__(64 * WN * WK) void pw_tile_kernel(PSArgs p) {
     for (int s = 0; s < 4; ++s) {
       const int k = it * KI + 64 * g + 16 * s;
       if (k < Kp) {
-        h[s] = ldb8(p.whi + woff + it * KI + 16 * s);
-        l[s] = ldb8(p.wlo + woff + it * KI + 16 * s);
+        h[s] = ldb8(wf + (long)(it * (KI / 16) + s) * 1024);
+        l[s] = ldb8(wf + (long)(it * (KI / 16) + s) * 1024 + 512);
       }
     }
   };
@@ -321,13 +335,8 @@ int launch_tile(const PSArgs& a, hipStream_t st) {
 }
 
 template <int WN>
-int launch_tile_wn(const PSArgs& a, int wk, int rt, hipStream_t st) {
-  if (rt == 2) return wk >= 2 ? launch_tile<WN, 2, 2>(a, st) : launch_tile<WN, 1, 2>(a, st);
-  if constexpr (WN <= 2) {
-    if (wk >= 4) return launch_tile<WN, 4, 1>(a, st);
-  }
-  if (wk >= 2) return launch_tile<WN, 2, 1>(a, st);
-  return launch_tile<WN, 1, 1>(a, st);
+int launch_tile_wn(const PSArgs& a, int wk, hipStream_t st) {
+  return wk >= 2 ? launch_tile<WN, 2, 1>(a, st) : launch_tile<WN, 1, 1>(a, st);
 }
 
 // ---------------------------------------------------------------------------
@@ -348,9 +357,10 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(PSArgs p) {
   const float* src = p.x + (ok ? m : 0) * K + 8 * hh;
   const float* gsrc = p.gate != nullptr ? p.gate + ((ok ? m : 0) / p.rows_per_image) * K + 8 * hh : nullptr;
   const int klim = ok ? K - 8 * hh : 0;        // this lane's octet of step s is in range iff 16 s < klim
-  long woff[NTL];
+  const int ntl_all = (p.N + 31) >> 5;
+  const __bf16* wf[NTL];
 #pragma unroll
-  for (int j = 0; j < NTL; ++j) woff[j] = (long)min(32 * j + l31, p.N - 1) * p.Kp + 8 * hh;
+  for (int j = 0; j < NTL; ++j) wf[j] = w_frag(p, min(j, ntl_all - 1), 0, lane);
   f32x16 acc[NTL];
 #pragma unroll
   for (int j = 0; j < NTL; ++j) acc[j] = f32x16{0};
@@ -369,8 +379,8 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(PSArgs p) {
       if (s < nsteps) {
 #pragma unroll
         for (int j = 0; j < NTL; ++j) {
-          wh[u][j] = ldb8(p.whi + woff[j] + 16 * s);
-          wl[u][j] = ldb8(p.wlo + woff[j] + 16 * s);
+          wh[u][j] = ldb8(wf[j] + (long)s * 1024);
+          wl[u][j] = ldb8(wf[j] + (long)s * 1024 + 512);
         }
       }
     }
@@ -398,16 +408,17 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(PSArgs p) {
   for (int j = 0; j < NTL; ++j) store_tile(p, acc[j], m_base, 32 * j + l31, hh);
 }
 
-// diagnostic override of the tile shape: OCV_PW_CFG="wn,wk,rt" (0 = heuristic); "stream" / "tile" force a kernel family
-struct PwCfg { int wn = 0, wk = 0, rt = 0, family = 0; };
+// diagnostic override of the dispatch: OCV_PW_CFG = "rows" | "stream" | "tile" | "wn,wk" (tile kernel with that shape)
+struct PwCfg { int wn = 0, wk = 0, family = 0; };
 const PwCfg& pw_cfg() {
   static PwCfg c = [] {
     PwCfg v;
     const char* e = getenv("OCV_PW_CFG");
     if (e != nullptr) {
-      if (strcmp(e, "stream") == 0) v.family = 1;
-      else if (strcmp(e, "tile") == 0) v.family = 2;
-      else if (sscanf(e, "%d,%d,%d", &v.wn, &v.wk, &v.rt) == 3) v.family = 2;
+      if (strcmp(e, "rows") == 0) v.family = 1;
+      else if (strcmp(e, "stream") == 0) v.family = 2;
+      else if (strcmp(e, "tile") == 0) v.family = 3;
+      else if (sscanf(e, "%d,%d", &v.wn, &v.wk) == 2) v.family = 3;
     }
     return v;
   }();
@@ -416,22 +427,37 @@ const PwCfg& pw_cfg() {
 
 }  // namespace
 
-extern "C" int ocv_pointwise_conv_nhwc_split_fwd(const float* x, const float* gate, int rows_per_image, const void* w_hi,
-                                                 const void* w_lo, int Kp, const float* bias, const float* residual,
+extern "C" size_t ocv_pointwise_packed_weight_elems(int Cin, int Cout) {
+  if (Cin < 1 || Cout < 1) return 0;
+  return (size_t)((Cout + 31) / 32) * ((Cin + 15) / 16) * 2 * 512;
+}
+
+extern "C" int ocv_pointwise_conv_nhwc_split_fwd(const float* x, const float* gate, int rows_per_image,
+                                                 const void* w_packed, const float* bias, const float* residual,
                                                  float* y, long M, int Cin, int Cout, int act, ocv_stream_t stream) {
-  OCV_CHECK_ARG(x && w_hi && w_lo && y, "ocv_pointwise_conv_nhwc_split_fwd: null pointer");
+  const int Kp = (Cin + 15) / 16 * 16;
+  OCV_CHECK_ARG(x && w_packed && y, "ocv_pointwise_conv_nhwc_split_fwd: null pointer");
   OCV_CHECK_ARG(M >= 0 && Cin >= 8 && Cin % 8 == 0 && Cout >= 1, "ocv_pointwise_conv_nhwc_split_fwd: Cin must be a positive multiple of 8 (got M=%ld Cin=%d Cout=%d)", M, Cin, Cout);
-  OCV_CHECK_ARG(Kp == (Cin + 15) / 16 * 16, "ocv_pointwise_conv_nhwc_split_fwd: weight rows must be padded to Kp = ceil16(Cin) = %d (got %d)", (Cin + 15) / 16 * 16, Kp);
   OCV_CHECK_ARG(gate == nullptr || rows_per_image >= 1, "ocv_pointwise_conv_nhwc_split_fwd: gate needs rows_per_image");
   OCV_CHECK_ARG(act >= 0 && act <= OCV_ACT_SIGMOID, "ocv_pointwise_conv_nhwc_split_fwd: unknown activation %d", act);
-  OCV_CHECK_ARG(ocv_aligned16(x) && ocv_aligned16(w_hi) && ocv_aligned16(w_lo) && ocv_aligned16(gate),
-                "ocv_pointwise_conv_nhwc_split_fwd: x / w_hi / w_lo / gate must be 16-byte aligned");
+  OCV_CHECK_ARG(ocv_aligned16(x) && ocv_aligned16(w_packed) && ocv_aligned16(gate),
+                "ocv_pointwise_conv_nhwc_split_fwd: x / w_packed / gate must be 16-byte aligned");
   if (M == 0) return 0;
-  PSArgs a{x, gate, bias, residual, (const __bf16*)w_hi, (const __bf16*)w_lo, y, M, Cin, Kp, Cout,
+  PSArgs a{x, gate, bias, residual, (const __bf16*)w_packed, y, M, Cin, Kp, Cout,
            rows_per_image > 0 ? rows_per_image : 1, act};
   hipStream_t st = (hipStream_t)stream;
+  // Dispatch (measured on MI355X, bs = 16 encoder shapes, tools/run_pw.py):
+  //   rows   : Cin <= 128 and >= 2 10^5 rows (the stage 1-2 expand layers: one pass over the rows, channels walked)
+  //   stream : <= 32 output channels and many rows (stage-1 project layers: pure row stream)
+  //   tile   : everything else; 32 rows x 128 (64) channels per workgroup -- the smallest tile won on every late-stage
+  //            shape because these launches are latency-bound and it keeps the most workgroups in flight -- with two
+  //            K groups when the launch would otherwise have fewer than 512 workgroups
   const PwCfg& cfg = pw_cfg();
-  if (cfg.family == 0 && Cin <= 128 && M >= 4096) {
+  int family = cfg.family;
+  if (family == 0) family = (Cout <= 32 && M >= 65536) ? 2 : ((Cin <= 128 && M >= 200000) ? 1 : 3);
+  if (family == 1 && Cin > 128) family = 3;
+  if (family == 2 && Cout > 32) family = 3;
+  if (family == 1) {
     const long mblocks = (M + 127) / 128;
     int ysplit = 1;
     const int ntl = (Cout + 31) / 32;
@@ -443,27 +469,15 @@ extern "C" int ocv_pointwise_conv_nhwc_split_fwd(const float* x, const float* ga
     OCV_CHECK_LAUNCH("ocv_pointwise_conv_nhwc_split_fwd(rows)");
     return 0;
   }
-  if (cfg.family != 2 && Cout <= 128 && (M >= 65536 || cfg.family == 1)) {
-    const dim3 grid((unsigned)((M + 127) / 128));
-    if (Cout <= 32) hipLaunchKernelGGL((pw_stream_kernel<1, 4>), grid, dim3(256), 0, st, a);
-    else if (Cout <= 64) hipLaunchKernelGGL((pw_stream_kernel<2, 4>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((pw_stream_kernel<4, 2>), grid, dim3(256), 0, st, a);
+  if (family == 2) {
+    hipLaunchKernelGGL((pw_stream_kernel<1, 4>), dim3((unsigned)((M + 127) / 128)), dim3(256), 0, st, a);
     OCV_CHECK_LAUNCH("ocv_pointwise_conv_nhwc_split_fwd(stream)");
     return 0;
   }
-  // tile shape: 128 channels wide unless there are fewer; two row tiles per wavefront (half the weight traffic) when
-  // that still leaves >= 512 workgroups; then K groups until the launch has a few thousand wavefronts
-  int wn = Cout > 64 ? 4 : (Cout > 32 ? 2 : 1);
-  if (cfg.wn) wn = cfg.wn;
-  const long nby = ocv_cdiv(Cout, 32 * wn);
-  int rt = ((M + 63) / 64) * nby >= 512 ? 2 : 1;
-  if (cfg.rt) rt = cfg.rt;
-  const long waves = ((M + 32 * rt - 1) / (32 * rt)) * nby * wn;
-  int wk = 1;
-  while (wk < 4 && wn * wk * 2 <= 8 && waves * wk < 4096 && Kp >= 256 * wk) wk *= 2;
+  int wn = Cout > 64 ? 4 : 2;
+  if (cfg.wn == 2 || cfg.wn == 4) wn = cfg.wn;
+  const long wgs = ((M + 31) / 32) * ocv_cdiv(Cout, 32 * wn);
+  int wk = (wgs < 512 && Kp >= 512) ? 2 : 1;
   if (cfg.wk) wk = cfg.wk;
-  if (rt == 2 && wk > 2) wk = 2;
-  if (wn == 4) return launch_tile_wn<4>(a, wk, rt, st);
-  if (wn == 2) return launch_tile_wn<2>(a, wk, rt, st);
-  return launch_tile_wn<1>(a, wk, rt, st);
+  return wn == 4 ? launch_tile_wn<4>(a, wk, st) : launch_tile_wn<2>(a, wk, st);
 }

@@ -512,17 +512,23 @@ def conv_nhwc(x1: torch.Tensor, x2: Optional[torch.Tensor], w_hi: torch.Tensor, 
 # NHWC encoder blocks (pointwise conv with fused gate / bias / act / residual, depthwise, squeeze)
 # ---------------------------------------------------------------------------
 class SplitWeight:
-    """A static [Cout, Cin] matrix pre-split for the bf16x3 kernels: hi = bf16(W), lo = bf16(W - hi), rows zero-padded
-    to Kp = ceil16(Cin).  Built once per weight version by the callers (cached next to their BN-folded weights)."""
+    """A static [Cout, Cin] matrix pre-split for the bf16x3 kernels (hi = bf16(W), lo = bf16(W - hi)) and packed in
+    matrix-core B-operand order (include/objcavit_hip.h, ocv_pointwise_conv_nhwc_split_fwd): one contiguous 1 KB
+    fragment per (32-channel tile, 16-wide K step, hi|lo).  Built once per weight version by the callers (cached
+    next to their BN-folded weights)."""
 
     def __init__(self, weight: torch.Tensor):
         w = weight.detach().float().reshape(weight.shape[0], -1)
         self.cout, self.cin = w.shape
         self.kp = (self.cin + 15) // 16 * 16
-        if self.kp != self.cin:
-            w = torch.nn.functional.pad(w, (0, self.kp - self.cin))
-        self.hi = w.to(torch.bfloat16).contiguous()
-        self.lo = (w - self.hi.float()).to(torch.bfloat16).contiguous()
+        npad = (self.cout + 31) // 32 * 32
+        w = torch.nn.functional.pad(w, (0, self.kp - self.cin, 0, npad - self.cout))
+        hi = w.to(torch.bfloat16)
+        lo = (w - hi.float()).to(torch.bfloat16)
+        nt, ns = npad // 32, self.kp // 16
+        parts = torch.stack([hi, lo], 0).reshape(2, nt, 32, ns, 2, 8)          # [part, jt, l31, s, hh, e]
+        self.packed = parts.permute(1, 3, 0, 4, 2, 5).contiguous().reshape(-1)   # [jt, s, part, hh, l31, e]
+        assert self.packed.numel() == nt * ns * 2 * 512
 
 
 def pointwise_weight(weight: torch.Tensor):
@@ -550,8 +556,7 @@ def pointwise_nhwc(x: torch.Tensor, weight, bias: Optional[torch.Tensor], act: i
         B, rpi = M, 1
     split = isinstance(weight, SplitWeight)
     if split:
-        _req(weight.hi, "weight.hi", torch.bfloat16)
-        _req(weight.lo, "weight.lo", torch.bfloat16)
+        _req(weight.packed, "weight.packed", torch.bfloat16)
         Cout, wcin = weight.cout, weight.cin
     else:
         w2 = _req(weight.reshape(weight.shape[0], -1), "weight")
@@ -576,9 +581,9 @@ def pointwise_nhwc(x: torch.Tensor, weight, bias: Optional[torch.Tensor], act: i
             raise ValueError("pointwise_nhwc: residual shape mismatch")
     with timed(f"pointwise|{M},{Cin},{Cout}"):
         if split:
-            check(lib.ocv_pointwise_conv_nhwc_split_fwd(x.data_ptr(), _ptr(gate), rpi, weight.hi.data_ptr(),
-                                                        weight.lo.data_ptr(), weight.kp, _ptr(bias), _ptr(residual),
-                                                        y.data_ptr(), M, Cin, Cout, act, _stream()),
+            check(lib.ocv_pointwise_conv_nhwc_split_fwd(x.data_ptr(), _ptr(gate), rpi, weight.packed.data_ptr(),
+                                                        _ptr(bias), _ptr(residual), y.data_ptr(), M, Cin, Cout, act,
+                                                        _stream()),
                   "ocv_pointwise_conv_nhwc_split_fwd")
         else:
             check(lib.ocv_pointwise_conv_nhwc_fwd(x.data_ptr(), _ptr(gate), rpi, w2.data_ptr(), _ptr(bias), _ptr(residual),

@@ -365,21 +365,21 @@ def test_pointwise_nhwc(ops, B, H, W, Cin, Cout, act, use_gate, use_res):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,act,use_gate,use_res", [
-    (2, 60, 80, 24, 144, 3, False, False),      # rows kernel (M >= 4096, Cin <= 32), Kp = 32 > Cin
-    (2, 60, 80, 48, 24, 0, True, False),        # rows kernel, Cin <= 64, gate, one ragged channel tile
-    (1, 64, 80, 40, 240, 3, False, False),      # rows kernel, Cin % 16 == 8
-    (3, 40, 40, 128, 768, 3, False, False),     # rows kernel, Cin = 128, channel tiles split over blockIdx.y
-    (2, 33, 67, 64, 200, 4, True, True),        # rows kernel, ragged M and N, sigmoid
-    (2, 30, 40, 144, 24, 0, True, True),        # tile kernel WN=1
-    (1, 8, 8, 512, 24, 0, True, True),          # tile kernel WN=1, 4 K groups
-    (3, 7, 9, 240, 40, 0, True, False),         # tile kernel WN=2, ragged rows
-    (1, 15, 20, 1824, 304, 0, True, True),      # tile kernel WN=2, 4 K groups, K not a multiple of the slab
-    (1, 5, 5, 3072, 512, 0, True, True),        # tile kernel WN=4, 2 K groups
+    (2, 60, 80, 24, 144, 3, False, False),      # Cin <= 32, Kp = 32 > Cin
+    (2, 60, 80, 48, 24, 0, True, False),        # Cin <= 64, gate, one ragged channel tile
+    (1, 64, 80, 40, 240, 3, False, False),      # Cin % 16 == 8
+    (3, 40, 40, 128, 768, 3, False, False),     # Cin = 128, 24 channel tiles
+    (2, 33, 67, 64, 200, 4, True, True),        # ragged M and N, sigmoid
+    (2, 30, 40, 144, 24, 0, True, True),        # <= 32 channels
+    (1, 8, 8, 512, 24, 0, True, True),          # long K, few channels
+    (3, 7, 9, 240, 40, 0, True, False),         # <= 64 channels, ragged rows
+    (1, 15, 20, 1824, 304, 0, True, True),      # two K groups, K not a multiple of the slab, ragged channel block
+    (1, 5, 5, 3072, 512, 0, True, True),        # two K groups
     (1, 15, 20, 512, 2048, 0, False, False),    # conv_head
-    (3, 7, 9, 40, 72, 3, False, False),         # tile kernel, Cin % 16 == 8, small M
+    (3, 7, 9, 40, 72, 3, False, False),         # Cin % 16 == 8, small M
     (2, 4, 4, 136, 200, 4, False, False),       # Kp = 144, sigmoid, ragged N
     (2, 30, 40, 176, 1056, 3, False, False),    # stage-5 expand
-    (4, 120, 160, 240, 40, 0, True, True),      # tile kernel, many rows
+    (4, 120, 160, 240, 40, 0, True, True),      # many rows
 ])
 def test_pointwise_nhwc_split(ops, B, H, W, Cin, Cout, act, use_gate, use_res):
     x, w, b = rnd("x", (B, Cin, H, W), 1), rnd("w", (Cout, Cin, 1, 1), 2, 1 / math.sqrt(Cin)), rnd("b", (Cout,), 3, 0.2)
@@ -392,7 +392,7 @@ def test_pointwise_nhwc_split(ops, B, H, W, Cin, Cout, act, use_gate, use_res):
         ref = ref + res
     cl = torch.channels_last
     sw = ops.SplitWeight(dev(w))
-    assert sw.kp == (Cin + 15) // 16 * 16 and sw.hi.shape == (Cout, sw.kp)
+    assert sw.kp == (Cin + 15) // 16 * 16 and sw.packed.numel() == ops._lib.load().ocv_pointwise_packed_weight_elems(Cin, Cout)
     xg = dev(x).contiguous(memory_format=cl)
     kw = dict(gate=None if gate is None else dev(gate), residual=None if res is None else dev(res).contiguous(memory_format=cl))
     got = ops.pointwise_nhwc(xg, sw, dev(b), act, **kw)
@@ -401,13 +401,15 @@ def test_pointwise_nhwc_split(ops, B, H, W, Cin, Cout, act, use_gate, use_res):
     assert torch.equal(got, ops.pointwise_nhwc(xg, sw, dev(b), act, **kw))      # fixed-order K-group reduction
 
 
-def test_pointwise_nhwc_split_two_row_tiles(ops):
-    """16 x 120 x 160 rows: the launch takes the two-row-tiles-per-wavefront shape (RT = 2)."""
-    B, H, W, Cin, Cout = 16, 120, 160, 240, 40
+@pytest.mark.parametrize("B,H,W,Cin,Cout,gate", [(16, 120, 160, 40, 240, False), (16, 240, 320, 48, 24, True), (16, 120, 160, 240, 40, True)])
+def test_pointwise_nhwc_split_many_rows(ops, B, H, W, Cin, Cout, gate):
+    """Full-size stage-1/2 shapes: these take the rows (Cin <= 128) / stream (<= 32 channels) / tile kernels."""
     x = torch.randn(B, Cin, H, W, generator=torch.Generator().manual_seed(1))
     w, b = rnd("w", (Cout, Cin, 1, 1), 2, 1 / math.sqrt(Cin)), rnd("b", (Cout,), 3, 0.2)
-    ref = F.conv2d(x, w, b)
-    got = ops.pointwise_nhwc(dev(x).contiguous(memory_format=torch.channels_last), ops.SplitWeight(dev(w)), dev(b), 0)
+    g = torch.sigmoid(rnd("g", (B, Cin), 4)) if gate else None
+    ref = F.conv2d(x if g is None else x * g[:, :, None, None], w, b)
+    got = ops.pointwise_nhwc(dev(x).contiguous(memory_format=torch.channels_last), ops.SplitWeight(dev(w)), dev(b), 0,
+                             gate=None if g is None else dev(g))
     assert rel_dev(got, ref) < SPLIT_TOL
 
 
