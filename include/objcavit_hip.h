@@ -191,6 +191,22 @@ int ocv_stem_conv_fwd(const float* x, const float* w, const float* bias, float* 
 int ocv_depthwise_conv_nhwc_fwd(const float* in, const float* w, const float* bias, float* out, int B, int C, int H,
                                 int W, int k, int stride, int pad_t, int pad_l, int Ho, int Wo, int act,
                                 ocv_stream_t stream);
+/* Depthwise convolution + bias + SiLU as ocv_depthwise_conv_nhwc_fwd, that ALSO emits the squeeze-excite pooling sums
+ * of its own output, so the activation is not read a second time: part [B][tiles][C] holds one partial sum per
+ * workgroup of the launch (tiles = ocv_depthwise_sum_tiles(...), fixed summation order -> reproducible), and
+ * ocv_se_gate_partials_fwd turns the partials into the gate (hidden_ws: B * R floats of scratch, R <= 256):
+ *   gate[b][c] = sigmoid( b2[c] + sum_r w2t[r][c] * silu( b1[r] + sum_c' w1[r][c'] * mean[b][c'] ) ),
+ *   mean[b][c] = (sum_tile part[b][tile][c]) / pixels_per_image.
+ * w1 [R][C], w2t [R][C] (= conv_expand's weight transposed).  Replaces conv_dw + bn + act + se.conv_reduce / act /
+ * conv_expand / sigmoid of the hub backbone's blocks (modules/DenseFeatureExtractor.py:18-27,149). */
+int ocv_depthwise_sum_tiles(int B, int C, int Ho, int Wo, int k, int stride);
+int ocv_depthwise_conv_nhwc_sum_fwd(const float* in, const float* w, const float* bias, float* out, float* part, int B,
+                                    int C, int H, int W, int k, int stride, int pad_t, int pad_l, int Ho, int Wo,
+                                    ocv_stream_t stream);
+int ocv_se_gate_partials_fwd(const float* part, int tiles, long pixels_per_image, const float* w1, const float* b1,
+                             const float* w2t, const float* b2, float* gate, float* hidden_ws, int B, int C, int R,
+                             ocv_stream_t stream);
+
 /* squeeze: out[b][c] = mean over the P = H*W pixels of x [B,P,C]; two-stage, fixed summation order. */
 size_t ocv_channel_mean_workspace_bytes(int B, int C, long P);
 int ocv_channel_mean_nhwc_fwd(const float* x, float* out, int B, int C, long P, void* workspace, size_t workspace_bytes,

@@ -52,6 +52,10 @@ PROTOTYPES = {
     "ocv_bin_head_fwd": (C.c_int, [_f32p, C.c_int, _f32p, C.c_long, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, _stream]),
     "ocv_depthwise_conv_fwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p] + [C.c_int] * 11 + [_stream]),
+    "ocv_depthwise_sum_tiles": (C.c_int, [C.c_int] * 6),
+    "ocv_depthwise_conv_nhwc_sum_fwd": (C.c_int, [_f32p] * 5 + [C.c_int] * 10 + [_stream]),
+    "ocv_se_gate_partials_fwd": (C.c_int, [_f32p, C.c_int, C.c_long, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int,
+                                           C.c_int, C.c_int, _stream]),
     "ocv_stem_conv_fwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p] + [C.c_int] * 12 + [_stream]),
     "ocv_pointwise_packed_weight_elems": (C.c_size_t, [C.c_int, C.c_int]),
     "ocv_pointwise_conv_nhwc_split_fwd": (C.c_int, [_f32p, _f32p, C.c_int, C.c_void_p, _f32p, _f32p, _f32p,

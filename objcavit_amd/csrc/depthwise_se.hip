@@ -1,0 +1,291 @@
+// Depthwise k x k convolution (+ folded BatchNorm + SiLU) that also produces the squeeze-excite pooling sums, and the
+// squeeze-excite gate computed from them -- 3 launches per MBConv block where csrc/encoder_nhwc.hip needs 5
+// (depthwise, channel sum, mean, hidden layer, gate), and no second pass over the depthwise output (the largest
+// activations of the network: 295 MB at 120 x 160 x 240 x 16 images).
+// Row N1 of SURVEY.md section 8; the reference runs conv_dw / bn / act / se of the hub backbone's blocks
+// (modules/DenseFeatureExtractor.py:18-27,149).
+//
+// dw_slide_kernel<K,S,PX>: a workgroup owns (image, chunk of <= 64 channel quads, PL work items); thread = (channel
+//   quad q, work item pl); a work item is a PX-wide, RY-tall strip of outputs walked top to bottom with the K input
+//   rows under it held in registers (see the kernel).  Every thread keeps the running sum of its own outputs; the
+//   work items of a quad are added through LDS in lane order and the workgroup writes ONE partial per channel:
+//   part[b][tile][c].  Fixed order everywhere -> bit-reproducible.
+// se_hidden_partials_kernel + se_gate_hid_kernel: pooling mean from the partials, hidden layer, gate (see there).
+#include "common.hpp"
+#include "../../include/objcavit_hip.h"
+
+namespace {
+
+struct DWSArgs {
+  const float *in, *w, *bias;
+  float *out, *part;
+  int C, H, W, Ho, Wo, pad_t, pad_l;
+  int QL, PL, RY;                  // quads per chunk, pixel lanes, output rows per work item
+  int wox, nwork, tiles, chunks;   // x-blocks per output row, work items per image, workgroups per (image, chunk), chunks
+};
+
+// Sliding window: a work item = (x-block of PX output columns, run of RY output rows) of one channel quad.  The K input
+// rows under the current output row live in VGPRs as a ring (static indices: the row loop is unrolled K times); moving
+// down one output row loads only the S NEW input rows.  Every input element is therefore fetched (PX - 1 + K) / PX / S
+// times per run (+ K - S rows of run-in) instead of K * (PX - 1 + K) / PX times: 1.5x instead of 4.5x at k = 3,
+// 3x instead of 15x at k = 5 (PX = 2).  The L1 <- L2 path, not HBM, is what bounded the plain kernel (its 18 / 40
+// loads per x-block moved 6.5 TB/s out of L2 for 2.9 TB/s of useful traffic).
+// Weights: K = 3 in VGPRs (36); K = 5 in LDS (the 100 registers go to the window instead).
+template <int K, int S, int PX>
+__global__ __launch_bounds__(256, K > 3 ? 2 : 3) void dw_slide_kernel(DWSArgs p) {
+  constexpr int NIN = (PX - 1) * S + K;
+  constexpr bool WLDS = K > 3;
+  __shared__ float4 red[256];
+  __shared__ float4 wsh[WLDS ? K * K * 64 : 1];
+  const int tid = threadIdx.x;
+  const int q = tid % p.QL, pl = tid / p.QL;
+  const int c4n = p.C >> 2;
+  // XCD-aware, bijective workgroup -> (image, chunk, tile) map: consecutive workgroup ids go round-robin to the 8 XCDs,
+  // and neighbouring work items share halo rows / columns through their XCD's own L2.  Give every XCD a contiguous run
+  // of tiles (whole images at bs = 16).
+  int tile, chunk;
+  long b;
+  {
+    const int nwg = gridDim.x;
+    int wg = blockIdx.x;
+    const int qq = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+    wg = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
+    tile = wg % p.tiles;
+    const int rest = wg / p.tiles;
+    chunk = rest % p.chunks;
+    b = rest / p.chunks;
+  }
+  const int cq = chunk * p.QL + q;
+  const int wi = tile * p.PL + pl;
+  const bool active = pl < p.PL && cq < c4n && wi < p.nwork;
+  const int c = (cq < c4n ? cq : 0) * 4;
+
+  float4 wv[WLDS ? 1 : K * K];
+  if (WLDS) {
+    for (int t = pl; t < K * K; t += 256 / p.QL) wsh[t * 64 + q] = ld4(p.w + (long)t * p.C + c);
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) wv[t] = ld4(p.w + (long)t * p.C + c);
+  }
+  const float4 bv = p.bias ? ld4(p.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  if (active) {
+    const int run = wi / p.wox, xb = wi - run * p.wox;
+    const int y0 = run * p.RY, y1 = min(p.Ho, y0 + p.RY);
+    const int ox = xb * PX, ix0 = ox * S - p.pad_l;
+    const int iyb = y0 * S - p.pad_t;                           // input row of window-relative row 0
+    const bool allc = ix0 >= 0 && ix0 + NIN <= p.W;
+    const float* ib = p.in + b * (long)p.H * p.W * p.C + c;
+    float* ob = p.out + ((b * p.Ho + y0) * (long)p.Wo + ox) * p.C + c;
+    float4 win[K][NIN];
+    auto load_row = [&](int rel, float4 (&dst)[NIN]) {
+      const int iy = iyb + rel;
+      const bool rok = iy >= 0 && iy < p.H;
+      const float* row = ib + ((long)(rok ? iy : 0) * p.W + ix0) * p.C;
+      if (rok && allc) {
+#pragma unroll
+        for (int j = 0; j < NIN; ++j) dst[j] = ld4(row + (long)j * p.C);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NIN; ++j) {
+          const int ix = ix0 + j;
+          dst[j] = (rok && ix >= 0 && ix < p.W) ? ld4(row + (long)j * p.C) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < K - S; ++i) load_row(i, win[i % K]);
+    for (int y = y0; y < y1; y += K) {
+#pragma unroll
+      for (int u = 0; u < K; ++u) {
+        if (y + u < y1) {
+#pragma unroll
+          for (int sidx = 0; sidx < S; ++sidx) load_row((y + u - y0) * S + K - S + sidx, win[(S * u + K - S + sidx) % K]);
+          float4 acc[PX];
+#pragma unroll
+          for (int o = 0; o < PX; ++o) acc[o] = bv;
+#pragma unroll
+          for (int r = 0; r < K; ++r) {
+            // LDS-resident weights: re-read one row of taps at a time (the fence keeps the compiler from hoisting all
+            // K x K x 4 weights of all K unrolled bodies into registers, which costs the occupancy the window needs)
+            if (WLDS) asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+              const float4 w4 = WLDS ? wsh[(r * K + j) * 64 + q] : wv[WLDS ? 0 : r * K + j];
+#pragma unroll
+              for (int o = 0; o < PX; ++o) {
+                const float4 x = win[(S * u + r) % K][o * S + j];
+                acc[o].x = fmaf(w4.x, x.x, acc[o].x); acc[o].y = fmaf(w4.y, x.y, acc[o].y);
+                acc[o].z = fmaf(w4.z, x.z, acc[o].z); acc[o].w = fmaf(w4.w, x.w, acc[o].w);
+              }
+            }
+          }
+          float* orow = ob + (long)(y + u - y0) * p.Wo * p.C;
+#pragma unroll
+          for (int o = 0; o < PX; ++o) {
+            if (ox + o < p.Wo) {
+              float4 r4 = acc[o];
+              r4.x = fast_silu(r4.x); r4.y = fast_silu(r4.y); r4.z = fast_silu(r4.z); r4.w = fast_silu(r4.w);
+              *reinterpret_cast<float4*>(orow + (long)o * p.C) = r4;
+              sum.x += r4.x; sum.y += r4.y; sum.z += r4.z; sum.w += r4.w;
+            }
+          }
+        }
+      }
+    }
+  }
+  red[tid] = sum;
+  __syncthreads();
+  if (pl == 0 && cq < c4n) {
+    float4 t = red[q];
+    for (int l = 1; l < p.PL; ++l) {
+      const float4 u = red[l * p.QL + q];
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    *reinterpret_cast<float4*>(p.part + ((b * p.tiles + tile) * (long)p.C) + c) = t;
+  }
+}
+
+// workgroup geometry shared by the size query and the launch
+struct DWSGeom { int QL, PL, RY, PX, chunks, wox, nruns, nwork, tiles; };
+DWSGeom dws_geom(int B, int C, int Ho, int Wo, int k, int stride) {
+  DWSGeom g;
+  g.PX = (stride == 1 && k == 3) ? 4 : ((stride == 2 && k == 5) ? 1 : 2);
+  const int c4n = C / 4;
+  g.chunks = (c4n + 63) / 64;
+  g.QL = (c4n + g.chunks - 1) / g.chunks;
+  g.PL = 256 / g.QL;
+  g.wox = (Wo + g.PX - 1) / g.PX;
+  // rows per work item: up to 8 (measured: 16 was slower on the 120 x 160 and 240 x 320 stages, fewer workgroups in
+  // flight), shorter while the launch would have fewer than ~800 workgroups (a run re-reads k - stride rows)
+  int ry = 8;
+  while (ry > 2 && (long)g.wox * ((Ho + ry - 1) / ry) * g.chunks * B < 800L * g.PL) ry >>= 1;
+  g.RY = ry;
+  g.nruns = (Ho + ry - 1) / ry;
+  g.nwork = g.wox * g.nruns;
+  g.tiles = (g.nwork + g.PL - 1) / g.PL;
+  return g;
+}
+
+// squeeze-excite gate from the pooling partials, two small launches (both latency-bound, so both are spread wide):
+//   se_hidden_partials_kernel  grid (ceil(R / 16), B): mean[c] = (sum_tile part) / P into LDS (every workgroup of an
+//                              image repeats this: tiles x C floats from L2), then one wavefront per hidden unit:
+//                              hid[b][r] = silu(b1[r] + W1[r] . mean)
+//   se_gate_hid_kernel         grid (ceil(C / 256), B): gate[b][c] = sigmoid(b2[c] + sum_r W2t[r][c] hid[b][r])
+__global__ __launch_bounds__(1024) void se_hidden_partials_kernel(const float* __restrict__ part, int tiles, float inv,
+                                                                 const float* __restrict__ w1, const float* __restrict__ b1,
+                                                                 float* __restrict__ hid, int C, int R) {
+  extern __shared__ float sm[];            // mean[C] | red[TG][C]
+  float* mean = sm;
+  float* red = sm + C;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long b = blockIdx.y;
+  const float* pb = part + b * tiles * (long)C;
+  // pooling: TG thread groups share the tiles of a channel (all 1024 threads busy for C <= 1024), summed in group order
+  const int TG = C >= 1024 ? 1 : 1024 / C;
+  for (int idx = tid; idx < TG * C; idx += 1024) {
+    const int c = idx % C, tg = idx / C;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int t = tg;
+    for (; t + 3 * TG < tiles; t += 4 * TG) {
+      s0 += pb[(long)t * C + c]; s1 += pb[(long)(t + TG) * C + c];
+      s2 += pb[(long)(t + 2 * TG) * C + c]; s3 += pb[(long)(t + 3 * TG) * C + c];
+    }
+    for (; t < tiles; t += TG) s0 += pb[(long)t * C + c];
+    red[idx] = (s0 + s1) + (s2 + s3);
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 1024) {
+    float s = red[c];
+    for (int tg = 1; tg < TG; ++tg) s += red[tg * C + c];
+    mean[c] = s * inv;
+  }
+  __syncthreads();
+  const int r = blockIdx.x * 16 + wave;
+  if (r >= R) return;
+  const float* wr = w1 + (long)r * C;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int c = lane;
+  for (; c + 192 < C; c += 256) {
+    s0 = fmaf(wr[c], mean[c], s0);
+    s1 = fmaf(wr[c + 64], mean[c + 64], s1);
+    s2 = fmaf(wr[c + 128], mean[c + 128], s2);
+    s3 = fmaf(wr[c + 192], mean[c + 192], s3);
+  }
+  for (; c < C; c += 64) s0 = fmaf(wr[c], mean[c], s0);
+  const float s = wave_sum((s0 + s1) + (s2 + s3));
+  if (lane == 0) hid[b * R + r] = fast_silu(s + b1[r]);
+}
+
+__global__ __launch_bounds__(256) void se_gate_hid_kernel(const float* __restrict__ hid, const float* __restrict__ w2t,
+                                                          const float* __restrict__ b2, float* __restrict__ gate, int C,
+                                                          int R) {
+  __shared__ float hs[256];
+  const long b = blockIdx.y;
+  if (threadIdx.x < R) hs[threadIdx.x] = hid[b * R + threadIdx.x];
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float* w = w2t + c;
+  float s0 = b2[c], s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = 0;
+  for (; r + 3 < R; r += 4) {
+    s0 = fmaf(w[(long)r * C], hs[r], s0);
+    s1 = fmaf(w[(long)(r + 1) * C], hs[r + 1], s1);
+    s2 = fmaf(w[(long)(r + 2) * C], hs[r + 2], s2);
+    s3 = fmaf(w[(long)(r + 3) * C], hs[r + 3], s3);
+  }
+  for (; r < R; ++r) s0 = fmaf(w[(long)r * C], hs[r], s0);
+  gate[b * C + c] = fast_sigmoid((s0 + s1) + (s2 + s3));
+}
+
+template <int K, int S, int PX>
+int launch_dws(const DWSArgs& a, const DWSGeom& g, int B, hipStream_t st) {
+  hipLaunchKernelGGL((dw_slide_kernel<K, S, PX>), dim3((unsigned)((long)g.tiles * g.chunks * B)), dim3(256), 0, st, a);
+  OCV_CHECK_LAUNCH("ocv_depthwise_conv_nhwc_sum_fwd");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int ocv_depthwise_sum_tiles(int B, int C, int Ho, int Wo, int k, int stride) {
+  if (B < 1 || C < 4 || C % 4 != 0 || Ho < 1 || Wo < 1 || (k != 3 && k != 5) || (stride != 1 && stride != 2)) return 0;
+  return dws_geom(B, C, Ho, Wo, k, stride).tiles;
+}
+
+extern "C" int ocv_depthwise_conv_nhwc_sum_fwd(const float* in, const float* w, const float* bias, float* out, float* part,
+                                               int B, int C, int H, int W, int k, int stride, int pad_t, int pad_l,
+                                               int Ho, int Wo, ocv_stream_t stream) {
+  OCV_CHECK_ARG(in && w && out && part, "ocv_depthwise_conv_nhwc_sum_fwd: null pointer");
+  OCV_CHECK_ARG(B >= 1 && C >= 4 && C % 4 == 0 && H >= 1 && W >= 1 && Ho >= 1 && Wo >= 1, "ocv_depthwise_conv_nhwc_sum_fwd: bad sizes (C must be a multiple of 4)");
+  OCV_CHECK_ARG((k == 3 || k == 5) && (stride == 1 || stride == 2), "ocv_depthwise_conv_nhwc_sum_fwd: k must be 3 or 5 and stride 1 or 2");
+  OCV_CHECK_ARG(pad_t >= 0 && pad_l >= 0 && pad_t < k && pad_l < k, "ocv_depthwise_conv_nhwc_sum_fwd: bad padding");
+  OCV_CHECK_ARG((Ho - 1) * stride - pad_t < H && (Wo - 1) * stride - pad_l < W, "ocv_depthwise_conv_nhwc_sum_fwd: output larger than the padded input allows");
+  OCV_CHECK_ARG(ocv_aligned16(in) && ocv_aligned16(w) && ocv_aligned16(out) && ocv_aligned16(bias) && ocv_aligned16(part), "ocv_depthwise_conv_nhwc_sum_fwd: operands must be 16-byte aligned");
+  const DWSGeom g = dws_geom(B, C, Ho, Wo, k, stride);
+  OCV_CHECK_ARG((long)g.tiles * g.chunks * B < (1L << 31), "ocv_depthwise_conv_nhwc_sum_fwd: too many workgroups");
+  DWSArgs a{in, w, bias, out, part, C, H, W, Ho, Wo, pad_t, pad_l, g.QL, g.PL, g.RY, g.wox, g.nwork, g.tiles, g.chunks};
+  hipStream_t st = (hipStream_t)stream;
+  if (k == 3 && stride == 1) return launch_dws<3, 1, 4>(a, g, B, st);
+  if (k == 3 && stride == 2) return launch_dws<3, 2, 2>(a, g, B, st);
+  if (k == 5 && stride == 1) return launch_dws<5, 1, 2>(a, g, B, st);
+  return launch_dws<5, 2, 1>(a, g, B, st);
+}
+
+extern "C" int ocv_se_gate_partials_fwd(const float* part, int tiles, long pixels_per_image, const float* w1,
+                                        const float* b1, const float* w2t, const float* b2, float* gate, float* hidden_ws,
+                                        int B, int C, int R, ocv_stream_t stream) {
+  OCV_CHECK_ARG(part && w1 && b1 && w2t && b2 && gate && hidden_ws, "ocv_se_gate_partials_fwd: null pointer");
+  OCV_CHECK_ARG(B >= 1 && B <= 65535 && C >= 1 && R >= 1 && R <= 256 && tiles >= 1 && pixels_per_image >= 1, "ocv_se_gate_partials_fwd: bad sizes (R <= 256)");
+  OCV_CHECK_ARG(C <= 8192, "ocv_se_gate_partials_fwd: C too large (%d)", C);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)(C + (C >= 1024 ? C : (1024 / C) * C)) * sizeof(float);
+  hipLaunchKernelGGL(se_hidden_partials_kernel, dim3((R + 15) / 16, B), dim3(1024), lds, st, part, tiles,
+                     1.0f / (float)pixels_per_image, w1, b1, hidden_ws, C, R);
+  OCV_CHECK_LAUNCH("ocv_se_gate_partials_fwd(hidden)");
+  hipLaunchKernelGGL(se_gate_hid_kernel, dim3((C + 255) / 256, B), dim3(256), 0, st, (const float*)hidden_ws, w2t, b2, gate, C, R);
+  OCV_CHECK_LAUNCH("ocv_se_gate_partials_fwd(gate)");
+  return 0;
+}

@@ -638,6 +638,43 @@ def depthwise_nhwc_same(x: torch.Tensor, weight_kkc: torch.Tensor, bias: Optiona
     return out
 
 
+def depthwise_se_gate(x: torch.Tensor, weight_kkc: torch.Tensor, bias: Optional[torch.Tensor], k: int, stride: int,
+                      w1: torch.Tensor, b1: torch.Tensor, w2t: torch.Tensor, b2: torch.Tensor):
+    """silu(depthwise k x k (TF 'SAME') + bias) of a channels_last tensor AND the squeeze-excite gate of that output,
+    in two launches: returns (y [B, C, Ho, Wo] channels_last, gate [B, C])."""
+    lib = _lib.load()
+    x = _nhwc(x, "x")
+    _req(weight_kkc, "weight")
+    B, Cc, H, W = x.shape
+    if weight_kkc.shape != (k * k, Cc):
+        raise ValueError(f"depthwise_se_gate: weight {tuple(weight_kkc.shape)} does not match k={k}, C={Cc}")
+    for n, t in (("bias", bias), ("w1", w1), ("b1", b1), ("w2t", w2t), ("b2", b2)):
+        if t is not None:
+            _req(t, n)
+    R = w1.shape[0]
+    if w1.shape != (R, Cc) or w2t.shape != (R, Cc) or b1.numel() != R or b2.numel() != Cc:
+        raise ValueError("depthwise_se_gate: squeeze-excite parameter shape mismatch")
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    ph = max((Ho - 1) * stride + k - H, 0)
+    pw = max((Wo - 1) * stride + k - W, 0)
+    tiles = lib.ocv_depthwise_sum_tiles(B, Cc, Ho, Wo, k, stride)
+    if tiles <= 0:
+        raise ValueError("depthwise_se_gate: unsupported shape")
+    out = torch.empty(B, Cc, Ho, Wo, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    part = workspace(B * tiles * Cc * 4, x.device, "dw_part")
+    gate = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
+    hid = workspace(B * R * 4, x.device, "se_hidden")
+    with timed(f"depthwise|{B},{H},{W},{Cc},k{k}s{stride}"):
+        check(lib.ocv_depthwise_conv_nhwc_sum_fwd(x.data_ptr(), weight_kkc.data_ptr(), _ptr(bias), out.data_ptr(),
+                                                  part.data_ptr(), B, Cc, H, W, k, stride, ph // 2, pw // 2, Ho, Wo,
+                                                  _stream()), "ocv_depthwise_conv_nhwc_sum_fwd")
+    with timed("se_gate"):
+        check(lib.ocv_se_gate_partials_fwd(part.data_ptr(), tiles, Ho * Wo, w1.data_ptr(), b1.data_ptr(), w2t.data_ptr(),
+                                           b2.data_ptr(), gate.data_ptr(), hid.data_ptr(), B, Cc, R, _stream()),
+              "ocv_se_gate_partials_fwd")
+    return out, gate
+
+
 def channel_mean_nhwc(x: torch.Tensor) -> torch.Tensor:
     """[B, C] = mean over H, W of a channels_last [B, C, H, W] tensor."""
     lib = _lib.load()

@@ -161,8 +161,7 @@ class DepthwiseSeparableConv(_FoldedMixin, nn.Module):
             # NHWC plan: depthwise+BN+SiLU -> squeeze-excite gate -> 1x1 (+BN) with the gate on its input + skip add
             wd, bd, wp, bp, s1, sb1, s2, sb2 = self._folded(x)
             k = self.conv_dw.kernel_size[0]
-            y = hip_ops.depthwise_nhwc_same(x, wd, bd, k, self.conv_dw.stride[0], hip_ops.ACT_SILU)
-            g = hip_ops.se_gate(y, s1, sb1, s2, sb2)
+            y, g = hip_ops.depthwise_se_gate(x, wd, bd, k, self.conv_dw.stride[0], s1, sb1, s2, sb2)
             return hip_ops.pointwise_nhwc(y, wp, bp, hip_ops.ACT_NONE, gate=g, residual=x if self.has_residual else None)
         y = self.act1(self.bn1(self.conv_dw(x)))
         y = self.act2(self.bn2(self.conv_pw(self.se(y))))
@@ -192,13 +191,12 @@ class InvertedResidual(_FoldedMixin, nn.Module):
 
     def forward(self, x):
         if self._fast(x):
-            # NHWC plan, 6 launches: expand 1x1 (+BN+SiLU) -> depthwise (+BN+SiLU) -> squeeze (2) -> gate ->
+            # NHWC plan, 4 launches: expand 1x1 (+BN+SiLU) -> depthwise (+BN+SiLU, + pooling partials) -> gate ->
             # project 1x1 (+BN) with the gate applied to its input rows and the skip connection added in the epilogue
             we, be, wd, bd, wl, bl, s1, sb1, s2, sb2 = self._folded(x)
             k = self.conv_dw.kernel_size[0]
             y = hip_ops.pointwise_nhwc(x, we, be, hip_ops.ACT_SILU)
-            y = hip_ops.depthwise_nhwc_same(y, wd, bd, k, self.conv_dw.stride[0], hip_ops.ACT_SILU)
-            g = hip_ops.se_gate(y, s1, sb1, s2, sb2)
+            y, g = hip_ops.depthwise_se_gate(y, wd, bd, k, self.conv_dw.stride[0], s1, sb1, s2, sb2)
             return hip_ops.pointwise_nhwc(y, wl, bl, hip_ops.ACT_NONE, gate=g, residual=x if self.has_residual else None)
         y = self.act1(self.bn1(self.conv_pw(x)))
         y = self.act2(self.bn2(self.conv_dw(y)))

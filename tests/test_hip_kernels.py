@@ -448,6 +448,24 @@ def test_depthwise_nhwc_same(ops, k, s, B, C, H, W):
     assert got.shape == ref.shape and rel_dev(got, ref) < TOL
 
 
+@pytest.mark.parametrize("k,s", [(3, 1), (3, 2), (5, 1), (5, 2)])
+@pytest.mark.parametrize("B,C,H,W,R", [(2, 48, 60, 80, 12), (1, 8, 15, 20, 2), (3, 12, 33, 47, 4), (1, 4, 1, 1, 1),
+                                       (2, 144, 30, 41, 6), (2, 1056, 9, 11, 44), (1, 3072, 4, 5, 128), (16, 240, 30, 40, 10)])
+def test_depthwise_se_gate(ops, k, s, B, C, H, W, R):
+    x, w, b = rnd("x", (B, C, H, W), 1), rnd("w", (C, 1, k, k), 2, 0.3), rnd("b", (C,), 3, 0.2)
+    w1, b1 = rnd("w1", (R, C), 4, 1 / math.sqrt(C)), rnd("b1", (R,), 5, 0.3)
+    w2, b2 = rnd("w2", (C, R), 6, 1 / math.sqrt(R)), rnd("b2", (C,), 7, 0.3)
+    ref = F.silu(F.conv2d(_same_pad(x, k, s), w, b, stride=s, groups=C))
+    gref = torch.sigmoid(F.silu(ref.mean((2, 3)) @ w1.T + b1) @ w2.T + b2)
+    args = (dev(x).contiguous(memory_format=torch.channels_last), dev(w).flatten(1).t().contiguous(), dev(b), k, s,
+            dev(w1), dev(b1), dev(w2).t().contiguous(), dev(b2))
+    y, g = ops.depthwise_se_gate(*args)
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last) and rel_dev(y, ref) < TOL
+    assert g.shape == gref.shape and rel_dev(g, gref) < TOL
+    y2, g2 = ops.depthwise_se_gate(*args)
+    assert torch.equal(y, y2) and torch.equal(g, g2)        # fixed-order pooling sums
+
+
 @pytest.mark.parametrize("B,C,H,W,R", [(16, 144, 120, 160, 6), (2, 48, 240, 320, 12), (3, 3072, 15, 20, 128), (1, 8, 1, 3, 2)])
 def test_channel_mean_and_se_gate(ops, B, C, H, W, R):
     x = rnd("x", (B, C, H, W), 1)
