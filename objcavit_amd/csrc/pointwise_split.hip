@@ -123,6 +123,26 @@ __device__ __forceinline__ void store_tile(const PSArgs& p, const f32x16& acc, l
   }
 }
 
+// The residual (skip connection) of a tile, fetched BEFORE the K loop: read in the epilogue its latency sat fully
+// exposed at the end of every wavefront (240 -> 40 at 120 x 160: 51 of 166 us for 49 MB).
+__device__ __forceinline__ void load_res(const PSArgs& p, float (&rv)[16], long m_base, int n, int hh) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const long m = m_base + acc_row(r, hh);
+    rv[r] = (p.res != nullptr && n < p.N && m < p.M) ? p.res[m * p.N + n] : 0.f;
+  }
+}
+
+__device__ __forceinline__ void store_tile_res(const PSArgs& p, const f32x16& acc, const float (&rv)[16], long m_base, int n, int hh) {
+  if (n >= p.N) return;
+  const float bv = p.bias != nullptr ? p.bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const long m = m_base + acc_row(r, hh);
+    if (m < p.M) p.y[m * p.N + n] = act_fn(acc[r] + bv, p.act) + rv[r];
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Cin <= 128: rows resident in registers.  KS = 16-wide K steps held (2 / 4 / 8).
 // ---------------------------------------------------------------------------
@@ -263,6 +283,14 @@ __global__ __launch_bounds__(64 * WN * WK) void pw_tile_kernel(PSArgs p) {
   f32x16 acc[RT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x16{0};
+  // single-K-group tiles fetch the residual up front (see load_res); with two K groups that measured slower
+  // (1824 -> 304: 53 vs 45 us) and the epilogue loads it
+  constexpr bool RES_EARLY = WK == 1;
+  float resv[RES_EARLY ? RT : 1][16];
+  if (RES_EARLY) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) load_res(p, resv[rt], m0 + rt * 32, n, hh);
+  }
 
   load_a(0);
   load_w(0, wh, wl);
@@ -274,6 +302,7 @@ __global__ __launch_bounds__(64 * WN * WK) void pw_tile_kernel(PSArgs p) {
       load_a(it + 1);
       load_w(it + 1, whn, wln);
     }
+
     const char* base = lds + (it & 1) * BUF + (g * 2) * PART + l31 * LROW + hh * 16;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -313,7 +342,10 @@ __global__ __launch_bounds__(64 * WN * WK) void pw_tile_kernel(PSArgs p) {
         for (int r = 0; r < 16; ++r) acc[rt][r] += red[((((gg - 1) * WN + wn) * RT + rt) * 16 + r) * 64 + lane];
   }
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) store_tile(p, acc[rt], m0 + rt * 32, n, hh);
+  for (int rt = 0; rt < RT; ++rt) {
+    if (RES_EARLY) store_tile_res(p, acc[rt], resv[rt], m0 + rt * 32, n, hh);
+    else store_tile(p, acc[rt], m0 + rt * 32, n, hh);
+  }
 }
 
 template <int WN, int WK, int RT>
@@ -346,7 +378,7 @@ int launch_tile_wn(const PSArgs& a, int wk, hipStream_t st) {
 // L1/L2.  No LDS, no barrier, nothing shared between wavefronts: the memory system sees one long independent stream
 // per wavefront, which is what the HBM-bound project layers (240 -> 40 at 120 x 160: 393 MB, 6 GFLOP) want.
 // ---------------------------------------------------------------------------
-template <int NTL, int U>
+template <int NTL, int U, bool RES>
 __global__ __launch_bounds__(256) void pw_stream_kernel(PSArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
@@ -364,6 +396,11 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(PSArgs p) {
   f32x16 acc[NTL];
 #pragma unroll
   for (int j = 0; j < NTL; ++j) acc[j] = f32x16{0};
+  float resv[RES ? NTL : 1][16];
+  if (RES) {
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) load_res(p, resv[j], m_base, 32 * j + l31, hh);
+  }
 
   for (int s0 = 0; s0 < nsteps; s0 += U) {
     float4 ra[U][2];
@@ -405,7 +442,10 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(PSArgs p) {
     }
   }
 #pragma unroll
-  for (int j = 0; j < NTL; ++j) store_tile(p, acc[j], m_base, 32 * j + l31, hh);
+  for (int j = 0; j < NTL; ++j) {
+    if (RES) store_tile_res(p, acc[j], resv[j], m_base, 32 * j + l31, hh);
+    else store_tile(p, acc[j], m_base, 32 * j + l31, hh);
+  }
 }
 
 // diagnostic override of the dispatch: OCV_PW_CFG = "rows" | "stream" | "tile" | "wn,wk" (tile kernel with that shape)
@@ -470,7 +510,9 @@ extern "C" int ocv_pointwise_conv_nhwc_split_fwd(const float* x, const float* ga
     return 0;
   }
   if (family == 2) {
-    hipLaunchKernelGGL((pw_stream_kernel<1, 4>), dim3((unsigned)((M + 127) / 128)), dim3(256), 0, st, a);
+    const dim3 grid((unsigned)((M + 127) / 128));
+    if (residual != nullptr) hipLaunchKernelGGL((pw_stream_kernel<1, 4, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((pw_stream_kernel<1, 4, false>), grid, dim3(256), 0, st, a);
     OCV_CHECK_LAUNCH("ocv_pointwise_conv_nhwc_split_fwd(stream)");
     return 0;
   }

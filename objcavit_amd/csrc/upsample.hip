@@ -38,9 +38,24 @@ __device__ __forceinline__ void store_split4(unsigned short* hi, unsigned short*
   *reinterpret_cast<uint2*>(lo + off) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
 }
 
+constexpr int UP_ITEMS = 8;
+
 __global__ __launch_bounds__(256) void upsample_concat_split_kernel(UpArgs p) {
   const int C = p.C1 + p.C2, c4n = C >> 2;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < p.total; idx += (long)gridDim.x * 256) {
+  // XCD-aware, bijective workgroup -> work map: consecutive workgroup ids go round-robin to the 8 XCDs, and the four
+  // bilinear taps of neighbouring output pixels re-read the same low-resolution rows -- through their XCD's own L2.
+  // Each XCD gets a contiguous band of output rows (FETCH_SIZE of the 240 x 320 launch was 3x the algorithmic bytes
+  // with the plain grid-stride order); a workgroup walks UP_ITEMS consecutive 256-element groups.
+  long wg = blockIdx.x;
+  {
+    const long nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7, i = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+  }
+  const long idx0 = wg * (256L * UP_ITEMS) + threadIdx.x;
+#pragma unroll 1
+  for (int it = 0; it < UP_ITEMS; ++it) {
+    const long idx = idx0 + it * 256L;
+    if (idx >= p.total) break;
     const int c = (int)(idx % c4n) * 4;
     long t = idx / c4n;
     const int X = (int)(t % p.W);
@@ -78,8 +93,8 @@ extern "C" int ocv_upsample_concat_split_fwd(const float* x, int h, int w, int C
   UpArgs a{x, skip, (unsigned short*)out_hi, (unsigned short*)out_lo, h, w, H, W, C1, C2,
            H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f,
            (long)B * H * W * ((C1 + C2) / 4)};
-  long blocks = (a.total + 255) / 256;
-  if (blocks > 256L * 64) blocks = 256L * 64;
+  const long blocks = (a.total + 256L * UP_ITEMS - 1) / (256L * UP_ITEMS);
+  OCV_CHECK_ARG(blocks < (1L << 31), "ocv_upsample_concat_split_fwd: tensor too large");
   hipLaunchKernelGGL(upsample_concat_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   OCV_CHECK_LAUNCH("ocv_upsample_concat_split_fwd");
   return 0;

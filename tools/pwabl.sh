@@ -1,5 +1,5 @@
-for v in "" NOW NOA NOGATE NOMFMA; do
+for v in "" NORES NOSTORE; do
   echo "=== variant ${v:-base}"
   if [ -n "$v" ]; then export OCV_LIB_PATH=$PWD/objcavit_amd/lib/variants/$v.so; fi
-  OCV_PW_CFG=0,0,0 python3 tools/run_pw.py 3 4 6 8 9 10 11 12 13 2>&1 | grep "M="
+  python3 tools/run_pw.py 0 2 3 4 5 12 13 2>&1 | grep "M=" | sed 's/fp32.*| split/split/'
 done
