@@ -463,7 +463,60 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
       __syncthreads();
     }
 
-    // accumulator (i, j): register r of lane l is output row 16 i + 4 (l >> 4) + r, column 16 j + (l & 15)
+    // ---- epilogue.  accumulator (i, j): register r of lane l is output row 16 i + 4 (l >> 4) + r, column 16 j + (l & 15)
+    // Storing straight from that layout costs 384 two- and four-byte store instructions per wavefront in 32- / 64-byte
+    // runs; it was store-ISSUE-bound and, with one workgroup per CU, fully exposed: 23 % of the 128 -> 128 launches
+    // (ablation: 1.63 -> 1.26 ms without the stores).  Instead the tile goes through this wavefront's own 34 KB of
+    // the (now idle) LDS and leaves as 16-byte-per-lane stores, 8 rows x 128 B (bf16) or 4 rows x 256 B (fp32) each.
+    constexpr int ERS = 68;                                       // floats per LDS row: 64 + 4 -> conflict-free writes
+    float* tile = reinterpret_cast<float*>(lds) + wave * (128 * ERS);
+    if ((p.Cout & 7) == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + l15;
+        const float bv = (p.bias != nullptr && n < p.Cout) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = acc[i][j][r] + bv;
+            if (p.act == OCV_ACT_LEAKY_RELU) v = v > 0.f ? v : 0.01f * v;
+            else if (p.act == OCV_ACT_SILU) v = fast_silu(v);
+            else if (p.act == OCV_ACT_RELU) v = fmaxf(v, 0.f);
+            tile[(16 * i + 4 * q4 + r) * ERS + 16 * j + l15] = v;
+          }
+      }
+      const int oct = lane & 7, rsub = lane >> 3;
+      const int ncol = n0 + wn * 64 + oct * 8;
+      if (ncol < p.Cout) {
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+          const int row = it * 8 + rsub;
+          const long m = m0 + wm * 128 + row;
+          if (m >= p.M) continue;
+          f32x4 a = *reinterpret_cast<const f32x4*>(tile + row * ERS + oct * 8);
+          f32x4 c = *reinterpret_cast<const f32x4*>(tile + row * ERS + oct * 8 + 4);
+          const long o = m * p.Cout + ncol;
+          if (p.res != nullptr) {
+            a += *reinterpret_cast<const f32x4*>(p.res + o);
+            c += *reinterpret_cast<const f32x4*>(p.res + o + 4);
+          }
+          if (p.y != nullptr) {
+            *reinterpret_cast<f32x4*>(p.y + o) = a;
+            *reinterpret_cast<f32x4*>(p.y + o + 4) = c;
+          }
+          if (p.yhi != nullptr) {
+            __bf16 hi[8], lo[8];
+            split4(a, hi, lo);
+            split4(c, hi + 4, lo + 4);
+            *reinterpret_cast<bf16x8*>(p.yhi + o) = *reinterpret_cast<bf16x8*>(hi);
+            *reinterpret_cast<bf16x8*>(p.ylo + o) = *reinterpret_cast<bf16x8*>(lo);
+          }
+        }
+      }
+      return;
+    }
+    // Cout not a multiple of 8: element-wise stores
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + wn * 64 + j * 16 + l15;
@@ -491,6 +544,7 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
     }
     return;
   }
+
   // =========================== PRODUCERS (LDS-DMA issuers) ===========================
   // wave pw moves A rows [64 pw, 64 pw + 64) (hi and lo: 8 x 1 KiB pieces) and B rows [32 pw, 32 pw + 32) (4 pieces).
   // Lane L of a piece lands at piece base + 16 L  =  row L >> 2, stored chunk L & 3, which must hold LOGICAL chunk
@@ -611,6 +665,7 @@ extern "C" int ocv_conv_nhwc_split_fwd(const void* x_hi, const void* x_lo, int C
                                        int B, int H, int W, int Cout, int ksize, int act, ocv_stream_t stream) {
   OCV_CHECK_ARG(x_hi && x_lo && w_hi && w_lo && (y || (y_hi && y_lo)), "ocv_conv_nhwc_split_fwd: null pointer");
   OCV_CHECK_ARG((y_hi == nullptr) == (y_lo == nullptr), "ocv_conv_nhwc_split_fwd: y_hi and y_lo go together");
+  OCV_CHECK_ARG(ocv_aligned16(y) && ocv_aligned16(y_hi) && ocv_aligned16(y_lo) && ocv_aligned16(residual), "ocv_conv_nhwc_split_fwd: outputs and residual must be 16-byte aligned");
   OCV_CHECK_ARG(ksize == 1 || ksize == 3, "ocv_conv_nhwc_split_fwd: kernel size must be 1 or 3 (got %d)", ksize);
   OCV_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && Cout >= 1 && Cin >= 8 && Cin % 8 == 0, "ocv_conv_nhwc_split_fwd: bad sizes (Cin must be a multiple of 8)");
   OCV_CHECK_ARG(act >= 0 && act <= 3, "ocv_conv_nhwc_split_fwd: unknown activation %d", act);
