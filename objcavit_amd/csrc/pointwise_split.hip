@@ -123,23 +123,52 @@ __device__ __forceinline__ void store_tile(const PSArgs& p, const f32x16& acc, l
   }
 }
 
-// The residual (skip connection) of a tile, fetched BEFORE the K loop: read in the epilogue its latency sat fully
-// exposed at the end of every wavefront (240 -> 40 at 120 x 160: 51 of 166 us for 49 MB).
-__device__ __forceinline__ void load_res(const PSArgs& p, float (&rv)[16], long m_base, int n, int hh) {
+// Coalesced epilogue.  Storing a 32 x 32 accumulator tile straight from its MFMA layout takes 16 four-byte store
+// instructions of two 128-byte runs each and is store-issue-bound (the expand layers spent as long in their stores as
+// in everything else: 24 -> 144 at 240 x 320, 269 us with and 135 us without them).  The tile is transposed through
+// 5 KB of LDS owned by the wavefront (row stride 40 floats: the two lane halves land 32 banks apart) and leaves as four
+// 16-byte-per-lane stores of 8 rows x 128 B.  Lane l owns columns 4 (l & 7) .. +3 of rows (l >> 3) + 8 it.
+constexpr int TS = 40;                          // floats per LDS row of the transpose scratch
+constexpr int TSCRATCH = 32 * TS;               // floats per wavefront
+
+// The residual (skip connection) of a tile in that same lane order, fetched BEFORE the K loop: read in the epilogue
+// its latency sat fully exposed at the end of every wavefront (240 -> 40 at 120 x 160: 51 of 166 us for 49 MB).
+__device__ __forceinline__ void load_res(const PSArgs& p, float4 (&rq)[4], long m_base, int n0, int lane) {
+  const int ncol = n0 + 4 * (lane & 7);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const long m = m_base + acc_row(r, hh);
-    rv[r] = (p.res != nullptr && n < p.N && m < p.M) ? p.res[m * p.N + n] : 0.f;
+  for (int it = 0; it < 4; ++it) {
+    const long m = m_base + (lane >> 3) + 8 * it;
+    rq[it] = (p.res != nullptr && ncol < p.N && m < p.M) ? ld4(p.res + m * p.N + ncol) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
-__device__ __forceinline__ void store_tile_res(const PSArgs& p, const f32x16& acc, const float (&rv)[16], long m_base, int n, int hh) {
-  if (n >= p.N) return;
-  const float bv = p.bias != nullptr ? p.bias[n] : 0.f;
+// n0 = first column of the tile; rq = residual prefetched by load_res (or nullptr: fetched here, coalesced)
+__device__ __forceinline__ void store_tile_lds(const PSArgs& p, const f32x16& acc, float* scratch, const float4* rq,
+                                               long m_base, int n0, int lane) {
+  const int l31 = lane & 31, hh = lane >> 5;
+  if ((p.N & 3) != 0) {                          // ragged rows cannot take 16-byte stores
+    store_tile(p, acc, m_base, n0 + l31, hh);
+    return;
+  }
+  const int n = n0 + l31;
+  const float bv = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const long m = m_base + acc_row(r, hh);
-    if (m < p.M) p.y[m * p.N + n] = act_fn(acc[r] + bv, p.act) + rv[r];
+  for (int r = 0; r < 16; ++r) scratch[acc_row(r, hh) * TS + l31] = act_fn(acc[r] + bv, p.act);
+  const int c4 = lane & 7, ncol = n0 + 4 * c4;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = (lane >> 3) + 8 * it;
+    const long m = m_base + row;
+    float4 v = *reinterpret_cast<const float4*>(scratch + row * TS + 4 * c4);
+    if (ncol < p.N && m < p.M) {
+      if (rq != nullptr) {
+        v.x += rq[it].x; v.y += rq[it].y; v.z += rq[it].z; v.w += rq[it].w;
+      } else if (p.res != nullptr) {
+        const float4 q = ld4(p.res + m * p.N + ncol);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+      }
+      *reinterpret_cast<float4*>(p.y + m * p.N + ncol) = v;
+    }
   }
 }
 
@@ -148,7 +177,9 @@ __device__ __forceinline__ void store_tile_res(const PSArgs& p, const f32x16& ac
 // ---------------------------------------------------------------------------
 template <int KS>
 __global__ __launch_bounds__(256) void pw_rows_kernel(PSArgs p) {
+  __shared__ __attribute__((aligned(16))) float tscratch[4 * TSCRATCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* scratch = tscratch + wave * TSCRATCH;
   const int l31 = lane & 31, hh = lane >> 5;
   const long m_base = (long)blockIdx.x * 128 + wave * 32;
   const int K = p.K;
@@ -184,7 +215,7 @@ __global__ __launch_bounds__(256) void pw_rows_kernel(PSArgs p) {
     for (int s = 0; s < KS; ++s) {
       if (16 * s < p.Kp) acc = mfma3(ahi[s], alo[s], ldb8(wf + s * 1024), ldb8(wf + s * 1024 + 512), acc);
     }
-    store_tile(p, acc, m_base, n, hh);
+    store_tile_lds(p, acc, scratch, nullptr, m_base, nt * 32, lane);
   }
 }
 
@@ -286,10 +317,11 @@ __global__ __launch_bounds__(64 * WN * WK) void pw_tile_kernel(PSArgs p) {
   // single-K-group tiles fetch the residual up front (see load_res); with two K groups that measured slower
   // (1824 -> 304: 53 vs 45 us) and the epilogue loads it
   constexpr bool RES_EARLY = WK == 1;
-  float resv[RES_EARLY ? RT : 1][16];
+  const int ntile0 = by * (32 * WN) + wn * 32;              // first column of this wavefront's tile
+  float4 resq[RES_EARLY ? RT : 1][4];
   if (RES_EARLY) {
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) load_res(p, resv[rt], m0 + rt * 32, n, hh);
+    for (int rt = 0; rt < RT; ++rt) load_res(p, resq[rt], m0 + rt * 32, ntile0, lane);
   }
 
   load_a(0);
@@ -341,17 +373,21 @@ __global__ __launch_bounds__(64 * WN * WK) void pw_tile_kernel(PSArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[rt][r] += red[((((gg - 1) * WN + wn) * RT + rt) * 16 + r) * 64 + lane];
   }
+  // transpose scratch: the staging buffers are idle now (every wavefront is past the last barrier of the K loop); with
+  // K groups it sits behind the reduction slabs, which the other wavefronts of group 0 may still be reading
+  constexpr int RED_FLOATS = (WK - 1) * WN * RT * 16 * 64;
+  float* scratch = reinterpret_cast<float*>(lds) + RED_FLOATS + wn * TSCRATCH;
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    if (RES_EARLY) store_tile_res(p, acc[rt], resv[rt], m0 + rt * 32, n, hh);
-    else store_tile(p, acc[rt], m0 + rt * 32, n, hh);
-  }
+  for (int rt = 0; rt < RT; ++rt)
+    store_tile_lds(p, acc[rt], scratch, RES_EARLY ? resq[rt] : nullptr, m0 + rt * 32, ntile0, lane);
 }
 
 template <int WN, int WK, int RT>
 int launch_tile(const PSArgs& a, hipStream_t st) {
   constexpr int ROWS = 32 * RT;
-  constexpr size_t LDS = (size_t)2 * WK * 2 * ROWS * LROW;
+  constexpr size_t STAGE = (size_t)2 * WK * 2 * ROWS * LROW;
+  constexpr size_t TRANS = ((size_t)(WK - 1) * WN * RT * 16 * 64 + (size_t)WN * TSCRATCH) * sizeof(float);   // reduction slabs + scratch
+  constexpr size_t LDS = STAGE > TRANS ? STAGE : TRANS;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)pw_tile_kernel<WN, WK, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -396,10 +432,12 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(PSArgs p) {
   f32x16 acc[NTL];
 #pragma unroll
   for (int j = 0; j < NTL; ++j) acc[j] = f32x16{0};
-  float resv[RES ? NTL : 1][16];
+  __shared__ __attribute__((aligned(16))) float tscratch[4 * TSCRATCH];
+  float* scratch = tscratch + wave * TSCRATCH;
+  float4 resq[RES ? NTL : 1][4];
   if (RES) {
 #pragma unroll
-    for (int j = 0; j < NTL; ++j) load_res(p, resv[j], m_base, 32 * j + l31, hh);
+    for (int j = 0; j < NTL; ++j) load_res(p, resq[j], m_base, 32 * j, lane);
   }
 
   for (int s0 = 0; s0 < nsteps; s0 += U) {
@@ -442,10 +480,7 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(PSArgs p) {
     }
   }
 #pragma unroll
-  for (int j = 0; j < NTL; ++j) {
-    if (RES) store_tile_res(p, acc[j], resv[j], m_base, 32 * j + l31, hh);
-    else store_tile(p, acc[j], m_base, 32 * j + l31, hh);
-  }
+  for (int j = 0; j < NTL; ++j) store_tile_lds(p, acc[j], scratch, RES ? resq[j] : nullptr, m_base, 32 * j, lane);
 }
 
 // diagnostic override of the dispatch: OCV_PW_CFG = "rows" | "stream" | "tile" | "wn,wk" (tile kernel with that shape)
@@ -480,8 +515,8 @@ extern "C" int ocv_pointwise_conv_nhwc_split_fwd(const float* x, const float* ga
   OCV_CHECK_ARG(M >= 0 && Cin >= 8 && Cin % 8 == 0 && Cout >= 1, "ocv_pointwise_conv_nhwc_split_fwd: Cin must be a positive multiple of 8 (got M=%ld Cin=%d Cout=%d)", M, Cin, Cout);
   OCV_CHECK_ARG(gate == nullptr || rows_per_image >= 1, "ocv_pointwise_conv_nhwc_split_fwd: gate needs rows_per_image");
   OCV_CHECK_ARG(act >= 0 && act <= OCV_ACT_SIGMOID, "ocv_pointwise_conv_nhwc_split_fwd: unknown activation %d", act);
-  OCV_CHECK_ARG(ocv_aligned16(x) && ocv_aligned16(w_packed) && ocv_aligned16(gate),
-                "ocv_pointwise_conv_nhwc_split_fwd: x / w_packed / gate must be 16-byte aligned");
+  OCV_CHECK_ARG(ocv_aligned16(x) && ocv_aligned16(w_packed) && ocv_aligned16(gate) && ocv_aligned16(y) && ocv_aligned16(residual),
+                "ocv_pointwise_conv_nhwc_split_fwd: x / w_packed / gate / y / residual must be 16-byte aligned");
   if (M == 0) return 0;
   PSArgs a{x, gate, bias, residual, (const __bf16*)w_packed, y, M, Cin, Kp, Cout,
            rows_per_image > 0 ? rows_per_image : 1, act};
