@@ -18,6 +18,9 @@
 // issue), then an online softmax update in registers.  A lane holds 16 bins of
 // the tile for its pixel, lane^32 the other 16: max / sum / weighted sum need
 // one wavefront shuffle (xor 32) per tile.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.hpp"
 #include "../../include/objcavit_hip.h"
 
@@ -130,6 +133,118 @@ __global__ __launch_bounds__(256) void bin_head_kernel(const float* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------
+// Split-bf16 bin head (NHWC feature map): the same computation with the 128 -> 256 logits on
+// v_mfma_f32_32x32x16_bf16, every product formed as hi*hi + hi*lo + lo*hi with fp32 accumulation (product error
+// <= 2^-17, as in the convolutions that produce the map).  24 MFMAs of 32 cycles per bin tile instead of 64 of 64:
+// the fp32 kernel above runs at 70 % of the fp32 matrix peak and is bound by it (0.75 ms at bs = 16); this one is
+// bound by streaming the map.  Wf[b] is split once per workgroup while it is staged, straight into MFMA A-operand
+// fragments (1 KB per (bin tile, K step, hi|lo): lane = 32 (k octet) + bin, read back with conflict-free linear
+// ds_read_b128); a pixel's 128 channels are split once per pixel tile and reused by all 8 bin tiles.
+// ---------------------------------------------------------------------------
+typedef __bf16 bh_bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void bh_split8(const float4 u, const float4 v, bh_bf16x8& hi, bh_bf16x8& lo) {
+  const float f[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 h = (__bf16)f[i];
+    hi[i] = h;
+    lo[i] = (__bf16)(f[i] - (float)h);
+  }
+}
+
+__global__ __launch_bounds__(256) void bin_head_split_kernel(const float* __restrict__ feat, const float* __restrict__ Wf,
+                                                             const float* __restrict__ bout,
+                                                             const float* __restrict__ centers, float* __restrict__ depth,
+                                                             long P, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __bf16* wfrag = reinterpret_cast<__bf16*>(lds);           // [8 bin tiles][8 K steps][hi, lo][64 lanes][8]
+  float* bl = lds + (NB * CH * 2 * 2) / 4;                   // [256]
+  float* cl = bl + NB;                                       // [256]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.y;
+  const float* fb = feat + (long)b * CH * P;
+  const float* wb = Wf + (long)b * NB * CH;
+
+  for (int idx = tid; idx < NB * CH / 8; idx += 256) {
+    const int k = idx >> 4, o = idx & 15;                    // bin, K octet
+    bh_bf16x8 hi, lo;
+    bh_split8(ld4(wb + (long)k * CH + 8 * o), ld4(wb + (long)k * CH + 8 * o + 4), hi, lo);
+    __bf16* d = wfrag + ((((k >> 5) * 8 + (o >> 1)) * 2) * 64 + (o & 1) * 32 + (k & 31)) * 8;
+    *reinterpret_cast<bh_bf16x8*>(d) = hi;
+    *reinterpret_cast<bh_bf16x8*>(d + 512) = lo;
+  }
+  bl[tid] = bout[tid];
+  cl[tid] = centers[(long)b * NB + tid];
+  __syncthreads();
+
+  float4 cur[16], nxt[16];
+  auto load_px = [&](float4 (&dst)[16], long pix) {
+    const bool ok = pix < P;
+    const float* src = fb + (ok ? pix : 0) * CH + 8 * hh;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      dst[2 * s] = ok ? ld4(src + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
+      dst[2 * s + 1] = ok ? ld4(src + 16 * s + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) load_px(cur, (long)tile * TP + wave * 32 + l31);
+  for (; tile < ntiles; tile += gridDim.x) {
+    const long pix = (long)tile * TP + wave * 32 + l31;
+    const int tn = tile + gridDim.x;
+    if (tn < ntiles) load_px(nxt, (long)tn * TP + wave * 32 + l31);
+
+    bh_bf16x8 ph[8], pl[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) bh_split8(cur[2 * s], cur[2 * s + 1], ph[s], pl[s]);
+
+    float m_run = -__builtin_inff(), l_half = 0.f, d_half = 0.f;
+#pragma unroll 1
+    for (int t = 0; t < NB / 32; ++t) {
+      f32x16 acc = {0};
+      const __bf16* wf = wfrag + (t * 8 * 2) * 512 + lane * 8;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const bh_bf16x8 ah = *reinterpret_cast<const bh_bf16x8*>(wf + s * 1024);
+        const bh_bf16x8 al = *reinterpret_cast<const bh_bf16x8*>(wf + s * 1024 + 512);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ph[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, pl[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ph[s], acc, 0, 0, 0);
+      }
+      float tmax = -__builtin_inff();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[r] += bl[t * 32 + acc_row(r, hh)];
+        tmax = fmaxf(tmax, acc[r]);
+      }
+      tmax = xor32_max(tmax);
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = fast_exp(m_run - m_new);
+      float ps = 0.f, ds = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pr = fast_exp(acc[r] - m_new);
+        ps += pr;
+        ds += pr * cl[t * 32 + acc_row(r, hh)];
+      }
+      l_half = l_half * alpha + ps;
+      d_half = d_half * alpha + ds;
+      m_run = m_new;
+    }
+    const float l = xor32_sum(l_half), d = xor32_sum(d_half);
+    if (hh == 0 && pix < P) depth[(long)b * P + pix] = d / l;
+
+    if (tn < ntiles) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) cur[s] = nxt[s];
+    }
+  }
+}
+
 // ram[b][q][p] = sum_c queries[b][q][c] * feat[b][c][p]
 template <bool NHWC>
 __global__ __launch_bounds__(256) void pixel_dot_kernel(const float* __restrict__ feat, const float* __restrict__ qm,
@@ -235,7 +350,19 @@ extern "C" int ocv_bin_head_folded_fwd(const float* feat, int channels_last, con
   const int ntiles = ocv_cdiv(P, TP);
   const int per = blocks_per_image(B, ntiles);
   const size_t lds = (size_t)(NB * WLD + 2 * NB) * sizeof(float);
-  if (channels_last)
+  // NHWC maps take the split-bf16 kernel; channels_last == 2 (or OCV_BINHEAD=fp32 in the environment) selects the
+  // exact-fp32 one
+  static const bool exact = [] { const char* e = getenv("OCV_BINHEAD"); return e != nullptr && strcmp(e, "fp32") == 0; }();
+  if (channels_last == 1 && !exact) {
+    static bool attr2 = false;
+    if (!attr2) {
+      (void)hipFuncSetAttribute((const void*)bin_head_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr2 = true;
+    }
+    const size_t lds2 = (size_t)NB * CH * 2 * 2 + 2 * NB * sizeof(float);
+    hipLaunchKernelGGL(bin_head_split_kernel, dim3(per, B), dim3(256), lds2, (hipStream_t)stream, feat, Wf, bout, centers,
+                       depth, (long)P, ntiles);
+  } else if (channels_last)
     hipLaunchKernelGGL(bin_head_kernel<true>, dim3(per, B), dim3(256), lds, (hipStream_t)stream, feat, Wf, bout,
                        centers, depth, (long)P, ntiles);
   else
