@@ -210,13 +210,13 @@ def main():
         roofline = None
         conv_dom = max(convs, key=lambda c: c["ms"]) if convs else None
         if conv_dom and (dom is None or conv_dom["ms"] > kernels[dom]["ms"]):
-            # dominant hand-written kernel = the split-bf16 implicit-GEMM convolution (conv_igemm_kernel): matrix-pipe
+            # dominant hand-written kernel = the split-bf16 implicit-GEMM convolution (conv_split_dma_kernel): matrix-pipe
             # bound (AI >> ridge); achieved = ISSUED bf16 FLOPs (3 MFMAs per product) / duration vs the dense bf16 peak
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
             if os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get("conv3x3")
-            roofline = dict(kernel="conv_igemm_kernel " + conv_dom["shape"], bound="mfma", achieved=conv_dom["issued_bf16_TFLOPs"],
+            roofline = dict(kernel="conv_split_dma_kernel " + conv_dom["shape"], bound="mfma", achieved=conv_dom["issued_bf16_TFLOPs"],
                             peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=conv_dom["frac_bf16_mfma"], traffic=traffic,
                             algorithmic_fp32_TFLOPs=conv_dom["alg_TFLOPs"],
                             x_over_fp32_mfma_peak=round(conv_dom["alg_TFLOPs"] / F32_MFMA_PEAK_TFLOPS, 2),
@@ -240,6 +240,7 @@ def main():
             "value": round(world * a.steps * B / dt, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dtype_note": "fp32 results; contractions of the convolutions / 1x1 layers / bin head run as split-bf16 (hi*hi + hi*lo + lo*hi on v_mfma_*_bf16, fp32 accumulate), the rest on fp32 MFMA",
             "launch": "eager" if a.eager else "hipGraph replay (+1 eager bin-head launch) per step",
             "config": {"workload": "BASELINE configs[2]: ObjCAViT enet-b5 NYU 480x640, emb_dim=128, learned pos-MLP, "
                                    f"{N_OBJ} objs/img with random 512-d text features, bs={B} per GPU, random-init weights",
