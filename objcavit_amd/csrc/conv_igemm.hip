@@ -390,7 +390,7 @@ namespace {
 // copies, so the producers move them global -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write: the
 // ablation of the register-staged kernel put 25 % of its time in the ds_write_b128 path).  An LDS-DMA instruction
 // writes wave-uniform base + lane x 16 B, i.e. rows cannot be padded; bank conflicts are avoided instead by an XOR
-// swizzle of the 16-byte chunk index with (row >> 2) & 3, applied on the SOURCE side (each lane fetches the logical
+// swizzle of the 16-byte chunk index with (row >> 1) & 3, applied on the SOURCE side (each lane fetches the logical
 // chunk that belongs at its linear LDS slot) and on the fragment reads.
 // ---------------------------------------------------------------------------
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -425,11 +425,12 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
     // The 16 x 16 x 32 shape costs the same matrix-pipe cycles as 48 of 32 x 32 x 16 over the same LDS image and the
     // same reads, but the chip sustains a higher clock under it: A/B in one process on one device, 3-9 % faster per
     // launch (2224 -> 1024 at 30 x 40: 2.55 -> 2.33 ms).  Operand lanes: row / column l & 15, K octet l >> 4 (one
-    // 16-byte chunk of the 64-byte row); the row swizzle key (row >> 2) & 3 makes the 16 lanes of an octet group
-    // cover all 64 banks.
+    // 16-byte chunk of the 64-byte row).  Swizzle key (row >> 1) & 3: any 8 consecutive rows of one K octet land in
+    // 8 different 16-byte bank groups of a 128-byte LDS cycle.  (With the key (row >> 2) & 3 of the 32 x 32 consumers
+    // this read pattern counted 1.4e8 SQ_LDS_BANK_CONFLICT cycles per launch and ran 1-3.5 % slower.)
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, q4 = lane >> 4;
-    const int co = ((q4 ^ ((l15 >> 2) & 3)) * 16);
+    const int co = ((q4 ^ ((l15 >> 1) & 3)) * 16);
     f32x4 acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -548,10 +549,10 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
   // =========================== PRODUCERS (LDS-DMA issuers) ===========================
   // wave pw moves A rows [64 pw, 64 pw + 64) (hi and lo: 8 x 1 KiB pieces) and B rows [32 pw, 32 pw + 32) (4 pieces).
   // Lane L of a piece lands at piece base + 16 L  =  row L >> 2, stored chunk L & 3, which must hold LOGICAL chunk
-  // (L & 3) ^ ((row >> 2) & 3) = (L & 3) ^ ((L >> 4) & 3)  (piece bases are multiples of 16 rows).
+  // (L & 3) ^ ((row >> 1) & 3) = (L & 3) ^ ((L >> 3) & 3)  (piece bases are multiples of 16 rows).
   const int pw = wave - 4;
   const int lrow = lane >> 2;
-  const int lchunk = (lane & 3) ^ ((lane >> 4) & 3);               // logical 16-byte chunk (8 channels) this lane fetches
+  const int lchunk = (lane & 3) ^ ((lane >> 3) & 3);               // logical 16-byte chunk (8 channels) this lane fetches
   unsigned rbA[4], tapmask[4];
   {
     const long hw = (long)p.H * p.W;

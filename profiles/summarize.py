@@ -23,7 +23,7 @@ OURS = ("bin_head_kernel", "pixel_dot_kernel", "patch_embed_partial_kernel", "pa
         "conv_igemm_kernel", "pointwise_kernel", "pointwise_smallk_kernel", "depthwise_kernel", "depthwise_nhwc_kernel",
         "channel_sum_kernel", "channel_mean_finish_kernel", "se_hidden_kernel", "se_gate_kernel",
         "conv_split_dma_kernel", "upsample_concat_split_kernel", "pw_rows_kernel", "pw_tile_kernel", "pw_stream_kernel",
-        "dw_slide_kernel", "se_hidden_partials_kernel", "se_gate_hid_kernel", "stem_conv_kernel")
+        "bin_head_split_kernel", "dw_slide_kernel", "se_hidden_partials_kernel", "se_gate_hid_kernel", "stem_conv_kernel")
 
 
 def short(name):
@@ -39,7 +39,7 @@ def main(src, tag):
     if kt:
         rows = list(csv.DictReader(open(kt[0])))
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-        idx = [i for i, r in enumerate(rows) if "bin_head_kernel" in r["Kernel_Name"]]
+        idx = [i for i, r in enumerate(rows) if "bin_head_kernel" in r["Kernel_Name"] or "bin_head_split_kernel" in r["Kernel_Name"]]
         step = rows[idx[-2] + 1: idx[-1] + 1]
         t0, t1 = int(step[0]["Start_Timestamp"]), int(step[-1]["End_Timestamp"])
         agg = collections.defaultdict(lambda: [0, 0])
@@ -73,7 +73,7 @@ def main(src, tag):
     if pmc:
         json.dump(pmc, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
         traffic = {}
-        for key, prefixes in (("bin_head", ("bin_head_kernel",)), ("patch_embed", ("patch_embed_partial_kernel",)),
+        for key, prefixes in (("bin_head", ("bin_head_split_kernel", "bin_head_kernel")), ("patch_embed", ("patch_embed_partial_kernel",)),
                               ("conv3x3", ("conv_split_dma_kernel", "conv_igemm_kernel"))):
             names = [n for n in series if n.startswith(prefixes) and len(series[n]) == 2
                      and len(series[n]["FETCH_SIZE"]) == len(series[n]["WRITE_SIZE"])]
