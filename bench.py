@@ -131,7 +131,11 @@ def main():
     B = a.batch
     img_cpu = synthetic_images(B, 42 + rank)
     img = img_cpu.to(device)
-    gt = (torch.rand(B, 1, H // 2, W // 2, generator=torch.Generator().manual_seed(7 + rank)) * 9.0 + 0.5).to(device)
+    # synthetic ground truth at the dataset's full resolution; metrics as the reference's validation step computes them
+    # (metrics/MetricsPreprocess.py: resize the prediction to the ground truth, NYU Eigen crop) -- one fused kernel
+    gt = (torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(7 + rank)) * 9.0 + 0.5).to(device)
+    from objcavit_amd.validation import crop_box
+    box = crop_box(args, H, W)
 
     def barrier():
         if world > 1:
@@ -146,7 +150,7 @@ def main():
         log("forward captured into a hipGraph")
     for i in range(a.warmup):
         out = run(img)
-        dp.per_image_metrics(out.depth_pred, gt, 0.001, 10.0)      # also warms the metric kernels (lazy code loading)
+        hip_ops.depth_metrics(out.depth_pred, gt, 0.001, 10.0, crop=box)      # also warms the metric kernel (lazy code loading)
         torch.cuda.synchronize()
         log(f"warm-up step {i} done")
     barrier()
@@ -156,7 +160,7 @@ def main():
     t0 = time.perf_counter()
     for step in range(a.steps):
         out = run(img)
-        records.append(dp.per_image_metrics(out.depth_pred, gt, 0.001, 10.0, first_image_id=(step * world + rank) * B))
+        records.append(hip_ops.depth_metrics(out.depth_pred, gt, 0.001, 10.0, crop=box, first_image_id=(step * world + rank) * B))
     table = dp.gather_records(torch.cat(records, 0), world)      # the one collective of the job
     barrier()
     dt = time.perf_counter() - t0

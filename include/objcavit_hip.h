@@ -247,6 +247,21 @@ int ocv_conv_nhwc_split_fwd(const void* x_hi, const void* x_lo, int Cin, const v
 int ocv_upsample_concat_split_fwd(const float* x, int h, int w, int C1, const float* skip, int C2, void* out_hi,
                                   void* out_lo, int B, int H, int W, ocv_stream_t stream);
 
+/* Validation-step arithmetic in one pass (next row N2: modules/GraphBinsLM.py:154-212, metrics/MetricsPreprocess.py:14-45,
+ * metrics/AbsRel.py:44-52, SqRel.py:45-52, RMSE.py:48-55, RMSELog.py:45-52, Log10.py:52-61, AccThresh.py:59-66).
+ * pred [B,1,h,w] = model output; pred_mirror (nullable) = model output for the horizontally flipped image (NOT flipped
+ * back): with it the flip-TTA average 0.5 (clamp(pred) + clamp(flip(pred_mirror))) is evaluated, without it clamp(pred).
+ * That map is resized to the ground truth's H x W (bilinear, align_corners = True), nan -> min_depth, +-inf ->
+ * max_depth; valid pixels: min_depth < gt <= max_depth inside the crop box [crop_y0, crop_y1) x [crop_x0, crop_x1)
+ * (pass 0, H, 0, W for none).  records [B][10] per image: abs_rel, sq_rel, rmse, rmse_log, log10, delta1, delta2,
+ * delta3 (means over the image's valid pixels; the two RMSEs square-rooted), n_valid, first_image_id + b.
+ * Deterministic (fixed-order double-precision reduction); workspace from ocv_depth_metrics_workspace_bytes. */
+size_t ocv_depth_metrics_workspace_bytes(int B, int H, int W);
+int ocv_depth_metrics_fwd(const float* pred, const float* pred_mirror, int h, int w, const float* gt, int H, int W,
+                          float min_depth, float max_depth, int crop_y0, int crop_y1, int crop_x0, int crop_x1,
+                          long first_image_id, float* records, int B, void* workspace, size_t workspace_bytes,
+                          ocv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

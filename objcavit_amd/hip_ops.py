@@ -592,6 +592,33 @@ def pointwise_nhwc(x: torch.Tensor, weight, bias: Optional[torch.Tensor], act: i
     return y
 
 
+def depth_metrics(pred: torch.Tensor, gt: torch.Tensor, min_depth: float, max_depth: float,
+                  crop: Optional[Tuple[int, int, int, int]] = None, pred_mirror: Optional[torch.Tensor] = None,
+                  first_image_id: int = 0) -> torch.Tensor:
+    """Per-image metric records [B, 10] (dp.RECORD_FIELDS) of a prediction [B,1,h,w] against ground truth [B,1,H,W]:
+    clamp (+ flip-TTA average with ``pred_mirror``, the un-flipped output for the mirrored image), bilinear
+    align_corners resize, nan/inf fix, validity mask and crop box (y0, y1, x0, x1), eight metrics -- one pass."""
+    lib = _lib.load()
+    _req(pred, "pred"); _req(gt, "gt")
+    if pred.dim() != 4 or gt.dim() != 4 or pred.shape[1] != 1 or gt.shape[1] != 1 or pred.shape[0] != gt.shape[0]:
+        raise ValueError("depth_metrics: expected pred [B,1,h,w] and gt [B,1,H,W]")
+    if pred_mirror is not None:
+        _req(pred_mirror, "pred_mirror")
+        if pred_mirror.shape != pred.shape:
+            raise ValueError("depth_metrics: pred_mirror must have pred's shape")
+    B, _, h, w = pred.shape
+    H, W = gt.shape[2:]
+    y0, y1, x0, x1 = crop if crop is not None else (0, H, 0, W)
+    nb = lib.ocv_depth_metrics_workspace_bytes(B, H, W)
+    ws = workspace(nb, pred.device, "metrics")
+    rec = torch.empty(B, 10, dtype=torch.float32, device=pred.device)
+    with timed("depth_metrics"):
+        check(lib.ocv_depth_metrics_fwd(pred.data_ptr(), _ptr(pred_mirror), h, w, gt.data_ptr(), H, W, float(min_depth),
+                                        float(max_depth), int(y0), int(y1), int(x0), int(x1), int(first_image_id),
+                                        rec.data_ptr(), B, ws.data_ptr(), ws.numel(), _stream()), "ocv_depth_metrics_fwd")
+    return rec
+
+
 def stem_conv_same(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int,
                    act: int = ACT_NONE) -> torch.Tensor:
     """Dense 3x3 convolution with TF 'SAME' padding of an NCHW image, + bias + act; returns a channels_last tensor.

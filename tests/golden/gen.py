@@ -84,3 +84,25 @@ def sample_pixels(n_pix: int, count: int, seed: int) -> np.ndarray:
 # Weight gains that make attention and the 256-way bin softmax non-trivial
 # (default init gives an almost constant depth map: SURVEY Q12).
 PEAKY = (("in_proj_weight", 2.0), ("conv_out", 6.0), ("conv3x3", 1.5), ("regressor.4", 3.0))
+
+
+VALIDATION_CASES = {
+    # tag: (dataset, garg_crop, eigen_crop, (H, W), (h, w), min_depth, max_depth, B, seed)
+    "nyu_eigen": ("nyu", False, True, (480, 640), (240, 320), 0.001, 10.0, 3, 61),
+    "nyu_nocrop": ("nyu", False, False, (96, 130), (48, 65), 0.001, 10.0, 2, 62),
+    "kitti_garg": ("kitti", True, False, (352, 1216), (176, 608), 0.001, 80.0, 2, 63),
+    "kitti_eigen": ("kitti", False, True, (352, 1216), (176, 608), 0.001, 80.0, 2, 64),
+}
+
+
+def validation_inputs(tag):
+    """(gt [B,1,H,W], pred [B,1,h,w], pred_mirror [B,1,h,w]) of a G6 case: ground truth with invalid pixels on both sides
+    of the range, predictions partly outside it, and a NaN, a +inf and a -inf planted in the first prediction."""
+    import torch
+    dataset, garg, eigen, (H, W), (h, w), dmin, dmax, B, seed = VALIDATION_CASES[tag]
+    rs = np.random.RandomState(seed)
+    gt = torch.from_numpy(rs.uniform(-0.2 * dmax, 1.1 * dmax, (B, 1, H, W)).astype(np.float32))
+    pa = torch.from_numpy(rs.uniform(0.2, 1.2 * dmax, (B, 1, h, w)).astype(np.float32))
+    pb = torch.from_numpy(rs.uniform(0.2, 1.2 * dmax, (B, 1, h, w)).astype(np.float32))
+    pa[0, 0, 3, 5], pa[0, 0, 7, 1], pa[0, 0, 9, 9] = float("nan"), float("inf"), float("-inf")
+    return gt, pa, pb

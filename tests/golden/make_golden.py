@@ -189,7 +189,69 @@ def g5_adabins():
               depth_stats=np.array([float(depth.min()), float(depth.max()), float(depth.mean())], dtype=np.float32))
 
 
+# ------------------------------------------------------------------ G6 validation-step arithmetic (row N2)
+def _reference_metrics():
+    """The reference's metrics/*.py classes.  They derive from torchmetrics.Metric, which is absent here; the only
+    base-class feature they use is add_state (metrics/AbsRel.py:16-17,43-44), so a stand-in base with that method is
+    placed in sys.modules before the import.  update() / compute() are the reference's own code."""
+    import importlib
+    import types
+    import torch.nn as nn
+    if "torchmetrics" not in sys.modules:
+        tm = types.ModuleType("torchmetrics")
+
+        class Metric(nn.Module):
+            def add_state(self, name, default, dist_reduce_fx=None):
+                setattr(self, name, default.clone() if isinstance(default, torch.Tensor) else default)
+
+        tm.Metric = Metric
+        sys.modules["torchmetrics"] = tm
+    if ref_import.REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, ref_import.REFERENCE_ROOT)
+    mods = {n: importlib.import_module(f"metrics.{n}") for n in ("AbsRel", "SqRel", "RMSE", "RMSELog", "Log10", "AccThresh",
+                                                                 "MetricsPreprocess")}
+    return mods
+
+
+def g6_validation():
+    from oracle import validation_ref as vr
+    mods = _reference_metrics()
+    for tag, (dataset, garg, eigen, (H, W), (h, w), dmin, dmax, B, seed) in gen.VALIDATION_CASES.items():
+        args = make_args(dataset=dataset)
+        args[dataset].min_depth, args[dataset].max_depth = dmin, dmax
+        args[dataset].garg_crop, args[dataset].eigen_crop = garg, eigen
+        gt, pa, pb = gen.validation_inputs(tag)
+        # the reference's arithmetic, GraphBinsLM.py:159-181,200-212, with its own classes
+        a = torch.clamp(pa, min=dmin, max=dmax)
+        b = torch.clamp(pb.flip(dims=[3]), min=dmin, max=dmax)
+        final = 0.5 * (a + b)
+        pre = mods["MetricsPreprocess"].MetricsPreprocess(args)
+        pm, mask = pre(depth_pred=final.clone(), depth_gt=gt.clone())
+        pv, gv = pm[mask], gt[mask]
+        ref = {}
+        for key, cls in (("abs_rel", mods["AbsRel"].AbsRel(args)), ("sq_rel", mods["SqRel"].SqRel(args)),
+                         ("rmse", mods["RMSE"].RMSE(args)), ("rmse_log", mods["RMSELog"].RMSELog(args)),
+                         ("log10", mods["Log10"].Log10(args)), ("delta1", mods["AccThresh"].AccThresh(args, 1.25)),
+                         ("delta2", mods["AccThresh"].AccThresh(args, 1.25 ** 2)),
+                         ("delta3", mods["AccThresh"].AccThresh(args, 1.25 ** 3))):
+            cls.update(depth_pred=pv.clone(), depth_gt=gv.clone())
+            ref[key] = float(cls.compute())
+        # restatement
+        po, mo = vr.metrics_preprocess(vr.tta_average(pa, pb, dmin, dmax), gt, dmin, dmax, dataset, garg, eigen)
+        assert torch.equal(mo, mask) and torch.equal(po.isnan(), pm.isnan()) and _dev(po, pm) < 1e-7
+        rec = vr.per_image_records(pa, gt, dmin, dmax, dataset, garg, eigen, depth_pred_mirror=pb)
+        tot = vr.batch_totals(rec)
+        d = max(abs(tot[k] - ref[k]) / (abs(ref[k]) + 1e-12) for k in vr.METRICS)
+        print(f"G6 validation[{tag}] valid px {int(mask.sum())}; restatement vs reference metric classes rel dev {d:.2e}; abs_rel {ref['abs_rel']:.4f}")
+        assert d < 2e-6
+        _save(f"g6_validation_{tag}", dict(seed=seed, dataset=dataset, garg=garg, eigen=eigen, H=H, W=W, h=h, w=w, B=B,
+                                           min_depth=dmin, max_depth=dmax, dev=d),
+              metrics=np.array([ref[k] for k in vr.METRICS], dtype=np.float64), n_valid=np.array(int(mask.sum())),
+              records=_np(rec), mask_rows=_np(mask.sum((1, 3)).to(torch.int32)),
+              pred_px=_np(pm.flatten()[gen.sample_pixels(pm.numel(), 256, seed)]))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
     for w in which:
-        {"g1": g1_mvit, "g2": g2_saca, "g3": g3_objcavit, "g4": g4_decoder, "g5": g5_adabins}[w]()
+        {"g1": g1_mvit, "g2": g2_saca, "g3": g3_objcavit, "g4": g4_decoder, "g5": g5_adabins, "g6": g6_validation}[w]()

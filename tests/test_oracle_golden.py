@@ -115,3 +115,24 @@ def test_grid_sample_restatement_matches_torch():
     grid = torch.from_numpy(rs.uniform(-1.3, 1.3, (2, 3, 11, 2)).astype(np.float32))
     ref = torch.nn.functional.grid_sample(inp, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
     assert rel_dev(restate.grid_sample_bilinear_zeros(inp, grid), ref) < 1e-6
+
+
+# ------------------------------------------------------------------ row N2: validation-step arithmetic
+@pytest.mark.parametrize("tag", list(gen.VALIDATION_CASES))
+def test_g6_validation_metrics(tag):
+    """oracle/validation_ref.py against the numbers the reference's own MetricsPreprocess + metric classes produced."""
+    from oracle import validation_ref as vr
+    meta, z = load_golden(f"g6_validation_{tag}")
+    gt, pa, pb = gen.validation_inputs(tag)
+    rec = vr.per_image_records(pa, gt, meta["min_depth"], meta["max_depth"], meta["dataset"], meta["garg"], meta["eigen"],
+                               depth_pred_mirror=pb)
+    assert int(rec[:, 8].sum()) == int(z["n_valid"])
+    tot = vr.batch_totals(rec)
+    for i, k in enumerate(vr.METRICS):
+        assert abs(tot[k] - float(z["metrics"][i])) <= 2e-6 * abs(float(z["metrics"][i])) + 1e-9, k
+    assert rel_dev(rec, z["records"]) < 1e-6
+    p, mask = vr.metrics_preprocess(vr.tta_average(pa, pb, meta["min_depth"], meta["max_depth"]), gt, meta["min_depth"],
+                                    meta["max_depth"], meta["dataset"], meta["garg"], meta["eigen"])
+    assert torch.equal(mask.sum((1, 3)).to(torch.int32), torch.from_numpy(z["mask_rows"]))
+    assert rel_dev(p.flatten()[gen.sample_pixels(p.numel(), 256, meta["seed"])], z["pred_px"]) < 1e-6
+    assert not bool(p.isnan().any()) and not bool(p.isinf().any())
