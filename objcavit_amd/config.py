@@ -60,6 +60,24 @@ _DATASETS = {
 }
 
 
+def load_reference_config(path: str, basic_params: str = None) -> AttrDict:
+    """A run's ``params/*.yaml`` as the reference sees it in validate / inference mode (main.py:161-179 ->
+    misc_utils.check_and_validate_args, misc_utils.py:40-48): the file itself, with its ``nyu`` and ``kitti`` blocks
+    REPLACED by those of ``params/basicParams.yaml`` ("those params never change").  ``basic_params`` is that file's
+    path; without it the same constants come from this module's table (basicParams.yaml:109-160, the keys the hot
+    path reads)."""
+    args = load_yaml(path)
+    if basic_params is not None:
+        base = load_yaml(basic_params)
+        args["nyu"], args["kitti"] = base["nyu"], base["kitti"]
+    else:
+        for name, consts in _DATASETS.items():
+            blk = AttrDict(args.get(name) or {})
+            blk.update(consts)
+            args[name] = blk
+    return args
+
+
 def make_args(model: str = "graphbins", dataset: str = "nyu", *, strategy: str = "learned",
               embedding_dim: int = 128, language: str = "control_obj_zeros_512", no_obj_sa: bool = False,
               use_2_saca: bool = False, n_bins: int = 256, encoder_name: str = "efficientnet-b5",

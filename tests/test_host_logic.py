@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from objcavit_amd import _lib
-from objcavit_amd.config import AttrDict, load_yaml, make_args
+from objcavit_amd.config import AttrDict, load_reference_config, load_yaml, make_args
 from util import load_golden
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -94,3 +94,71 @@ def test_full_model_state_dict_keys_match_reference():
         a = make_args(dimensions_train=[352, 384], dimensions_test=[352, 384], **kw)
         sd = ObjCAViT(a, embedding_dim=128, max_seq_len=500).state_dict()
         assert {k: list(v.shape) for k, v in sd.items()} == meta["shapes"], tag
+
+
+# ------------------------------------------------------------------ row N3: checkpoint / config ingestion
+def test_lightning_checkpoint_ingestion(tmp_path):
+    """A checkpoint laid out like the reference's Lightning .ckpt (model.* keys + metric / loss states) loads into the
+    drop-in by key; a wrong shape or a missing key is reported, not swallowed."""
+    import torch
+    from objcavit_amd.checkpoint import extract_model_state, load_reference_checkpoint
+    from objcavit_amd.modules.miniViT import mViT
+    src, dst = mViT(128), mViT(128)
+    with torch.no_grad():
+        for i, p in enumerate(src.parameters()):
+            p.copy_(torch.full_like(p, 0.01 * (i + 1)))
+    lightning_sd = {"model." + k: v.clone() for k, v in src.state_dict().items()}
+    lightning_sd.update({"abs_rel.normed_abs_diff_total": torch.zeros(1), "abs_rel_ra.batch_count": torch.tensor(0),
+                         "loss.some_buffer": torch.ones(2)})
+    ckpt = {"state_dict": lightning_sd, "epoch": 3, "global_step": 100, "pytorch-lightning_version": "1.7.0"}
+    path = tmp_path / "last.ckpt"
+    torch.save(ckpt, path)
+    missing, unexpected = load_reference_checkpoint(dst, str(path))
+    assert not missing and not unexpected
+    for (k, a), (_, b) in zip(src.state_dict().items(), dst.state_dict().items()):
+        assert torch.equal(a, b), k
+    # bare state dicts pass through; prototype-layer keys survive the prefix strip
+    bare = extract_model_state(src.state_dict())
+    assert set(bare) == set(src.state_dict())
+    # damage is reported
+    bad = dict(lightning_sd)
+    bad.pop("model." + next(iter(src.state_dict())))
+    with pytest.raises(RuntimeError, match="missing"):
+        load_reference_checkpoint(mViT(128), {"state_dict": bad})
+    k0 = "model." + next(iter(src.state_dict()))
+    bad = dict(lightning_sd)
+    bad[k0] = torch.zeros(3)
+    with pytest.raises(RuntimeError, match="shapes"):
+        load_reference_checkpoint(mViT(128), {"state_dict": bad})
+
+
+def test_every_reference_params_file_builds_args():
+    """All of the reference's params/*.yaml parse without OmegaConf and carry the knobs the hot path reads."""
+    import glob
+    files = sorted(glob.glob("/root/reference/params/*graphbins*.yaml") + glob.glob("/root/reference/params/*adabins*.yaml"))
+    if not files:
+        pytest.skip("reference tree not present")
+    import yaml
+    malformed = []
+    for f in files:
+        try:
+            a = load_reference_config(f) if len(malformed) % 2 == 0 else load_reference_config(f, "/root/reference/params/basicParams.yaml")
+        except yaml.YAMLError:                # a stray "." line in one of the reference's files: not valid YAML for anyone
+            malformed.append(os.path.basename(f))
+            continue
+        blk = a[a.model.name]
+        assert a.model.name in ("graphbins", "adabins") and a.basic.dataset in ("nyu", "kitti"), f
+        assert blk.n_bins == 256 and "efficientnet" in blk.encoder_name, f
+        ds = a[a.basic.dataset]
+        assert ds.min_depth > 0 and ds.max_depth in (10, 80) and len(ds.dimensions_test) == 2, f
+        if a.model.name == "graphbins":
+            oc = blk.objcavit
+            assert oc.positional_embedding_strategy in ("learned", "learned_bbox_wh", "grid_random", "grid_random_roi_align"), f
+            assert oc.embedding_dim == 128, f
+    assert len(malformed) <= 2 and len(files) - len(malformed) >= 10, malformed
+    # the built-in dataset constants are basicParams.yaml's
+    f = files[0] if os.path.basename(files[0]) not in malformed else files[-1]
+    a, b = load_reference_config(f), load_reference_config(f, "/root/reference/params/basicParams.yaml")
+    for ds in ("nyu", "kitti"):
+        for k in ("min_depth", "max_depth", "dimensions_test", "eigen_crop", "garg_crop", "do_kb_crop"):
+            assert a[ds][k] == b[ds][k], (ds, k)
