@@ -140,8 +140,9 @@ int ocv_pixel_dot_fwd(const float* feat, int channels_last, const float* queries
 size_t ocv_bin_head_workspace_bytes(int B, int n_bins, int C);
 /* The two stages of ocv_bin_head_fwd as separate calls (same arithmetic, lets a caller time the main kernel):
  *   ocv_bin_head_fold_fwd   Wf[b] = Wout (n_bins x Q) . queries[b] (Q x C)            -> Wf [B, n_bins, C]
- *   ocv_bin_head_folded_fwd depth[b][p] = sum_k softmax_k(bout + Wf[b] . feat[b][:, p]) * centers[b][k]  * channels_last: 0 = feat is NCHW (exact fp32 MFMA); 1 = NHWC, logits on the bf16 matrix cores in split form (hi*hi +
- * hi*lo + lo*hi, fp32 accumulate: product error <= 2^-17, twice as fast); 2 = NHWC, exact fp32 MFMA. */
+ *   ocv_bin_head_folded_fwd depth[b][p] = sum_k softmax_k(bout + Wf[b] . feat[b][:, p]) * centers[b][k]  * channels_last: 0 = feat is NCHW, 1 = NHWC (both exact fp32 MFMA); 2 = NHWC with the logits on the bf16 matrix cores
+ * in split form (hi*hi + hi*lo + lo*hi, fp32 accumulate: product error <= 2^-17; twice as fast, opt-in because a
+ * near-one-hot softmax passes logit errors straight into depth). */
 int ocv_bin_head_fold_fwd(const float* queries, long q_bs, int q_ld, const float* Wout, float* Wf, int B, int C, int Q,
                           int n_bins, ocv_stream_t stream);
 int ocv_bin_head_folded_fwd(const float* feat, int channels_last, const float* Wf, const float* bout,

@@ -394,10 +394,10 @@ def pixel_dot(feat: torch.Tensor, queries: torch.Tensor) -> torch.Tensor:
 
 
 def bin_head(feat: torch.Tensor, queries: torch.Tensor, w_out: torch.Tensor, b_out: torch.Tensor,
-             centers: torch.Tensor, exact: bool = False) -> torch.Tensor:
+             centers: torch.Tensor, split: bool = False) -> torch.Tensor:
     """depth [B,1,h,w] = sum_k softmax_k(conv1x1(pixel_dot(feat, queries)))_k * centers_k, fused.
-    feat may be NCHW-contiguous (exact fp32 MFMA) or channels_last (split-bf16 logits; ``exact=True`` selects the
-    fp32-MFMA kernel there too)."""
+    feat may be NCHW-contiguous or channels_last (exact fp32 MFMA either way); ``split=True`` (channels_last only)
+    computes the logits in split bf16 -- 2x faster, ~3x the depth error under near-one-hot softmaxes."""
     lib = _lib.load()
     feat, cl = _map4(feat, "feat")
     _req(b_out, "b_out"); _req(centers, "centers")
@@ -417,7 +417,7 @@ def bin_head(feat: torch.Tensor, queries: torch.Tensor, w_out: torch.Tensor, b_o
     check(lib.ocv_bin_head_fold_fwd(queries.data_ptr(), queries.stride(0), queries.stride(1), w2.data_ptr(), wf.data_ptr(), B,
                                     Cc, Q, nbins, _stream()), "ocv_bin_head_fold_fwd")
     with timed("bin_head"):          # brackets exactly one launch of bin_head_kernel
-        check(lib.ocv_bin_head_folded_fwd(feat.data_ptr(), 2 if (cl and exact) else cl, wf.data_ptr(), b_out.data_ptr(), centers.data_ptr(),
+        check(lib.ocv_bin_head_folded_fwd(feat.data_ptr(), 2 if (cl and split) else cl, wf.data_ptr(), b_out.data_ptr(), centers.data_ptr(),
                                           depth.data_ptr(), B, Cc, nbins, h * w, _stream()), "ocv_bin_head_folded_fwd")
     return depth
 

@@ -269,17 +269,17 @@ def test_pixel_dot_and_bin_head_channels_last(ops, B, h, w):
     assert got_ram.is_contiguous() and rel_dev(got_ram, ram) < TOL
     ref_depth, _ = restate.bin_head(widths, ram, wout, bout, 0.001, 10.0)
     _, centers = bin_edges_and_centers(dev(widths), 0.001, 10.0)
-    got = ops.bin_head(fg, qg, dev(wout), dev(bout), centers, exact=True)
+    got = ops.bin_head(fg, qg, dev(wout), dev(bout), centers)
     assert float(((got.cpu() - ref_depth).abs() / ref_depth).max()) < 1e-4
     # NCHW and NHWC paths agree to rounding
     got_nchw = ops.bin_head(dev(feat), qg, dev(wout), dev(bout), centers)
     assert float(((got - got_nchw).abs() / got_nchw).max()) < 1e-4      # different K order inside the MFMA chains
-    # default NHWC path: logits in split bf16 (product error 2^-17).  This input is a stress case -- logit gain 6, a
-    # near one-hot softmax over 256 bins, so logit errors pass straight into depth -- and is held to the north-star bar
-    got_split = ops.bin_head(fg, qg, dev(wout), dev(bout), centers)
+    # opt-in path: logits in split bf16 (product error 2^-17).  This input is a stress case -- logit gain 6, a near
+    # one-hot softmax over 256 bins, so logit errors pass straight into depth -- and is held to the north-star bar
+    got_split = ops.bin_head(fg, qg, dev(wout), dev(bout), centers, split=True)
     assert float(((got_split.cpu() - ref_depth).abs() / ref_depth).max()) < 1e-3
     assert float(((got_split.cpu() - ref_depth).abs() / ref_depth).mean()) < 2e-5
-    assert torch.equal(got_split, ops.bin_head(fg, qg, dev(wout), dev(bout), centers))
+    assert torch.equal(got_split, ops.bin_head(fg, qg, dev(wout), dev(bout), centers, split=True))
 
 
 # ------------------------------------------------------------------ depthwise convolution

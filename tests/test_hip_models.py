@@ -122,6 +122,25 @@ def test_graphbins_end_to_end_vs_oracle(kw, n_obj):
     assert float(ref_depth.max() - ref_depth.min()) > 0.1
 
 
+def test_graphbins_with_table_object_provider():
+    """Row N4: ragged detections (incl. an image without any) served from a class table, end to end vs the oracle."""
+    from objcavit_amd.modules.GraphBins import GraphBins
+    from objcavit_amd.objects import TableObjectProvider
+    H, W, seed = 352, 384, 91
+    args = make_args(dimensions_train=[H, W], dimensions_test=[H, W], language="clip")
+    table = gen.randn("table", (40, 512), seed, 10.0 / np.sqrt(512))
+    cls = [torch.tensor([3, 17, 17, 39, 0]), None, torch.tensor([8])]
+    xywh = [gen.boxes("b0", 5, seed, H, W), None, gen.boxes("b2", 1, seed, H, W)]
+    prov = TableObjectProvider(lambda image: ([None if b is None else b.to(image.device) for b in xywh], cls), class_table=table.cuda())
+    m = GraphBins(args, object_provider=prov).eval()
+    sd = gen.load_into(m, seed, gen.PEAKY)
+    img = gen.randn("img", (3, 3, H, W), seed)
+    out = m.cuda()(img.cuda())
+    feats = [table[c] if c is not None else torch.zeros(1, 512) for c in cls]
+    ref_depth, ref_edges = restate.graphbins_forward(img, feats, xywh, sd, 0.001, 10, strategy="learned")
+    assert rel_dev(out.bin_edges, ref_edges) < 1e-4 and max_rel(out.depth_pred, ref_depth) < 1e-3
+
+
 def test_config2_full_size_properties():
     """BASELINE configs[1] shape (NYU 480x640, 16 zero-feature objects, bs=8): runs, is finite, bin edges are
     monotone from min_depth to max_depth, depth lies inside the bin range, and an image's result does not depend

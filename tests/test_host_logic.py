@@ -162,3 +162,51 @@ def test_every_reference_params_file_builds_args():
     for ds in ("nyu", "kitti"):
         for k in ("min_depth", "max_depth", "dimensions_test", "eigen_crop", "garg_crop", "do_kb_crop"):
             assert a[ds][k] == b[ds][k], (ds, k)
+
+
+# ------------------------------------------------------------------ row N4: object front-end formats
+def test_relative_size_index_matches_hand_computed_cases():
+    import torch
+    from objcavit_amd.objects import REL_SIZE_SCALE, relative_size_index
+    assert len(REL_SIZE_SCALE) == 7
+    assert relative_size_index(None) == [] and relative_size_index(torch.tensor([[1., 1., 5., 5.]])) == []
+    # areas 100, 100, 1, 10000: equal -> log 0 -> (0+1)/2*4 = 2 -> index 3 ("about the same size as")
+    boxes = torch.tensor([[0., 0., 10., 10.], [0., 0., 20., 5.], [0., 0., 1., 1.], [0., 0., 100., 100.]])
+    idx = relative_size_index(boxes)
+    assert idx[0] == 3
+    # 100 vs 1: log(100) = 4.6 -> (5.6/2)*4 = 11.2 -> 12 -> clipped to 6 ("much bigger than")
+    assert idx[1] == 6
+    # 1 vs 10000: log = -9.2 -> negative -> clipped to 0 ("much smaller than"); 10000 vs 100 (cyclic) -> 6
+    assert idx[2] == 0 and idx[3] == 6
+    # just inside the scale: ratio e -> (1+1)/2*4 = 4 -> 5 ("bigger than"); ratio 1/e -> 0 -> 1 ("smaller than")
+    import math
+    b = torch.tensor([[0., 0., math.e, 1.], [0., 0., 1., 1.]], dtype=torch.float64)
+    assert relative_size_index(b) == [5, 1]
+
+
+def test_table_object_provider_formats():
+    import torch
+    from objcavit_amd.objects import TableObjectProvider
+    table = torch.arange(6 * 512, dtype=torch.float32).reshape(6, 512)
+    dets = ([torch.tensor([[10., 20., 30., 40.], [50., 60., 8., 8.]]), None, torch.tensor([[1., 2., 3., 4.]])],
+            [torch.tensor([5, 2]), None, [0]])
+    prov = TableObjectProvider(lambda img: dets, class_table=table)
+    feats, boxes, ann = prov(torch.zeros(3, 3, 8, 8))
+    assert ann is None and [f.shape for f in feats] == [(2, 512), (1, 512), (1, 512)]
+    assert torch.equal(feats[0], table[[5, 2]]) and float(feats[1].abs().sum()) == 0.0 and boxes[1] is None
+    assert torch.equal(boxes[0], dets[0][0]) and feats[2].dtype == torch.float32
+    # relative-size strategy: the cache is asked for (class, next class, relation)
+    asked = []
+
+    def phrase(c, cn, rel):
+        asked.append((c, cn, rel))
+        return torch.full((512,), float(c * 100 + cn * 10 + rel))
+
+    prov = TableObjectProvider(lambda img: dets, phrase_features=phrase)
+    feats, boxes, _ = prov(torch.zeros(3, 3, 8, 8))
+    assert asked == [(5, 2, 6), (2, 5, 0), (0, 0, -1)]          # areas 1200 vs 64; a lone object has no relation
+    assert float(feats[0][0, 0]) == 526.0 and float(feats[0][1, 0]) == 250.0
+    with pytest.raises(ValueError):
+        TableObjectProvider(lambda img: dets)
+    with pytest.raises(ValueError):
+        TableObjectProvider(lambda img: ([torch.zeros(1, 4)], [torch.tensor([9])]), class_table=table)(torch.zeros(1, 3, 8, 8))
