@@ -7,7 +7,7 @@ kt/        : rocprofv3 --kernel-trace --stats --output-format csv -- python3 ben
 pmc_fetch/ : rocprofv3 --kernel-trace --pmc FETCH_SIZE ...      (separate pass, no other trace domains)
 pmc_write/ : rocprofv3 --kernel-trace --pmc WRITE_SIZE ...
 Writes <tag>_kernel_stats.csv (rocprof's own per-kernel stats for the whole process, MIOpen's first-call
-solver search included), <tag>_step_breakdown.txt (the LAST bench step only, from the kernel trace) and
+solver search included), <tag>_step_breakdown.txt (the fastest bench step, from the kernel trace) and
 <tag>_pmc.json (+ roofline_traffic.json, which bench.py reads for roofline.traffic).
 """
 import collections
@@ -40,7 +40,10 @@ def main(src, tag):
         rows = list(csv.DictReader(open(kt[0])))
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))
         idx = [i for i, r in enumerate(rows) if "bin_head_kernel" in r["Kernel_Name"] or "bin_head_split_kernel" in r["Kernel_Name"]]
-        step = rows[idx[-2] + 1: idx[-1] + 1]
+        # a bench step = the launches between two bin-head launches; take the step with the shortest wall time (the
+        # first steps still load code objects lazily and the last one is disturbed by the profiler's buffer flush)
+        steps = [rows[a + 1: b + 1] for a, b in zip(idx[:-1], idx[1:])]
+        step = min(steps, key=lambda st: int(st[-1]["End_Timestamp"]) - int(st[0]["Start_Timestamp"]))
         t0, t1 = int(step[0]["Start_Timestamp"]), int(step[-1]["End_Timestamp"])
         agg = collections.defaultdict(lambda: [0, 0])
         for r in step:
@@ -50,7 +53,7 @@ def main(src, tag):
         tot = sum(v[1] for v in agg.values())
         ours = sum(v[1] for k, v in agg.items() if any(o in k for o in OURS))
         with open(os.path.join(out, f"{tag}_step_breakdown.txt"), "w") as f:
-            f.write(f"# last bench step from {os.path.basename(kt[0])}: wall {(t1 - t0) / 1e6:.3f} ms, {len(step)} kernels, "
+            f.write(f"# fastest bench step of {len(steps)} in {os.path.basename(kt[0])}: wall {(t1 - t0) / 1e6:.3f} ms, {len(step)} kernels, "
                     f"sum of kernel time {tot / 1e6:.3f} ms, hand-written kernels {ours / 1e6:.3f} ms\n")
             f.write(f"{'kernel':110s} {'n':>5s} {'total_ms':>9s} {'avg_us':>9s} {'pct':>6s}\n")
             for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
