@@ -319,22 +319,8 @@ __global__ __launch_bounds__(64 * WN * WK) void pw_tile_kernel(PSArgs p) {
   constexpr bool RES_EARLY = WK == 1;
   const int ntile0 = by * (32 * WN) + wn * 32;              // first column of this wavefront's tile
   float4 resq[RES_EARLY ? RT : 1][4];
-  if (RES_EARLY) {
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) load_res(p, resq[rt], m0 + rt * 32, ntile0, lane);
-  }
 
-  load_a(0);
-  load_w(0, wh, wl);
-  store_a(0);
-  __syncthreads();
-  for (int it = 0; it < nit; ++it) {
-    const bool more = it + 1 < nit;
-    if (more) {
-      load_a(it + 1);
-      load_w(it + 1, whn, wln);
-    }
-
+  auto multiply = [&](int it) {
     const char* base = lds + (it & 1) * BUF + (g * 2) * PART + l31 * LROW + hh * 16;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -347,14 +333,28 @@ __global__ __launch_bounds__(64 * WN * WK) void pw_tile_kernel(PSArgs p) {
         }
       }
     }
-    if (more) {
-      store_a((it + 1) & 1);
+  };
+  load_a(0);
+  load_w(0, wh, wl);
+  store_a(0);
+  __syncthreads();
+  for (int it = 0; it + 1 < nit; ++it) {
+    load_a(it + 1);
+    load_w(it + 1, whn, wln);
+    multiply(it);
+    store_a((it + 1) & 1);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) { wh[s] = whn[s]; wl[s] = wln[s]; }
-    }
+    for (int s = 0; s < 4; ++s) { wh[s] = whn[s]; wl[s] = wln[s]; }
     __syncthreads();
   }
-
+  // last slab, peeled: no prefetch registers are live any more, so the residual (see load_res) is fetched here, in
+  // front of the last MFMAs, without raising the register count of the loop (it cost one wavefront per SIMD there)
+  if (RES_EARLY) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) load_res(p, resq[rt], m0 + rt * 32, ntile0, lane);
+  }
+  multiply(nit - 1);
+  __syncthreads();
   // K groups 1.. hand their partial tiles to group 0 through LDS ([group - 1][wn][rt][reg][lane], fixed order)
   if (WK > 1) {
     float* red = reinterpret_cast<float*>(lds);
