@@ -1,38 +1,76 @@
 """hipGraph replay of the forward (BASELINE config 5 asks for a "hipGraph-captured forward").
 
 Every C-ABI entry point only enqueues on the caller's stream (no allocation, no sync), so the whole forward
-(~740 launches at bs = 16) is capturable with ``torch.cuda.CUDAGraph`` (= hipGraph on ROCm): one replay per step.
-Measured on MI355X / ROCm 7.2 (bench.py --graph): replay 77 ms per step against 51 ms for eager dispatch, whose
-launches the GPU already executes back to back (profiles/r01b) -- graph replay pays a per-node cost here, so it is
-kept as an option for launch-bound small batches, not as the default.
+(~280 launches at bs = 16, all of them our own kernels plus a handful of element-wise glue ops) is capturable with
+``torch.cuda.CUDAGraph`` (= hipGraph on ROCm).  Measured on MI355X / ROCm 7.2 (bench.py): replay 24.2 ms per step
+against 25.9 ms for eager dispatch -- the ~1 ms the GPU idles between dependent launches of the eager stream.  (While
+the decoder still ran on MIOpen / ATen kernels replay was SLOWER than eager, 77 vs 51 ms; that went away with them.)
 
 ``GraphedGraphBins`` captures ``GraphBins.forward_until_head`` (shapes fixed by the example image; object boxes /
 features come from the model's provider and are baked in as static device tensors) and runs the fused bin-head
-kernel eagerly after each replay, so that kernel can still be bracketed by HIP events.
+kernel eagerly after each replay.  Launches named in ``eager_ops`` (timing names of hip_ops, e.g.
+``"conv3x3|16,240,320,280,128"``) are kept out of the graph as EAGER ISLANDS: capture ends in front of them and a new
+graph segment starts behind them, so a step is  segment, island, segment, ..., head  -- that is how bench.py times
+its roofline kernel live with HIP events inside the timed region (events recorded inside a captured graph cannot be
+read back on ROCm 7.2).
 """
 from __future__ import annotations
 
+from typing import Callable, List, Sequence, Tuple, Union
+
 import torch
+
+from . import hip_ops
 
 
 class GraphedGraphBins:
-    def __init__(self, model, example_image: torch.Tensor, warmup: int = 2):
+    def __init__(self, model, example_image: torch.Tensor, warmup: int = 2, eager_ops: Sequence[str] = ()):
         if example_image.device.type != "cuda":
             raise RuntimeError("graph capture needs a GPU tensor")
         self.model = model
         self.static_image = example_image.clone()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad():
+        self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream), torch.no_grad():
             for _ in range(warmup):                      # sizes every workspace / weight cache before capture
-                out = model(self.static_image)
-        torch.cuda.current_stream().wait_stream(side)
+                model(self.static_image)
+        torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
-            parts = model.forward_until_head(self.static_image)
+
+        self.segments: List[Union[torch.cuda.CUDAGraph, Tuple[str, Callable]]] = []
+        pool = torch.cuda.graph_pool_handle()
+        state = {"g": None}
+
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            g.capture_begin(pool=pool)
+            state["g"] = g
+
+        def end():
+            state["g"].capture_end()
+            self.segments.append(state["g"])
+            state["g"] = None
+
+        def on_break(name, call):
+            end()
+            with hip_ops.timed(name):
+                call()                                   # the capture run executes the island once, eagerly
+            self.segments.append((name, call))
+            begin()
+
+        hip_ops._Islands.names, hip_ops._Islands.on_break = tuple(eager_ops), on_break
+        try:
+            with torch.cuda.stream(self.stream), torch.no_grad():
+                begin()
+                parts = model.forward_until_head(self.static_image)
+                end()
+        finally:
+            hip_ops._Islands.names, hip_ops._Islands.on_break = (), None
+        torch.cuda.current_stream().wait_stream(self.stream)
+        torch.cuda.synchronize()
         self.feat, self.queries, self.centers, self.bin_edges, self.detections = parts
         self.ReturnType = model.ReturnType
+        self.islands = [s[0] for s in self.segments if isinstance(s, tuple)]
 
     @torch.no_grad()
     def __call__(self, image: torch.Tensor):
@@ -40,6 +78,11 @@ class GraphedGraphBins:
             raise ValueError(f"captured for {tuple(self.static_image.shape)}, got {tuple(image.shape)}")
         if image.data_ptr() != self.static_image.data_ptr():
             self.static_image.copy_(image)
-        self.graph.replay()
+        for seg in self.segments:
+            if isinstance(seg, tuple):
+                with hip_ops.timed(seg[0]):
+                    seg[1]()
+            else:
+                seg.replay()
         depth = self.model.head(self.feat, self.queries, self.centers)
         return self.ReturnType(depth_pred=depth, bin_edges=self.bin_edges, detections=self.detections)

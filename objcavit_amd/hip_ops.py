@@ -62,6 +62,24 @@ def timing_results() -> Dict[str, Tuple[int, float]]:
     return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in _Timing.events.items() if v}
 
 
+class _Islands:
+    """Set by objcavit_amd.graph while it captures: launches whose timing name is in ``names`` are kept OUT of the
+    hipGraph (capture is ended in front of them and re-opened behind them) so that they run eagerly between two
+    graph segments on every step and can be bracketed by HIP events."""
+    names: tuple = ()
+    on_break = None            # callable(name, closure) installed by the capturer
+
+
+def launch(name: str, call) -> None:
+    """Issue one C-ABI launch (``call`` enqueues it on the current stream) under the timing hook -- or hand it to the
+    graph capturer as an eager island."""
+    if _Islands.on_break is not None and name in _Islands.names:
+        _Islands.on_break(name, call)
+        return
+    with timed(name):
+        call()
+
+
 class timed:
     """Brackets a C-ABI call with a pair of events on the current stream when timing is enabled."""
 
@@ -802,10 +820,11 @@ def conv_nhwc_split(x: SplitAct, w_hi: torch.Tensor, w_lo: torch.Tensor, bias: O
     y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.hi.device, memory_format=cl) if out_fp32 else None
     yh = torch.empty(B, Cout, H, W, dtype=torch.bfloat16, device=x.hi.device, memory_format=cl) if out_split else None
     yl = torch.empty_like(yh) if out_split else None
-    with timed(f"conv{ksize}x{ksize}|{B},{H},{W},{Cin},{Cout}"):
-        check(lib.ocv_conv_nhwc_split_fwd(x.hi.data_ptr(), x.lo.data_ptr(), Cin, w_hi.data_ptr(), w_lo.data_ptr(), _ptr(bias),
-                                          None, _ptr(y), _ptr(yh), _ptr(yl), B, H, W, Cout, ksize, act, _stream()),
-              "ocv_conv_nhwc_split_fwd")
+    ptrs = (x.hi.data_ptr(), x.lo.data_ptr(), Cin, w_hi.data_ptr(), w_lo.data_ptr(), _ptr(bias), None, _ptr(y), _ptr(yh),
+            _ptr(yl), B, H, W, Cout, ksize, act)
+    keep = (x, w_hi, w_lo, bias, y, yh, yl)          # an eager island re-issues this launch on every replay
+    launch(f"conv{ksize}x{ksize}|{B},{H},{W},{Cin},{Cout}",
+           lambda: (keep, check(lib.ocv_conv_nhwc_split_fwd(*ptrs, _stream()), "ocv_conv_nhwc_split_fwd"))[1])
     if out_fp32 and out_split:
         return y, SplitAct(yh, yl)
     return y if out_fp32 else SplitAct(yh, yl)
