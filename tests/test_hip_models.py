@@ -141,6 +141,34 @@ def test_graphbins_with_table_object_provider():
     assert rel_dev(out.bin_edges, ref_edges) < 1e-4 and max_rel(out.depth_pred, ref_depth) < 1e-3
 
 
+def test_graph_replay_with_eager_island_equals_eager_dispatch():
+    """GraphedGraphBins: graph segments + an eager island + the eager head give bit-identical depth to plain dispatch,
+    for the captured image and for new contents of the static input."""
+    from objcavit_amd import hip_ops
+    from objcavit_amd.graph import GraphedGraphBins
+    from objcavit_amd.modules.GraphBins import GraphBins, SyntheticObjectProvider
+    H, W = 352, 384
+    args = make_args(dimensions_train=[H, W], dimensions_test=[H, W], language="clip")
+    m = GraphBins(args, object_provider=SyntheticObjectProvider(8, "clip", seed=3)).eval()
+    gen.load_into(m, 55, gen.PEAKY)
+    m = m.cuda()
+    img = gen.randn("img", (2, 3, H, W), 55).cuda()
+    ref = m(img).depth_pred.clone()
+    island = f"conv3x3|2,{H // 2},{W // 2},280,128"
+    g = GraphedGraphBins(m, img, eager_ops=(island,))
+    assert g.islands == [island] and len(g.segments) == 3
+    assert torch.equal(g(img).depth_pred, ref)
+    img2 = gen.randn("img2", (2, 3, H, W), 56).cuda()
+    ref2 = m(img2).depth_pred.clone()
+    hip_ops.enable_timing(True)
+    out2 = g(img2)
+    t = hip_ops.timing_results()
+    hip_ops.enable_timing(False)
+    assert torch.equal(out2.depth_pred, ref2) and not torch.equal(ref2, ref)
+    assert island in t and "bin_head" in t and t[island][0] == 1          # the island is event-timed on every replay
+    assert torch.equal(g(img).depth_pred, ref)
+
+
 def test_config2_full_size_properties():
     """BASELINE configs[1] shape (NYU 480x640, 16 zero-feature objects, bs=8): runs, is finite, bin edges are
     monotone from min_depth to max_depth, depth lies inside the bin range, and an image's result does not depend
