@@ -32,10 +32,14 @@ def short(name):
 
 def main(src, tag):
     out = os.path.dirname(os.path.abspath(__file__))
-    ks = glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv"))
+    def newest(pattern):
+        """gpurun merges every call's output into the same local directory: take the most recent run's file"""
+        return sorted(glob.glob(pattern), key=os.path.getmtime)[-1:]
+
+    ks = newest(os.path.join(src, "kt", "*", "*_kernel_stats.csv"))
     if ks:
         shutil.copy(ks[0], os.path.join(out, f"{tag}_kernel_stats.csv"))
-    kt = glob.glob(os.path.join(src, "kt", "*", "*_kernel_trace.csv"))
+    kt = newest(os.path.join(src, "kt", "*", "*_kernel_trace.csv"))
     if kt:
         rows = list(csv.DictReader(open(kt[0])))
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -60,7 +64,7 @@ def main(src, tag):
                 f.write(f"{k:110s} {v[0]:5d} {v[1] / 1e6:9.3f} {v[1] / v[0] / 1e3:9.1f} {100 * v[1] / tot:6.2f}\n")
     pmc, series = {}, {}
     for d, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-        fs = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
+        fs = newest(os.path.join(src, d, "*", "*_counter_collection.csv"))
         if not fs:
             continue
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -84,8 +88,12 @@ def main(src, tag):
                 f, w = series[names[0]]["FETCH_SIZE"], series[names[0]]["WRITE_SIZE"]
                 # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE tallies 128-B requests at 64 B -> x2; WRITE_SIZE exact.
                 # The two counters come from separate passes of the same deterministic launch sequence: pair launch i
-                # with launch i and report the launch that moves the most bytes (= the roofline kernel of bench.py).
-                traffic[key] = int(max(2 * a + b for a, b in zip(f, w)) * 1024)
+                # with launch i.  The roofline kernel of bench.py is the launch that moves the most bytes; report the
+                # MEDIAN over the launches within 5 % of that maximum (= the same shape on other steps), so one
+                # cold-cache launch does not set the number.
+                tot = sorted(2 * a + b for a, b in zip(f, w))
+                top = [t for t in tot if t >= 0.95 * tot[-1]]
+                traffic[key] = int(top[len(top) // 2] * 1024)
         json.dump(traffic, open(os.path.join(out, "roofline_traffic.json"), "w"), indent=1, sort_keys=True)
     print("wrote summaries to", out)
 
