@@ -196,6 +196,32 @@ def test_config2_full_size_properties():
     assert max_rel(d[3:4], ref) < 1e-3 and max_rel(solo, ref) < 1e-3
 
 
+@pytest.mark.parametrize("tag,kw,dataset,H,W,n_obj,B", [
+    ("configs[3] KITTI 2xSA/CA", dict(strategy="learned_bbox_wh", use_2_saca=True), "kitti", 352, 1216, 24, 2),
+    ("configs[4] NYU roi_align 64 objs", dict(strategy="grid_random_roi_align"), "nyu", 480, 640, 64, 2),
+])
+def test_baseline_configs_3_and_4_full_size_vs_oracle(tag, kw, dataset, H, W, n_obj, B):
+    """The other BASELINE configurations at their full image size (per-GPU shard of the batch): one image against the
+    CPU oracle, all of them finite / inside the bin range, bin edges monotone up to the dataset's max depth."""
+    from objcavit_amd.modules.GraphBins import GraphBins, SyntheticObjectProvider
+    args = make_args(dataset=dataset, language="clip", dimensions_train=[H, W], dimensions_test=[H, W], **kw)
+    dmax = float(args[dataset].max_depth)
+    m = GraphBins(args, object_provider=SyntheticObjectProvider(n_obj, "clip", seed=9)).eval()
+    gen.load_into(m, 31, gen.PEAKY)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.cuda()
+    img = gen.randn("img", (B, 3, H, W), 31).cuda()
+    out = m(img)
+    d, e = out.depth_pred, out.bin_edges
+    assert tuple(d.shape) == (B, 1, H // 2, W // 2) and bool(torch.isfinite(d).all())
+    assert bool((e[:, 1:] > e[:, :-1]).all()) and abs(float(e[0, -1]) - dmax) < 1e-3 * dmax
+    assert float(d.min()) >= 0.001 and float(d.max()) <= dmax
+    feats, boxes, _ = m.object_provider(img)
+    ref, ref_e = restate.graphbins_forward(img[1:2].cpu(), [feats[1].cpu()], [boxes[1].cpu()], sd, 0.001, dmax, **kw)
+    assert rel_dev(e[1:2], ref_e) < 1e-4
+    assert max_rel(d[1:2], ref) < 1e-3, tag
+
+
 def test_encoder_fast_path_vs_oracle():
     """EfficientNet-B5 encoder inference plan (folded BN, HIP depthwise kernel) vs the oracle's functional
     restatement on identical weights: every one of the five skip activations."""
