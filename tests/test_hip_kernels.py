@@ -535,3 +535,26 @@ def test_conv_nhwc_split_in_and_out(ops, B, H, W, Cin, Cout, k, act):
     # and it agrees with the fp32-input kernel to rounding
     y3 = ops.conv_nhwc(dev(x), None, hi, lo, dev(b), k, act)
     assert rel_dev(y, y3) < 1e-5
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,act", [
+    (3, 150, 154, 40, 96, 3, 2),        # 271 row tiles x 1: more tiles than CUs, ragged rows
+    (3, 150, 154, 32, 136, 3, 0),       # 542 tiles, two channel tiles (second ragged), tile count not a multiple of 8
+    (2, 240, 320, 24, 16, 3, 2),        # 600 tiles, Cout % 8 == 0 but < one tile; one K chunk only (9 steps)
+    (1, 300, 301, 8, 12, 1, 0),         # 353 tiles, 1x1 (ONE K step per tile), Cout % 8 != 0: element-wise epilogue
+])
+def test_conv_nhwc_split_many_tiles(ops, B, H, W, Cin, Cout, k, act):
+    """More output tiles than CUs (several rounds of workgroups, tile counts that are not multiples of 8 for the XCD
+    map, single-K-step tiles, ragged rows / channels) against an fp64 convolution and the fp32-input kernel."""
+    x = rnd("x", (B, Cin, H, W), 1)
+    w, b = rnd("w", (Cout, Cin, k, k), 3, 1 / math.sqrt(Cin * k * k)), rnd("b", (Cout,), 4, 0.2)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=k // 2).float()
+    ref = [ref, torch.relu(ref), F.leaky_relu(ref, 0.01), F.silu(ref)][act]
+    hi, lo = ops.prep_conv_weight(dev(w))
+    xs = ops.upsample_concat_split(dev(x), None, (H, W))
+    y, ys = ops.conv_nhwc_split(xs, hi, lo, dev(b), k, act, out_fp32=True, out_split=True)
+    assert rel_dev(y, ref) < SPLIT_TOL
+    assert rel_dev(ys.float(), y) < 1e-5
+    assert torch.equal(y, ops.conv_nhwc_split(xs, hi, lo, dev(b), k, act, out_fp32=True, out_split=False))
+    y3 = ops.conv_nhwc(dev(x), None, hi, lo, dev(b), k, act)        # fp32-input kernel
+    assert rel_dev(y, y3) < 1e-5
