@@ -16,7 +16,10 @@
  *     scratch memory is supplied by the caller (`*_workspace_bytes`);
  *   - return 0 on success, a hipError_t (> 0) if a launch failed, -1 for a
  *     rejected argument; ocv_last_error() returns the message (thread-local).
- *   - arithmetic is fp32 end to end (v_mfma_f32_32x32x2_f32 for contractions).
+ *   - results are fp32.  Contractions run on v_mfma_f32_32x32x2_f32 (exact fp32) or, where an entry point says so
+ *     (3x3 / 1x1 convolutions, the opt-in bin-head mode), in SPLIT bf16: every operand v = hi + lo with
+ *     hi = bf16(v), lo = bf16(v - hi), every product formed as hi*hi + hi*lo + lo*hi on the bf16 matrix cores with
+ *     fp32 accumulation (relative error of a product <= 2^-17).
  */
 #ifndef OBJCAVIT_HIP_H
 #define OBJCAVIT_HIP_H
