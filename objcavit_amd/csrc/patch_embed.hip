@@ -165,7 +165,7 @@ int pick_ksplit(int M, int C) {
   // enough 64-row x ksplit workgroups for ~2 per CU; ksplit is a power of two dividing the C*4 K steps
   const int mt = ocv_cdiv(M, BM), kts = C * 4;
   int ks = 1;
-  while (ks < kts && mt * ks < 512 && kts % (ks * 2) == 0) ks *= 2;
+  while (ks < kts && mt * ks < 1024 && kts % (ks * 2) == 0) ks *= 2;
   return ks;
 }
 
