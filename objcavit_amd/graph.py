@@ -43,7 +43,9 @@ class GraphedGraphBins:
 
         def begin():
             g = torch.cuda.CUDAGraph()
-            g.capture_begin(pool=pool)
+            # thread_local: calls made by OTHER threads while we capture (the RCCL watchdog of a data-parallel job
+            # polls events) must not invalidate the capture
+            g.capture_begin(pool=pool, capture_error_mode="thread_local")
             state["g"] = g
 
         def end():
