@@ -98,25 +98,29 @@ __global__ __launch_bounds__(256) void depth_metrics_partial_kernel(MetArgs p) {
   }
 }
 
-__global__ void depth_metrics_finish_kernel(const double* __restrict__ part, int tiles, float* __restrict__ rec, int B,
-                                            long first_id) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  double s[NSUM];
-  for (int i = 0; i < NSUM; ++i) s[i] = 0.0;
-  for (int t = 0; t < tiles; ++t)
-    for (int i = 0; i < NSUM; ++i) s[i] += part[((long)b * tiles + t) * NSUM + i];
-  const double n = s[8] > 0.0 ? s[8] : 1.0;
+// one workgroup per image, one wavefront per sum: lanes stride over the tiles, then a fixed xor-tree adds the 64 lanes
+__global__ __launch_bounds__(64 * NSUM) void depth_metrics_finish_kernel(const double* __restrict__ part, int tiles,
+                                                                       float* __restrict__ rec, int B, long first_id) {
+  __shared__ double tot[NSUM];
+  const int b = blockIdx.x, i = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double s = 0.0;
+  for (int t = lane; t < tiles; t += 64) s += part[((long)b * tiles + t) * NSUM + i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) tot[i] = s;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const double n = tot[8] > 0.0 ? tot[8] : 1.0;
   float* r = rec + (long)b * 10;
-  r[0] = (float)(s[0] / n);
-  r[1] = (float)(s[1] / n);
-  r[2] = (float)sqrt(s[2] / n);
-  r[3] = (float)sqrt(s[3] / n);
-  r[4] = (float)(s[4] / n);
-  r[5] = (float)(s[5] / n);
-  r[6] = (float)(s[6] / n);
-  r[7] = (float)(s[7] / n);
-  r[8] = (float)s[8];
+  r[0] = (float)(tot[0] / n);
+  r[1] = (float)(tot[1] / n);
+  r[2] = (float)sqrt(tot[2] / n);
+  r[3] = (float)sqrt(tot[3] / n);
+  r[4] = (float)(tot[4] / n);
+  r[5] = (float)(tot[5] / n);
+  r[6] = (float)(tot[6] / n);
+  r[7] = (float)(tot[7] / n);
+  r[8] = (float)tot[8];
   r[9] = (float)(first_id + b);
 }
 
@@ -151,7 +155,7 @@ extern "C" int ocv_depth_metrics_fwd(const float* pred, const float* pred_mirror
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(depth_metrics_partial_kernel, dim3(tiles, B), dim3(256), 0, st, a);
   OCV_CHECK_LAUNCH("ocv_depth_metrics_fwd(partial)");
-  hipLaunchKernelGGL(depth_metrics_finish_kernel, dim3((B + 63) / 64), dim3(64), 0, st, (const double*)workspace, tiles, records, B,
+  hipLaunchKernelGGL(depth_metrics_finish_kernel, dim3(B), dim3(64 * NSUM), 0, st, (const double*)workspace, tiles, records, B,
                      first_image_id);
   OCV_CHECK_LAUNCH("ocv_depth_metrics_fwd(finish)");
   return 0;
