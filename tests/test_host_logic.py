@@ -30,7 +30,7 @@ def test_library_loads_and_exports_every_symbol():
         assert hasattr(lib, name), name
     assert lib.ocv_abi_version() == 1
     # argument validation runs on the host before any launch
-    assert lib.ocv_patch_embed_workspace_bytes(16, 128, 240, 320, 128) == 8 * 4800 * 128 * 4
+    assert lib.ocv_patch_embed_workspace_bytes(16, 128, 240, 320, 128) == 16 * 4800 * 128 * 4      # 16 K slices x [M, E] fp32
     assert lib.ocv_patch_embed_workspace_bytes(1, 128, 240, 320, 64) == 0
     assert lib.ocv_bin_head_workspace_bytes(2, 256, 128) == 2 * 256 * 128 * 4
     rc = lib.ocv_linear_fwd(None, 4, 0, None, 4, 0, 0, None, None, 4, 0, 1, 1, 1, 4, 0, None)
