@@ -94,7 +94,8 @@ int ocv_attention_fwd(const float* q, long q_bs, int q_ss, const float* k, long 
  * q_src [B,Sq,E], k_src / v_src [B,Sk,E] dense; out [B,Sq,E].  E == 128, H == 4.
  * kv_limit: 0, or a number of leading keys such that EVERY key j >= kv_limit is masked in every batch row (the
  * caller knows it from the object counts: key_padding_mask is True for j >= n_b, so kv_limit = max_b n_b).  Keys
- * beyond it are then neither projected nor scored -- identical result, since they carry zero probability. */
+ * beyond it are then neither projected nor scored -- identical result, since they carry zero probability.  * With E = 128, H = 4 and at most 32 live keys (kv_limit <= 32, or Sk <= 32) the whole operation is one launch
+ * (projections, scores, softmax, context, output projection per 32-query tile); otherwise five. */
 size_t ocv_mha_workspace_bytes(int B, int Sq, int Sk, int E);
 int ocv_mha_fwd(const float* q_src, const float* k_src, const float* v_src, const uint8_t* key_padding_mask,
                 const float* in_proj_w, const float* in_proj_b, const float* out_w, const float* out_b, float* out,

@@ -6,6 +6,8 @@
 #include <stdio.h>
 #include <math.h>
 
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "../../include/objcavit_hip.h"
 
@@ -53,6 +55,15 @@ extern "C" int ocv_mha_fwd(const float* q_src, const float* k_src, const float* 
   OCV_CHECK_ARG(kv_limit == 0 || key_padding_mask != nullptr, "ocv_mha_fwd: kv_limit needs a key_padding_mask");
   // keys >= kv_limit are all masked (caller's promise): project and score only the first Se keys of every batch row
   const int Se = (kv_limit > 0 && kv_limit < Sk) ? kv_limit : Sk;
+  {
+    // at most 32 live keys (the image <- object cross-attention): everything in one launch
+    static const bool unfused = getenv("OCV_MHA_UNFUSED") != nullptr;
+    if (!unfused) {
+      rc = ocv_cross_attn_fused_launch(q_src, k_src, v_src, key_padding_mask, Sk, in_proj_w, in_proj_b, out_w, out_b, out, B,
+                                       Sq, Sk, Se, E, H, (hipStream_t)stream);
+      if (rc != 1) return rc;
+    }
+  }
   if ((rc = ocv_linear_fwd(q_src, E, 0, in_proj_w, E, 0, 0, in_proj_b, qp, E, 0, 1, B * Sq, E, E, OCV_ACT_NONE, stream))) return rc;
   if ((rc = ocv_linear_fwd(k_src, E, (long)Sk * E, in_proj_w + (size_t)E * E, E, 0, 0, in_proj_b + E, kp, E, (long)Se * E, B, Se, E, E, OCV_ACT_NONE, stream))) return rc;
   if ((rc = ocv_linear_fwd(v_src, E, (long)Sk * E, in_proj_w + (size_t)2 * E * E, E, 0, 0, in_proj_b + 2 * E, vp, E, (long)Se * E, B, Se, E, E, OCV_ACT_NONE, stream))) return rc;

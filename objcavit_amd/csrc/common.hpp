@@ -69,5 +69,10 @@ int ocv_attention_launch(const float* q, long q_bs, int q_ss, const float* k, lo
                          long v_bs, int v_ss, const uint8_t* key_padding_mask, int mask_ld, float* ctx, long o_bs,
                          int o_ss, int B, int H, int Sq, int Sk, float scale, hipStream_t stream);
 
+// fused few-key multi-head attention (csrc/linear.hip); 0 = launched, 1 = shape not covered, other = launch error
+int ocv_cross_attn_fused_launch(const float* q_src, const float* k_src, const float* v_src, const uint8_t* mask, int mask_ld,
+                                const float* in_w, const float* in_b, const float* out_w, const float* out_b, float* out, int B,
+                                int Sq, int Sk, int Se, int E, int H, hipStream_t st);
+
 static inline bool ocv_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline int ocv_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

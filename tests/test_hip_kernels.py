@@ -167,6 +167,25 @@ def test_mha_kv_limit_skips_only_masked_keys(ops, counts):
     assert rel_dev(full, ref) < TOL and rel_dev(lim, ref) < TOL
 
 
+@pytest.mark.parametrize("Sq,counts", [(300, [32, 7, 1]), (45, [5, 0]), (32, [32]), (1, [3, 3])])
+def test_mha_fused_few_keys(ops, Sq, counts):
+    """kv_limit <= 32 takes the single-launch kernel (projections + attention + output projection): ragged query
+    tiles, a batch row without any live key (NaN rows, as torch), V taken from a different tensor than K."""
+    B, Sk, E = len(counts), 300, 128
+    qs, ks, vs = rnd("qs", (B, Sq, E), 1), rnd("ks", (B, Sk, E), 2), rnd("vs", (B, Sk, E), 3)
+    iw, ib = rnd("iw", (3 * E, E), 4, 2 / math.sqrt(E)), rnd("ib", (3 * E,), 5, 0.1)
+    ow, ob = rnd("ow", (E, E), 6, 1 / math.sqrt(E)), rnd("ob", (E,), 7, 0.1)
+    mask = torch.arange(Sk)[None, :] >= torch.tensor(counts)[:, None]
+    ref = restate.multi_head_attention(qs, ks, vs, iw, ib, ow, ob, mask)
+    got = ops.mha(dev(qs), dev(ks), dev(vs), dev(iw), dev(ib), dev(ow), dev(ob), dev(mask), kv_limit=max(max(counts), 1)).cpu()
+    nan_ref = torch.isnan(ref)
+    assert torch.equal(torch.isnan(got), nan_ref)
+    assert nan_ref.any() == (0 in counts)
+    assert rel_dev(torch.where(nan_ref, torch.zeros_like(got), got), torch.where(nan_ref, torch.zeros_like(ref), ref)) < TOL
+    full = ops.mha(dev(qs), dev(ks), dev(vs), dev(iw), dev(ib), dev(ow), dev(ob), dev(mask)).cpu()      # five-launch path
+    assert rel_dev(torch.where(nan_ref, torch.zeros_like(got), got), torch.where(nan_ref, torch.zeros_like(full), full)) < TOL
+
+
 def _encoder_sd(seed, prefix="layers."):
     import torch.nn as nn
     enc = nn.TransformerEncoder(nn.TransformerEncoderLayer(128, 4, 1024, batch_first=True), 4, enable_nested_tensor=False).eval()
