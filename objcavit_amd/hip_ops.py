@@ -305,7 +305,7 @@ def encoder_layer(x: torch.Tensor, params: EncoderLayerParams, key_padding_mask:
     ws = workspace(nb, x.device)
     if out is None:
         out = torch.empty_like(x)
-    with timed("encoder_layer"):
+    with timed("encoder_layer" if S > 64 else "encoder_layer_obj"):
       check(lib.ocv_encoder_layer_fwd(x.data_ptr(), C.byref(params), _ptr(m), int(zero_padded_rows), out.data_ptr(), B, S, E,
                                       n_heads, dim_ff, eps, ws.data_ptr(), ws.numel(), _stream()), "ocv_encoder_layer_fwd")
     return out
