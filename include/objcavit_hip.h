@@ -238,19 +238,29 @@ int ocv_conv_nhwc_fwd(const float* x1, int C1, const float* x2, int C2, const vo
                       const float* bias, const float* residual, float* y, int B, int H, int W, int Cout, int ksize,
                       int act, ocv_stream_t stream);
 
-/* The same convolution on an input that is ALREADY split: x_hi / x_lo bf16 [B,H,W,Cin] (Cin a multiple of 8), as
- * produced by ocv_upsample_concat_split_fwd or by a previous convolution's y_hi / y_lo.  Outputs: y (fp32, nullable)
- * and / or y_hi, y_lo (bf16 split of the same values, nullable pair).  No fp32->bf16 work per tap in the kernel. */
-int ocv_conv_nhwc_split_fwd(const void* x_hi, const void* x_lo, int Cin, const void* w_hi, const void* w_lo,
-                            const float* bias, const float* residual, float* y, void* y_hi, void* y_lo, int B, int H,
-                            int W, int Cout, int ksize, int act, ocv_stream_t stream);
+/* Split-bf16 activation layout "hl32" shared by ocv_upsample_concat_split_fwd and ocv_conv_nhwc_split_fwd: for a
+ * logical NHWC activation [B,H,W,C] one bf16 buffer [B*H*W][2*Cp], Cp = C rounded up to 32, holding per pixel and per
+ * block of 32 channels the 32 hi values (hi = bf16(v)) followed by the 32 lo values (lo = bf16(v - hi)); element
+ * (m, c, part) sits at  m * 2*Cp + (c / 32) * 64 + part * 32 + (c % 32).  Channels C..Cp-1 are stored as zeros.  One
+ * (pixel, 32-channel) K step of the convolution is therefore one 128-byte line.  Returns the number of bf16 elements
+ * of such a buffer (B*H*W*2*Cp), or 0 on bad sizes. */
+size_t ocv_split_act_elems(int B, int H, int W, int C);
+
+/* The same convolution on an input that is ALREADY split: x_hl in the hl32 layout above for Cin channels (128-byte
+ * aligned), as produced by ocv_upsample_concat_split_fwd or by a previous convolution's y_hl.  Outputs: y (fp32
+ * [B,H,W,Cout], nullable) and / or y_hl (hl32 layout for Cout channels, nullable; needs Cout a multiple of 32).  No
+ * fp32->bf16 work per tap in the kernel. */
+int ocv_conv_nhwc_split_fwd(const void* x_hl, int Cin, const void* w_hi, const void* w_lo, const float* bias,
+                            const float* residual, float* y, void* y_hl, int B, int H, int W, int Cout, int ksize,
+                            int act, ocv_stream_t stream);
 
 /* Bilinear resize of x [B,h,w,C1] (NHWC fp32) to H x W with align_corners = True, concatenated along channels with
- * skip [B,H,W,C2] (nullable, then C2 = 0), written as the split-bf16 pair out_hi / out_lo [B,H,W,C1+C2]
- * (hi = bf16(v), lo = bf16(v - hi)).  Replaces F.interpolate + torch.cat of UpSampleWithSkip.forward
- * (modules/DenseFeatureExtractor.py:44-47) and feeds ocv_conv_nhwc_split_fwd. */
-int ocv_upsample_concat_split_fwd(const float* x, int h, int w, int C1, const float* skip, int C2, void* out_hi,
-                                  void* out_lo, int B, int H, int W, ocv_stream_t stream);
+ * skip [B,H,W,C2] (nullable, then C2 = 0), written in the hl32 split layout for C1+C2 channels (out_hl,
+ * ocv_split_act_elems(B,H,W,C1+C2) bf16 elements, 16-byte aligned; pad channels zeroed).  C1, C2 multiples of 4.
+ * Replaces F.interpolate + torch.cat of UpSampleWithSkip.forward (modules/DenseFeatureExtractor.py:44-47) and feeds
+ * ocv_conv_nhwc_split_fwd. */
+int ocv_upsample_concat_split_fwd(const float* x, int h, int w, int C1, const float* skip, int C2, void* out_hl, int B,
+                                  int H, int W, ocv_stream_t stream);
 
 /* Validation-step arithmetic in one pass (next row N2: modules/GraphBinsLM.py:154-212, metrics/MetricsPreprocess.py:14-45,
  * metrics/AbsRel.py:44-52, SqRel.py:45-52, RMSE.py:48-55, RMSELog.py:45-52, Log10.py:52-61, AccThresh.py:59-66).

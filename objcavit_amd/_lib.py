@@ -71,9 +71,10 @@ PROTOTYPES = {
     "ocv_se_gate_fwd": (C.c_int, [_f32p] * 7 + [C.c_int] * 3 + [_stream]),
     "ocv_conv_nhwc_fwd": (C.c_int, [_f32p, C.c_int, _f32p, C.c_int, C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p] +
                           [C.c_int] * 6 + [_stream]),
-    "ocv_conv_nhwc_split_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p,
-                                          C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [_stream]),
-    "ocv_upsample_concat_split_fwd": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_void_p, C.c_void_p,
+    "ocv_split_act_elems": (C.c_size_t, [C.c_int] * 4),
+    "ocv_conv_nhwc_split_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p, C.c_void_p]
+                                + [C.c_int] * 6 + [_stream]),
+    "ocv_upsample_concat_split_fwd": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_void_p,
                                                 C.c_int, C.c_int, C.c_int, _stream]),
 }
 

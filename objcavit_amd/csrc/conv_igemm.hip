@@ -53,8 +53,9 @@ constexpr int BUF_BYTES = 2 * A_BYTES + 2 * B_BYTES;      // 61440
 
 struct ConvArgs {
   const float* x1; const float* x2;     // NHWC fp32; x2 (nullable) is concatenated after x1's channels
-  const __bf16* xhi; const __bf16* xlo; // OR the input already split (hi, lo), NHWC bf16 [.., Cin]  (IN_SPLIT kernel)
-  __bf16* yhi; __bf16* ylo;             // optional split copy of the output (for the next convolution)
+  const __bf16* xhl;                    // OR the input already split, "hl32" layout (see hl_index)   (DMA kernel)
+  __bf16* yhl;                          // optional split copy of the output in the same layout (for the next convolution)
+  int Cpo;                              // Cout rounded up to 32 (channel blocks of the split output)
   const __bf16* whi; const __bf16* wlo; // [taps][Cout][Cp]
   const float* bias; const float* res; float* y;
   int C1, C2, Cin, Cp, Cout, H, W, ks, act;
@@ -82,6 +83,15 @@ __device__ __forceinline__ void split4(const f32x4 v, __bf16* hi, __bf16* lo) {
   }
 }
 
+// "hl32" layout of a split activation: per pixel, per block of 32 channels, 32 hi values followed by their 32 lo values
+// (bf16; hi = bf16(v), lo = bf16(v - hi)); channels padded with zeros to a multiple of 32:
+//   element (pixel m, channel c, part) at  m * 2 Cp + (c >> 5) * 64 + part * 32 + (c & 31)
+// One (pixel, 32-channel) chunk -- what a K step of the implicit GEMM consumes -- is ONE 128-byte line holding both
+// parts.  With hi and lo in two separate NHWC tensors the same chunk was two half lines in two places, whose other
+// halves (the next K chunk) were needed nine taps later, after the 4 MB L2 had lost them: every line came in from
+// beyond L2 twice (FETCH_SIZE 2.2x the algorithmic bytes) and the LDS-DMA pieces touched twice as many lines.
+__device__ __forceinline__ long hl_index(long m, int c, int Cp) { return m * 2 * Cp + (c >> 5) * 64 + (c & 31); }
+
 __device__ __attribute__((aligned(256))) float ocv_zero_page[64];      // zero-initialised: source of padded taps
 
 // Diagnostic build only (-DOCV_STAMPS): per-phase cycle sums of workgroup 0 (s_memtime), never in the product build.
@@ -94,7 +104,7 @@ __device__ unsigned long long ocv_conv_stamps[16];
 #define STAMP_ADD(slot, t0, t1)
 #endif
 
-template <bool IN_SPLIT>
+template <bool IN_SPLIT>   /* always false: pre-split inputs take conv_split_dma_kernel */
 __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
@@ -186,10 +196,10 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
             else if (p.act == OCV_ACT_RELU) v = fmaxf(v, 0.f);
             if (p.res != nullptr) v += p.res[m * p.Cout + n];
             if (p.y != nullptr) p.y[m * p.Cout + n] = v;
-            if (p.yhi != nullptr) {                      // pre-split copy for the next convolution's A operand
+            if (p.yhl != nullptr) {                      // pre-split copy for the next convolution's A operand
               const __bf16 hb = (__bf16)v;
-              p.yhi[m * p.Cout + n] = hb;
-              p.ylo[m * p.Cout + n] = (__bf16)(v - (float)hb);
+              p.yhl[hl_index(m, n, p.Cpo)] = hb;
+              p.yhl[hl_index(m, n, p.Cpo) + 32] = (__bf16)(v - (float)hb);
             }
           }
         }
@@ -232,7 +242,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
       }
       tapmask[i] = mask;
       const long pix = valid ? am : 0;
-      rb1[i] = IN_SPLIT ? (unsigned)((pix * p.Cin + apart) * 2) : (unsigned)((pix * p.C1 + apart) * 4);
+      rb1[i] = IN_SPLIT ? (unsigned)((pix * 2 * p.Cp + apart) * 2) : (unsigned)((pix * p.C1 + apart) * 4);
       rb2[i] = (unsigned)((pix * p.C2 + apart) * 4);
     }
   }
@@ -256,18 +266,17 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
     const int ky = tap / p.ks, kx = tap - ky * p.ks;                     // scalar, ks in {1, 3}
     if (IN_SPLIT) {
       // pre-split input: 8 channels = 16 B of hi and 16 B of lo per lane and row, no conversion later
-      const int soff = (((ky - pad) * p.W + (kx - pad)) * p.Cin + c0) * 2;
-      const bool cok = c0 + apart + 8 <= p.Cin;
+      const int soff = (((ky - pad) * p.W + (kx - pad)) * 2 * p.Cp + 2 * c0) * 2;      // hl32: chunk c0 starts at 2 c0
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const bool ok = ((tapmask[i] >> tap) & 1u) && cok;
+        const bool ok = ((tapmask[i] >> tap) & 1u);
 #ifdef OCV_ABL_SMALLFOOT
         const unsigned off = (rb1[i] + (unsigned)soff) & 0x3FF0u;          // diagnostic: every load hits a 16 KB window
 #else
         const unsigned off = rb1[i] + (unsigned)soff;
 #endif
-        st.a[2 * i + 0] = gload16(ok ? (const void*)((const char*)p.xhi + off) : (const void*)ocv_zero_page);
-        st.a[2 * i + 1] = gload16(ok ? (const void*)((const char*)p.xlo + off) : (const void*)ocv_zero_page);
+        st.a[2 * i + 0] = gload16(ok ? (const void*)((const char*)p.xhl + off) : (const void*)ocv_zero_page);
+        st.a[2 * i + 1] = gload16(ok ? (const void*)((const char*)p.xhl + off + 64) : (const void*)ocv_zero_page);
       }
     } else {
     const bool first = c0 < p.C1;
@@ -506,12 +515,13 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
             *reinterpret_cast<f32x4*>(p.y + o) = a;
             *reinterpret_cast<f32x4*>(p.y + o + 4) = c;
           }
-          if (p.yhi != nullptr) {
+          if (p.yhl != nullptr) {
             __bf16 hi[8], lo[8];
             split4(a, hi, lo);
             split4(c, hi + 4, lo + 4);
-            *reinterpret_cast<bf16x8*>(p.yhi + o) = *reinterpret_cast<bf16x8*>(hi);
-            *reinterpret_cast<bf16x8*>(p.ylo + o) = *reinterpret_cast<bf16x8*>(lo);
+            const long oh = hl_index(m, ncol, p.Cpo);          // ncol % 8 == 0: the octet stays inside one 32-block
+            *reinterpret_cast<bf16x8*>(p.yhl + oh) = *reinterpret_cast<bf16x8*>(hi);
+            *reinterpret_cast<bf16x8*>(p.yhl + oh + 32) = *reinterpret_cast<bf16x8*>(lo);
           }
         }
       }
@@ -535,10 +545,10 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
             else if (p.act == OCV_ACT_RELU) v = fmaxf(v, 0.f);
             if (p.res != nullptr) v += p.res[m * p.Cout + n];
             if (p.y != nullptr) p.y[m * p.Cout + n] = v;
-            if (p.yhi != nullptr) {
+            if (p.yhl != nullptr) {
               const __bf16 hb = (__bf16)v;
-              p.yhi[m * p.Cout + n] = hb;
-              p.ylo[m * p.Cout + n] = (__bf16)(v - (float)hb);
+              p.yhl[hl_index(m, n, p.Cpo)] = hb;
+              p.yhl[hl_index(m, n, p.Cpo) + 32] = (__bf16)(v - (float)hb);
             }
           }
         }
@@ -568,7 +578,7 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
         if (valid && (unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W) mask |= 1u << t;
       }
       tapmask[i] = mask;
-      rbA[i] = (unsigned)(((valid ? am : 0) * p.Cin + lchunk * 8) * 2);
+      rbA[i] = (unsigned)(((valid ? am : 0) * 2 * p.Cp + lchunk * 8) * 2);
     }
   }
   unsigned rbB[2];
@@ -584,15 +594,14 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
     const int tap = nx_tap, c0 = nx_c0;
     if (++nx_tap == taps) { nx_tap = 0; nx_c0 += CBK; }
     const int ky = tap / p.ks, kx = tap - ky * p.ks;
-    const int soff = (((ky - pad) * p.W + (kx - pad)) * p.Cin + c0) * 2;
-    const bool cok = c0 + lchunk * 8 + 8 <= p.Cin;
+    const int soff = (((ky - pad) * p.W + (kx - pad)) * 2 * p.Cp + 2 * c0) * 2;       // hl32: chunk c0 starts at 2 c0
     unsigned char* base = lds + buf * DBUF;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const bool ok = ((tapmask[i] >> tap) & 1u) && cok;
+      const bool ok = ((tapmask[i] >> tap) & 1u);               // pad channels are zeros in memory: no channel check
       const unsigned off = rbA[i] + (unsigned)soff;
-      const void* sh = ok ? (const void*)((const char*)p.xhi + off) : (const void*)ocv_zero_page;
-      const void* sl = ok ? (const void*)((const char*)p.xlo + off) : (const void*)ocv_zero_page;
+      const void* sh = ok ? (const void*)((const char*)p.xhl + off) : (const void*)ocv_zero_page;
+      const void* sl = ok ? (const void*)((const char*)p.xhl + off + 64) : (const void*)ocv_zero_page;   // same 128-B line
       unsigned char* dst = base + (64 * pw + 16 * i) * DROW;
       __builtin_amdgcn_global_load_lds((gptr_t)sh, (lptr_t)dst, 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)sl, (lptr_t)(dst + DA), 16, 0, 0);
@@ -661,21 +670,29 @@ int launch_conv(ConvArgs& a, int B, bool in_split, hipStream_t st) {
 }
 }  // namespace
 
-extern "C" int ocv_conv_nhwc_split_fwd(const void* x_hi, const void* x_lo, int Cin, const void* w_hi, const void* w_lo,
-                                       const float* bias, const float* residual, float* y, void* y_hi, void* y_lo,
-                                       int B, int H, int W, int Cout, int ksize, int act, ocv_stream_t stream) {
-  OCV_CHECK_ARG(x_hi && x_lo && w_hi && w_lo && (y || (y_hi && y_lo)), "ocv_conv_nhwc_split_fwd: null pointer");
-  OCV_CHECK_ARG((y_hi == nullptr) == (y_lo == nullptr), "ocv_conv_nhwc_split_fwd: y_hi and y_lo go together");
-  OCV_CHECK_ARG(ocv_aligned16(y) && ocv_aligned16(y_hi) && ocv_aligned16(y_lo) && ocv_aligned16(residual), "ocv_conv_nhwc_split_fwd: outputs and residual must be 16-byte aligned");
+extern "C" size_t ocv_split_act_elems(int B, int H, int W, int C) {
+  if (B < 1 || H < 1 || W < 1 || C < 1) return 0;
+  return (size_t)B * H * W * 2 * ((C + 31) / 32 * 32);
+}
+
+extern "C" int ocv_conv_nhwc_split_fwd(const void* x_hl, int Cin, const void* w_hi, const void* w_lo, const float* bias,
+                                       const float* residual, float* y, void* y_hl, int B, int H, int W, int Cout,
+                                       int ksize, int act, ocv_stream_t stream) {
+  OCV_CHECK_ARG(x_hl && w_hi && w_lo && (y || y_hl), "ocv_conv_nhwc_split_fwd: null pointer");
+  OCV_CHECK_ARG(ocv_aligned16(y) && ocv_aligned16(y_hl) && ocv_aligned16(residual), "ocv_conv_nhwc_split_fwd: outputs and residual must be 16-byte aligned");
   OCV_CHECK_ARG(ksize == 1 || ksize == 3, "ocv_conv_nhwc_split_fwd: kernel size must be 1 or 3 (got %d)", ksize);
-  OCV_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && Cout >= 1 && Cin >= 8 && Cin % 8 == 0, "ocv_conv_nhwc_split_fwd: bad sizes (Cin must be a multiple of 8)");
+  OCV_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && Cout >= 1 && Cin >= 1, "ocv_conv_nhwc_split_fwd: bad sizes");
   OCV_CHECK_ARG(act >= 0 && act <= 3, "ocv_conv_nhwc_split_fwd: unknown activation %d", act);
-  OCV_CHECK_ARG(ocv_aligned16(x_hi) && ocv_aligned16(x_lo) && ocv_aligned16(w_hi) && ocv_aligned16(w_lo), "ocv_conv_nhwc_split_fwd: operands must be 16-byte aligned");
-  OCV_CHECK_ARG((long)B * H * W * Cin * 2 < (1L << 32) && 9L * Cout * (Cin + 32) * 2 < (1L << 32), "ocv_conv_nhwc_split_fwd: each operand must be smaller than 4 GiB");
+  OCV_CHECK_ARG((reinterpret_cast<uintptr_t>(x_hl) & 127) == 0 && ocv_aligned16(w_hi) && ocv_aligned16(w_lo), "ocv_conv_nhwc_split_fwd: x_hl must be 128-byte aligned, weights 16-byte aligned");
+  OCV_CHECK_ARG((long)B * H * W * (Cin + 32) * 4 < (1L << 32) && 9L * Cout * (Cin + 32) * 2 < (1L << 32), "ocv_conv_nhwc_split_fwd: each operand must be smaller than 4 GiB");
   ConvArgs a{};
-  a.xhi = (const __bf16*)x_hi; a.xlo = (const __bf16*)x_lo; a.yhi = (__bf16*)y_hi; a.ylo = (__bf16*)y_lo;
+  a.xhl = (const __bf16*)x_hl; a.yhl = (__bf16*)y_hl; a.Cpo = (Cout + 31) / 32 * 32;
   a.whi = (const __bf16*)w_hi; a.wlo = (const __bf16*)w_lo; a.bias = bias; a.res = residual; a.y = y;
   a.C1 = Cin; a.C2 = 0; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.ks = ksize; a.act = act;
+  if (y_hl != nullptr && Cout % 32 != 0) {       // the kernel writes channels < Cout only: pad channels must read as zero
+    const hipError_t e = hipMemsetAsync(y_hl, 0, ocv_split_act_elems(B, H, W, Cout) * sizeof(__bf16), (hipStream_t)stream);
+    OCV_CHECK_ARG(e == hipSuccess, "ocv_conv_nhwc_split_fwd: hipMemsetAsync failed: %s", hipGetErrorString(e));
+  }
   return launch_conv(a, B, true, (hipStream_t)stream);
 }
 

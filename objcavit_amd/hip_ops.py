@@ -758,20 +758,48 @@ def se_gate(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2t: torch.Tens
 # split-bf16 activations between our convolutions
 # ---------------------------------------------------------------------------
 class SplitAct:
-    """An activation held as two bf16 channels_last tensors hi = bf16(v), lo = bf16(v - hi), logical shape
-    [B, C, H, W].  Produced by ``upsample_concat_split`` / ``conv_nhwc_split(..., out_split=True)``, consumed by
-    ``conv_nhwc_split`` with no per-tap conversion work."""
-    __slots__ = ("hi", "lo")
+    """An activation of logical shape [B, C, H, W] held in the "hl32" split-bf16 layout of include/objcavit_hip.h: one
+    bf16 buffer ``hl`` [B, H, W, 2 * Cp] (Cp = C rounded up to 32) with, per pixel and per 32-channel block, the 32
+    hi = bf16(v) values followed by the 32 lo = bf16(v - hi) values; pad channels are zero.  Produced by
+    ``upsample_concat_split`` / ``conv_nhwc_split(..., out_split=True)``, consumed by ``conv_nhwc_split`` with no
+    per-tap conversion work."""
+    __slots__ = ("hl", "C")
 
-    def __init__(self, hi: torch.Tensor, lo: torch.Tensor):
-        self.hi, self.lo = hi, lo
+    def __init__(self, hl: torch.Tensor, C: int):
+        self.hl, self.C = hl, int(C)
+
+    @staticmethod
+    def empty(B: int, C: int, H: int, W: int, device) -> "SplitAct":
+        Cp = (C + 31) // 32 * 32
+        n = int(_lib.load().ocv_split_act_elems(B, H, W, C))
+        if n != B * H * W * 2 * Cp:
+            raise ValueError(f"SplitAct: bad sizes {(B, C, H, W)}")
+        return SplitAct(torch.empty(B, H, W, 2 * Cp, dtype=torch.bfloat16, device=device), C)
 
     @property
     def shape(self):
-        return self.hi.shape
+        B, H, W, _ = self.hl.shape
+        return torch.Size((B, self.C, H, W))
+
+    def parts(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(hi, lo) as [B, C, H, W] bf16 views of the buffer (pad channels dropped)."""
+        B, H, W, c2 = self.hl.shape
+        v = self.hl.view(B, H, W, c2 // 64, 2, 32)
+        hi = v[..., 0, :].reshape(B, H, W, c2 // 2)[..., :self.C].permute(0, 3, 1, 2)
+        lo = v[..., 1, :].reshape(B, H, W, c2 // 2)[..., :self.C].permute(0, 3, 1, 2)
+        return hi, lo
+
+    @property
+    def hi(self) -> torch.Tensor:
+        return self.parts()[0]
+
+    @property
+    def lo(self) -> torch.Tensor:
+        return self.parts()[1]
 
     def float(self) -> torch.Tensor:
-        return self.hi.float() + self.lo.float()
+        hi, lo = self.parts()
+        return hi.float() + lo.float()
 
 
 def upsample_concat_split(x: torch.Tensor, skip: Optional[torch.Tensor], size: Tuple[int, int]) -> SplitAct:
@@ -786,12 +814,11 @@ def upsample_concat_split(x: torch.Tensor, skip: Optional[torch.Tensor], size: T
         if skip.shape[0] != B or tuple(skip.shape[2:]) != (H, W):
             raise ValueError("upsample_concat_split: skip must be [B, C2, H, W] at the target size")
         C2 = skip.shape[1]
-    hi = torch.empty(B, C1 + C2, H, W, dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
-    lo = torch.empty_like(hi)
+    out = SplitAct.empty(B, C1 + C2, H, W, x.device)
     with timed("upsample_concat_split"):
-        check(lib.ocv_upsample_concat_split_fwd(x.data_ptr(), h, w, C1, _ptr(skip), C2, hi.data_ptr(), lo.data_ptr(), B, H, W,
+        check(lib.ocv_upsample_concat_split_fwd(x.data_ptr(), h, w, C1, _ptr(skip), C2, out.hl.data_ptr(), B, H, W,
                                                 _stream()), "ocv_upsample_concat_split_fwd")
-    return SplitAct(hi, lo)
+    return out
 
 
 def conv_nhwc_split(x: SplitAct, w_hi: torch.Tensor, w_lo: torch.Tensor, bias: Optional[torch.Tensor], ksize: int,
@@ -800,13 +827,10 @@ def conv_nhwc_split(x: SplitAct, w_hi: torch.Tensor, w_lo: torch.Tensor, bias: O
     lib = _lib.load()
     if not (out_fp32 or out_split):
         raise ValueError("conv_nhwc_split: nothing to output")
-    for n, t in (("x.hi", x.hi), ("x.lo", x.lo)):
-        _req(t, n, torch.bfloat16, contiguous=False)
-        if t.dim() != 4 or not t.is_contiguous(memory_format=torch.channels_last):
-            raise ValueError(f"{n}: expected a channels_last [B, C, H, W] bf16 tensor")
-    B, Cin, H, W = x.hi.shape
-    if x.lo.shape != x.hi.shape:
-        raise ValueError("conv_nhwc_split: hi / lo shape mismatch")
+    _req(x.hl, "x.hl", torch.bfloat16)
+    B, Cin, H, W = x.shape
+    if x.hl.dim() != 4 or x.hl.shape[3] != 2 * ((Cin + 31) // 32 * 32):
+        raise ValueError("conv_nhwc_split: x.hl must be [B, H, W, 2 * ceil32(C)] bf16")
     for n, t in (("w_hi", w_hi), ("w_lo", w_lo)):
         _req(t, n, torch.bfloat16)
     taps, Cout, Cp = w_hi.shape
@@ -816,15 +840,13 @@ def conv_nhwc_split(x: SplitAct, w_hi: torch.Tensor, w_lo: torch.Tensor, bias: O
         _req(bias, "bias")
         if bias.numel() != Cout:
             raise ValueError("conv_nhwc_split: bias size mismatch")
-    cl = torch.channels_last
-    y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.hi.device, memory_format=cl) if out_fp32 else None
-    yh = torch.empty(B, Cout, H, W, dtype=torch.bfloat16, device=x.hi.device, memory_format=cl) if out_split else None
-    yl = torch.empty_like(yh) if out_split else None
-    ptrs = (x.hi.data_ptr(), x.lo.data_ptr(), Cin, w_hi.data_ptr(), w_lo.data_ptr(), _ptr(bias), None, _ptr(y), _ptr(yh),
-            _ptr(yl), B, H, W, Cout, ksize, act)
-    keep = (x, w_hi, w_lo, bias, y, yh, yl)          # an eager island re-issues this launch on every replay
+    y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.hl.device, memory_format=torch.channels_last) if out_fp32 else None
+    ys = SplitAct.empty(B, Cout, H, W, x.hl.device) if out_split else None
+    ptrs = (x.hl.data_ptr(), Cin, w_hi.data_ptr(), w_lo.data_ptr(), _ptr(bias), None, _ptr(y),
+            ys.hl.data_ptr() if out_split else None, B, H, W, Cout, ksize, act)
+    keep = (x, w_hi, w_lo, bias, y, ys)          # an eager island re-issues this launch on every replay
     launch(f"conv{ksize}x{ksize}|{B},{H},{W},{Cin},{Cout}",
            lambda: (keep, check(lib.ocv_conv_nhwc_split_fwd(*ptrs, _stream()), "ocv_conv_nhwc_split_fwd"))[1])
     if out_fp32 and out_split:
-        return y, SplitAct(yh, yl)
-    return y if out_fp32 else SplitAct(yh, yl)
+        return y, ys
+    return y if out_fp32 else ys

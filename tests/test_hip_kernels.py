@@ -532,7 +532,11 @@ def test_upsample_concat_split(ops, B, h, w, H, W, C1, C2):
     if skip is not None:
         ref = torch.cat([ref, skip], 1)
     got = ops.upsample_concat_split(dev(x), None if skip is None else dev(skip), (H, W))
-    assert got.hi.dtype == torch.bfloat16 and got.hi.is_contiguous(memory_format=torch.channels_last)
+    Cp = (C1 + C2 + 31) // 32 * 32
+    assert got.hl.dtype == torch.bfloat16 and tuple(got.hl.shape) == (B, H, W, 2 * Cp) and got.hl.is_contiguous()
+    assert tuple(got.shape) == (B, C1 + C2, H, W)
+    blocks = got.hl.view(B, H, W, Cp // 32, 2, 32).permute(0, 1, 2, 4, 3, 5).reshape(B, H, W, 2, Cp)
+    assert not bool(blocks[..., C1 + C2:].any())       # pad channels of the last 32-block are zero
     assert rel_dev(got.float(), ref) < 1e-5            # hi + lo carries 16 bits: 2^-17 relative per element
     assert rel_dev(got.hi.float(), ref) < 5e-3         # hi alone is plain bf16
 
