@@ -62,7 +62,7 @@ def main(src, tag):
             f.write(f"{'kernel':110s} {'n':>5s} {'total_ms':>9s} {'avg_us':>9s} {'pct':>6s}\n")
             for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 f.write(f"{k:110s} {v[0]:5d} {v[1] / 1e6:9.3f} {v[1] / v[0] / 1e3:9.1f} {100 * v[1] / tot:6.2f}\n")
-    pmc, series = {}, {}
+    pmc, series, grids = {}, {}, {}
     for d, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         fs = newest(os.path.join(src, d, "*", "*_counter_collection.csv"))
         if not fs:
@@ -71,6 +71,7 @@ def main(src, tag):
         for r in csv.DictReader(open(fs[0])):
             if r["Counter_Name"] == cname and any(o in r["Kernel_Name"] for o in OURS):
                 agg[short(r["Kernel_Name"]).split("(")[0]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
+                grids.setdefault(short(r["Kernel_Name"]).split("(")[0], {}).setdefault(cname, {})[int(r["Dispatch_Id"])] = int(r.get("Grid_Size", 0) or 0)
         for k, byd in agg.items():
             v = [byd[i] for i in sorted(byd)]            # launches in dispatch order (same order in both passes)
             series.setdefault(k, {})[cname] = v
@@ -91,6 +92,14 @@ def main(src, tag):
                 # with launch i.  The roofline kernel of bench.py is the launch that moves the most bytes; report the
                 # MEDIAN over the launches within 5 % of that maximum (= the same shape on other steps), so one
                 # cold-cache launch does not set the number.
+                # (the convolution kernel runs ten shapes per step: only its LARGEST-GRID launches compete -- bench.py's
+                # roofline launch, 280 -> 128 at 240 x 320, is the heaviest of those; the 2224 -> 1024 launch at 30 x 40
+                # moves about as many bytes through a grid 8x smaller and must not be mixed in)
+                g = grids.get(names[0], {}).get("FETCH_SIZE", {})
+                gl = [g[i] for i in sorted(g)]
+                if len(gl) == len(f) and max(gl) > 0:
+                    keep = [i for i in range(len(f)) if gl[i] == max(gl)]
+                    f, w = [f[i] for i in keep], [w[i] for i in keep]
                 tot = sorted(2 * a + b for a, b in zip(f, w))
                 top = [t for t in tot if t >= 0.95 * tot[-1]]
                 traffic[key] = int(top[len(top) // 2] * 1024)
