@@ -238,6 +238,20 @@ int ocv_conv_nhwc_fwd(const float* x1, int C1, const float* x2, int C2, const vo
                       const float* bias, const float* residual, float* y, int B, int H, int W, int Cout, int ksize,
                       int act, ocv_stream_t stream);
 
+/* Expand 1x1 convolution (+ bias = folded BN, SiLU) and the depthwise k x k convolution (+ bias, SiLU) behind it, fused:
+ * the expanded tensor is never written to memory.  x [B,H,W,Cin] NHWC fp32, Cin a multiple of 8 in [24, 64];
+ * w_packed = the expand weight [mid][Cin] in the packed split-bf16 layout of ocv_pointwise_conv_nhwc_split_fwd;
+ * w_dw [k*k][mid], bias_dw [mid]; y [B,Ho,Wo,mid]; part [B][tiles][mid] = squeeze-excite pooling partials for
+ * ocv_se_gate_partials_fwd with tiles = ocv_mbconv_expand_dw_tiles(Ho, Wo, k, stride).  k in {3,5}, stride in {1,2},
+ * padding as ocv_depthwise_conv_fwd (out-of-image taps of the EXPANDED tensor are zero).  Numerics: expand as
+ * ocv_pointwise_conv_nhwc_split_fwd (split-bf16, fp32 accumulate), depthwise exact fp32.  Replaces conv_pw + bn1 + act1 +
+ * conv_dw + bn2 + act2 (+ the pooling of se) of the hub backbone's InvertedResidual blocks
+ * (modules/DenseFeatureExtractor.py:18-27). */
+int ocv_mbconv_expand_dw_tiles(int Ho, int Wo, int k, int stride);
+int ocv_mbconv_expand_dw_fwd(const float* x, const void* w_packed, const float* bias_expand, const float* w_dw,
+                             const float* bias_dw, float* y, float* part, int B, int H, int W, int Cin, int mid, int k,
+                             int stride, int pad_t, int pad_l, int Ho, int Wo, ocv_stream_t stream);
+
 /* Split-bf16 activation layout "hl32" shared by ocv_upsample_concat_split_fwd and ocv_conv_nhwc_split_fwd: for a
  * logical NHWC activation [B,H,W,C] one bf16 buffer [B*H*W][2*Cp], Cp = C rounded up to 32, holding per pixel and per
  * block of 32 channels the 32 hi values (hi = bf16(v)) followed by the 32 lo values (lo = bf16(v - hi)); element

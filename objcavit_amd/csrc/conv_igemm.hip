@@ -98,7 +98,8 @@ __device__ __attribute__((aligned(256))) float ocv_zero_page[64];      // zero-i
 #ifdef OCV_STAMPS
 __device__ unsigned long long ocv_conv_stamps[16];
 #define STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
-#define STAMP_ADD(slot, t0, t1) do { if (blockIdx.x == 0 && lane == 0) stamp_acc[slot] += (t1) - (t0); } while (0)
+#define OCV_STAMP_BLOCK ((gridDim.x >> 4) << 3)      // a workgroup from the middle of the launch (steady state, not the cold first round)
+#define STAMP_ADD(slot, t0, t1) do { if (blockIdx.x == OCV_STAMP_BLOCK && lane == 0) stamp_acc[slot] += (t1) - (t0); } while (0)
 #else
 #define STAMP(var)
 #define STAMP_ADD(slot, t0, t1)
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
       STAMP_ADD(1, tc1, tc2);       // consumer: barrier wait
     }
 #ifdef OCV_STAMPS
-    if (blockIdx.x == 0 && tid == 0) { ocv_conv_stamps[0] = stamp_acc[0]; ocv_conv_stamps[1] = stamp_acc[1]; ocv_conv_stamps[7] = nsteps; }
+    if (blockIdx.x == OCV_STAMP_BLOCK && tid == 0) { ocv_conv_stamps[0] = stamp_acc[0]; ocv_conv_stamps[1] = stamp_acc[1]; ocv_conv_stamps[7] = nsteps; }
 #endif
 
     // ---- epilogue: bias, activation, optional residual, NHWC store (128-byte runs per half-wave)
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
     }
   }
 #ifdef OCV_STAMPS
-  if (blockIdx.x == 0 && tid == 256) { for (int i = 0; i < 5; ++i) ocv_conv_stamps[2 + i] = stamp_acc[i]; }
+  if (blockIdx.x == OCV_STAMP_BLOCK && tid == 256) { for (int i = 0; i < 5; ++i) ocv_conv_stamps[2 + i] = stamp_acc[i]; }
 #endif
 }
 
@@ -409,6 +410,61 @@ constexpr int DROW = 64;                                        // bytes per LDS
 constexpr int DA = CBM * DROW, DB = CBN * DROW;                 // 16384, 8192
 constexpr int DBUF = 2 * DA + 2 * DB;                           // 49152 per buffer
 constexpr int DNBUF = 3;                                         // 3 x 48 KiB: the DMA runs two K steps ahead
+
+// Second half of the epilogue of conv_split_dma_kernel, run by ALL EIGHT wavefronts: the four consumers have parked
+// their raw accumulators in LDS (one 128 x 64 fp32 image of ERS-float rows each); wavefront w turns rows
+// [64 (w >> 2), +64) of consumer (w & 3)'s image into bias + activation (+ residual) and 16-byte stores, lane = (row
+// it * 8 + (lane >> 3), channel octet lane & 7).  Stamps (tools/run_conv_split.py, -DOCV_STAMPS) had put the epilogue
+// at 20 K cycles per tile when the four consumer wavefronts did all of it while the producers idled -- instruction
+// issue on one wavefront per SIMD, not memory: 19 % of a 128 -> 128 tile at 240 x 320.
+constexpr int ERS = 68;                                       // floats per LDS row: 64 + 4 -> conflict-free writes
+__device__ __forceinline__ float conv_act(float v, int act) {
+  if (act == OCV_ACT_LEAKY_RELU) return v > 0.f ? v : 0.01f * v;
+  if (act == OCV_ACT_SILU) return fast_silu(v);
+  if (act == OCV_ACT_RELU) return fmaxf(v, 0.f);
+  return v;
+}
+__device__ __forceinline__ void conv_store_rows(const ConvArgs& p, const unsigned char* lds, int wave, int lane, long m0, int n0) {
+  const int cw = wave & 3, half = wave >> 2;
+  const int wm = cw >> 1, wn = cw & 1;
+  const float* tile = reinterpret_cast<const float*>(lds) + cw * (128 * ERS);
+  const int oct = lane & 7, rsub = lane >> 3;
+  const int ncol = n0 + wn * 64 + oct * 8;
+  if (ncol >= p.Cout) return;
+  float bv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bv[e] = p.bias != nullptr ? p.bias[ncol + e] : 0.f;
+#pragma unroll 4
+  for (int it = 0; it < 8; ++it) {
+    const int row = half * 64 + it * 8 + rsub;
+    const long m = m0 + wm * 128 + row;
+    if (m >= p.M) continue;
+    f32x4 a = *reinterpret_cast<const f32x4*>(tile + row * ERS + oct * 8);
+    f32x4 c = *reinterpret_cast<const f32x4*>(tile + row * ERS + oct * 8 + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a[e] = conv_act(a[e] + bv[e], p.act);
+      c[e] = conv_act(c[e] + bv[4 + e], p.act);
+    }
+    const long o = m * p.Cout + ncol;
+    if (p.res != nullptr) {
+      a += *reinterpret_cast<const f32x4*>(p.res + o);
+      c += *reinterpret_cast<const f32x4*>(p.res + o + 4);
+    }
+    if (p.y != nullptr) {
+      *reinterpret_cast<f32x4*>(p.y + o) = a;
+      *reinterpret_cast<f32x4*>(p.y + o + 4) = c;
+    }
+    if (p.yhl != nullptr) {
+      __bf16 hi[8], lo[8];
+      split4(a, hi, lo);
+      split4(c, hi + 4, lo + 4);
+      const long oh = hl_index(m, ncol, p.Cpo);          // ncol % 8 == 0: the octet stays inside one 32-block
+      *reinterpret_cast<bf16x8*>(p.yhl + oh) = *reinterpret_cast<bf16x8*>(hi);
+      *reinterpret_cast<bf16x8*>(p.yhl + oh + 32) = *reinterpret_cast<bf16x8*>(lo);
+    }
+  }
+}
 
 __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
@@ -446,8 +502,14 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#ifdef OCV_STAMPS
+    unsigned long long stamp_acc[4] = {0, 0, 0, 0};
+#endif
+    STAMP(tk0);
     __syncthreads();
+    STAMP(tk1);
     for (int step = 0; step < nsteps; ++step) {
+      STAMP(tc0);
       const unsigned char* base = lds + (step % DNBUF) * DBUF;
       const unsigned char* pa = base + (wm * 128 + l15) * DROW + co;
       const unsigned char* pb = base + 2 * DA + (wn * 64 + l15) * DROW + co;
@@ -470,61 +532,38 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
         }
+      STAMP(tc1);
       __syncthreads();
+      STAMP(tc2);
+      STAMP_ADD(0, tc0, tc1);       // reads + MFMA issue
+      STAMP_ADD(1, tc1, tc2);       // barrier wait
     }
+    STAMP(te0);
 
     // ---- epilogue.  accumulator (i, j): register r of lane l is output row 16 i + 4 (l >> 4) + r, column 16 j + (l & 15)
     // Storing straight from that layout costs 384 two- and four-byte store instructions per wavefront in 32- / 64-byte
     // runs; it was store-ISSUE-bound and, with one workgroup per CU, fully exposed: 23 % of the 128 -> 128 launches
-    // (ablation: 1.63 -> 1.26 ms without the stores).  Instead the tile goes through this wavefront's own 34 KB of
-    // the (now idle) LDS and leaves as 16-byte-per-lane stores, 8 rows x 128 B (bf16) or 4 rows x 256 B (fp32) each.
-    constexpr int ERS = 68;                                       // floats per LDS row: 64 + 4 -> conflict-free writes
-    float* tile = reinterpret_cast<float*>(lds) + wave * (128 * ERS);
+    // (ablation: 1.63 -> 1.26 ms without the stores).  Instead the raw tile goes through this wavefront's own 34 KB of
+    // the (now idle) LDS and leaves, from all eight wavefronts (conv_store_rows), as 16-byte-per-lane stores.
     if ((p.Cout & 7) == 0) {
+      float* tile = reinterpret_cast<float*>(lds) + wave * (128 * ERS);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + l15;
-        const float bv = (p.bias != nullptr && n < p.Cout) ? p.bias[n] : 0.f;
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float v = acc[i][j][r] + bv;
-            if (p.act == OCV_ACT_LEAKY_RELU) v = v > 0.f ? v : 0.01f * v;
-            else if (p.act == OCV_ACT_SILU) v = fast_silu(v);
-            else if (p.act == OCV_ACT_RELU) v = fmaxf(v, 0.f);
-            tile[(16 * i + 4 * q4 + r) * ERS + 16 * j + l15] = v;
-          }
+          for (int r = 0; r < 4; ++r) tile[(16 * i + 4 * q4 + r) * ERS + 16 * j + l15] = acc[i][j][r];
+      __syncthreads();
+      STAMP(te05);
+      conv_store_rows(p, lds, wave, lane, m0, n0);
+#ifdef OCV_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      STAMP(te1);
+      if (blockIdx.x == OCV_STAMP_BLOCK && tid == 0) {
+        ocv_conv_stamps[0] = stamp_acc[0]; ocv_conv_stamps[1] = stamp_acc[1]; ocv_conv_stamps[7] = nsteps;
+        ocv_conv_stamps[8] = tk1 - tk0; ocv_conv_stamps[9] = te1 - te0; ocv_conv_stamps[10] = te1 - tk0; ocv_conv_stamps[11] = te05 - te0;
       }
-      const int oct = lane & 7, rsub = lane >> 3;
-      const int ncol = n0 + wn * 64 + oct * 8;
-      if (ncol < p.Cout) {
-#pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-          const int row = it * 8 + rsub;
-          const long m = m0 + wm * 128 + row;
-          if (m >= p.M) continue;
-          f32x4 a = *reinterpret_cast<const f32x4*>(tile + row * ERS + oct * 8);
-          f32x4 c = *reinterpret_cast<const f32x4*>(tile + row * ERS + oct * 8 + 4);
-          const long o = m * p.Cout + ncol;
-          if (p.res != nullptr) {
-            a += *reinterpret_cast<const f32x4*>(p.res + o);
-            c += *reinterpret_cast<const f32x4*>(p.res + o + 4);
-          }
-          if (p.y != nullptr) {
-            *reinterpret_cast<f32x4*>(p.y + o) = a;
-            *reinterpret_cast<f32x4*>(p.y + o + 4) = c;
-          }
-          if (p.yhl != nullptr) {
-            __bf16 hi[8], lo[8];
-            split4(a, hi, lo);
-            split4(c, hi + 4, lo + 4);
-            const long oh = hl_index(m, ncol, p.Cpo);          // ncol % 8 == 0: the octet stays inside one 32-block
-            *reinterpret_cast<bf16x8*>(p.yhl + oh) = *reinterpret_cast<bf16x8*>(hi);
-            *reinterpret_cast<bf16x8*>(p.yhl + oh + 32) = *reinterpret_cast<bf16x8*>(lo);
-          }
-        }
-      }
+#endif
       return;
     }
     // Cout not a multiple of 8: element-wise stores
@@ -563,22 +602,24 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
   const int pw = wave - 4;
   const int lrow = lane >> 2;
   const int lchunk = (lane & 3) ^ ((lane >> 3) & 3);               // logical 16-byte chunk (8 channels) this lane fetches
+  // (32-bit arithmetic and no division by the runtime kernel size: the 64-bit % and / of a first version, eight per
+  // lane plus two per tap, were most of a 14 K-cycle prologue in front of every tile's first load)
   unsigned rbA[4], tapmask[4];
   {
-    const long hw = (long)p.H * p.W;
+    const unsigned hw = (unsigned)(p.H * p.W);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const long am = m0 + 64 * pw + 16 * i + lrow;
-      const bool valid = am < p.M;
-      const long rem = valid ? am % hw : 0;
-      const int y = (int)(rem / p.W), x = (int)(rem - (long)y * p.W);
+      const unsigned am = (unsigned)m0 + 64 * pw + 16 * i + lrow;           // M < 2^30 (4 GiB operand limit)
+      const bool valid = am < (unsigned)p.M;
+      const unsigned rem = valid ? am % hw : 0u;
+      const int y = (int)(rem / (unsigned)p.W), x = (int)(rem - (unsigned)y * (unsigned)p.W);
       unsigned mask = 0;
-      for (int t = 0; t < taps; ++t) {
-        const int dy = t / p.ks - pad, dx = t % p.ks - pad;
-        if (valid && (unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W) mask |= 1u << t;
-      }
+      int t = 0;
+      for (int dy = -pad; dy <= pad; ++dy)
+        for (int dx = -pad; dx <= pad; ++dx, ++t)
+          if (valid && (unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W) mask |= 1u << t;
       tapmask[i] = mask;
-      rbA[i] = (unsigned)(((valid ? am : 0) * 2 * p.Cp + lchunk * 8) * 2);
+      rbA[i] = (valid ? am : 0u) * (unsigned)(4 * p.Cp) + (unsigned)(lchunk * 16);
     }
   }
   unsigned rbB[2];
@@ -589,11 +630,11 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
   }
   const unsigned wtap = (unsigned)((long)p.Cout * p.Cp * 2);
 
-  int nx_tap = 0, nx_c0 = 0;
+  int nx_tap = 0, nx_c0 = 0, nx_ky = 0, nx_kx = 0;
   auto issue_dma = [&](int buf) {
-    const int tap = nx_tap, c0 = nx_c0;
-    if (++nx_tap == taps) { nx_tap = 0; nx_c0 += CBK; }
-    const int ky = tap / p.ks, kx = tap - ky * p.ks;
+    const int tap = nx_tap, c0 = nx_c0, ky = nx_ky, kx = nx_kx;
+    if (++nx_kx == p.ks) { nx_kx = 0; ++nx_ky; }
+    if (++nx_tap == taps) { nx_tap = 0; nx_ky = 0; nx_c0 += CBK; }
     const int soff = (((ky - pad) * p.W + (kx - pad)) * 2 * p.Cp + 2 * c0) * 2;       // hl32: chunk c0 starts at 2 c0
     unsigned char* base = lds + buf * DBUF;
 #pragma unroll
@@ -640,6 +681,10 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
     __builtin_amdgcn_s_barrier();
   }
 #undef OCV_WAIT_VM
+  if ((p.Cout & 7) == 0) {                             // the consumers park their accumulators in LDS; all eight waves store
+    __syncthreads();
+    conv_store_rows(p, lds, wave, lane, m0, n0);
+  }
 }
 
 }  // namespace

@@ -40,8 +40,8 @@ __device__ __forceinline__ void store_split4(unsigned short* hl, long pix, int c
     h[i] = __builtin_bit_cast(unsigned short, hb);
     l[i] = __builtin_bit_cast(unsigned short, lb);
   }
-  *reinterpret_cast<uint2*>(hi + off) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
-  *reinterpret_cast<uint2*>(lo + off) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+  *reinterpret_cast<uint2*>(hi) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+  *reinterpret_cast<uint2*>(lo) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
 }
 
 constexpr int UP_ITEMS = 8;

@@ -721,6 +721,62 @@ def depthwise_se_gate(x: torch.Tensor, weight_kkc: torch.Tensor, bias: Optional[
     return out, gate
 
 
+def expand_depthwise_fusable(cin: int, weight, k: int = 3) -> bool:
+    """Whether ``expand_depthwise_se_gate`` is the faster plan for an MBConv block: packed split-bf16 expand weight,
+    24 <= Cin <= 64 and a 3 x 3 depthwise kernel (measured at B = 16: 40 -> 240 at 120 x 160 181 us fused against 123 + 150
+    as two launches, 24 -> 144 stride 2 at 240 x 320 239 against 202 + 203; the 5 x 5 blocks -- 25 FMAs per output and
+    1.7x halo recompute of the expand SiLU -- are VALU-bound fused and stay on the two-launch path: 64 -> 384 at 60 x 80
+    219 us fused against 42 + 71).  OCV_MBCONV_FUSED=0 / =all in the environment forces never / whenever supported."""
+    mode = os.environ.get("OCV_MBCONV_FUSED", "1")
+    if mode == "0" or not isinstance(weight, SplitWeight) or not (24 <= cin <= 64 and cin % 8 == 0):
+        return False
+    return k == 3 or mode == "all"
+
+
+def expand_depthwise_se_gate(x: torch.Tensor, w_expand: "SplitWeight", b_expand: Optional[torch.Tensor], weight_kkc: torch.Tensor,
+                             bias: Optional[torch.Tensor], k: int, stride: int, w1: torch.Tensor, b1: torch.Tensor,
+                             w2t: torch.Tensor, b2: torch.Tensor):
+    """silu(depthwise(silu(x @ We^T + be)) + bd) of a channels_last tensor without materialising the expanded tensor, AND
+    the squeeze-excite gate of that output: returns (y [B, mid, Ho, Wo] channels_last, gate [B, mid])."""
+    lib = _lib.load()
+    x = _nhwc(x, "x")
+    B, Cin, H, W = x.shape
+    if not isinstance(w_expand, SplitWeight) or w_expand.cin != Cin:
+        raise ValueError("expand_depthwise_se_gate: expand weight must be a SplitWeight matching x's channels")
+    _req(w_expand.packed, "w_expand.packed", torch.bfloat16)
+    mid = w_expand.cout
+    _req(weight_kkc, "weight")
+    if weight_kkc.shape != (k * k, mid):
+        raise ValueError(f"expand_depthwise_se_gate: depthwise weight {tuple(weight_kkc.shape)} does not match k={k}, C={mid}")
+    for n, t in (("b_expand", b_expand), ("bias", bias), ("w1", w1), ("b1", b1), ("w2t", w2t), ("b2", b2)):
+        if t is not None:
+            _req(t, n)
+    R = w1.shape[0]
+    if w1.shape != (R, mid) or w2t.shape != (R, mid) or b1.numel() != R or b2.numel() != mid:
+        raise ValueError("expand_depthwise_se_gate: squeeze-excite parameter shape mismatch")
+    if (b_expand is not None and b_expand.numel() != mid) or (bias is not None and bias.numel() != mid):
+        raise ValueError("expand_depthwise_se_gate: bias size mismatch")
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    ph = max((Ho - 1) * stride + k - H, 0)
+    pw = max((Wo - 1) * stride + k - W, 0)
+    tiles = lib.ocv_mbconv_expand_dw_tiles(Ho, Wo, k, stride)
+    if tiles <= 0:
+        raise ValueError("expand_depthwise_se_gate: unsupported shape")
+    out = torch.empty(B, mid, Ho, Wo, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    part = workspace(B * tiles * mid * 4, x.device, "dw_part")
+    gate = torch.empty(B, mid, dtype=torch.float32, device=x.device)
+    hid = workspace(B * R * 4, x.device, "se_hidden")
+    with timed(f"expand_dw|{B},{H},{W},{Cin},{mid},k{k}s{stride}"):
+        check(lib.ocv_mbconv_expand_dw_fwd(x.data_ptr(), w_expand.packed.data_ptr(), _ptr(b_expand), weight_kkc.data_ptr(),
+                                           _ptr(bias), out.data_ptr(), part.data_ptr(), B, H, W, Cin, mid, k, stride,
+                                           ph // 2, pw // 2, Ho, Wo, _stream()), "ocv_mbconv_expand_dw_fwd")
+    with timed("se_gate"):
+        check(lib.ocv_se_gate_partials_fwd(part.data_ptr(), tiles, Ho * Wo, w1.data_ptr(), b1.data_ptr(), w2t.data_ptr(),
+                                           b2.data_ptr(), gate.data_ptr(), hid.data_ptr(), B, mid, R, _stream()),
+              "ocv_se_gate_partials_fwd")
+    return out, gate
+
+
 def channel_mean_nhwc(x: torch.Tensor) -> torch.Tensor:
     """[B, C] = mean over H, W of a channels_last [B, C, H, W] tensor."""
     lib = _lib.load()

@@ -195,8 +195,12 @@ class InvertedResidual(_FoldedMixin, nn.Module):
             # project 1x1 (+BN) with the gate applied to its input rows and the skip connection added in the epilogue
             we, be, wd, bd, wl, bl, s1, sb1, s2, sb2 = self._folded(x)
             k = self.conv_dw.kernel_size[0]
-            y = hip_ops.pointwise_nhwc(x, we, be, hip_ops.ACT_SILU)
-            y, g = hip_ops.depthwise_se_gate(y, wd, bd, k, self.conv_dw.stride[0], s1, sb1, s2, sb2)
+            if hip_ops.expand_depthwise_fusable(x.shape[1], we, k):
+                # 3 launches: the expanded tensor stays in LDS (csrc/mbconv_fused.hip)
+                y, g = hip_ops.expand_depthwise_se_gate(x, we, be, wd, bd, k, self.conv_dw.stride[0], s1, sb1, s2, sb2)
+            else:
+                y = hip_ops.pointwise_nhwc(x, we, be, hip_ops.ACT_SILU)
+                y, g = hip_ops.depthwise_se_gate(y, wd, bd, k, self.conv_dw.stride[0], s1, sb1, s2, sb2)
             return hip_ops.pointwise_nhwc(y, wl, bl, hip_ops.ACT_NONE, gate=g, residual=x if self.has_residual else None)
         y = self.act1(self.bn1(self.conv_pw(x)))
         y = self.act2(self.bn2(self.conv_dw(y)))

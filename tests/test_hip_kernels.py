@@ -491,6 +491,35 @@ def test_depthwise_se_gate(ops, k, s, B, C, H, W, R):
     assert torch.equal(y, y2) and torch.equal(g, g2)        # fixed-order pooling sums
 
 
+@pytest.mark.parametrize("k,s", [(3, 1), (3, 2), (5, 1), (5, 2)])
+@pytest.mark.parametrize("B,H,W,Cin,mid", [(2, 17, 23, 24, 144), (1, 30, 40, 40, 240), (2, 33, 47, 64, 384), (1, 8, 32, 40, 48),
+                                           (1, 3, 2, 24, 36), (3, 64, 70, 32, 100)])
+def test_expand_depthwise_fused(ops, k, s, B, H, W, Cin, mid):
+    """Fused expand 1x1 + depthwise (+ squeeze-excite gate) against the fp32 formulation and against the two-launch
+    path: image sizes that are not multiples of the 8 x 32 / 8 x 16 tiles, channel counts that do not fill the last
+    32-channel chunk, images smaller than one tile, asymmetric 'SAME' padding at stride 2."""
+    R = max(1, Cin // 4)
+    x = rnd("x", (B, Cin, H, W), 1)
+    we, be = rnd("we", (mid, Cin), 2, 1 / math.sqrt(Cin)), rnd("be", (mid,), 3, 0.3)
+    wd, bd = rnd("wd", (mid, 1, k, k), 4, 0.3), rnd("bd", (mid,), 5, 0.2)
+    w1, b1 = rnd("w1", (R, mid), 6, 1 / math.sqrt(mid)), rnd("b1", (R,), 7, 0.3)
+    w2, b2 = rnd("w2", (mid, R), 8, 1 / math.sqrt(R)), rnd("b2", (mid,), 9, 0.3)
+    e = F.silu(F.conv2d(x.double(), we.double()[:, :, None, None], be.double())).float()
+    ref = F.silu(F.conv2d(_same_pad(e, k, s), wd, bd, stride=s, groups=mid))
+    gref = torch.sigmoid(F.silu(ref.mean((2, 3)) @ w1.T + b1) @ w2.T + b2)
+    xg = dev(x).contiguous(memory_format=torch.channels_last)
+    wsp = ops.SplitWeight(dev(we))
+    se = (dev(w1), dev(b1), dev(w2).t().contiguous(), dev(b2))
+    wdk = dev(wd).flatten(1).t().contiguous()
+    y, g = ops.expand_depthwise_se_gate(xg, wsp, dev(be), wdk, dev(bd), k, s, *se)
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert rel_dev(y, ref) < SPLIT_TOL and rel_dev(g, gref) < SPLIT_TOL
+    y2, g2 = ops.depthwise_se_gate(ops.pointwise_nhwc(xg, wsp, dev(be), ops.ACT_SILU), wdk, dev(bd), k, s, *se)
+    assert rel_dev(y, y2) < 1e-5 and rel_dev(g, g2) < 1e-5
+    y3, g3 = ops.expand_depthwise_se_gate(xg, wsp, dev(be), wdk, dev(bd), k, s, *se)
+    assert torch.equal(y, y3) and torch.equal(g, g3)        # fixed-order pooling sums
+
+
 @pytest.mark.parametrize("B,C,H,W,R", [(16, 144, 120, 160, 6), (2, 48, 240, 320, 12), (3, 3072, 15, 20, 128), (1, 8, 1, 3, 2)])
 def test_channel_mean_and_se_gate(ops, B, C, H, W, R):
     x = rnd("x", (B, C, H, W), 1)

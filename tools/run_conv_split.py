@@ -11,7 +11,7 @@ hi, lo = hip_ops.prep_conv_weight(torch.randn(Cout, Cin, 3, 3, device="cuda") * 
 b = torch.zeros(Cout, device="cuda")
 for _ in range(2): y = hip_ops.conv_nhwc_split(xs, hi, lo, b, 3, 2, out_fp32=False, out_split=True)
 torch.cuda.synchronize()
-t0 = time.perf_counter(); n = 5
+t0 = time.perf_counter(); n = int(os.environ.get('OCV_ITERS', '5'))
 for _ in range(n): y = hip_ops.conv_nhwc_split(xs, hi, lo, b, 3, 2, out_fp32=False, out_split=True)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
@@ -22,5 +22,6 @@ if hasattr(lib, "ocv_conv_read_stamps"):
     out = (ctypes.c_ulonglong * 16)(); lib.ocv_conv_read_stamps.restype = ctypes.c_int; lib.ocv_conv_read_stamps(out)
     v = list(out); nn = max(v[7], 1)
     print(f"stamps: steps {v[7]}; consumer compute {v[0]/nn:.0f} ticks/step, barrier wait {v[1]/nn:.0f} ticks/step")
+    print(f"tile of workgroup 0: prologue {v[8]} ticks, epilogue {v[9]}, whole {v[10]}  (loop {v[0]+v[1]})")
     h = nn / 2
     print(f"producer group 0 (per own interval): convert-interval: wait+convert {v[2]/h:.0f}, barrier {v[3]/h:.0f} | write-interval: lds write {v[4]/h:.0f}, issue {v[5]/h:.0f}, barrier {v[6]/h:.0f}")
