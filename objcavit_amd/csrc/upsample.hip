@@ -9,10 +9,23 @@
 // (and in the convolution epilogues) instead of inside every convolution removes 5 VALU operations per element from
 // each of the 9 taps x N-tiles that re-read the element -- the limiter of the first convolution kernel -- and the
 // resized tensor and the concatenated tensor are never materialised in fp32.
-// HBM-bound: reads C1 x 4 B x (h w / H W, through L2) + C2 x 4 B, writes (C1 + C2) x 4 B per output pixel; a lane owns
-// 4 consecutive channels of one output pixel (16-byte loads, 8-byte stores).
+// Algorithmic traffic: reads C1 x 4 B x (h w / H W) + C2 x 4 B, writes (C1 + C2) x 4 B per output pixel.  Three kernels,
+// chosen per launch (ocv_upsample_concat_split_fwd at the end of this file):
+//   upsample_concat_split_2x2_kernel   channel counts multiples of 8, not shrinking: item = 8 channels of a 2 x 2 output
+//                                      block, 9 shared taps instead of 16; every load of the item ahead of its stores
+//   upsample_concat_split8_kernel      multiples of 8, any scale: item = 8 channels of one pixel, 4 items per thread, all
+//                                      loads ahead of all stores
+//   upsample_concat_split_kernel       multiples of 4: item = 4 channels of one pixel, flat index decode
+// What bounded them, in the order found (B = 16, the four decoder launches together): 1.30 ms for the last kernel --
+// neither its index arithmetic (octet items with incremental indices: 1.33 ms) nor the shape of its stores (full
+// 128-byte lines per lane group: 1.44 ms) but the ORDER of loads and stores: a store counts in vmcnt like a load and
+// vmcnt retires in order, so each wait for an item's loads also waited for the previous item's stores (loads first:
+// 1.14 ms); then the four-taps-per-output L1 traffic, 8 TB/s (2 x 2 blocks: 0.96 ms).  torch's fill of the 240 x 320
+// output alone takes 0.21 ms and a copy of it 0.55 ms (tools/membw.py); that launch is now at 0.51 ms.
 // Arithmetic follows ATen's upsample_bilinear2d (scale = (in-1)/(out-1), src = scale*dst, lambda1 = src - floor(src),
 // out = h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)) so the fp32 value before splitting matches torch to rounding.
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "../../include/objcavit_hip.h"
 
@@ -90,6 +103,215 @@ __global__ __launch_bounds__(256) void upsample_concat_split_kernel(UpArgs p) {
   }
 }
 
+// Octet form (C1 and C2 multiples of 8): a work item is 8 consecutive channels of one output pixel (two 16-byte loads per
+// bilinear tap, one 16-byte hi store and one 16-byte lo store); a workgroup owns PB consecutive output pixels and its
+// threads walk the (pixel, octet) items in order, so a wavefront's loads are 2 KB runs of one pixel's channels and the
+// pixel's row / column / interpolation weights are derived from the workgroup's first pixel by increments.  The quad
+// kernel above decodes (b, Y, X, c) from a flat index for every 16 bytes it moves -- six 64-bit divisions, ~250 VALU
+// instructions per item -- and sat at 2.8 TB/s with the vector ALU 60 % busy; this form spends ~70 per 32 bytes.
+typedef __bf16 up_bf16x8 __attribute__((ext_vector_type(8)));
+
+struct Up8Args {
+  const float *x, *skip;
+  __bf16* hl;
+  int Cp, h, w, H, W, C1, C2;
+  float sh, sw, inv_noct;
+  int noct, PB;                  // octets per pixel (Cp / 8), pixels per workgroup
+  long npix;                     // B * H * W
+};
+
+__device__ __forceinline__ float4 up_lerp(const float4 a, const float4 b, const float4 c, const float4 d, float h0, float h1,
+                                          float w0, float w1) {
+  float4 v;
+  v.x = h0 * (w0 * a.x + w1 * b.x) + h1 * (w0 * c.x + w1 * d.x);
+  v.y = h0 * (w0 * a.y + w1 * b.y) + h1 * (w0 * c.y + w1 * d.y);
+  v.z = h0 * (w0 * a.z + w1 * b.z) + h1 * (w0 * c.z + w1 * d.z);
+  v.w = h0 * (w0 * a.w + w1 * b.w) + h1 * (w0 * c.w + w1 * d.w);
+  return v;
+}
+
+constexpr int UP8_ITEMS = 4;          // items per thread, all loaded before the first store
+
+__global__ __launch_bounds__(256) void upsample_concat_split8_kernel(Up8Args p) {
+  const int C = p.C1 + p.C2;
+  long wg = blockIdx.x;
+  {
+    const long nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7, i = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+  }
+  const long pix0 = wg * p.PB;                                   // wave-uniform: scalar divisions, once per workgroup
+  const int X0 = (int)(pix0 % p.W);
+  const long t0 = pix0 / p.W;
+  const int Y0 = (int)(t0 % p.H);
+  const long b0 = t0 / p.H;
+  const int nitems = (int)(min((long)p.PB, p.npix - pix0)) * p.noct;      // <= 256 * UP8_ITEMS
+  // Branch-free body, loads of all items ahead of the first store: on gfx9 a store counts in vmcnt like a load and
+  // vmcnt retires in order, so a loop of (loads, wait, stores) makes every wait for an item's loads also wait for the
+  // previous item's stores to be acknowledged.
+  up_bf16x8 hi[UP8_ITEMS], lo[UP8_ITEMS];
+  __bf16* dst[UP8_ITEMS];
+#pragma unroll
+  for (int u = 0; u < UP8_ITEMS; ++u) {
+    const int item = min((int)threadIdx.x + 256 * u, nitems - 1);          // clamped: stores are predicated below
+    const int dp = (int)(((float)item + 0.5f) * p.inv_noct);               // item / noct (exact: item < 2^16, noct <= 2^12)
+    const int c = (item - dp * p.noct) * 8;
+    int X = X0 + dp, Y = Y0;
+    long b = b0;
+    while (X >= p.W) { X -= p.W; ++Y; }
+    while (Y >= p.H) { Y -= p.H; ++b; }
+    const bool is_up = c < p.C1, is_skip = !is_up && c < C;
+    const float sy = p.sh * Y, sx = p.sw * X;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < p.h - 1 ? 1 : 0), x1 = x0 + (x0 < p.w - 1 ? 1 : 0);
+    const float h1 = sy - (float)y0, h0 = 1.0f - h1, w1 = sx - (float)x0, w0 = 1.0f - w1;
+    const float* base = p.x + b * (long)p.h * p.w * p.C1 + (is_up ? c : 0);
+    const float* sk = is_skip ? p.skip + ((b * p.H + Y) * (long)p.W + X) * p.C2 + (c - p.C1) : base;
+    const float* r00 = is_up ? base + ((long)y0 * p.w + x0) * p.C1 : sk;    // skip / pad octets: four (L1-resident) copies
+    const float* r01 = is_up ? base + ((long)y0 * p.w + x1) * p.C1 : sk;
+    const float* r10 = is_up ? base + ((long)y1 * p.w + x0) * p.C1 : sk;
+    const float* r11 = is_up ? base + ((long)y1 * p.w + x1) * p.C1 : sk;
+    const float4 a0 = ld4(r00), a1 = ld4(r00 + 4), b0v = ld4(r01), b1v = ld4(r01 + 4);
+    const float4 c0 = ld4(r10), c1 = ld4(r10 + 4), d0 = ld4(r11), d1 = ld4(r11 + 4);
+    const float4 la = up_lerp(a0, b0v, c0, d0, h0, h1, w0, w1), lb = up_lerp(a1, b1v, c1, d1, h0, h1, w0, w1);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 va = is_up ? la : (is_skip ? a0 : z), vb = is_up ? lb : (is_skip ? a1 : z);
+    const float f[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const __bf16 hb = (__bf16)f[i];
+      hi[u][i] = hb;
+      lo[u][i] = (__bf16)(f[i] - (float)hb);
+    }
+    dst[u] = p.hl + ((b * p.H + Y) * (long)p.W + X) * 2 * p.Cp + (c >> 5) * 64 + (c & 31);
+  }
+#pragma unroll
+  for (int u = 0; u < UP8_ITEMS; ++u) {
+    if ((int)threadIdx.x + 256 * u < nitems) {
+      *reinterpret_cast<up_bf16x8*>(dst[u]) = hi[u];
+      *reinterpret_cast<up_bf16x8*>(dst[u] + 32) = lo[u];
+    }
+  }
+}
+
+// 2 x 2 form (octets, and a resize that does not shrink: sh, sw <= 1): a work item is 8 channels of a 2 x 2 block of
+// output pixels.  Neighbouring outputs of an up-scaling share taps -- the block's sixteen taps lie in a 3 x 3
+// neighbourhood of the source -- so an item issues 9 x 2 loads instead of 16 x 2.  The octet kernel moved 8 TB/s through
+// L1 (four taps of 32 B per output octet), which is where every re-reading kernel of this project has topped out.
+struct UpBArgs {
+  const float *x, *skip;
+  __bf16* hl;
+  int Cp, h, w, H, W, C1, C2;
+  float sh, sw, inv_noct;
+  int noct, PB;                  // octets per pixel, blocks per workgroup
+  int BW, BH;                    // blocks per row / column of one image
+  long nblk;                     // B * BH * BW
+};
+
+__device__ __forceinline__ float4 up_sel(bool second, const float4 a, const float4 b) {
+  return make_float4(second ? b.x : a.x, second ? b.y : a.y, second ? b.z : a.z, second ? b.w : a.w);
+}
+
+__global__ __launch_bounds__(256) void upsample_concat_split_2x2_kernel(UpBArgs p) {
+  const int C = p.C1 + p.C2;
+  long wg = blockIdx.x;
+  {
+    const long nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7, i = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+  }
+  const long blk0 = wg * p.PB;                                   // wave-uniform
+  const int bx0 = (int)(blk0 % p.BW);
+  const long t0 = blk0 / p.BW;
+  const int by0 = (int)(t0 % p.BH);
+  const long b0 = t0 / p.BH;
+  const int nitems = (int)(min((long)p.PB, p.nblk - blk0)) * p.noct;       // <= blockDim.x
+  const bool live = (int)threadIdx.x < nitems;
+  const int item = live ? (int)threadIdx.x : nitems - 1;
+  const int dp = (int)(((float)item + 0.5f) * p.inv_noct);
+  const int c = (item - dp * p.noct) * 8;
+  int bx = bx0 + dp, by = by0;
+  long b = b0;
+  while (bx >= p.BW) { bx -= p.BW; ++by; }
+  while (by >= p.BH) { by -= p.BH; ++b; }
+  const int X = 2 * bx, Y = 2 * by;
+  const bool is_up = c < p.C1, is_skip = !is_up && c < C;
+
+  // source neighbourhood: rows yc0 .. yc0 + 2, columns xc0 .. xc0 + 2 (clamped); output (Y + j, X + i) uses rows
+  // (dy_j, dy_j + 1) and columns (dx_i, dx_i + 1) of it, dy_0 = dx_0 = 0, dy_1, dx_1 in {0, 1}
+  const float sy0 = p.sh * Y, sy1 = p.sh * (Y + 1), sx0 = p.sw * X, sx1 = p.sw * (X + 1);
+  const int yc0 = (int)sy0, xc0 = (int)sx0;
+  const int dy1 = min(max((int)sy1 - yc0, 0), 1), dx1 = min(max((int)sx1 - xc0, 0), 1);
+  const float hy1[2] = {sy0 - (float)yc0, sy1 - (float)(yc0 + dy1)};
+  const float wx1[2] = {sx0 - (float)xc0, sx1 - (float)(xc0 + dx1)};
+  float4 n0[3][3], n1[3][3];
+  if (is_up) {
+    const float* base = p.x + b * (long)p.h * p.w * p.C1 + c;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int yy = min(yc0 + j, p.h - 1);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int xx = min(xc0 + i, p.w - 1);
+        const float* r = base + ((long)yy * p.w + xx) * p.C1;
+        n0[j][i] = ld4(r);
+        n1[j][i] = ld4(r + 4);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int yy = min(Y + j, p.H - 1), xx = min(X + i, p.W - 1);
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* r = p.skip + ((b * p.H + yy) * (long)p.W + xx) * p.C2 + (c - p.C1);
+        n0[j][i] = is_skip ? ld4(r) : z;
+        n1[j][i] = is_skip ? ld4(r + 4) : z;
+      }
+  }
+  up_bf16x8 hi[4], lo[4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float4 va, vb;
+      if (is_up) {
+        const bool ry = j == 1 && dy1 == 1, rx = i == 1 && dx1 == 1;      // second row / column pair of the neighbourhood
+        const float h1 = hy1[j], h0 = 1.0f - h1, w1 = wx1[i], w0 = 1.0f - w1;
+        // rows (t, u) = (0, 1) or (1, 2); columns (l, r) = (0, 1) or (1, 2)
+        const float4 tl0 = up_sel(rx, up_sel(ry, n0[0][0], n0[1][0]), up_sel(ry, n0[0][1], n0[1][1]));
+        const float4 tr0 = up_sel(rx, up_sel(ry, n0[0][1], n0[1][1]), up_sel(ry, n0[0][2], n0[1][2]));
+        const float4 bl0 = up_sel(rx, up_sel(ry, n0[1][0], n0[2][0]), up_sel(ry, n0[1][1], n0[2][1]));
+        const float4 br0 = up_sel(rx, up_sel(ry, n0[1][1], n0[2][1]), up_sel(ry, n0[1][2], n0[2][2]));
+        const float4 tl1 = up_sel(rx, up_sel(ry, n1[0][0], n1[1][0]), up_sel(ry, n1[0][1], n1[1][1]));
+        const float4 tr1 = up_sel(rx, up_sel(ry, n1[0][1], n1[1][1]), up_sel(ry, n1[0][2], n1[1][2]));
+        const float4 bl1 = up_sel(rx, up_sel(ry, n1[1][0], n1[2][0]), up_sel(ry, n1[1][1], n1[2][1]));
+        const float4 br1 = up_sel(rx, up_sel(ry, n1[1][1], n1[2][1]), up_sel(ry, n1[1][2], n1[2][2]));
+        va = up_lerp(tl0, tr0, bl0, br0, h0, h1, w0, w1);
+        vb = up_lerp(tl1, tr1, bl1, br1, h0, h1, w0, w1);
+      } else {
+        va = n0[j][i];
+        vb = n1[j][i];
+      }
+      const float f[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const __bf16 hb = (__bf16)f[e];
+        hi[2 * j + i][e] = hb;
+        lo[2 * j + i][e] = (__bf16)(f[e] - (float)hb);
+      }
+    }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (live && Y + j < p.H && X + i < p.W) {
+        __bf16* dst = p.hl + ((b * p.H + Y + j) * (long)p.W + X + i) * 2 * p.Cp + (c >> 5) * 64 + (c & 31);
+        *reinterpret_cast<up_bf16x8*>(dst) = hi[2 * j + i];
+        *reinterpret_cast<up_bf16x8*>(dst + 32) = lo[2 * j + i];
+      }
+    }
+}
+
 }  // namespace
 
 extern "C" int ocv_upsample_concat_split_fwd(const float* x, int h, int w, int C1, const float* skip, int C2, void* out_hl,
@@ -102,6 +324,32 @@ extern "C" int ocv_upsample_concat_split_fwd(const float* x, int h, int w, int C
   UpArgs a{x, skip, (unsigned short*)out_hl, Cp, h, w, H, W, C1, C2,
            H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f,
            (long)B * H * W * (Cp / 4)};
+  static const bool quad_only = getenv("OCV_UPSAMPLE_QUAD") != nullptr;
+  static const bool no_2x2 = getenv("OCV_UPSAMPLE_NO2X2") != nullptr;
+  if (C1 % 8 == 0 && C2 % 8 == 0 && Cp / 8 <= 256 && a.sh <= 1.0f && a.sw <= 1.0f && !quad_only && !no_2x2) {
+    UpBArgs g{x, skip, (__bf16*)out_hl, Cp, h, w, H, W, C1, C2, a.sh, a.sw, 0.f, Cp / 8, 1, (W + 1) / 2, (H + 1) / 2, 0};
+    g.inv_noct = 1.0f / (float)g.noct;
+    g.nblk = (long)B * g.BH * g.BW;
+    int threads = 256;                                            // workgroup size with the fewest idle lanes
+    for (int t = 64; t <= 256; t += 64)
+      if (t >= g.noct && (t / g.noct) * g.noct * threads > (threads / g.noct) * g.noct * t) threads = t;
+    g.PB = threads / g.noct;
+    const long nb = (g.nblk + g.PB - 1) / g.PB;
+    OCV_CHECK_ARG(nb < (1L << 31), "ocv_upsample_concat_split_fwd: tensor too large");
+    hipLaunchKernelGGL(upsample_concat_split_2x2_kernel, dim3((unsigned)nb), dim3(threads), 0, (hipStream_t)stream, g);
+    OCV_CHECK_LAUNCH("ocv_upsample_concat_split_fwd");
+    return 0;
+  }
+  if (C1 % 8 == 0 && C2 % 8 == 0 && Cp / 8 <= 256 * UP8_ITEMS && !quad_only) {
+    Up8Args g{x, skip, (__bf16*)out_hl, Cp, h, w, H, W, C1, C2, a.sh, a.sw, 0.f, Cp / 8, 1, (long)B * H * W};
+    g.inv_noct = 1.0f / (float)g.noct;
+    g.PB = (256 * UP8_ITEMS) / g.noct;                           // a workgroup's items fit one pass of its threads
+    const long nb = (g.npix + g.PB - 1) / g.PB;
+    OCV_CHECK_ARG(nb < (1L << 31), "ocv_upsample_concat_split_fwd: tensor too large");
+    hipLaunchKernelGGL(upsample_concat_split8_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, g);
+    OCV_CHECK_LAUNCH("ocv_upsample_concat_split_fwd");
+    return 0;
+  }
   const long blocks = (a.total + 256L * UP_ITEMS - 1) / (256L * UP_ITEMS);
   OCV_CHECK_ARG(blocks < (1L << 31), "ocv_upsample_concat_split_fwd: tensor too large");
   hipLaunchKernelGGL(upsample_concat_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);

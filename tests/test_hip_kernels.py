@@ -553,7 +553,12 @@ def test_conv_nhwc_does_not_depend_on_stale_memory(ops):
 
 # ------------------------------------------------------------------ split activations between convolutions
 @pytest.mark.parametrize("B,h,w,H,W,C1,C2", [(2, 17, 22, 30, 40, 64, 24), (1, 30, 40, 60, 80, 32, 0), (3, 5, 7, 11, 13, 8, 4),
-                                             (1, 120, 160, 240, 320, 16, 8)])
+                                             (1, 120, 160, 240, 320, 16, 8),
+                                             (2, 9, 11, 17, 21, 16, 8),      # odd output size: ragged 2 x 2 blocks
+                                             (1, 7, 9, 7, 9, 8, 0),          # identity resize through the 2 x 2 kernel
+                                             (1, 20, 24, 11, 13, 8, 8),      # shrinking: the per-pixel octet kernel
+                                             (1, 1, 1, 6, 5, 40, 16),        # one source pixel
+                                             (2, 8, 10, 16, 20, 1096, 0)])   # 137 octets per pixel: 192-thread blocks
 def test_upsample_concat_split(ops, B, h, w, H, W, C1, C2):
     x = rnd("x", (B, C1, h, w), 1)
     skip = rnd("s", (B, C2, H, W), 2) if C2 else None
