@@ -32,7 +32,7 @@ struct DWSArgs {
 // loads per x-block moved 6.5 TB/s out of L2 for 2.9 TB/s of useful traffic).
 // Weights: K = 3 in VGPRs (36); K = 5 in LDS (the 100 registers go to the window instead).
 template <int K, int S, int PX>
-__global__ __launch_bounds__(256, K > 3 ? 2 : 3) void dw_slide_kernel(DWSArgs p) {
+__global__ __launch_bounds__(256, 2) void dw_slide_kernel(DWSArgs p) {
   constexpr int NIN = (PX - 1) * S + K;
   constexpr bool WLDS = K > 3;
   __shared__ float4 red[256];
@@ -95,14 +95,22 @@ __global__ __launch_bounds__(256, K > 3 ? 2 : 3) void dw_slide_kernel(DWSArgs p)
         }
       }
     };
+    // PRE (k = 3): the S input rows the NEXT output row adds are requested BEFORE this row's stores, into the ring slots
+    // this row has just finished with.  A store counts in vmcnt like a load and vmcnt retires in order, so loads issued
+    // behind the stores cannot be waited for without waiting for the stores' acknowledgement as well (240 x 320 x 24:
+    // 79 -> 66 us).  It keeps the accumulators alive across the load issue, +16 VGPRs: at k = 5 that costs the second
+    // wavefront per SIMD and loses (56 -> 80 us at 30 x 40 x 1056), so k = 5 loads at the top of the row.
+    constexpr bool PRE = K == 3;
 #pragma unroll
-    for (int i = 0; i < K - S; ++i) load_row(i, win[i % K]);
+    for (int i = 0; i < (PRE ? K : K - S); ++i) load_row(i, win[i % K]);
     for (int y = y0; y < y1; y += K) {
 #pragma unroll
       for (int u = 0; u < K; ++u) {
         if (y + u < y1) {
+          if (!PRE) {
 #pragma unroll
-          for (int sidx = 0; sidx < S; ++sidx) load_row((y + u - y0) * S + K - S + sidx, win[(S * u + K - S + sidx) % K]);
+            for (int sidx = 0; sidx < S; ++sidx) load_row((y + u - y0) * S + K - S + sidx, win[(S * u + K - S + sidx) % K]);
+          }
           float4 acc[PX];
 #pragma unroll
           for (int o = 0; o < PX; ++o) acc[o] = bv;
@@ -121,6 +129,10 @@ __global__ __launch_bounds__(256, K > 3 ? 2 : 3) void dw_slide_kernel(DWSArgs p)
                 acc[o].z = fmaf(w4.z, x.z, acc[o].z); acc[o].w = fmaf(w4.w, x.w, acc[o].w);
               }
             }
+          }
+          if (PRE && y + u + 1 < y1) {
+#pragma unroll
+            for (int sidx = 0; sidx < S; ++sidx) load_row((y + u + 1 - y0) * S + K - S + sidx, win[(S * (u + 1) + K - S + sidx) % K]);
           }
           float* orow = ob + (long)(y + u - y0) * p.Wo * p.C;
 #pragma unroll
