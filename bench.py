@@ -234,7 +234,10 @@ def main():
                             peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=conv_dom["frac_bf16_mfma"], traffic=traffic,
                             algorithmic_fp32_TFLOPs=conv_dom["alg_TFLOPs"],
                             x_over_fp32_mfma_peak=round(conv_dom["alg_TFLOPs"] / F32_MFMA_PEAK_TFLOPS, 2),
-                            ms=conv_dom["ms"], alg_MB=conv_dom["alg_MB"])
+                            ms=conv_dom["ms"], alg_MB=conv_dom["alg_MB"],
+                            note="this launch runs at the package power cap (rocm-smi: 1385-1397 W of 1400 W, sclk held at "
+                                 "2.02-2.08 GHz; tools/power_probe_conv.sh): `peak` assumes 2.4 GHz, the clock-adjusted "
+                                 "fraction is frac * 2.4 / 2.05; inside the K loop the matrix pipe is ~95 % busy")
         elif dom:
             k = kernels[dom]
             # fp32 contraction kernels sit above the ridge point (157.3 TF / 8 TB/s = 19.7 flop/B): matrix-pipe bound

@@ -71,7 +71,7 @@ __device__ __forceinline__ float4 fx_fma4(const float4 w, const float4 v, float4
 }
 
 template <int K, int S, int KS>
-__global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(FXArgs p) {
+__global__ __launch_bounds__(256, K == 3 ? 2 : 1) void mbconv_expand_dw_kernel(FXArgs p) {
   using G = FXGeom<K, S>;
   extern __shared__ __attribute__((aligned(16))) float e[];        // [MT * 32 pixels][32 channels]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
@@ -136,9 +136,11 @@ __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(FXArgs p) {
         }
       }
     }
-    f32x16 acc[GRP];
+    f32x16 acc[GRP];                              // start from the bias: column l31 of every accumulator row
 #pragma unroll
-    for (int i = 0; i < GRP; ++i) acc[i] = f32x16{0};
+    for (int i = 0; i < GRP; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = bev;
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(FXArgs p) {
         float* dst = e + (mt * 32 + 4 * hh) * 32 + l31;           // accumulator row r -> pixel mt * 32 + acc_row(r, hh)
         if (interior) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) dst[acc_row(r, 0) * 32] = nok ? fast_silu(acc[i][r] + bev) : 0.f;
+          for (int r = 0; r < 16; ++r) dst[acc_row(r, 0) * 32] = fast_silu(acc[i][r]);   // channels >= mid: weights and bias are 0 -> silu(0) = 0
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(FXArgs p) {
             const int pry = pr / G::IW, jr = pr - pry * G::IW;
             const int prx = S == 1 ? jr : (jr < G::HALF ? 2 * jr : 2 * (jr - G::HALF) + 1);
             const bool in = nok && (unsigned)(iy0 + pry) < (unsigned)p.H && (unsigned)(ix0 + prx) < (unsigned)p.W;
-            dst[acc_row(r, 0) * 32] = in ? fast_silu(acc[i][r] + bev) : 0.f;
+            dst[acc_row(r, 0) * 32] = in ? fast_silu(acc[i][r]) : 0.f;
           }
         }
       }
@@ -200,13 +202,15 @@ __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(FXArgs p) {
   }
   float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
   const int ox = ox0 + col;
+  float* orow = p.y + (((long)b * p.Ho + oy0 + rg * G::NR) * p.Wo + ox) * p.mid + cq;
+  const long ostep = (long)p.Wo * p.mid;
 #pragma unroll
-  for (int o = 0; o < G::NR; ++o) {
+  for (int o = 0; o < G::NR; ++o, orow += ostep) {
     const int oy = oy0 + rg * G::NR + o;
     if (cok && oy < p.Ho && ox < p.Wo) {
       float4 r = acc[o];
       r.x = fast_silu(r.x); r.y = fast_silu(r.y); r.z = fast_silu(r.z); r.w = fast_silu(r.w);
-      *reinterpret_cast<float4*>(p.y + (((long)b * p.Ho + oy) * p.Wo + ox) * p.mid + cq) = r;
+      *reinterpret_cast<float4*>(orow) = r;
       psum.x += r.x; psum.y += r.y; psum.z += r.z; psum.w += r.w;
     }
   }
