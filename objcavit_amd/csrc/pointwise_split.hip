@@ -167,6 +167,9 @@ __device__ __forceinline__ void store_tile_lds(const PSArgs& p, const f32x16& ac
         const float4 q = ld4(p.res + m * p.N + ncol);
         v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
       }
+#ifdef PW_ABL_NOSTORE            // diagnostic build: (almost) no stores
+      if (v.x == 123456.f)
+#endif
       *reinterpret_cast<float4*>(p.y + m * p.N + ncol) = v;
     }
   }
