@@ -267,6 +267,15 @@ size_t ocv_split_act_elems(int B, int H, int W, int C);
 int ocv_conv_nhwc_split_fwd(const void* x_hl, int Cin, const void* w_hi, const void* w_lo, const float* bias,
                             const float* residual, float* y, void* y_hl, int B, int H, int W, int Cout, int ksize,
                             int act, ocv_stream_t stream);
+/* The same with a caller-provided workspace of ocv_conv_nhwc_split_workspace_bytes(...) bytes (0 for most shapes): when
+ * the tile count would leave the last round of workgroups mostly empty (the 30 x 40 stages of the decoder at B = 16:
+ * 600 tiles on 256 CUs) the channel chunks are halved between two workgroups per tile, which write fp32 partial sums
+ * to the workspace, and a second pass adds them in a fixed order and applies bias / activation / residual / split.
+ * Without a workspace (or with one that is too small) it is ocv_conv_nhwc_split_fwd. */
+size_t ocv_conv_nhwc_split_workspace_bytes(int B, int H, int W, int Cin, int Cout, int ksize);
+int ocv_conv_nhwc_split_ws_fwd(const void* x_hl, int Cin, const void* w_hi, const void* w_lo, const float* bias,
+                               const float* residual, float* y, void* y_hl, int B, int H, int W, int Cout, int ksize,
+                               int act, void* workspace, size_t workspace_bytes, ocv_stream_t stream);
 
 /* Bilinear resize of x [B,h,w,C1] (NHWC fp32) to H x W with align_corners = True, concatenated along channels with
  * skip [B,H,W,C2] (nullable, then C2 = 0), written in the hl32 split layout for C1+C2 channels (out_hl,

@@ -76,6 +76,9 @@ PROTOTYPES = {
     "ocv_split_act_elems": (C.c_size_t, [C.c_int] * 4),
     "ocv_conv_nhwc_split_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p, C.c_void_p]
                                 + [C.c_int] * 6 + [_stream]),
+    "ocv_conv_nhwc_split_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
+    "ocv_conv_nhwc_split_ws_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p, C.c_void_p]
+                                   + [C.c_int] * 6 + [C.c_void_p, C.c_size_t, _stream]),
     "ocv_upsample_concat_split_fwd": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_void_p,
                                                 C.c_int, C.c_int, C.c_int, _stream]),
 }

@@ -61,6 +61,9 @@ struct ConvArgs {
   int C1, C2, Cin, Cp, Cout, H, W, ks, act;
   long M;
   int mtiles, ntiles;
+  int ksplit;                           // conv_split_dma_kernel: 1, or 2 = the channel chunks are halved between two workgroups
+                                        // per tile, each writing raw fp32 partial sums to y + khalf * M * Cout (bias / act /
+                                        // residual / split output then belong to conv_splitk_finish_kernel)
 };
 
 // 16-byte global load (compiler-visible: hipcc tracks it and inserts the s_waitcnt before the first use).
@@ -424,7 +427,8 @@ __device__ __forceinline__ float conv_act(float v, int act) {
   if (act == OCV_ACT_RELU) return fmaxf(v, 0.f);
   return v;
 }
-__device__ __forceinline__ void conv_store_rows(const ConvArgs& p, const unsigned char* lds, int wave, int lane, long m0, int n0) {
+__device__ __forceinline__ void conv_store_rows(const ConvArgs& p, const unsigned char* lds, int wave, int lane, long m0, int n0,
+                                                long yoff) {
   const int cw = wave & 3, half = wave >> 2;
   const int wm = cw >> 1, wn = cw & 1;
   const float* tile = reinterpret_cast<const float*>(lds) + cw * (128 * ERS);
@@ -452,8 +456,8 @@ __device__ __forceinline__ void conv_store_rows(const ConvArgs& p, const unsigne
       c += *reinterpret_cast<const f32x4*>(p.res + o + 4);
     }
     if (p.y != nullptr) {
-      *reinterpret_cast<f32x4*>(p.y + o) = a;
-      *reinterpret_cast<f32x4*>(p.y + o + 4) = c;
+      *reinterpret_cast<f32x4*>(p.y + yoff + o) = a;
+      *reinterpret_cast<f32x4*>(p.y + yoff + o + 4) = c;
     }
     if (p.yhl != nullptr) {
       __bf16 hi[8], lo[8];
@@ -472,17 +476,22 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
 
-  const int nwg = p.mtiles * p.ntiles;
+  const int ntile = p.mtiles * p.ntiles, nwg = ntile * p.ksplit;
   int wg = blockIdx.x;
   {
     const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  const int kh = wg / ntile;                                     // K part of this workgroup (0 unless ksplit == 2)
+  wg -= kh * ntile;
   const int mt = wg / p.ntiles, nt = wg - mt * p.ntiles;
   const long m0 = (long)mt * CBM;
   const int n0 = nt * CBN;
   const int taps = p.ks * p.ks, pad = p.ks >> 1;
-  const int nsteps = taps * (p.Cp / CBK);
+  const int nchunk = p.Cp / CBK;
+  const int ch0 = nchunk * kh / p.ksplit, ch1 = nchunk * (kh + 1) / p.ksplit;      // channel chunks [ch0, ch1)
+  const int nsteps = taps * (ch1 - ch0);
+  const long yoff = (long)kh * p.M * p.Cout;
 
   if (wave < 4) {
     // =========================== CONSUMERS, v_mfma_f32_16x16x32_bf16 ===========================
@@ -555,7 +564,7 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
           for (int r = 0; r < 4; ++r) tile[(16 * i + 4 * q4 + r) * ERS + 16 * j + l15] = acc[i][j][r];
       __syncthreads();
       STAMP(te05);
-      conv_store_rows(p, lds, wave, lane, m0, n0);
+      conv_store_rows(p, lds, wave, lane, m0, n0, yoff);
 #ifdef OCV_STAMPS
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       STAMP(te1);
@@ -583,7 +592,7 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
             else if (p.act == OCV_ACT_SILU) v = fast_silu(v);
             else if (p.act == OCV_ACT_RELU) v = fmaxf(v, 0.f);
             if (p.res != nullptr) v += p.res[m * p.Cout + n];
-            if (p.y != nullptr) p.y[m * p.Cout + n] = v;
+            if (p.y != nullptr) p.y[yoff + m * p.Cout + n] = v;
             if (p.yhl != nullptr) {
               const __bf16 hb = (__bf16)v;
               p.yhl[hl_index(m, n, p.Cpo)] = hb;
@@ -630,7 +639,7 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
   }
   const unsigned wtap = (unsigned)((long)p.Cout * p.Cp * 2);
 
-  int nx_tap = 0, nx_c0 = 0, nx_ky = 0, nx_kx = 0;
+  int nx_tap = 0, nx_c0 = ch0 * CBK, nx_ky = 0, nx_kx = 0;
   auto issue_dma = [&](int buf) {
     const int tap = nx_tap, c0 = nx_c0, ky = nx_ky, kx = nx_kx;
     if (++nx_kx == p.ks) { nx_kx = 0; ++nx_ky; }
@@ -683,13 +692,70 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
 #undef OCV_WAIT_VM
   if ((p.Cout & 7) == 0) {                             // the consumers park their accumulators in LDS; all eight waves store
     __syncthreads();
-    conv_store_rows(p, lds, wave, lane, m0, n0);
+    conv_store_rows(p, lds, wave, lane, m0, n0, yoff);
+  }
+}
+
+
+// Second pass of a split-K convolution: y = act(part0 + part1 + bias) (+ residual), fp32 and / or hl32 split output.
+// One thread per (pixel, channel octet); fixed summation order.
+struct FinArgs {
+  const float *part, *bias, *res;
+  float* y;
+  __bf16* yhl;
+  long M, items;         // items = M * Cout / 8
+  int Cout, Cpo, act, ksplit;
+};
+
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(FinArgs p) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.items) return;
+  const int noct = p.Cout >> 3;
+  const long m = i / noct;
+  const int n = (int)(i - m * noct) * 8;
+  const long o = m * p.Cout + n;
+  f32x4 a = *reinterpret_cast<const f32x4*>(p.part + o), c = *reinterpret_cast<const f32x4*>(p.part + o + 4);
+  for (int k = 1; k < p.ksplit; ++k) {
+    a += *reinterpret_cast<const f32x4*>(p.part + k * p.M * p.Cout + o);
+    c += *reinterpret_cast<const f32x4*>(p.part + k * p.M * p.Cout + o + 4);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    a[e] = conv_act(a[e] + (p.bias != nullptr ? p.bias[n + e] : 0.f), p.act);
+    c[e] = conv_act(c[e] + (p.bias != nullptr ? p.bias[n + 4 + e] : 0.f), p.act);
+  }
+  if (p.res != nullptr) {
+    a += *reinterpret_cast<const f32x4*>(p.res + o);
+    c += *reinterpret_cast<const f32x4*>(p.res + o + 4);
+  }
+  if (p.y != nullptr) {
+    *reinterpret_cast<f32x4*>(p.y + o) = a;
+    *reinterpret_cast<f32x4*>(p.y + o + 4) = c;
+  }
+  if (p.yhl != nullptr) {
+    __bf16 hi[8], lo[8];
+    split4(a, hi, lo);
+    split4(c, hi + 4, lo + 4);
+    const long oh = hl_index(m, n, p.Cpo);
+    *reinterpret_cast<bf16x8*>(p.yhl + oh) = *reinterpret_cast<bf16x8*>(hi);
+    *reinterpret_cast<bf16x8*>(p.yhl + oh + 32) = *reinterpret_cast<bf16x8*>(lo);
   }
 }
 
 }  // namespace
 
 namespace {
+// Split-K pays when the tile count leaves the last round of workgroups mostly empty: 600 tiles on 256 CUs run three
+// rounds for 2.34 rounds of work; as 1200 half-K workgroups they run five half-rounds = 2.5.  Returns 1 or 2.
+int conv_ksplit(long M, int Cout, int Cin, int ksize) {
+  static const int forced = getenv("OCV_CONV_KSPLIT") ? atoi(getenv("OCV_CONV_KSPLIT")) : 0;
+  if (forced == 1 || forced == 2) return (Cout & 7) == 0 ? forced : 1;
+  const long tiles = (long)ocv_cdiv(M, CBM) * ocv_cdiv(Cout, CBN);
+  const int nsteps = ksize * ksize * ((Cin + CBK - 1) / CBK);
+  if ((Cout & 7) != 0 || nsteps < 128 || tiles <= 256) return 1;
+  const double c1 = (double)((tiles + 255) / 256), c2 = (double)((2 * tiles + 255) / 256) / 2.0;
+  return c2 <= 0.9 * c1 ? 2 : 1;
+}
 int launch_conv(ConvArgs& a, int B, bool in_split, hipStream_t st) {
   a.Cp = (a.Cin + CBK - 1) / CBK * CBK;
   a.M = (long)B * a.H * a.W;
@@ -707,7 +773,8 @@ int launch_conv(ConvArgs& a, int B, bool in_split, hipStream_t st) {
       (void)hipFuncSetAttribute((const void*)conv_split_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr2 = true;
     }
-    hipLaunchKernelGGL(conv_split_dma_kernel, dim3(a.mtiles * a.ntiles), dim3(512), DNBUF * DBUF, st, a);
+    if (a.ksplit < 1) a.ksplit = 1;
+    hipLaunchKernelGGL(conv_split_dma_kernel, dim3(a.mtiles * a.ntiles * a.ksplit), dim3(512), DNBUF * DBUF, st, a);
   } else if (in_split) hipLaunchKernelGGL(conv_igemm_kernel<true>, dim3(a.mtiles * a.ntiles), dim3(512), 2 * BUF_BYTES, st, a);
   else hipLaunchKernelGGL(conv_igemm_kernel<false>, dim3(a.mtiles * a.ntiles), dim3(512), 2 * BUF_BYTES, st, a);
   OCV_CHECK_LAUNCH("ocv_conv_nhwc");
@@ -720,11 +787,18 @@ extern "C" size_t ocv_split_act_elems(int B, int H, int W, int C) {
   return (size_t)B * H * W * 2 * ((C + 31) / 32 * 32);
 }
 
-extern "C" int ocv_conv_nhwc_split_fwd(const void* x_hl, int Cin, const void* w_hi, const void* w_lo, const float* bias,
-                                       const float* residual, float* y, void* y_hl, int B, int H, int W, int Cout,
-                                       int ksize, int act, ocv_stream_t stream) {
+extern "C" size_t ocv_conv_nhwc_split_workspace_bytes(int B, int H, int W, int Cin, int Cout, int ksize) {
+  if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || (ksize != 1 && ksize != 3)) return 0;
+  const long M = (long)B * H * W;
+  const int ks = conv_ksplit(M, Cout, Cin, ksize);
+  return ks > 1 ? (size_t)ks * M * Cout * sizeof(float) : 0;
+}
+
+extern "C" int ocv_conv_nhwc_split_ws_fwd(const void* x_hl, int Cin, const void* w_hi, const void* w_lo, const float* bias,
+                                          const float* residual, float* y, void* y_hl, int B, int H, int W, int Cout,
+                                          int ksize, int act, void* workspace, size_t workspace_bytes, ocv_stream_t stream) {
   OCV_CHECK_ARG(x_hl && w_hi && w_lo && (y || y_hl), "ocv_conv_nhwc_split_fwd: null pointer");
-  OCV_CHECK_ARG(ocv_aligned16(y) && ocv_aligned16(y_hl) && ocv_aligned16(residual), "ocv_conv_nhwc_split_fwd: outputs and residual must be 16-byte aligned");
+  OCV_CHECK_ARG(ocv_aligned16(y) && ocv_aligned16(y_hl) && ocv_aligned16(residual) && ocv_aligned16(workspace), "ocv_conv_nhwc_split_fwd: outputs, residual and workspace must be 16-byte aligned");
   OCV_CHECK_ARG(ksize == 1 || ksize == 3, "ocv_conv_nhwc_split_fwd: kernel size must be 1 or 3 (got %d)", ksize);
   OCV_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && Cout >= 1 && Cin >= 1, "ocv_conv_nhwc_split_fwd: bad sizes");
   OCV_CHECK_ARG(act >= 0 && act <= 3, "ocv_conv_nhwc_split_fwd: unknown activation %d", act);
@@ -733,12 +807,32 @@ extern "C" int ocv_conv_nhwc_split_fwd(const void* x_hl, int Cin, const void* w_
   ConvArgs a{};
   a.xhl = (const __bf16*)x_hl; a.yhl = (__bf16*)y_hl; a.Cpo = (Cout + 31) / 32 * 32;
   a.whi = (const __bf16*)w_hi; a.wlo = (const __bf16*)w_lo; a.bias = bias; a.res = residual; a.y = y;
-  a.C1 = Cin; a.C2 = 0; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.ks = ksize; a.act = act;
-  if (y_hl != nullptr && Cout % 32 != 0) {       // the kernel writes channels < Cout only: pad channels must read as zero
+  a.C1 = Cin; a.C2 = 0; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.ks = ksize; a.act = act; a.ksplit = 1;
+  if (y_hl != nullptr && Cout % 32 != 0) {       // the kernels write channels < Cout only: pad channels must read as zero
     const hipError_t e = hipMemsetAsync(y_hl, 0, ocv_split_act_elems(B, H, W, Cout) * sizeof(__bf16), (hipStream_t)stream);
     OCV_CHECK_ARG(e == hipSuccess, "ocv_conv_nhwc_split_fwd: hipMemsetAsync failed: %s", hipGetErrorString(e));
   }
+  const long M = (long)B * H * W;
+  const int ks = conv_ksplit(M, Cout, Cin, ksize);
+  static const bool use_dma = getenv("OCV_CONV_NO_DMA") == nullptr;
+  if (ks > 1 && use_dma && workspace != nullptr && workspace_bytes >= (size_t)ks * M * Cout * sizeof(float)) {
+    // two workgroups per tile, each over half of the channel chunks -> raw partial sums -> finish pass
+    ConvArgs h = a;
+    h.bias = nullptr; h.res = nullptr; h.yhl = nullptr; h.act = OCV_ACT_NONE; h.y = (float*)workspace; h.ksplit = ks;
+    const int rc = launch_conv(h, B, true, (hipStream_t)stream);
+    if (rc != 0) return rc;
+    FinArgs f{(const float*)workspace, bias, residual, y, (__bf16*)y_hl, M, M * Cout / 8, Cout, a.Cpo, act, ks};
+    hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)((f.items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, f);
+    OCV_CHECK_LAUNCH("ocv_conv_nhwc_split_fwd(finish)");
+    return 0;
+  }
   return launch_conv(a, B, true, (hipStream_t)stream);
+}
+
+extern "C" int ocv_conv_nhwc_split_fwd(const void* x_hl, int Cin, const void* w_hi, const void* w_lo, const float* bias,
+                                       const float* residual, float* y, void* y_hl, int B, int H, int W, int Cout,
+                                       int ksize, int act, ocv_stream_t stream) {
+  return ocv_conv_nhwc_split_ws_fwd(x_hl, Cin, w_hi, w_lo, bias, residual, y, y_hl, B, H, W, Cout, ksize, act, nullptr, 0, stream);
 }
 
 extern "C" int ocv_conv_nhwc_fwd(const float* x1, int C1, const float* x2, int C2, const void* w_hi, const void* w_lo,

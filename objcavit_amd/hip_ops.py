@@ -898,11 +898,13 @@ def conv_nhwc_split(x: SplitAct, w_hi: torch.Tensor, w_lo: torch.Tensor, bias: O
             raise ValueError("conv_nhwc_split: bias size mismatch")
     y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.hl.device, memory_format=torch.channels_last) if out_fp32 else None
     ys = SplitAct.empty(B, Cout, H, W, x.hl.device) if out_split else None
+    nws = int(lib.ocv_conv_nhwc_split_workspace_bytes(B, H, W, Cin, Cout, ksize))      # split-K partial sums (most shapes: 0)
+    ws = workspace(nws, x.hl.device, "conv_splitk") if nws else None
     ptrs = (x.hl.data_ptr(), Cin, w_hi.data_ptr(), w_lo.data_ptr(), _ptr(bias), None, _ptr(y),
-            ys.hl.data_ptr() if out_split else None, B, H, W, Cout, ksize, act)
-    keep = (x, w_hi, w_lo, bias, y, ys)          # an eager island re-issues this launch on every replay
+            ys.hl.data_ptr() if out_split else None, B, H, W, Cout, ksize, act, _ptr(ws), nws)
+    keep = (x, w_hi, w_lo, bias, y, ys, ws)      # an eager island re-issues this launch on every replay
     launch(f"conv{ksize}x{ksize}|{B},{H},{W},{Cin},{Cout}",
-           lambda: (keep, check(lib.ocv_conv_nhwc_split_fwd(*ptrs, _stream()), "ocv_conv_nhwc_split_fwd"))[1])
+           lambda: (keep, check(lib.ocv_conv_nhwc_split_ws_fwd(*ptrs, _stream()), "ocv_conv_nhwc_split_ws_fwd"))[1])
     if out_fp32 and out_split:
         return y, ys
     return y if out_fp32 else ys

@@ -594,6 +594,32 @@ def test_conv_nhwc_split_in_and_out(ops, B, H, W, Cin, Cout, k, act):
     assert rel_dev(y, y3) < 1e-5
 
 
+@pytest.mark.parametrize("out_fp32,out_split", [(True, False), (False, True), (True, True)])
+def test_conv_nhwc_split_k_halves(ops, out_fp32, out_split):
+    """300 tiles on 256 CUs: the launcher halves the channel chunks between two workgroups per tile (fp32 partial
+    sums in a workspace) and a finish pass adds them, applies bias + LeakyReLU and writes fp32 and / or split output.
+    Checked against the fp32-input kernel (no split-K) and torch's convolution on the GPU."""
+    B, H, W, Cin, Cout, k, act = 4, 60, 80, 464, 512, 3, 2
+    from objcavit_amd import _lib
+    assert _lib.load().ocv_conv_nhwc_split_workspace_bytes(B, H, W, Cin, Cout, k) == 2 * B * H * W * Cout * 4
+    assert _lib.load().ocv_conv_nhwc_split_workspace_bytes(16, 60, 80, 1088, 512, 3) == 0       # 1200 tiles: no split
+    x = dev(rnd("x", (B, Cin, H, W), 1)).contiguous(memory_format=torch.channels_last)
+    w, b = dev(rnd("w", (Cout, Cin, k, k), 3, 1 / math.sqrt(Cin * k * k))), dev(rnd("b", (Cout,), 4, 0.2))
+    hi, lo = ops.prep_conv_weight(w)
+    xs = ops.upsample_concat_split(x, None, (H, W))
+    got = ops.conv_nhwc_split(xs, hi, lo, b, k, act, out_fp32=out_fp32, out_split=out_split)
+    outs = got if isinstance(got, tuple) else (got,)
+    y3 = ops.conv_nhwc(x, None, hi, lo, b, k, act)                      # fp32-input kernel, one workgroup per tile
+    ref = F.leaky_relu(F.conv2d(x, w, b, padding=1), 0.01)
+    for o in outs:
+        v = o.float() if isinstance(o, ops.SplitAct) else o
+        assert rel_dev(v, y3) < 1e-5 and rel_dev(v, ref) < 2e-4
+    again = ops.conv_nhwc_split(xs, hi, lo, b, k, act, out_fp32=out_fp32, out_split=out_split)
+    a0 = again[0] if isinstance(again, tuple) else again
+    g0 = outs[0]
+    assert torch.equal(a0.hl if isinstance(a0, ops.SplitAct) else a0, g0.hl if isinstance(g0, ops.SplitAct) else g0)
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,act", [
     (3, 150, 154, 40, 96, 3, 2),        # 271 row tiles x 1: more tiles than CUs, ragged rows
     (3, 150, 154, 32, 136, 3, 0),       # 542 tiles, two channel tiles (second ragged), tile count not a multiple of 8
