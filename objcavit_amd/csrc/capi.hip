@@ -110,6 +110,10 @@ extern "C" int ocv_encoder_layer_fwd(const float* x, const ocv_encoder_layer_par
   const uint8_t* zmask = (zero_padded_rows && key_padding_mask) ? key_padding_mask : nullptr;
   if (FF % 128 == 0) {
     // out = LN2(x1 + W2 relu(W1 x1 + b1) + b2), hidden activations stay in LDS
+    const int ns = ocv_ffn_split_count(M, FF);       // partials live in the (otherwise unused) hid region: ns * 128 <= FF
+    if (ns > 1)
+      return ocv_ffn_split_launch(x1, p->linear1_w, p->linear1_b, p->linear2_w, p->linear2_b, p->norm2_w, p->norm2_b, eps,
+                                  zmask, out, M, FF, hid, ns, (hipStream_t)stream);
     return ocv_ffn_residual_layernorm_fwd(x1, p->linear1_w, p->linear1_b, p->linear2_w, p->linear2_b, p->norm2_w,
                                           p->norm2_b, eps, zmask, out, M, E, FF, stream);
   }

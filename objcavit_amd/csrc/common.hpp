@@ -74,5 +74,11 @@ int ocv_cross_attn_fused_launch(const float* q_src, const float* k_src, const fl
                                 const float* in_w, const float* in_b, const float* out_w, const float* out_b, float* out, int B,
                                 int Sq, int Sk, int Se, int E, int H, hipStream_t st);
 
+// FFN with a row tile's hidden units shared out over several workgroups + finish pass (csrc/linear.hip)
+int ocv_ffn_split_count(int M, int FF);
+int ocv_ffn_split_launch(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                         const float* gamma, const float* beta, float eps, const uint8_t* zero_row_mask, float* out, int M,
+                         int FF, float* part, int nsplit, hipStream_t st);
+
 static inline bool ocv_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline int ocv_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -9,6 +9,8 @@
 // two 4-byte LDS reads per MFMA are far from the LDS limit; the kernel is
 // bound by the matrix pipe (157 TFLOP/s chip peak) or, for the tiny object-side
 // layers, by launch latency.
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "../../include/objcavit_hip.h"
 
@@ -321,6 +323,8 @@ struct FFNArgs {
   const uint8_t* zero_mask;
   float* out;
   int M, FF;
+  float* part;           // nsplit > 1: raw partial outputs [nsplit][M][128] (ffn_finish_kernel adds them)
+  int nsplit;            // workgroups per row tile, each over FF / nsplit hidden units
 };
 
 __global__ __launch_bounds__(256) void ffn_fused_kernel(FFNArgs p) {
@@ -336,11 +340,15 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FFNArgs p) {
   stage_rows(Xs, p.x, BN, m0, p.M, 0, BN, tid);
   f32x16 acc = {0};
   float4 w1r[FKC / 8], w2r[FKC / 8];
-  load_wregs(w1r, p.w1 + (long)col * BN + 4 * hh, BN);
+  // A row tile's hidden units may be shared out over nsplit workgroups (blockIdx.y): with 150 row tiles (4800 image
+  // tokens) or 16 (512 object tokens) on 256 CUs the chain of FF / 128 dependent chunk rounds per workgroup, not the
+  // matrix pipe, set the launch time.
+  const int nchunk_all = p.FF / FKC;
+  const int cbeg = nchunk_all * (int)blockIdx.y / p.nsplit, nchunk = nchunk_all * ((int)blockIdx.y + 1) / p.nsplit;
+  load_wregs(w1r, p.w1 + (long)(cbeg * FKC + col) * BN + 4 * hh, BN);
   __syncthreads();
 
-  const int nchunk = p.FF / FKC;
-  for (int c = 0; c < nchunk; ++c) {
+  for (int c = cbeg; c < nchunk; ++c) {
     load_wregs(w2r, p.w2 + (long)col * p.FF + c * FKC + 4 * hh, FKC);        // in flight during phase 1
     f32x16 h = {0};
     h = chunk_mfma(h, Xs, w1r, BN, l31, hh);
@@ -353,11 +361,40 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FFNArgs p) {
     __syncthreads();
   }
 
+  if (p.nsplit > 1) {
+    float* dst = p.part + ((long)blockIdx.y * p.M + m0) * BN + col;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = acc_row(r, hh);
+      if (m0 + row < p.M) dst[(long)row * BN] = acc[r];
+    }
+    return;
+  }
   const float b2 = p.b2[col];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = acc_row(r, hh);
     Cs[row][col] = acc[r] + b2 + Xs[row][col];      // residual = the layer input rows (zero beyond M)
+  }
+  __syncthreads();
+  ln_rows(Cs, p.gamma, p.beta, p.eps, p.zero_mask, p.out, BN, m0, p.M, lane, wave);
+}
+
+// second pass of a split FFN: out = LayerNorm(x + sum_s part[s] + b2), partials added in split order
+__global__ __launch_bounds__(256) void ffn_finish_kernel(FFNArgs p) {
+  __shared__ float Cs[FM][BN + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * FM;
+  for (int i = tid; i < FM * BN; i += 256) {
+    const int row = i / BN, col = i % BN;
+    const long m = m0 + row;
+    float v = 0.f;
+    if (m < p.M) {
+      v = p.part[m * BN + col];
+      for (int sidx = 1; sidx < p.nsplit; ++sidx) v += p.part[((long)sidx * p.M + m) * BN + col];
+      v += p.b2[col] + p.x[m * BN + col];
+    }
+    Cs[row][col] = v;
   }
   __syncthreads();
   ln_rows(Cs, p.gamma, p.beta, p.eps, p.zero_mask, p.out, BN, m0, p.M, lane, wave);
@@ -545,9 +582,31 @@ extern "C" int ocv_ffn_residual_layernorm_fwd(const float* x, const float* w1, c
   OCV_CHECK_ARG(M >= 0, "ocv_ffn_residual_layernorm_fwd: bad M");
   OCV_CHECK_ARG(ocv_aligned16(x) && ocv_aligned16(w1) && ocv_aligned16(w2), "ocv_ffn_residual_layernorm_fwd: x / w1 / w2 must be 16-byte aligned");
   if (M == 0) return 0;
-  FFNArgs a{x, w1, b1, w2, b2, gamma, beta, eps, zero_row_mask, out, M, FF};
+  FFNArgs a{x, w1, b1, w2, b2, gamma, beta, eps, zero_row_mask, out, M, FF, nullptr, 1};
   hipLaunchKernelGGL(ffn_fused_kernel, dim3(ocv_cdiv(M, FM)), dim3(256), 0, (hipStream_t)stream, a);
   OCV_CHECK_LAUNCH("ocv_ffn_residual_layernorm_fwd");
+  return 0;
+}
+
+// FFN with the hidden units of a row tile shared out over several workgroups (see ffn_fused_kernel); part: scratch of
+// ocv_ffn_split_count(M, FF) * M * 128 floats.  Same contract as ocv_ffn_residual_layernorm_fwd otherwise.
+int ocv_ffn_split_count(int M, int FF) {
+  static const int forced = getenv("OCV_FFN_SPLIT") ? atoi(getenv("OCV_FFN_SPLIT")) : 0;
+  const int nchunk = FF / FKC, tiles = ocv_cdiv(M, FM);
+  int ns = 1;
+  while (2 * ns <= nchunk && nchunk % (2 * ns) == 0 && tiles * 2 * ns <= 256) ns *= 2;      // measured: 150 tiles x 2 lost 6 % (0.48 -> 0.51 ms for 4 layers), 16 tiles x 8 won 27 % (0.37 -> 0.27)
+  if (forced >= 1) { ns = 1; while (2 * ns <= forced && 2 * ns <= nchunk && nchunk % (2 * ns) == 0) ns *= 2; }
+  return ns;
+}
+
+int ocv_ffn_split_launch(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                         const float* gamma, const float* beta, float eps, const uint8_t* zero_row_mask, float* out, int M,
+                         int FF, float* part, int nsplit, hipStream_t st) {
+  FFNArgs a{x, w1, b1, w2, b2, gamma, beta, eps, zero_row_mask, out, M, FF, part, nsplit};
+  hipLaunchKernelGGL(ffn_fused_kernel, dim3(ocv_cdiv(M, FM), nsplit), dim3(256), 0, st, a);
+  OCV_CHECK_LAUNCH("ocv_ffn_split_launch");
+  hipLaunchKernelGGL(ffn_finish_kernel, dim3(ocv_cdiv(M, FM)), dim3(256), 0, st, a);
+  OCV_CHECK_LAUNCH("ocv_ffn_split_launch(finish)");
   return 0;
 }
 
