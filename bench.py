@@ -257,7 +257,7 @@ def main():
             "value": round(world * a.steps * B / dt, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "dtype_note": "fp32 results; contractions of the convolutions / 1x1 layers / bin head run as split-bf16 (hi*hi + hi*lo + lo*hi on v_mfma_*_bf16, fp32 accumulate), the rest on fp32 MFMA",
+            "dtype_note": "fp32 results; contractions of the 3x3 / 1x1 convolutions run as split-bf16 (hi*hi + hi*lo + lo*hi on v_mfma_*_bf16, fp32 accumulate: product error <= 2^-17); patch embedding, transformer stacks, bin head and depthwise on exact fp32 (MFMA f32 / FMA)",
             "launch": "eager" if a.eager else "hipGraph replay in 2 segments + 2 eager, event-timed launches (roofline convolution, bin head) per step",
             "config": {"workload": "BASELINE configs[2]: ObjCAViT enet-b5 NYU 480x640, emb_dim=128, learned pos-MLP, "
                                    f"{N_OBJ} objs/img with random 512-d text features, bs={B} per GPU, random-init weights",
