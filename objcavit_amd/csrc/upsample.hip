@@ -9,8 +9,9 @@
 // (and in the convolution epilogues) instead of inside every convolution removes 5 VALU operations per element from
 // each of the 9 taps x N-tiles that re-read the element -- the limiter of the first convolution kernel -- and the
 // resized tensor and the concatenated tensor are never materialised in fp32.
-// Algorithmic traffic: reads C1 x 4 B x (h w / H W) + C2 x 4 B, writes (C1 + C2) x 4 B per output pixel.  Three kernels,
+// Algorithmic traffic: reads C1 x 4 B x (h w / H W) + C2 x 4 B, writes (C1 + C2) x 4 B per output pixel.  Four kernels,
 // chosen per launch (ocv_upsample_concat_split_fwd at the end of this file):
+//   upsample_concat_split_lds_kernel   >= 2x up-scaling, C1 % 32 == 0: source tile through LDS (the decoder's case; see there)
 //   upsample_concat_split_2x2_kernel   channel counts multiples of 8, not shrinking: item = 8 channels of a 2 x 2 output
 //                                      block, 9 shared taps instead of 16; every load of the item ahead of its stores
 //   upsample_concat_split8_kernel      multiples of 8, any scale: item = 8 channels of one pixel, 4 items per thread, all
@@ -20,8 +21,9 @@
 // neither its index arithmetic (octet items with incremental indices: 1.33 ms) nor the shape of its stores (full
 // 128-byte lines per lane group: 1.44 ms) but the ORDER of loads and stores: a store counts in vmcnt like a load and
 // vmcnt retires in order, so each wait for an item's loads also waited for the previous item's stores (loads first:
-// 1.14 ms); then the four-taps-per-output L1 traffic, 8 TB/s (2 x 2 blocks: 0.96 ms).  torch's fill of the 240 x 320
-// output alone takes 0.21 ms and a copy of it 0.55 ms (tools/membw.py); that launch is now at 0.51 ms.
+// 1.14 ms); then the four-taps-per-output L1 traffic, 8 TB/s (2 x 2 blocks: 0.96 ms; source tile in LDS: 0.74 ms).
+// torch's fill of the 240 x 320 output alone takes 0.21 ms and a copy of it 0.55 ms (tools/membw.py); that launch is
+// now at 0.38 ms.
 // Arithmetic follows ATen's upsample_bilinear2d (scale = (in-1)/(out-1), src = scale*dst, lambda1 = src - floor(src),
 // out = h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)) so the fp32 value before splitting matches torch to rounding.
 #include <stdlib.h>
@@ -312,6 +314,109 @@ __global__ __launch_bounds__(256) void upsample_concat_split_2x2_kernel(UpBArgs 
     }
 }
 
+// LDS form (at least 2x up-scaling, C1 a multiple of 32, C2 of 8): a workgroup owns a 16 x 32 tile of output pixels and
+// 32 channels of the resized tensor; the 10 x 18 source pixels under the tile are loaded ONCE into LDS (23 KB, one
+// 128-byte line per pixel) and every bilinear tap is an LDS read.  The 2 x 2 kernel still moved 2.25 taps of 32 B per
+// output octet through L1 -- 6.3 TB/s, the level at which every re-reading kernel of this project has stalled; here L1
+// carries the source once.  LDS reads are counted in lgkmcnt, not vmcnt, so the stores of one item never hold up the
+// next item's taps.  blockIdx.y >= C1 / 32 are the skip-connection / pad channels: no resize, straight split.
+// Measured (B = 16, four decoder launches): 0.74 ms against 0.96 for the 2 x 2 kernel; 240 x 320: 383 us = 4.8 TB/s of
+// algorithmic traffic (torch's copy of the output alone: 5.1 TB/s).  64 channels per workgroup (46 KB, 3 workgroups per
+// CU): 0.86 ms; 8- or 32-row tiles: 0.74 / 0.81 ms.
+#ifndef OCV_ULC
+#define OCV_ULC 32
+#endif
+#ifndef OCV_ULT_H
+#define OCV_ULT_H 16
+#endif
+constexpr int ULT_H = OCV_ULT_H, ULT_W = 32, ULS_H = ULT_H / 2 + 2, ULS_W = 18, ULC = OCV_ULC;
+
+struct UpLArgs {
+  const float *x, *skip;
+  __bf16* hl;
+  int Cp, h, w, H, W, C1, C2;
+  float sh, sw;
+  int tiles_x, tiles_per_image, nup;     // nup = C1 / 64 resize chunks; further chunks: 64 skip / pad channels each
+};
+
+__global__ __launch_bounds__(256) void upsample_concat_split_lds_kernel(UpLArgs p) {
+  __shared__ __attribute__((aligned(16))) float4 src[ULS_H * ULS_W][ULC / 4];
+  const int tid = threadIdx.x;
+  int wg = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7, i = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+  }
+  const long b = wg / p.tiles_per_image;
+  const int t2 = wg - (int)b * p.tiles_per_image;
+  const int ty = t2 / p.tiles_x, tx = t2 - ty * p.tiles_x;
+  const int Y0 = ty * ULT_H, X0 = tx * ULT_W;
+  const int chunk = blockIdx.y;
+  if (chunk < p.nup) {
+    const int ys0 = (int)(p.sh * Y0), xs0 = (int)(p.sw * X0);
+    const float* xb = p.x + b * (long)p.h * p.w * p.C1 + chunk * ULC;
+    for (int idx = tid; idx < ULS_H * ULS_W * (ULC / 4); idx += 256) {
+      const int px = idx / (ULC / 4), f = idx % (ULC / 4);
+      const int sy = min(ys0 + px / ULS_W, p.h - 1), sx = min(xs0 + px % ULS_W, p.w - 1);
+      src[px][f] = ld4(xb + ((long)sy * p.w + sx) * p.C1 + 4 * f);
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int item = tid; item < ULT_H * ULT_W * (ULC / 8); item += 256) {
+      const int oct = item % (ULC / 8), pix = item / (ULC / 8);
+      const int X = X0 + (pix & (ULT_W - 1)), Y = Y0 + (pix >> 5);
+      if (Y >= p.H || X >= p.W) continue;
+      const float sy = p.sh * Y, sx = p.sw * X;
+      const int y0 = (int)sy, x0 = (int)sx;
+      const int y1 = y0 + (y0 < p.h - 1 ? 1 : 0), x1 = x0 + (x0 < p.w - 1 ? 1 : 0);
+      const float h1 = sy - (float)y0, h0 = 1.0f - h1, w1 = sx - (float)x0, w0 = 1.0f - w1;
+      const int r0 = (y0 - ys0) * ULS_W, r1 = (y1 - ys0) * ULS_W, c0 = x0 - xs0, c1 = x1 - xs0;
+      const float4 va = up_lerp(src[r0 + c0][2 * oct], src[r0 + c1][2 * oct], src[r1 + c0][2 * oct], src[r1 + c1][2 * oct], h0, h1, w0, w1);
+      const float4 vb = up_lerp(src[r0 + c0][2 * oct + 1], src[r0 + c1][2 * oct + 1], src[r1 + c0][2 * oct + 1], src[r1 + c1][2 * oct + 1], h0, h1, w0, w1);
+      const float f[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+      up_bf16x8 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const __bf16 hb = (__bf16)f[e];
+        hi[e] = hb;
+        lo[e] = (__bf16)(f[e] - (float)hb);
+      }
+      const int c = chunk * ULC + oct * 8;
+      __bf16* dst = p.hl + ((b * p.H + Y) * (long)p.W + X) * 2 * p.Cp + (c >> 5) * 64 + (c & 31);
+      *reinterpret_cast<up_bf16x8*>(dst) = hi;
+      *reinterpret_cast<up_bf16x8*>(dst + 32) = lo;
+    }
+    return;
+  }
+  // skip-connection and pad channels [cbase, cbase + 64) of the tile's pixels
+  const int cbase = p.C1 + (chunk - p.nup) * ULC;
+  const int noct = min(ULC, p.Cp - cbase) >> 3;                  // octets of this chunk (Cp % 32 == 0)
+  const int C = p.C1 + p.C2;
+  for (int item = tid; item < ULT_H * ULT_W * noct; item += 256) {
+    const int pix = item / noct, oct = item - pix * noct;
+    const int X = X0 + (pix & (ULT_W - 1)), Y = Y0 + (pix >> 5);
+    if (Y >= p.H || X >= p.W) continue;
+    const int c = cbase + oct * 8;
+    float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+    if (c < C) {
+      const float* sp = p.skip + ((b * p.H + Y) * (long)p.W + X) * p.C2 + (c - p.C1);
+      va = ld4(sp);
+      vb = ld4(sp + 4);
+    }
+    const float f[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+    up_bf16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const __bf16 hb = (__bf16)f[e];
+      hi[e] = hb;
+      lo[e] = (__bf16)(f[e] - (float)hb);
+    }
+    __bf16* dst = p.hl + ((b * p.H + Y) * (long)p.W + X) * 2 * p.Cp + (c >> 5) * 64 + (c & 31);
+    *reinterpret_cast<up_bf16x8*>(dst) = hi;
+    *reinterpret_cast<up_bf16x8*>(dst + 32) = lo;
+  }
+}
+
 }  // namespace
 
 extern "C" int ocv_upsample_concat_split_fwd(const float* x, int h, int w, int C1, const float* skip, int C2, void* out_hl,
@@ -325,6 +430,17 @@ extern "C" int ocv_upsample_concat_split_fwd(const float* x, int h, int w, int C
            H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f,
            (long)B * H * W * (Cp / 4)};
   static const bool quad_only = getenv("OCV_UPSAMPLE_QUAD") != nullptr;
+  static const bool no_lds = getenv("OCV_UPSAMPLE_NOLDS") != nullptr;
+  if (C1 % ULC == 0 && C2 % 8 == 0 && a.sh <= 0.5f && a.sw <= 0.5f && !no_lds && getenv("OCV_UPSAMPLE_QUAD") == nullptr) {
+    UpLArgs g{x, skip, (__bf16*)out_hl, Cp, h, w, H, W, C1, C2, a.sh, a.sw, (W + ULT_W - 1) / ULT_W, 0, C1 / ULC};
+    g.tiles_per_image = ((H + ULT_H - 1) / ULT_H) * g.tiles_x;
+    const long nb = (long)B * g.tiles_per_image;
+    const int nchunk = g.nup + (Cp - C1 + ULC - 1) / ULC;
+    OCV_CHECK_ARG(nb < (1L << 31) && nchunk < 65536, "ocv_upsample_concat_split_fwd: tensor too large");
+    hipLaunchKernelGGL(upsample_concat_split_lds_kernel, dim3((unsigned)nb, (unsigned)nchunk), dim3(256), 0, (hipStream_t)stream, g);
+    OCV_CHECK_LAUNCH("ocv_upsample_concat_split_fwd");
+    return 0;
+  }
   static const bool no_2x2 = getenv("OCV_UPSAMPLE_NO2X2") != nullptr;
   if (C1 % 8 == 0 && C2 % 8 == 0 && Cp / 8 <= 256 && a.sh <= 1.0f && a.sw <= 1.0f && !quad_only && !no_2x2) {
     UpBArgs g{x, skip, (__bf16*)out_hl, Cp, h, w, H, W, C1, C2, a.sh, a.sw, 0.f, Cp / 8, 1, (W + 1) / 2, (H + 1) / 2, 0};

@@ -558,7 +558,11 @@ def test_conv_nhwc_does_not_depend_on_stale_memory(ops):
                                              (1, 7, 9, 7, 9, 8, 0),          # identity resize through the 2 x 2 kernel
                                              (1, 20, 24, 11, 13, 8, 8),      # shrinking: the per-pixel octet kernel
                                              (1, 1, 1, 6, 5, 40, 16),        # one source pixel
-                                             (2, 8, 10, 16, 20, 1096, 0)])   # 137 octets per pixel: 192-thread blocks
+                                             (2, 8, 10, 16, 20, 1096, 0),    # 137 octets per pixel: 192-thread blocks
+                                             (2, 15, 20, 30, 40, 64, 24),    # >= 2x and C1 % 64 == 0: the LDS-tiled kernel
+                                             (1, 9, 11, 19, 23, 128, 8),     # ... ragged 16 x 32 tiles, two resize chunks
+                                             (1, 1, 1, 5, 7, 64, 0),         # ... one source pixel, no skip tensor
+                                             (1, 40, 50, 97, 131, 64, 40)])  # ... several tiles per image, 2.4x / 2.6x
 def test_upsample_concat_split(ops, B, h, w, H, W, C1, C2):
     x = rnd("x", (B, C1, h, w), 1)
     skip = rnd("s", (B, C2, H, W), 2) if C2 else None
