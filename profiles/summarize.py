@@ -24,7 +24,7 @@ OURS = ("bin_head_kernel", "pixel_dot_kernel", "patch_embed_partial_kernel", "pa
         "channel_sum_kernel", "channel_mean_finish_kernel", "se_hidden_kernel", "se_gate_kernel",
         "conv_split_dma_kernel", "upsample_concat_split_kernel", "pw_rows_kernel", "pw_tile_kernel", "pw_stream_kernel",
         "bin_head_split_kernel", "cross_attn_fused_kernel", "depth_metrics_partial_kernel", "depth_metrics_finish_kernel", "dw_slide_kernel", "se_hidden_partials_kernel", "se_gate_hid_kernel", "stem_conv_kernel",
-        "mbconv_expand_dw_kernel", "upsample_concat_split8_kernel", "upsample_concat_split_2x2_kernel", "conv_splitk_finish_kernel", "ffn_finish_kernel")
+        "mbconv_expand_dw_kernel", "upsample_concat_split8_kernel", "upsample_concat_split_2x2_kernel", "conv_splitk_finish_kernel", "ffn_finish_kernel", "upsample_concat_split_lds_kernel")
 
 
 def short(name):
