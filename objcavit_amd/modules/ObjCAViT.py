@@ -176,15 +176,19 @@ class SelfAttnCrossAttn(nn.Module):
         mask = torch.arange(nmax, device=device)[None, :] >= torch.tensor(counts, device=device)[:, None]
         return feats, mask
 
-    def forward(self, image_patch_embeddings, object_features, want_object_output: bool = True):
+    def object_self_attention(self, object_features, device):
+        """The object half of ``forward`` -- pad + mask, self-attention stack -- which does not depend on the image
+        tokens: (att_obj [B, Nmax, E], mask [B, Nmax]).  May be issued ahead of time on another stream."""
+        feats, mask = self._pad_objects(object_features, device)
+        if self._obj_stack is None:
+            return feats, mask                                                            # :186
+        return self._obj_stack(feats, mask), mask                                         # :188 (padded rows -> 0)
+
+    def forward(self, image_patch_embeddings, object_features, want_object_output: bool = True, pre_obj=None):
         x = image_patch_embeddings.contiguous()
         B, S, E = x.shape
         att_img = self._img_stack(x)                                                      # reference :169
-        feats, mask = self._pad_objects(object_features, x.device)
-        if self._obj_stack is None:
-            att_obj = feats                                                               # :186
-        else:
-            att_obj = self._obj_stack(feats, mask)                                        # :188 (padded rows -> 0)
+        att_obj, mask = pre_obj if pre_obj is not None else self.object_self_attention(object_features, x.device)
         amt = S - att_obj.shape[1]                                                        # :192
         if amt < 0:
             raise ValueError(f"more objects per image ({att_obj.shape[1]}) than image tokens ({S})")
@@ -285,15 +289,10 @@ class ObjCAViT(nn.Module):
         return self.positional_encoder(pc[..., 0:n], image_features, "img").contiguous()
 
     # -- forward ---------------------------------------------------------------
-    def forward_parts(self, image_features, object_features, object_xywh_list):
-        """-> (bin_widths_normed, conv3x3 features, queries view B x n_query x E)."""
-        if self.training:
-            raise RuntimeError("the HIP path implements inference (eval mode) only")
-        dev = image_features.device
-        B = image_features.shape[0]
-        if len(object_features) != B or len(object_xywh_list) != B:
-            raise ValueError("object_features / object_xywh_list must have one entry per image")
-        # 1. objects: Linear(512 -> E) + positional embedding, all images in one launch (reference :311-330)
+    def _embed_objects(self, object_features, object_xywh_list, dev, image_features):
+        """Linear(512 -> E) + positional embedding of all objects of the batch in one launch (reference :311-330);
+        overwrites the caller's list like the reference (:330).  ``image_features`` is only read by the grid strategies."""
+        B = len(object_features)
         boxes = [torch.full((1, 4), -1.0, device=dev) if b is None else b.to(dev, torch.float32) for b in object_xywh_list]
         counts = [int(f.shape[0]) for f in object_features]
         for c, b in zip(counts, boxes):
@@ -310,6 +309,35 @@ class ObjCAViT(nn.Module):
         objs = list(torch.split(emb, counts, dim=0))
         for i in range(B):
             object_features[i] = objs[i]                       # the reference overwrites the caller's list (:330)
+        return objs
+
+    def can_prepass(self) -> bool:
+        """Whether the object branch (embedding + first self-attention stack) is independent of the image features --
+        true for the MLP positional strategies -- so that it can run beside the encoder on a second stream."""
+        return self.strategy in _MLP_IN and not self.training
+
+    def object_prepass(self, object_features, object_xywh_list, dev):
+        """Steps of ``forward_parts`` that do not need the dense features: (embedded objects, (att_obj, mask))."""
+        if len(object_features) != len(object_xywh_list):
+            raise ValueError("object_features / object_xywh_list must have one entry per image")
+        objs = self._embed_objects(object_features, object_xywh_list, dev, None)
+        return objs, self.saca_1.object_self_attention(objs, dev)
+
+    def forward_parts(self, image_features, object_features, object_xywh_list, pre=None):
+        """-> (bin_widths_normed, conv3x3 features, queries view B x n_query x E).  ``pre``: result of
+        ``object_prepass`` when the caller has already issued the object branch."""
+        if self.training:
+            raise RuntimeError("the HIP path implements inference (eval mode) only")
+        dev = image_features.device
+        B = image_features.shape[0]
+        if len(object_features) != B or len(object_xywh_list) != B:
+            raise ValueError("object_features / object_xywh_list must have one entry per image")
+        # 1. objects: Linear(512 -> E) + positional embedding, all images in one launch (reference :311-330)
+        if pre is None:
+            objs = self._embed_objects(object_features, object_xywh_list, dev, image_features)
+            pre_obj = None
+        else:
+            objs, pre_obj = pre
 
         # 2. image tokens: patch conv + bias + positional embedding, token-major (reference :333-364)
         if self.patch_size != 16:
@@ -322,7 +350,7 @@ class ObjCAViT(nn.Module):
                                   cl_cache=self._w_cl)
 
         # 3. self-attention / cross-attention stacks (reference :366-368)
-        tok, obj = self.saca_1(tok, objs, want_object_output=self.use_2_saca)
+        tok, obj = self.saca_1(tok, objs, want_object_output=self.use_2_saca, pre_obj=pre_obj)
         if self.use_2_saca:
             tok, obj = self.saca_2(tok, obj, want_object_output=False)
 

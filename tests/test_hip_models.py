@@ -141,6 +141,30 @@ def test_graphbins_with_table_object_provider():
     assert rel_dev(out.bin_edges, ref_edges) < 1e-4 and max_rel(out.depth_pred, ref_depth) < 1e-3
 
 
+def test_object_branch_on_second_stream_equals_single_stream(monkeypatch):
+    """OCV_OBJ_OVERLAP=1 issues the object embedding + first self-attention stack on a second stream beside the
+    encoder (eager and captured): same bits as the single-stream forward, ragged object counts included."""
+    from objcavit_amd.graph import GraphedGraphBins
+    from objcavit_amd.modules.GraphBins import GraphBins, SyntheticObjectProvider
+    H, W = 352, 384
+    args = make_args(dimensions_train=[H, W], dimensions_test=[H, W], language="clip")
+    m = GraphBins(args, object_provider=SyntheticObjectProvider(8, "clip", seed=3)).eval()
+    gen.load_into(m, 57, gen.PEAKY)
+    m = m.cuda()
+    img = gen.randn("img", (2, 3, H, W), 57).cuda()
+    feats = [gen.randn("f0", (5, 512), 1).cuda(), gen.randn("f1", (2, 512), 2).cuda()]
+    boxes = [torch.rand(5, 4, device="cuda") * 100 + 10, torch.rand(2, 4, device="cuda") * 100 + 10]
+    monkeypatch.setenv("OCV_OBJ_OVERLAP", "0")
+    ref = m(img).depth_pred.clone()
+    ref_r = m(img, [f.clone() for f in feats], [b.clone() for b in boxes]).depth_pred.clone()
+    monkeypatch.setenv("OCV_OBJ_OVERLAP", "1")
+    for _ in range(2):
+        assert torch.equal(m(img).depth_pred, ref)
+        assert torch.equal(m(img, [f.clone() for f in feats], [b.clone() for b in boxes]).depth_pred, ref_r)
+    g = GraphedGraphBins(m, img)
+    assert torch.equal(g(img).depth_pred, ref) and torch.equal(g(img).depth_pred, ref)
+
+
 def test_graph_replay_with_eager_island_equals_eager_dispatch():
     """GraphedGraphBins: graph segments + an eager island + the eager head give bit-identical depth to plain dispatch,
     for the captured image and for new contents of the static input."""
