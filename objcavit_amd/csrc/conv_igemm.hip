@@ -96,6 +96,9 @@ __device__ __forceinline__ void split4(const f32x4 v, __bf16* hi, __bf16* lo) {
 __device__ __forceinline__ long hl_index(long m, int c, int Cp) { return m * 2 * Cp + (c >> 5) * 64 + (c & 31); }
 
 __device__ __attribute__((aligned(256))) float ocv_zero_page[64];      // zero-initialised: source of padded taps
+#ifdef OCV_ABL_KXRAND
+__device__ __attribute__((aligned(256))) unsigned short ocv_rand_page[256 * 64];   // diagnostic build: 32 KB of random bf16
+#endif
 
 // Diagnostic build only (-DOCV_STAMPS): per-phase cycle sums of workgroup 0 (s_memtime), never in the product build.
 #ifdef OCV_STAMPS
@@ -648,10 +651,20 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
     unsigned char* base = lds + buf * DBUF;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+#if defined(OCV_ABL_KXSHARE) || defined(OCV_ABL_KXRAND)   // diagnostic builds: only the centre column of taps fetches real data (wrong values; timing of a 3x smaller A stream)
+      const bool ok = ((tapmask[i] >> tap) & 1u) && kx == 1;
+#else
       const bool ok = ((tapmask[i] >> tap) & 1u);               // pad channels are zeros in memory: no channel check
+#endif
       const unsigned off = rbA[i] + (unsigned)soff;
+#ifdef OCV_ABL_KXRAND             // ... the other taps read RANDOM (L1-resident) rows, so that the matrix pipe toggles as with real data
+      const char* rp = (const char*)ocv_rand_page + (64 * pw + 16 * i + lrow) * 128 + lchunk * 16;
+      const void* sh = ok ? (const void*)((const char*)p.xhl + off) : (const void*)rp;
+      const void* sl = ok ? (const void*)((const char*)p.xhl + off + 64) : (const void*)(rp + 64);
+#else
       const void* sh = ok ? (const void*)((const char*)p.xhl + off) : (const void*)ocv_zero_page;
       const void* sl = ok ? (const void*)((const char*)p.xhl + off + 64) : (const void*)ocv_zero_page;   // same 128-B line
+#endif
       unsigned char* dst = base + (64 * pw + 16 * i) * DROW;
       __builtin_amdgcn_global_load_lds((gptr_t)sh, (lptr_t)dst, 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)sl, (lptr_t)(dst + DA), 16, 0, 0);
@@ -766,6 +779,18 @@ int launch_conv(ConvArgs& a, int B, bool in_split, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
+#ifdef OCV_ABL_KXRAND
+  {
+    static bool filled = false;
+    if (!filled) {
+      static unsigned short hostbuf[256 * 64];
+      unsigned x = 12345u;
+      for (int i = 0; i < 256 * 64; ++i) { x = x * 1664525u + 1013904223u; hostbuf[i] = (unsigned short)(0x3c00u + ((x >> 16) & 0x3ffu) + (((x >> 8) & 1u) << 15)); }   // |v| in [~0.008, ~0.03], random sign
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(ocv_rand_page), hostbuf, sizeof(hostbuf));
+      filled = true;
+    }
+  }
+#endif
   static const bool use_dma = getenv("OCV_CONV_NO_DMA") == nullptr;
   if (in_split && use_dma) {
     static bool attr2 = false;
