@@ -300,6 +300,28 @@ int ocv_depth_metrics_fwd(const float* pred, const float* pred_mirror, int h, in
                           long first_image_id, float* records, int B, void* workspace, size_t workspace_bytes,
                           ocv_stream_t stream);
 
+/* Positional-embedding samplers of GridRandomPositionalEmbeddings.forward (modules/ObjCAViT.py:50-147) on the learnable
+ * table `table` [>= gh*gw][E], viewed as a gh x gw grid of E-vectors (row y*gw + x; reference :82-83).  One output row
+ * per coordinate row: out[r][0..E) = sample (+ addend[r][0..E) when addend is not NULL -- the object embedding it is
+ * added to at :330).  coords [n_rows][coord_ld] fp32.
+ *   OCV_POS_CENTRE_OBJ  coords = (x, y, ...) in full-resolution pixels; F.grid_sample(bilinear, zeros,
+ *                       align_corners=False) at (x / p0 * 2 - 1, y / p1 * 2 - 1); the reference passes
+ *                       p0 = image HEIGHT, p1 = image WIDTH (:104-105).                       (:102-110)
+ *   OCV_POS_CENTRE_IMG  coords = (x, y, ...) of the image tokens, rows_per_image = S rows per image; row s = r % S:
+ *                       s == 0 -> both components / p0 * 2 - 1 (p0 = gh), s == 1 -> both / p1 * 2 - 1 (p1 = gw),
+ *                       s >= 2 -> raw coordinates (the reference indexes dim 1 of a B x S x 2 tensor; Q6).   (:93-100)
+ *   OCV_POS_ROI         coords = (cx, cy, w, h): x1y1x2y2 = centre -+ half size clamped at 0 from below, then
+ *                       torchvision.ops.ps_roi_align(output_size=[1,1], spatial_scale=p0, sampling_ratio=-1):
+ *                       corners * p0 - 0.5, ceil(roi_h) x ceil(roi_w) bilinear samples averaged (samples outside
+ *                       [-1, gh] x [-1, gw] count as 0; a box without extent gives 0/0 = NaN).            (:111-145)
+ * The sample loops are bounded by the grid size whatever the box; no host synchronisation (hipGraph-capturable). */
+#define OCV_POS_CENTRE_OBJ 0
+#define OCV_POS_CENTRE_IMG 1
+#define OCV_POS_ROI 2
+int ocv_pos_grid_sample_fwd(const float* table, int gh, int gw, int E, const float* coords, int coord_ld, int n_rows,
+                            int mode, float p0, float p1, int rows_per_image, const float* addend, float* out,
+                            ocv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,8 @@ PROTOTYPES = {
     "ocv_conv_nhwc_split_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
     "ocv_conv_nhwc_split_ws_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p, C.c_void_p]
                                    + [C.c_int] * 6 + [C.c_void_p, C.c_size_t, _stream]),
+    "ocv_pos_grid_sample_fwd": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                          C.c_int, _f32p, _f32p, _stream]),
     "ocv_upsample_concat_split_fwd": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_void_p,
                                                 C.c_int, C.c_int, C.c_int, _stream]),
 }

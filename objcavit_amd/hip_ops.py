@@ -441,6 +441,42 @@ def bin_head(feat: torch.Tensor, queries: torch.Tensor, w_out: torch.Tensor, b_o
 
 
 # ---------------------------------------------------------------------------
+# positional-embedding samplers (GridRandomPositionalEmbeddings)
+# ---------------------------------------------------------------------------
+POS_CENTRE_OBJ, POS_CENTRE_IMG, POS_ROI = 0, 1, 2
+
+
+def pos_grid_sample(table: torch.Tensor, gh: int, gw: int, coords: torch.Tensor, mode: int, p0: float, p1: float = 0.0,
+                    rows_per_image: int = 1, addend: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[n, E] samples of the gh x gw grid held in the first gh*gw rows of ``table`` [L, E] at ``coords`` [n, >=2|4]
+    (include/objcavit_hip.h, ocv_pos_grid_sample_fwd); ``addend`` [n, E] is added to the samples when given.
+    No host synchronisation, no data-dependent launch shape."""
+    lib = _lib.load()
+    _req(table, "table"); _req(coords, "coords", contiguous=False)
+    if table.dim() != 2 or coords.dim() != 2:
+        raise ValueError("pos_grid_sample: table must be [L, E], coords [n, k]")
+    L, E = table.shape
+    n, k = coords.shape
+    if coords.stride(1) != 1 or (n > 1 and coords.stride(0) < k):
+        coords = coords.contiguous()
+    ld = coords.stride(0) if n > 1 else k           # rows may be a column slice of a wider matrix (xywh[:, 0:2])
+    if gh < 1 or gw < 1 or gh * gw > L:
+        raise ValueError(f"pos_grid_sample: a {gh} x {gw} grid needs {gh * gw} table rows, the table has {L}")
+    if k < (4 if mode == POS_ROI else 2):
+        raise ValueError(f"pos_grid_sample: coords with {k} columns are too narrow for mode {mode}")
+    if addend is not None:
+        _req(addend, "addend")
+        if addend.shape != (n, E):
+            raise ValueError(f"pos_grid_sample: addend must be {(n, E)}, got {tuple(addend.shape)}")
+    out = torch.empty(n, E, dtype=torch.float32, device=table.device)
+    with timed("pos_grid_sample"):
+        check(lib.ocv_pos_grid_sample_fwd(table.data_ptr(), gh, gw, E, coords.data_ptr(), ld, n, mode, float(p0), float(p1),
+                                          int(rows_per_image), _ptr(addend), out.data_ptr(), _stream()),
+              "ocv_pos_grid_sample_fwd")
+    return out
+
+
+# ---------------------------------------------------------------------------
 # depthwise convolution (EfficientNet MBConv)
 # ---------------------------------------------------------------------------
 def depthwise_conv_same(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int,

@@ -11,9 +11,11 @@ HIP (libobjcavit_hip.so): patch-embedding convolution fused with bias +
   projection, masked multi-head attention, out-proj + residual + LayerNorm,
   FFN + residual + LayerNorm), both cross-attentions, every Linear (object
   embedding, positional MLP, regressor) and the pixel-wise dot product.
-MIOpen through PyTorch-ROCm: the 3x3 convolution.
+  The 3x3 convolution is the split-bf16 implicit GEMM of csrc/conv_igemm.hip
+  (ocv_conv_nhwc_split_fwd) and the grid_random / grid_random_roi_align
+  positional strategies are ocv_pos_grid_sample_fwd (csrc/pos_sample.hip).
 PyTorch glue (a few KB of data): padding ragged object lists, bin-width
-  normalisation, grid_sample / roi-align positional strategies.
+  normalisation.
 
 Reference behaviours that are reproduced on purpose:
 Q1 key rows are FRONT-padded with 1e-4 while the mask is BACK-padded; Q2 the
@@ -38,60 +40,35 @@ from .miniViT import regress_bin_widths
 PAD_VALUE = 0.0001          # reference :183,194
 
 
+class _PerDevice:
+    """Small constant device tensors built on first use (outside graph capture) and reused: building them inside a
+    forward would be a host -> device copy, which a hipGraph capture cannot contain."""
+
+    def __init__(self, make):
+        self._make, self._vals = make, {}
+
+    def get(self, dev, *key):
+        k = (str(dev),) + key
+        v = self._vals.get(k)
+        if v is None:
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("constant not cached yet: run one eager warm-up call before graph capture")
+            v = self._vals[k] = self._make(dev, *key)
+        return v
+
+
+_NO_BOX = _PerDevice(lambda dev: torch.full((1, 4), -1.0, device=dev))                      # reference :313
+_RAGGED_MASK = _PerDevice(lambda dev, counts: (torch.arange(max(counts))[None, :] >= torch.tensor(counts)[:, None]).to(dev))
+
+
 # ---------------------------------------------------------------------------
 # positional embeddings
 # ---------------------------------------------------------------------------
-def _ps_roi_align_1x1(grid: torch.Tensor, boxes: torch.Tensor, spatial_scale: float) -> torch.Tensor:
-    """Position-sensitive RoI-align with a 1x1 output on a 1 x C x H x W grid
-    (torchvision.ops.ps_roi_align(..., output_size=[1,1], sampling_ratio=-1)),
-    vectorised over boxes.  boxes K x 4 (x1,y1,x2,y2) -> K x C."""
-    C, H, W = grid.shape[1:]
-    K = boxes.shape[0]
-    b = boxes * spatial_scale - 0.5
-    x1, y1 = b[:, 0], b[:, 1]
-    rw = (b[:, 2] - x1).clamp(min=0.1)
-    rh = (b[:, 3] - y1).clamp(min=0.1)
-    gw = torch.ceil(rw).clamp(min=1)
-    gh = torch.ceil(rh).clamp(min=1)
-    nmax_y, nmax_x = int(gh.max().item()), int(gw.max().item())
-    iy = torch.arange(nmax_y, device=grid.device, dtype=grid.dtype)
-    ix = torch.arange(nmax_x, device=grid.device, dtype=grid.dtype)
-    yy = y1[:, None] + (iy[None, :] + 0.5) * (rh / gh)[:, None]          # K x ny
-    xx = x1[:, None] + (ix[None, :] + 0.5) * (rw / gw)[:, None]          # K x nx
-    vy = iy[None, :] < gh[:, None]
-    vx = ix[None, :] < gw[:, None]
-
-    def prep(v, size):
-        inside = (v >= -1.0) & (v <= size)
-        v = v.clamp(min=0.0)
-        lo = v.floor()
-        top = lo >= size - 1
-        lo = torch.where(top, torch.full_like(lo, size - 1), lo)
-        hi = torch.where(top, lo, lo + 1)
-        v = torch.where(top, lo, v)
-        frac = v - lo
-        return lo.long(), hi.long(), frac, inside
-
-    yl, yh, ly, oky = prep(yy, H)
-    xl, xh, lx, okx = prep(xx, W)
-    g = grid[0]                                                          # C x H x W
-
-    def gather(yi, xi):                                                  # -> K x ny x nx x C
-        return g[:, yi[:, :, None], xi[:, None, :]].permute(1, 2, 3, 0)
-
-    hy, hx = 1 - ly, 1 - lx
-    val = (gather(yl, xl) * (hy[:, :, None] * hx[:, None, :])[..., None]
-           + gather(yl, xh) * (hy[:, :, None] * lx[:, None, :])[..., None]
-           + gather(yh, xl) * (ly[:, :, None] * hx[:, None, :])[..., None]
-           + gather(yh, xh) * (ly[:, :, None] * lx[:, None, :])[..., None])
-    wgt = ((vy & oky)[:, :, None] & (vx & okx)[:, None, :]).to(grid.dtype)[..., None]
-    return (val * wgt).sum(dim=(1, 2)) / (gh * gw)[:, None]
-
-
 class GridRandomPositionalEmbeddings(nn.Module):
-    """One learnable vector per image patch (reference :18-147).  ``forward``
-    reproduces the reference's sampling literally, including its coordinate
-    normalisation."""
+    """One learnable vector per image patch (reference :18-147).  ``forward`` is ONE launch of
+    ``ocv_pos_grid_sample_fwd`` (csrc/pos_sample.hip) whatever the mode: the reference's coordinate normalisation
+    (SURVEY.md Q6), F.grid_sample and torchvision's ps_roi_align (third-party, restated: DESIGN.md section 2) all
+    happen inside the kernel -- no host synchronisation, no per-image loop, capturable."""
 
     def __init__(self, args, embedding_dim, patch_size, mode="centre"):
         super().__init__()
@@ -106,31 +83,29 @@ class GridRandomPositionalEmbeddings(nn.Module):
         self.sequence_length = max(lengths)
         self.positional_encodings = nn.Parameter(torch.rand(self.sequence_length, self.embedding_dim), requires_grad=True)
 
-    def forward(self, coords, image_features, input_coord_space="img", factor=2.0):
+    def forward(self, coords, image_features, input_coord_space="img", factor=2.0, addend=None):
+        """coords N x {2,4} ("obj", full-resolution pixels) -> N x E, or B x S x {2,4} ("img") -> B x S x E.
+        ``addend`` (same shape as the result) is added to the samples inside the kernel."""
         fh, fw = image_features.shape[2], image_features.shape[3]
-        gh, gw = math.ceil(fh / self.patch_size), math.ceil(fw / self.patch_size)
-        grid = self.positional_encodings[0:gh * gw, :].view(gh, gw, -1).permute(2, 0, 1).unsqueeze(0).contiguous()
-        if self.mode == "centre":
-            nc = coords.clone()
-            if input_coord_space == "img":
-                nc[:, 0] = ((nc[:, 0] / gh) * 2) - 1          # dim 1 of B x S x 2: tokens 0 and 1 (reference :95-96)
-                nc[:, 1] = ((nc[:, 1] / gw) * 2) - 1
-                nc = nc.unsqueeze(1)
-                s = F.grid_sample(grid.expand(nc.shape[0], -1, -1, -1), nc, mode="bilinear", padding_mode="zeros",
-                                  align_corners=False)
-                return s.squeeze(2).permute(0, 2, 1).contiguous()
-            nc[:, 0] = ((nc[:, 0] / (fh * factor)) * 2) - 1   # x over HEIGHT, y over WIDTH (reference :104-105)
-            nc[:, 1] = ((nc[:, 1] / (fw * factor)) * 2) - 1
-            s = F.grid_sample(grid, nc.view(1, 1, nc.shape[0], 2), mode="bilinear", padding_mode="zeros",
-                              align_corners=False)
-            return s.squeeze(2).squeeze(0).permute(1, 0).contiguous()
-        hw, hh = coords[..., 2] / 2, coords[..., 3] / 2
-        xyxy = torch.stack([coords[..., 0] - hw, coords[..., 1] - hh, coords[..., 0] + hw, coords[..., 1] + hh],
-                           dim=-1).clamp(min=0.0)
+        gh, gw = math.ceil(fh / self.patch_size), math.ceil(fw / self.patch_size)          # :78-79
+        table = self.positional_encodings.detach()
+        need = 2 if self.mode == "centre" else 4
+        if coords.shape[-1] < need:
+            raise ValueError(f"GridRandomPositionalEmbeddings({self.mode}): coords need {need} columns")
         if input_coord_space == "img":
-            B, S = xyxy.shape[:2]
-            return _ps_roi_align_1x1(grid, xyxy.reshape(B * S, 4), 1 / self.patch_size).view(B, S, -1)
-        return _ps_roi_align_1x1(grid, xyxy, 1 / (self.patch_size * factor))
+            B, S = coords.shape[:2]
+            flat = coords.reshape(B * S, coords.shape[-1])
+            add = None if addend is None else addend.reshape(B * S, -1)
+            if self.mode == "centre":
+                out = hip_ops.pos_grid_sample(table, gh, gw, flat, hip_ops.POS_CENTRE_IMG, gh, gw, rows_per_image=S, addend=add)
+            else:
+                out = hip_ops.pos_grid_sample(table, gh, gw, flat, hip_ops.POS_ROI, 1.0 / self.patch_size, addend=add)  # :128
+            return out.view(B, S, -1)
+        if self.mode == "centre":
+            return hip_ops.pos_grid_sample(table, gh, gw, coords, hip_ops.POS_CENTRE_OBJ, fh * factor, fw * factor,
+                                           addend=addend)                                                            # :104-109
+        return hip_ops.pos_grid_sample(table, gh, gw, coords, hip_ops.POS_ROI, 1.0 / (self.patch_size * factor),
+                                       addend=addend)                                                                # :144
 
 
 def _mlp_hip(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
@@ -173,8 +148,7 @@ class SelfAttnCrossAttn(nn.Module):
         if all(c == nmax for c in counts):
             return torch.stack(list(object_features), dim=0), torch.zeros(len(counts), nmax, dtype=torch.bool, device=device)
         feats = nn.utils.rnn.pad_sequence(list(object_features), batch_first=True, padding_value=PAD_VALUE)
-        mask = torch.arange(nmax, device=device)[None, :] >= torch.tensor(counts, device=device)[:, None]
-        return feats, mask
+        return feats, _RAGGED_MASK.get(device, tuple(counts))     # True = padding (:180-181)
 
     def object_self_attention(self, object_features, device):
         """The object half of ``forward`` -- pad + mask, self-attention stack -- which does not depend on the image
@@ -264,48 +238,49 @@ class ObjCAViT(nn.Module):
         pc = pc.expand(B, -1, -1).permute(0, 2, 1).float()
         return torch.cat([pc, torch.ones_like(pc) * self.patch_size], dim=2)
 
-    def _object_pos(self, xywh: torch.Tensor, image_features: torch.Tensor) -> torch.Tensor:
-        if self.strategy == "grid_random":
-            return self.positional_encoder(xywh[:, 0:2], image_features, "obj")
-        if self.strategy == "grid_random_roi_align":
-            return self.positional_encoder(xywh[:, 0:4], image_features, "obj")
-        return _mlp_hip(self.positional_encoder, xywh[:, 0:_MLP_IN[self.strategy]])
+    def _object_pos(self, xywh: torch.Tensor, image_features: torch.Tensor, addend: torch.Tensor) -> torch.Tensor:
+        """addend + positional embedding of every object row of the batch, one launch (reference :316-330)."""
+        if self.strategy.startswith("grid_random"):
+            return self.positional_encoder(xywh, image_features, "obj", addend=addend)
+        return _mlp_hip(self.positional_encoder, xywh[:, 0:_MLP_IN[self.strategy]]) + addend
 
     def _image_pos(self, image_features: torch.Tensor, gh: int, gw: int) -> torch.Tensor:
-        """Positional embedding of the image tokens: [S, E] (shared by the batch) for the MLP strategies -- it
-        depends only on (gh, gw) and the weights, so in eval it is computed once and cached --
-        or [B, S, E] for the grid strategies."""
-        B = image_features.shape[0]
-        if self.strategy in _MLP_IN:
-            params = [p for p in self.positional_encoder.parameters()]
-            key = (gh, gw, image_features.device, tuple(p.data_ptr() for p in params), tuple(p._version for p in params))
-            hit = self._img_pos_cache.get("k") == key
-            if not hit:
-                pc = self._patch_coords(1, gh, gw, image_features.device)[0]
-                self._img_pos_cache = {"k": key, "v": _mlp_hip(self.positional_encoder, pc[:, 0:_MLP_IN[self.strategy]])}
-            return self._img_pos_cache["v"]
-        pc = self._patch_coords(B, gh, gw, image_features.device)
-        n = 2 if self.strategy == "grid_random" else 4
-        return self.positional_encoder(pc[..., 0:n], image_features, "img").contiguous()
+        """Positional embedding of the image tokens, [S, E] shared by the batch: it depends only on (gh, gw) and the
+        weights -- the patch coordinates are the same for every image (:336-347) -- so in eval it is computed once
+        per parameter version and cached."""
+        params = [p for p in self.positional_encoder.parameters()]
+        key = (gh, gw, tuple(image_features.shape[2:]), image_features.device, tuple(p.data_ptr() for p in params),
+               tuple(p._version for p in params))
+        if self._img_pos_cache.get("k") != key:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("image positional embedding not cached yet: run one eager warm-up call before capture")
+            pc = self._patch_coords(1, gh, gw, image_features.device)
+            if self.strategy in _MLP_IN:
+                v = _mlp_hip(self.positional_encoder, pc[0, :, 0:_MLP_IN[self.strategy]])
+            else:
+                v = self.positional_encoder(pc, image_features[:1], "img")[0]
+            self._img_pos_cache = {"k": key, "v": v.contiguous()}
+        return self._img_pos_cache["v"]
 
     # -- forward ---------------------------------------------------------------
     def _embed_objects(self, object_features, object_xywh_list, dev, image_features):
-        """Linear(512 -> E) + positional embedding of all objects of the batch in one launch (reference :311-330);
-        overwrites the caller's list like the reference (:330).  ``image_features`` is only read by the grid strategies."""
+        """Linear(512 -> E) + positional embedding of all objects of the batch as ONE flattened [sum N_i, .] problem
+        (reference :311-330: a Python loop over images); overwrites the caller's list like the reference (:330).
+        ``image_features`` is only read (for its shape) by the grid strategies."""
         B = len(object_features)
-        boxes = [torch.full((1, 4), -1.0, device=dev) if b is None else b.to(dev, torch.float32) for b in object_xywh_list]
+        boxes = [_NO_BOX.get(dev) if b is None else b.to(dev, torch.float32) for b in object_xywh_list]    # :313
         counts = [int(f.shape[0]) for f in object_features]
+        need = 2 if self.strategy in ("learned", "grid_random") else 4
         for c, b in zip(counts, boxes):
-            if b.shape[0] != c:
-                raise ValueError("object_features and object_xywh_list disagree on the number of objects")
+            if b.dim() != 2 or b.shape[0] != c or b.shape[1] < need:
+                raise ValueError("object_features and object_xywh_list disagree on the number of objects "
+                                 f"(or boxes have fewer than {need} columns)")
         all_feat = torch.cat([f.to(dev, torch.float32) for f in object_features], dim=0)
-        all_box = torch.cat(boxes, dim=0)
-        if self.strategy.startswith("grid_random"):
-            pos = torch.cat([self._object_pos(b, image_features) for b in boxes], dim=0)
-        else:
-            pos = self._object_pos(all_box, image_features)
+        width = min(b.shape[1] for b in boxes)
+        all_box = torch.cat([b[:, :width] for b in boxes], dim=0)
         emb = hip_ops.linear(all_feat.contiguous(), self.obj_embedding_layer.weight.detach(),
-                             self.obj_embedding_layer.bias.detach()) + pos
+                             self.obj_embedding_layer.bias.detach())
+        emb = self._object_pos(all_box, image_features, emb)
         objs = list(torch.split(emb, counts, dim=0))
         for i in range(B):
             object_features[i] = objs[i]                       # the reference overwrites the caller's list (:330)

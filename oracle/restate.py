@@ -19,6 +19,7 @@ from __future__ import annotations
 import math
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -196,11 +197,11 @@ def grid_sample_bilinear_zeros(inp: torch.Tensor, grid: torch.Tensor) -> torch.T
     return out
 
 
-def _roi_bilinear(ch: torch.Tensor, y: float, x: float) -> float:
-    """torchvision bilinear_interpolate for one H x W channel."""
-    H, W = ch.shape
+def _roi_bilinear(g: torch.Tensor, y: float, x: float):
+    """torchvision bilinear_interpolate at one (y, x) for all channels of a C x H x W grid (0 outside [-1, size])."""
+    C, H, W = g.shape
     if y < -1.0 or y > H or x < -1.0 or x > W:
-        return 0.0
+        return None
     y = max(y, 0.0)
     x = max(x, 0.0)
     yl, xl = int(y), int(x)
@@ -216,7 +217,7 @@ def _roi_bilinear(ch: torch.Tensor, y: float, x: float) -> float:
         xh = xl + 1
     ly, lx = y - yl, x - xl
     hy, hx = 1.0 - ly, 1.0 - lx
-    return float(hy * hx * ch[yl, xl] + hy * lx * ch[yl, xh] + ly * hx * ch[yh, xl] + ly * lx * ch[yh, xh])
+    return hy * hx * g[:, yl, xl] + hy * lx * g[:, yl, xh] + ly * hx * g[:, yh, xl] + ly * lx * g[:, yh, xh]
 
 
 def ps_roi_align_1x1(grid: torch.Tensor, boxes: torch.Tensor, spatial_scale: float) -> torch.Tensor:
@@ -224,28 +225,55 @@ def ps_roi_align_1x1(grid: torch.Tensor, boxes: torch.Tensor, spatial_scale: flo
     output_size=[1,1], spatial_scale, sampling_ratio=-1) -> K x C.
 
     PARITY UNPINNED (torchvision==0.13.1, conda_environment_files/graphbins.yml:168,
-    is absent from the container).  Published algorithm: roi corners are
-    scaled and shifted by -0.5; bin = roi (pooled 1x1, min size 0.1); adaptive
-    sampling grid ceil(roi_h) x ceil(roi_w); output channel c reads input
-    channel c (1x1 pooling => identity channel map); samples are averaged.
+    is absent from the container and the reference holds no fixture for it).
+    Published algorithm (torchvision/csrc/ops/cpu/ps_roi_align_kernel.cpp,
+    restated from memory of the public source): roi corners are scaled and
+    shifted by -0.5 ("do not use rounding"); pooled 1x1 => bin = roi, with NO
+    minimum extent (the 0.1 floor belongs to ps_roi_POOL); adaptive sampling
+    grid ceil(roi_h) x ceil(roi_w); sample (iy, ix) at start + (i + .5) *
+    extent / n; bilinear_interpolate returns 0 outside [-1, size], clamps
+    negatives to 0 and the last row / column to itself; samples are summed and
+    divided by the FULL count (a box without extent: 0 / 0 = NaN); with a 1x1
+    output, output channel c reads input channel c.  Samples that cannot lie
+    inside [-1, size] are skipped here by index window (same sum: they are 0),
+    which bounds the loops by the grid size.
     Call sites: modules/ObjCAViT.py:128,144."""
     C, H, W = grid.shape[1:]
-    out = torch.zeros(boxes.shape[0], C, dtype=grid.dtype)
+    g = grid[0].double()
+    out = torch.zeros(boxes.shape[0], C, dtype=torch.float64)
+
+    f32 = np.float32
+
+    def window(start, step, n, size):
+        start, step = float(start), float(step)
+        lo = max(int(math.floor((-1.0 - start) / step - 0.5)) - 1, 0)
+        hi = min(int(math.ceil((size - start) / step - 0.5)) + 1, n - 1)
+        return lo, hi
+
     for n in range(boxes.shape[0]):
-        x1, y1, x2, y2 = (float(v) * spatial_scale - 0.5 for v in boxes[n])
-        rw = max(x2 - x1, 0.1)
-        rh = max(y2 - y1, 0.1)
-        gh = max(int(math.ceil(rh)), 1)
-        gw = max(int(math.ceil(rw)), 1)
-        for c in range(C):
-            acc = 0.0
-            for iy in range(gh):
-                yy = y1 + (iy + 0.5) * rh / gh
-                for ix in range(gw):
-                    xx = x1 + (ix + 0.5) * rw / gw
-                    acc += _roi_bilinear(grid[0, c], yy, xx)
-            out[n, c] = acc / (gh * gw)
-    return out
+        # coordinate arithmetic in fp32 like the published kernel (T = float): ceil() and the inside test are
+        # discontinuous, so the restatement must round where the reference rounds; the sum itself is kept in fp64
+        x1, y1, x2, y2 = (f32(float(v)) * f32(spatial_scale) - f32(0.5) for v in boxes[n])
+        rw, rh = x2 - x1, y2 - y1
+        if not all(math.isfinite(float(v)) for v in (x1, y1, rw, rh)):
+            out[n] = float("nan")
+            continue
+        gh, gw = max(int(math.ceil(float(rh))), 0), max(int(math.ceil(float(rw))), 0)
+        if gh * gw == 0:
+            out[n] = float("nan")                      # 0 / 0
+            continue
+        acc = torch.zeros(C, dtype=torch.float64)
+        ylo, yhi = window(y1, rh / gh, gh, H)
+        xlo, xhi = window(x1, rw / gw, gw, W)
+        for iy in range(ylo, yhi + 1):
+            yy = y1 + f32(iy + 0.5) * rh / f32(gh)
+            for ix in range(xlo, xhi + 1):
+                xx = x1 + f32(ix + 0.5) * rw / f32(gw)
+                v = _roi_bilinear(g, float(yy), float(xx))
+                if v is not None:
+                    acc += v
+        out[n] = acc / (gh * gw)
+    return out.to(grid.dtype)
 
 
 def _xywh_to_xyxy_clamped(c: torch.Tensor) -> torch.Tensor:

@@ -1,0 +1,79 @@
+"""-m gpu: the BASELINE.json configurations at their FULL size and per-GPU batch, through boundary A
+(GraphBins.forward -> C ABI), eager dispatch AND hipGraph replay:
+
+  configs[2]  NYU 480x640, learned positional MLP, 32 objects / image with random 512-d text features, bs = 16
+  configs[3]  KITTI 352x1216, learned_bbox_wh, 2 x SA/CA, bs = 32 over 4 GPUs -> 8 per GPU
+  configs[4]  NYU 480x640, grid_random_roi_align, 64 objects / image, bs = 128 over 8 GPUs -> 16 per GPU,
+              hipGraph-captured forward
+
+Every image of the batch is checked: ORACLE_IMAGES of them against the CPU oracle (north-star bar: 1e-3 relative on
+the depth map), all of them for finiteness / bin range / monotone edges, for batch independence (the same image in a
+different sub-batch gives the same depth: what makes data-parallel sharding safe) and for replay == eager, bit for
+bit."""
+import pytest
+import torch
+
+import gen
+from oracle import restate
+from objcavit_amd.config import make_args
+from util import max_rel, rel_dev
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+CONFIGS = {
+    "configs[2]": dict(kw=dict(strategy="learned"), dataset="nyu", H=480, W=640, n_obj=32, B=16, oracle=(0, 5, 10, 15)),
+    "configs[3]": dict(kw=dict(strategy="learned_bbox_wh", use_2_saca=True), dataset="kitti", H=352, W=1216, n_obj=24, B=8,
+                       oracle=(0, 3, 7)),
+    "configs[4]": dict(kw=dict(strategy="grid_random_roi_align"), dataset="nyu", H=480, W=640, n_obj=64, B=16,
+                       oracle=(1, 6, 11, 15)),
+}
+
+
+@pytest.mark.parametrize("tag", list(CONFIGS))
+def test_baseline_config_full_size_every_image(tag):
+    from objcavit_amd.graph import GraphedGraphBins
+    from objcavit_amd.modules.GraphBins import GraphBins, SyntheticObjectProvider
+    c = CONFIGS[tag]
+    H, W, B, kw = c["H"], c["W"], c["B"], c["kw"]
+    args = make_args(dataset=c["dataset"], language="clip", dimensions_train=[H, W], dimensions_test=[H, W], **kw)
+    dmax = float(args[c["dataset"]].max_depth)
+    m = GraphBins(args, object_provider=SyntheticObjectProvider(c["n_obj"], "clip", seed=9)).eval()
+    gen.load_into(m, 31, gen.PEAKY)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.cuda()
+    img = gen.randn("img", (B, 3, H, W), 31).cuda()
+
+    out = m(img)
+    d, e = out.depth_pred.clone(), out.bin_edges.clone()
+    # properties, every image
+    assert tuple(d.shape) == (B, 1, H // 2, W // 2) and tuple(e.shape) == (B, 257)
+    assert bool(torch.isfinite(d).all()) and bool(torch.isfinite(e).all())
+    assert bool((e[:, 1:] > e[:, :-1]).all())
+    assert float((e[:, 0] - 0.001).abs().max()) < 1e-6 and float((e[:, -1] - dmax).abs().max()) < 1e-3 * dmax
+    assert float(d.min()) >= 0.001 and float(d.max()) <= dmax
+    assert min(float(x.max() - x.min()) for x in d) > 0.05                              # no image is a constant map
+
+    # oracle, ORACLE_IMAGES of the batch (each alone: the oracle's cost is per image)
+    feats, boxes, _ = m.object_provider(img)
+    for i in c["oracle"]:
+        ref, ref_e = restate.graphbins_forward(img[i:i + 1].cpu(), [feats[i].cpu()], [boxes[i].cpu()], sd, 0.001, dmax, **kw)
+        assert rel_dev(e[i:i + 1], ref_e) < 1e-4, (tag, i)
+        assert max_rel(d[i:i + 1], ref) < 1e-3, (tag, i)
+
+    # batch independence, every image: the two halves of the batch as batches of their own
+    # (use_2_saca couples images through Nmax only -- SURVEY.md Q3 -- and every image has the same object count here)
+    h = B // 2
+    for lo in (0, h):
+        sub = m(img[lo:lo + h], [f.clone() for f in feats[lo:lo + h]], [b.clone() for b in boxes[lo:lo + h]])
+        assert max_rel(sub.depth_pred, d[lo:lo + h]) < 1e-3, (tag, lo)
+        assert rel_dev(sub.bin_edges, e[lo:lo + h]) < 1e-4
+
+    # hipGraph replay == eager dispatch, bit for bit, every image; also for new contents of the static input
+    g = GraphedGraphBins(m, img)
+    r = g(img)
+    assert torch.equal(r.depth_pred, d) and torch.equal(r.bin_edges, e), tag
+    img2 = gen.randn("img2", (B, 3, H, W), 32).cuda()
+    d2 = m(img2).depth_pred.clone()
+    assert torch.equal(g(img2).depth_pred, d2) and not torch.equal(d2, d)
+    assert torch.equal(g(img).depth_pred, d)

@@ -645,3 +645,74 @@ def test_conv_nhwc_split_many_tiles(ops, B, H, W, Cin, Cout, k, act):
     assert torch.equal(y, ops.conv_nhwc_split(xs, hi, lo, dev(b), k, act, out_fp32=True, out_split=False))
     y3 = ops.conv_nhwc(dev(x), None, hi, lo, dev(b), k, act)        # fp32-input kernel
     assert rel_dev(y, y3) < 1e-5
+
+
+# ------------------------------------------------------------------ positional-embedding samplers
+def test_pos_grid_sample_roi_vs_hand_computed_boxes(ops):
+    """ocv_pos_grid_sample_fwd, RoI mode, against the hand-computed boxes of tests/roi_cases.py (box inside one cell,
+    spanning cells, clipped at 0, beyond the grid, adaptive counts; no extent -> NaN) -- independent of the oracle."""
+    import roi_cases as rc
+    table = dev(rc.grid_table())
+    boxes = dev(torch.tensor([c[1] for c in rc.CASES]))
+    want = torch.tensor([c[2] for c in rc.CASES], dtype=torch.float64)
+    got = ops.pos_grid_sample(table, rc.GH, rc.GW, boxes, ops.POS_ROI, rc.SCALE)
+    assert float((got.cpu().double() - want).abs().max()) < 1e-6, (got, want)
+    nan = ops.pos_grid_sample(table, rc.GH, rc.GW, dev(torch.tensor(rc.NAN_BOXES)), ops.POS_ROI, rc.SCALE)
+    assert bool(torch.isnan(nan).all())
+    # huge and non-finite boxes terminate (bounded sample window) and give finite values / NaN
+    wild = dev(torch.tensor([[64.0, 48.0, 3e6, 3e6], [64.0, 48.0, 1e30, 16.0], [float("nan"), 48.0, 16.0, 16.0],
+                             [64.0, 48.0, float("inf"), 16.0]]))
+    w = ops.pos_grid_sample(table, rc.GH, rc.GW, wild, ops.POS_ROI, rc.SCALE).cpu()
+    ind = rc.vectorised_expected(rc.grid_table().numpy(), rc.GH, rc.GW, wild[:1].cpu().numpy(), rc.SCALE)[0]   # ~46877^2 samples
+    assert bool(torch.isfinite(w[0]).all()) and float(np.abs(w[0].double().numpy() / ind - 1).max()) < 1e-3
+    assert bool(torch.isnan(w[1:]).all())
+
+
+@pytest.mark.parametrize("gh,gw,E", [(15, 20, 128), (11, 38, 128), (3, 5, 40), (1, 1, 7)])
+def test_pos_grid_sample_vs_oracle(ops, gh, gw, E):
+    """All four (mode, coordinate space) combinations of GridRandomPositionalEmbeddings.forward against the oracle's
+    literal restatement (grid_sample pinned by torch and the G3 fixture; ps_roi_align by tests/roi_cases.py), plus
+    the fused addend and a column-slice (strided) coordinate operand."""
+    import roi_cases as rc
+    fh, fw, patch, seed = gh * 16, gw * 16, 16, 11 * gh + gw
+    table = gen.uniform("tab", (gh * gw + 3, E), seed)                      # table longer than the grid (:81)
+    H, W = 2 * fh, 2 * fw
+    n = 50
+    rs = np.random.RandomState(seed)
+    xywh = torch.from_numpy(np.stack([rs.uniform(-0.2 * W, 1.3 * W, n), rs.uniform(-0.2 * H, 1.3 * H, n),
+                                      rs.uniform(0.5, 1.5 * W, n), rs.uniform(0.5, 1.5 * H, n)], 1).astype(np.float32))
+    xywh[0] = -1.0                                                          # the reference's "no detections" box (:313)
+    add = rnd("add", (n, E), seed)
+    # objects, centre
+    ref = restate.grid_random_pos_emb(table, xywh[:, 0:2], (fh, fw), patch, "centre", "obj")
+    got = ops.pos_grid_sample(dev(table), gh, gw, dev(xywh)[:, 0:2], ops.POS_CENTRE_OBJ, fh * 2.0, fw * 2.0)
+    assert float((got.cpu() - ref).abs().max()) < 1e-5
+    got = ops.pos_grid_sample(dev(table), gh, gw, dev(xywh), ops.POS_CENTRE_OBJ, fh * 2.0, fw * 2.0, addend=dev(add))
+    assert float((got.cpu() - (ref + add)).abs().max()) < 1e-5
+    # objects, roi_align (box 0 has no extent: NaN on both sides)
+    ref = restate.grid_random_pos_emb(table, xywh, (fh, fw), patch, "roi_align", "obj")
+    got = ops.pos_grid_sample(dev(table), gh, gw, dev(xywh), ops.POS_ROI, 1.0 / 32.0).cpu()
+    assert bool(torch.isnan(ref[0]).all()) and bool(torch.isnan(got[0]).all())
+    assert float((got[1:] - ref[1:]).abs().max()) < 1e-5
+    ind = rc.vectorised_expected(table.numpy(), gh, gw, xywh[1:].numpy(), 1 / 32)
+    assert float(np.abs(got[1:].double().numpy() - ind).max()) < 1e-5
+    # image tokens (patch centres / sizes in feature-map pixels), both modes, B = 2
+    pc = restate.patch_coords(2, gh, gw, patch)
+    S = gh * gw
+    ref = restate.grid_random_pos_emb(table, pc[..., 0:2], (fh, fw), patch, "centre", "img")
+    got = ops.pos_grid_sample(dev(table), gh, gw, dev(pc).reshape(2 * S, 4), ops.POS_CENTRE_IMG, gh, gw, rows_per_image=S)
+    assert float((got.cpu().view(2, S, E) - ref).abs().max()) < 1e-5
+    ref = restate.grid_random_pos_emb(table, pc, (fh, fw), patch, "roi_align", "img")
+    got = ops.pos_grid_sample(dev(table), gh, gw, dev(pc).reshape(2 * S, 4), ops.POS_ROI, 1.0 / patch)
+    assert float((got.cpu().view(2, S, E) - ref).abs().max()) < 1e-5
+
+
+def test_pos_grid_sample_rejects_bad_operands(ops):
+    t = dev(torch.zeros(12, 8))
+    with pytest.raises(ValueError):
+        ops.pos_grid_sample(t, 4, 4, dev(torch.zeros(3, 4)), ops.POS_ROI, 1.0)          # grid larger than the table
+    with pytest.raises(ValueError):
+        ops.pos_grid_sample(t, 3, 4, dev(torch.zeros(3, 2)), ops.POS_ROI, 1.0)          # boxes need 4 columns
+    with pytest.raises(Exception):
+        ops.pos_grid_sample(t, 3, 4, torch.zeros(3, 4), ops.POS_ROI, 1.0)               # CPU tensor
+    assert tuple(ops.pos_grid_sample(t, 3, 4, dev(torch.zeros(0, 4)), ops.POS_ROI, 1.0).shape) == (0, 8)

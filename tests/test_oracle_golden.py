@@ -109,6 +109,34 @@ def test_g5_adabins_config1(tag):
     assert abs(float(depth.min()) - float(z["depth_stats"][0])) < 1e-3
 
 
+def test_ps_roi_align_restatement_vs_hand_computed_boxes():
+    """ps_roi_align is third-party and absent (parity unpinned): the restatement is checked against hand-computed
+    boxes (tests/roi_cases.py) and against an independent separable float64 formulation on random boxes."""
+    import roi_cases as rc
+    table = rc.grid_table()
+    grid = table.view(rc.GH, rc.GW, 2).permute(2, 0, 1).unsqueeze(0).contiguous()
+    boxes = torch.tensor([c[1] for c in rc.CASES])
+    got = restate.ps_roi_align_1x1(grid, restate._xywh_to_xyxy_clamped(boxes), rc.SCALE)
+    want = torch.tensor([c[2] for c in rc.CASES], dtype=torch.float64)
+    assert float((got.double() - want).abs().max()) < 1e-6, (got, want)
+    nan = restate.ps_roi_align_1x1(grid, restate._xywh_to_xyxy_clamped(torch.tensor(rc.NAN_BOXES)), rc.SCALE)
+    assert bool(torch.isnan(nan).all())
+    # the module-level wrapper: "obj" space (scale 1 / (patch * factor)) and "img" space (scale 1 / patch)
+    pos = restate.grid_random_pos_emb(table, boxes, (rc.GH * 16, rc.GW * 16), 16, "roi_align", "obj")
+    assert float((pos.double() - want).abs().max()) < 1e-6
+    pos_img = restate.grid_random_pos_emb(table, (boxes / 2)[None], (rc.GH * 16, rc.GW * 16), 16, "roi_align", "img")
+    assert float((pos_img[0].double() - want).abs().max()) < 1e-6
+    # random boxes on a random table, incl. boxes far larger than the image and boxes hanging over every edge
+    rs = np.random.RandomState(5)
+    gh, gw, E = 15, 20, 8
+    tab = rs.uniform(0, 1, (gh * gw, E)).astype(np.float32)
+    bx = np.stack([rs.uniform(-50, 700, 60), rs.uniform(-50, 530, 60), rs.uniform(0.5, 900, 60), rs.uniform(0.5, 700, 60)], 1)
+    g2 = torch.from_numpy(tab).view(gh, gw, E).permute(2, 0, 1).unsqueeze(0).contiguous()
+    got = restate.ps_roi_align_1x1(g2, restate._xywh_to_xyxy_clamped(torch.from_numpy(bx.astype(np.float32))), 1 / 32)
+    want = rc.vectorised_expected(tab, gh, gw, bx, 1 / 32)
+    assert float(np.abs(got.double().numpy() - want).max()) < 1e-6
+
+
 def test_grid_sample_restatement_matches_torch():
     rs = np.random.RandomState(0)
     inp = torch.from_numpy(rs.standard_normal((2, 5, 7, 9)).astype(np.float32))
