@@ -9,7 +9,7 @@ dist_reduce_fx=...)``; formulas metrics/AbsRel.py:23 etc.).
 from __future__ import annotations
 
 import os
-from typing import Dict, List, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -38,47 +38,52 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def per_image_metrics(pred: torch.Tensor, gt: torch.Tensor, min_depth: float, max_depth: float,
-                      first_image_id: int = 0) -> torch.Tensor:
-    """B x len(RECORD_FIELDS) fp32 record per image (valid = gt inside (min_depth, max_depth)).
-    pred / gt: B x 1 x h x w at the same resolution."""
-    B = pred.shape[0]
-    p = pred.reshape(B, -1).clamp(min_depth, max_depth)
-    g = gt.reshape(B, -1)
-    valid = (g > min_depth) & (g < max_depth)
-    n = valid.sum(1).clamp(min=1).to(p.dtype)
-    gs = torch.where(valid, g, torch.ones_like(g))
-    ps = torch.where(valid, p, torch.ones_like(p))
-    vf = valid.to(p.dtype)
-
-    def mean(t):
-        return (t * vf).sum(1) / n
-
-    ratio = torch.maximum(gs / ps, ps / gs)
-    rec = torch.stack([
-        mean((gs - ps).abs() / gs),
-        mean((gs - ps) ** 2 / gs),
-        torch.sqrt(mean((gs - ps) ** 2)),
-        torch.sqrt(mean((torch.log(gs) - torch.log(ps)) ** 2)),
-        mean((torch.log10(gs) - torch.log10(ps)).abs()),
-        mean((ratio < 1.25).to(p.dtype)), mean((ratio < 1.25 ** 2).to(p.dtype)), mean((ratio < 1.25 ** 3).to(p.dtype)),
-        valid.sum(1).to(p.dtype),
-        torch.arange(first_image_id, first_image_id + B, device=p.device, dtype=p.dtype),
-    ], dim=1)
-    return rec.float().contiguous()
+def rows_per_rank(n_items: int, world: int) -> int:
+    """Rows every rank contributes to the gather: the largest shard of ``shard_range`` (shards differ by at most one)."""
+    return -(-n_items // world) if n_items > 0 else 0
 
 
-def gather_records(local: torch.Tensor, world: int) -> torch.Tensor:
-    """The single collective of an evaluation step: all-gather of the packed per-image records
-    (equal shard sizes) -> (world * B_local) x F, ordered by rank."""
+def pad_records(local: torch.Tensor, rows: int) -> torch.Tensor:
+    """Pad a rank's record table to ``rows`` rows with empty records (n_valid = 0, image_id = -1)."""
+    if local.shape[0] > rows:
+        raise ValueError(f"rank holds {local.shape[0]} records, more than the agreed {rows} per rank")
+    if local.shape[0] == rows:
+        return local.contiguous()
+    pad = torch.zeros(rows - local.shape[0], local.shape[1], dtype=local.dtype, device=local.device)
+    pad[:, RECORD_FIELDS.index("image_id")] = -1.0
+    return torch.cat([local, pad], 0)
+
+
+def drop_padding(table: torch.Tensor) -> torch.Tensor:
+    return table[table[:, RECORD_FIELDS.index("image_id")] >= 0]
+
+
+def gather_records(local: torch.Tensor, world: int, n_total: Optional[int] = None) -> torch.Tensor:
+    """The single collective of an evaluation job: all-gather of the packed per-image records -> table ordered by
+    rank (= by image id for contiguous shards).
+
+    ``all_gather_into_tensor`` needs the same row count on every rank, and ``shard_range`` hands out shards that
+    differ by one when ``n_total`` is not a multiple of ``world`` (654 NYU / 697 KITTI evaluation images on 8 ranks):
+    with ``n_total`` every rank pads its table to ``rows_per_rank(n_total, world)`` rows with empty records
+    (image_id = -1) that are dropped again after the gather -- the row count is agreed from host-side arithmetic, so
+    this stays ONE collective.  Without ``n_total`` the caller asserts equal shards; that is verified with a MIN/MAX
+    all-reduce of the row counts (a mismatch would otherwise hang RCCL or return garbage rows)."""
     if world == 1:
         return local
+    if n_total is not None:
+        local = pad_records(local, rows_per_rank(n_total, world))
+    else:
+        n = torch.tensor([local.shape[0], -local.shape[0]], dtype=torch.int64, device=local.device)
+        dist.all_reduce(n, op=dist.ReduceOp.MAX)
+        if int(n[0]) != -int(n[1]):
+            raise RuntimeError(f"gather_records: ranks hold between {-int(n[1])} and {int(n[0])} records; pass n_total "
+                               "so that every rank pads to the same row count")
     out = torch.empty(world * local.shape[0], local.shape[1], dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous())
-    return out
+    return drop_padding(out) if n_total is not None else out
 
 
 def summarise(records: torch.Tensor) -> Dict[str, float]:
     """Image-wise averages (the reference's ``*RunningAvg`` metrics) from the gathered table."""
-    r = records.double().cpu()
+    r = drop_padding(records).double().cpu()
     return {name: float(r[:, i].mean()) for i, name in enumerate(RECORD_FIELDS[:8])} | {"images": int(r.shape[0])}

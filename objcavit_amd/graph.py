@@ -31,7 +31,10 @@ class GraphedGraphBins:
         self.static_image = example_image.clone()
         self.stream = torch.cuda.Stream()
         self.stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.stream), torch.no_grad():
+        # the graph OWNS its scratch: every workspace requested during warm-up, capture and replay comes from this
+        # store, so no eager call or later capture at other shapes can free a buffer whose address is baked in here
+        self.scratch = hip_ops.WorkspaceStore()
+        with hip_ops.workspace_scope(self.scratch), torch.cuda.stream(self.stream), torch.no_grad():
             for _ in range(warmup):                      # sizes every workspace / weight cache before capture
                 model(self.static_image)
         torch.cuda.current_stream().wait_stream(self.stream)
@@ -62,7 +65,7 @@ class GraphedGraphBins:
 
         hip_ops._Islands.names, hip_ops._Islands.on_break = tuple(eager_ops), on_break
         try:
-            with torch.cuda.stream(self.stream), torch.no_grad():
+            with hip_ops.workspace_scope(self.scratch), torch.cuda.stream(self.stream), torch.no_grad():
                 begin()
                 parts = model.forward_until_head(self.static_image)
                 end()
@@ -70,6 +73,7 @@ class GraphedGraphBins:
             hip_ops._Islands.names, hip_ops._Islands.on_break = (), None
         torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
+        self.scratch.freeze()
         self.feat, self.queries, self.centers, self.bin_edges, self.detections = parts
         self.ReturnType = model.ReturnType
         self.islands = [s[0] for s in self.segments if isinstance(s, tuple)]
@@ -80,11 +84,12 @@ class GraphedGraphBins:
             raise ValueError(f"captured for {tuple(self.static_image.shape)}, got {tuple(image.shape)}")
         if image.data_ptr() != self.static_image.data_ptr():
             self.static_image.copy_(image)
-        for seg in self.segments:
-            if isinstance(seg, tuple):
-                with hip_ops.timed(seg[0]):
-                    seg[1]()
-            else:
-                seg.replay()
-        depth = self.model.head(self.feat, self.queries, self.centers)
+        with hip_ops.workspace_scope(self.scratch):
+            for seg in self.segments:
+                if isinstance(seg, tuple):
+                    with hip_ops.timed(seg[0]):
+                        seg[1]()
+                else:
+                    seg.replay()
+            depth = self.model.head(self.feat, self.queries, self.centers)
         return self.ReturnType(depth_pred=depth, bin_edges=self.bin_edges, detections=self.detections)

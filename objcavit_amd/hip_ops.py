@@ -101,19 +101,54 @@ class timed:
 
 
 # ---------------------------------------------------------------------------
-# workspace: one growing byte buffer per (device, tag)
+# workspace: one growing byte buffer per (device, stream, tag), held in a STORE
 # ---------------------------------------------------------------------------
-_WS: Dict[Tuple[int, str], torch.Tensor] = {}
+class WorkspaceStore(dict):
+    """(device index, stream handle, tag) -> uint8 buffer.  The module-level store serves eager calls.  A captured
+    hipGraph bakes the buffers' addresses into its nodes, so a graph owns a store of its own
+    (``with workspace_scope(store)`` around its warm-up, capture and replays): nothing outside can grow -- i.e. free --
+    scratch that the graph still writes on every replay, and ``freeze()`` turns a later growth request inside the
+    scope into an error instead of a silent re-allocation.  Buffers are keyed by stream as well as tag: two streams of
+    one forward (OCV_OBJ_OVERLAP) never share scratch."""
+
+    def __init__(self):
+        super().__init__()
+        self.frozen = False
+
+    def freeze(self):
+        self.frozen = True
+
+
+_WS = WorkspaceStore()
+_WS_STACK = [_WS]
+
+
+class workspace_scope:
+    def __init__(self, store: WorkspaceStore):
+        self.store = store
+
+    def __enter__(self):
+        _WS_STACK.append(self.store)
+        return self.store
+
+    def __exit__(self, *exc):
+        _WS_STACK.pop()
+        return False
 
 
 def workspace(nbytes: int, device: torch.device, tag: str = "default") -> torch.Tensor:
-    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
-    buf = _WS.get(key)
+    store = _WS_STACK[-1]
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream, tag)
+    buf = store.get(key)
     if buf is None or buf.numel() < nbytes:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("workspace would grow during graph capture: run one eager warm-up call first")
+        if store.frozen and buf is not None:
+            raise RuntimeError(f"workspace {key} of a captured graph would have to grow from {buf.numel()} to {nbytes} "
+                               "bytes: the graph's nodes hold the old address -- capture a new graph for the new shapes")
         buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
-        _WS[key] = buf
+        store[key] = buf
     return buf
 
 

@@ -118,11 +118,20 @@ class _FoldedMixin:
     def _fast(self, x: torch.Tensor) -> bool:
         return (not self.training) and (not torch.is_grad_enabled()) and x.device.type == "cuda"
 
+    def _fold_key(self, x: torch.Tensor):
+        """Identity AND version of every parameter / buffer that enters the fold: an in-place update in eval mode
+        (param.copy_(), EMA / SWA weight swap, edited BN statistics) must re-fold, like every other weight cache here."""
+        ts = list(self.parameters(recurse=True)) + list(self.buffers(recurse=True))
+        return (x.device,) + tuple((t.data_ptr(), t._version) for t in ts)
+
     def _folded(self, x: torch.Tensor):
         c = self.__dict__.get("_fold_cache")
-        if c is None or c[0] != x.device:
+        key = self._fold_key(x)
+        if c is None or c[0] != key:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("BN-folded weights are stale during graph capture: run one eager warm-up call first")
             with torch.no_grad():
-                c = (x.device, self._fold())
+                c = (key, self._fold())
             self.__dict__["_fold_cache"] = c
         return c[1]
 

@@ -11,6 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from objcavit_amd import dp
+from oracle import validation_ref
 
 
 def _free_port():
@@ -23,8 +24,15 @@ def _fake_depths(n, seed=0):
     g = torch.Generator().manual_seed(seed)
     gt = torch.rand(n, 1, 24, 32, generator=g) * 9.5 + 0.2
     gt[:, :, :2, :] = 0.0                                   # invalid pixels (no ground truth)
+    gt[:, :, 2, :] = 10.0                                   # exactly max_depth: VALID (metrics/MetricsPreprocess.py:26, <=)
     pred = gt * (1 + 0.2 * (torch.rand(n, 1, 24, 32, generator=g) - 0.5)) + 0.01
     return pred, gt
+
+
+def _records(pred, gt, first_image_id=0):
+    """Per-image records as the device kernel produces them, here from the pinned CPU oracle of the validation step
+    (the product has exactly one implementation of these formulas, csrc/metrics.hip; no GPU in this suite)."""
+    return validation_ref.per_image_records(pred, gt, 0.001, 10.0, first_image_id=first_image_id)
 
 
 def _worker(rank, world, port, n_images, out_path):
@@ -34,8 +42,9 @@ def _worker(rank, world, port, n_images, out_path):
     assert (r, w) == (rank, world)
     pred, gt = _fake_depths(n_images)
     lo, hi = dp.shard_range(n_images, rank, world)
-    rec = dp.per_image_metrics(pred[lo:hi], gt[lo:hi], 0.001, 10.0, first_image_id=lo)
-    table = dp.gather_records(rec, world)
+    rec = _records(pred[lo:hi], gt[lo:hi], first_image_id=lo)
+    assert rec.shape[0] == hi - lo
+    table = dp.gather_records(rec, world, n_total=n_images)
     if rank == 0:
         torch.save(table, out_path)
     dist.barrier()
@@ -52,29 +61,27 @@ def test_shard_range_partitions_everything():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_per_image_metrics_formulas():
-    """AbsRel = mean(|gt - pred| / gt) over valid pixels (reference metrics/AbsRel.py:23); delta thresholds
-    (reference metrics/AccThresh.py:31-32)."""
-    pred, gt = _fake_depths(3)
-    rec = dp.per_image_metrics(pred, gt, 0.001, 10.0)
-    for i in range(3):
-        m = (gt[i] > 0.001) & (gt[i] < 10.0)
-        p, g = pred[i].clamp(0.001, 10.0)[m].double(), gt[i][m].double()
-        assert abs(float(rec[i, 0]) - float(((g - p).abs() / g).mean())) < 1e-6
-        assert abs(float(rec[i, 2]) - float(((g - p) ** 2).mean().sqrt())) < 1e-5
-        ratio = torch.maximum(g / p, p / g)
-        assert abs(float(rec[i, 5]) - float((ratio < 1.25).double().mean())) < 1e-6
-        assert int(rec[i, 8]) == int(m.sum()) and int(rec[i, 9]) == i
+def test_pad_and_drop_records():
+    rec = _records(*_fake_depths(3))
+    padded = dp.pad_records(rec, 5)
+    assert padded.shape == (5, 10) and padded[3:, 9].tolist() == [-1.0, -1.0] and float(padded[3:, 8].sum()) == 0
+    assert torch.equal(dp.drop_padding(padded), rec)
+    assert dp.summarise(padded) == dp.summarise(rec)
+    assert dp.rows_per_rank(654, 8) == 82 and dp.rows_per_rank(697, 8) == 88 and dp.rows_per_rank(16, 8) == 2
+    with pytest.raises(ValueError):
+        dp.pad_records(rec, 2)
 
 
 @pytest.mark.timeout(120)
-def test_two_rank_gather_equals_single_process(tmp_path):
-    n, world = 8, 2
+@pytest.mark.parametrize("n", [8, 7])
+def test_two_rank_gather_equals_single_process(tmp_path, n):
+    """n = 7: shards of 4 and 3 images -- the short rank pads one empty record, the gathered table drops it."""
+    world = 2
     out = str(tmp_path / "table.pt")
     mp.spawn(_worker, args=(world, _free_port(), n, out), nprocs=world, join=True)
     table = torch.load(out)
     pred, gt = _fake_depths(n)
-    single = dp.per_image_metrics(pred, gt, 0.001, 10.0)
+    single = _records(pred, gt)
     assert table.shape == single.shape
     assert torch.equal(table, single)                       # sharding + one all-gather changes nothing
     assert table[:, 9].tolist() == list(range(n))           # rank-ordered, contiguous image ids

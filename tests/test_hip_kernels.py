@@ -693,9 +693,11 @@ def test_pos_grid_sample_vs_oracle(ops, gh, gw, E):
     ref = restate.grid_random_pos_emb(table, xywh, (fh, fw), patch, "roi_align", "obj")
     got = ops.pos_grid_sample(dev(table), gh, gw, dev(xywh), ops.POS_ROI, 1.0 / 32.0).cpu()
     assert bool(torch.isnan(ref[0]).all()) and bool(torch.isnan(got[0]).all())
-    assert float((got[1:] - ref[1:]).abs().max()) < 1e-5
-    ind = rc.vectorised_expected(table.numpy(), gh, gw, xywh[1:].numpy(), 1 / 32)
-    assert float(np.abs(got[1:].double().numpy() - ind).max()) < 1e-5
+    assert torch.equal(torch.isnan(got), torch.isnan(ref))                  # boxes entirely left of / above the image too
+    assert float((got.nan_to_num(-7.0) - ref.nan_to_num(-7.0)).abs().max()) < 1e-5
+    ind = torch.from_numpy(rc.vectorised_expected(table.numpy(), gh, gw, xywh.numpy(), 1 / 32))
+    assert torch.equal(torch.isnan(ind), torch.isnan(got))
+    assert float((got.double().nan_to_num(-7.0) - ind.nan_to_num(-7.0)).abs().max()) < 1e-5
     # image tokens (patch centres / sizes in feature-map pixels), both modes, B = 2
     pc = restate.patch_coords(2, gh, gw, patch)
     S = gh * gw

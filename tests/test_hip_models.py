@@ -262,3 +262,52 @@ def test_encoder_fast_path_vs_oracle():
     ref_out = restate.decoder_forward(ref, sd, "decoder.")
     assert rel_dev(out, ref_out) < 1e-4
     assert out.is_contiguous(memory_format=torch.channels_last)       # decoder runs NHWC on the GPU
+
+
+def test_graph_owns_its_scratch_and_survives_larger_eager_calls():
+    """A captured graph bakes workspace addresses into its nodes: it keeps its own WorkspaceStore, so an eager forward
+    at a LARGER batch afterwards (which re-allocates the module-level buffers) cannot free memory the graph still
+    writes; growth inside the graph's frozen store raises instead of re-allocating silently."""
+    from objcavit_amd import hip_ops
+    from objcavit_amd.graph import GraphedGraphBins
+    from objcavit_amd.modules.GraphBins import GraphBins, SyntheticObjectProvider
+    H, W = 352, 384
+    args = make_args(dimensions_train=[H, W], dimensions_test=[H, W], language="clip")
+    m = GraphBins(args, object_provider=SyntheticObjectProvider(8, "clip", seed=3)).eval()
+    gen.load_into(m, 58, gen.PEAKY)
+    m = m.cuda()
+    img = gen.randn("img", (1, 3, H, W), 58).cuda()
+    ref = m(img).depth_pred.clone()
+    g = GraphedGraphBins(m, img)
+    assert g.scratch.frozen and len(g.scratch) > 0
+    own = {k: v.data_ptr() for k, v in g.scratch.items()}
+    big = gen.randn("big", (4, 3, H, W), 59).cuda()
+    m(big)                                                   # grows the module-level store, never the graph's
+    junk = [torch.full((1 << 22,), float("nan"), device="cuda") for _ in range(16)]     # recycle whatever was freed
+    assert all(g.scratch[k].data_ptr() == p for k, p in own.items())
+    assert not (set(v.data_ptr() for v in g.scratch.values()) & set(v.data_ptr() for v in hip_ops._WS.values()))
+    assert torch.equal(g(img).depth_pred, ref)
+    del junk
+    with hip_ops.workspace_scope(g.scratch), torch.cuda.stream(g.stream):
+        k = next(k for k in g.scratch if k[1] == g.stream.cuda_stream)
+        with pytest.raises(RuntimeError, match="captured graph"):
+            hip_ops.workspace(g.scratch[k].numel() + 1, img.device, k[2])
+
+
+def test_folded_encoder_weights_follow_in_place_updates():
+    """The BN-folded / split-packed encoder weights are keyed on (data_ptr, version) of every parameter and buffer of
+    the block: an in-place edit in eval mode must change the fast path's output exactly as it changes the oracle's."""
+    from oracle import effnet_ref
+    from objcavit_amd.modules.DenseFeatureExtractor import DenseFeatureExtractor
+    m = DenseFeatureExtractor(make_args()).eval()
+    gen.load_into(m, 9)
+    m = m.cuda()
+    img = gen.randn("img", (1, 3, 96, 128), 9)
+    before = m.encoder(img.cuda())[11].clone()
+    blk = m.encoder.original_model.blocks[2][1]
+    blk.bn2.running_var.mul_(4.0)                            # in place, eval mode, no load_state_dict / train()
+    blk.conv_pwl.weight.data.mul_(0.5)
+    after = m.encoder(img.cuda())[11]
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    ref = effnet_ref.encoder_features(img, sd, "encoder.original_model.")[11]
+    assert rel_dev(after, ref) < 1e-4 and rel_dev(before, ref) > 1e-3
