@@ -2,12 +2,15 @@
 the reference's ``modules/DenseFeatureExtractor.py`` (same class names,
 constructor arguments, attribute names and state_dict keys).
 
-Dense convolutions stay on PyTorch-ROCm / MIOpen (SURVEY.md section 8 row a3 and
-"next" row N1); what is done here on our own terms is the inference-time
-plan: in ``eval()`` every conv+BatchNorm pair of the decoder is folded once
-into a single biased convolution and the folded weights are cached, and the
-encoder keeps only the five activations the decoder reads instead of all
-sixteen.
+GPU inference plan (eval + no_grad), all on
+libobjcavit_hip.so: every conv+BatchNorm pair of the decoder is folded once
+into a single biased convolution (cached per parameter version); resize +
+concat + fp32 -> split-bf16 is one kernel (ocv_upsample_concat_split_fwd) and
+the 3x3 convolutions run on pre-split activations (ocv_conv_nhwc_split_ws_fwd);
+the encoder keeps only the five activations the decoder reads instead of all
+sixteen.  PyTorch-ROCm / MIOpen convolutions run only on request
+(OCV_CONV=miopen, ``third_party_conv``) and in training / on the CPU, where the
+plain module graph is what the golden generator wraps.
 """
 from __future__ import annotations
 
@@ -28,6 +31,23 @@ def split_bf16_convs_enabled() -> bool:
     (OCV_CONV=miopen).  Both are checked against the CPU oracle by the parity tests."""
     import os
     return os.environ.get("OCV_CONV", "split_bf16") != "miopen"
+
+
+_warned_third_party = set()
+
+
+def third_party_conv(what: str) -> None:
+    """Gate in front of every place where the GPU inference path would hand a convolution to PyTorch-ROCm / MIOpen
+    instead of a kernel of libobjcavit_hip.so.  That only happens on request (OCV_CONV=miopen: the exact-fp32
+    third-party route, kept for A/B numerics) -- a shape our kernels do not cover raises instead of silently running
+    somebody else's kernels."""
+    if split_bf16_convs_enabled():
+        from .._lib import HipLibraryError
+        raise HipLibraryError(f"{what}: no hand-written kernel covers this configuration; set OCV_CONV=miopen to route the "
+                              "dense convolutions through PyTorch-ROCm / MIOpen explicitly")
+    if what not in _warned_third_party:
+        _warned_third_party.add(what)
+        logging.getLogger(__name__).warning("OCV_CONV=miopen: %s runs on PyTorch-ROCm / MIOpen, not on libobjcavit_hip.so", what)
 
 
 class SplitConv3x3:
@@ -203,6 +223,8 @@ class UpSampleWithSkip(nn.Module):
         f = torch.cat([up, skip_features], dim=1)
         if self.training or torch.is_grad_enabled():
             return self._net(f)
+        if f.device.type == "cuda":
+            third_party_conv(f"UpSampleWithSkip {tuple(f.shape)}")
         cl = f.device.type == "cuda" and f.is_contiguous(memory_format=torch.channels_last)
         if self._folded is None or self._folded[0].device != f.device or self._folded_cl != cl:
             with torch.no_grad():
@@ -248,6 +270,8 @@ class Decoder(nn.Module):
         if not (b4.device.type == "cuda" and not self.training and not torch.is_grad_enabled()
                 and c.kernel_size == (1, 1) and c.padding == (1, 1) and c.stride == (1, 1) and c.groups == 1
                 and c.in_channels % 8 == 0 and b4.dtype == torch.float32):
+            if b4.device.type == "cuda" and not self.training and not torch.is_grad_enabled():
+                third_party_conv(f"Decoder.conv2 {tuple(b4.shape)}")
             return c(b4)
         key = (b4.device, c.weight._version, c.weight.data_ptr(), None if c.bias is None else c.bias._version)
         cache = self.__dict__.get("_conv2_cache")
@@ -293,8 +317,10 @@ class Decoder(nn.Module):
             x = up(x, skip)
         if self.final_upscale is not None:
             x = self.final_upscale(x, features[0])
-        if x.device.type == "cuda" and not self.training and not torch.is_grad_enabled() and self._split3.usable(x.shape[1]):
-            return self._split3(x)
+        if x.device.type == "cuda" and not self.training and not torch.is_grad_enabled():
+            if self._split3.usable(x.shape[1]):
+                return self._split3(x)
+            third_party_conv(f"Decoder.conv3 {tuple(x.shape)}")
         return self.conv3(x)
 
 

@@ -14,10 +14,11 @@ classifier) and parameter names follow that model family, so that
   .weight`` etc.) loads by key.
 
 Inference plan on the GPU (eval + no_grad): every
-BatchNorm is folded into the preceding convolution once and cached; the
-depthwise k x k stages (+ folded BN + SiLU) run as one hand-written HIP kernel
-(``ocv_depthwise_conv_fwd`` -- MIOpen falls back to a naive kernel for them on
-gfx950); pointwise / stem convolutions stay on MIOpen / hipBLASLt.  In
+BatchNorm is folded into the preceding convolution once and cached per
+parameter version; stem, 1x1 expand / project (+ gate + skip), depthwise
+(+ squeeze-excite pooling) and the gate all run as hand-written NHWC HIP
+kernels (csrc/stem.hip, pointwise_split.hip, depthwise_se.hip,
+mbconv_fused.hip) -- nothing of the encoder reaches MIOpen / hipBLASLt.  In
 training mode or on the CPU the plain PyTorch module graph runs (that is also
 what the golden generator wraps in the reference's ``Encoder``).
 Architecture table: oracle/effnet_ref.py header (width x1.6, depth x2.2,

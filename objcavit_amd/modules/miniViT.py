@@ -1,8 +1,9 @@
 """Drop-in for the reference's ``modules/miniViT.py`` (class ``mViT``): same
 constructor, forward signature, return values and state_dict keys; the
 patch-embedding convolution, the four transformer layers, the regressor and
-the pixel-wise dot product run as HIP kernels, the 3x3 convolution through
-MIOpen.
+the pixel-wise dot product run as HIP kernels, the 3x3 convolution as the
+split-bf16 implicit GEMM of csrc/conv_igemm.hip (MIOpen only on request:
+OCV_CONV=miopen).
 """
 from __future__ import annotations
 
@@ -63,6 +64,8 @@ class mViT(nn.Module):
             if pre is not None and tuple(pre.shape) == tuple(x.shape):
                 return plan.run_split(pre)
             return plan(x)                                            # split-bf16 implicit GEMM, NHWC in / out
+        from .DenseFeatureExtractor import third_party_conv
+        third_party_conv(f"conv3x3 {tuple(x.shape)}")                 # raises unless OCV_CONV=miopen was asked for
         if x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous() \
                 and not self.conv3x3.weight.is_contiguous(memory_format=torch.channels_last):
             self.conv3x3.to(memory_format=torch.channels_last)

@@ -14,8 +14,10 @@ for "name_synset_def_wn_rel_sz" the phrase also names the next object and one of
 side of both: detections in, ``(features_list, xywh_list, None)`` out -- the ``object_provider`` of ``GraphBins`` --
 with no CLIP in the loop.
 
-Parity: the relation index below restates ObjectLanguageStrategy.py:69-81 (unpinned: that module imports nltk, which is
-absent here, so it cannot be run; the arithmetic is five lines and is tested against hand-computed cases).
+Parity: the relation index below restates ObjectLanguageStrategy.py:69-81 and is PINNED: tests/golden/make_golden.py g7
+runs the reference's own get_single_relative_size_clause (nltk, imported at the module top but unused by that method,
+replaced by an empty stand-in module) on boxes that include equal areas, both ends of the scale and the half-way points
+of the rounding; tests/golden/g7_relsize.npz holds its clauses and relation indices.
 """
 from __future__ import annotations
 
@@ -35,11 +37,15 @@ def relative_size_index(xywh: torch.Tensor) -> List[int]:
     n = 0 if xywh is None else int(xywh.shape[0])
     if n <= 1:
         return []
-    area = (xywh[:, 2].double() * xywh[:, 3].double()).tolist()
+    # the reference multiplies and divides 0-d fp32 TENSORS (obj_xywh[2] * obj_xywh[3], area / next_area) and only then
+    # leaves torch (math.log of the fp32 quotient): areas and the ratio are rounded to fp32, the rest is double
+    b = xywh.detach().to("cpu", torch.float32)
+    area = b[:, 2] * b[:, 3]
+    ratio = (area / torch.roll(area, -1)).tolist()
     out = []
     L = len(REL_SIZE_SCALE)
     for j in range(n):
-        f = (math.log(area[j] / area[(j + 1) % n]) + 1.0) / 2.0 * (L - 3)
+        f = (math.log(ratio[j]) + 1.0) / 2.0 * (L - 3)
         r = round(f) + 1                      # Python's round == numpy's: half to even
         out.append(int(min(max(r, 0), L - 1)))
     return out

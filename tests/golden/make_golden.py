@@ -251,7 +251,68 @@ def g6_validation():
               pred_px=_np(pm.flatten()[gen.sample_pixels(pm.numel(), 256, seed)]))
 
 
+# ------------------------------------------------------------------ G7 relative-size relation (row N4)
+def _reference_object_language_strategy():
+    """modules/ObjectLanguageStrategy.py imports ``nltk.corpus.wordnet`` at module top (absent here) but
+    get_single_relative_size_clause (:49-93) never touches it: an empty stand-in module satisfies the import; the
+    method that runs is the reference's own code."""
+    import types
+    if "nltk" not in sys.modules:
+        nltk = types.ModuleType("nltk")
+        corpus = types.ModuleType("nltk.corpus")
+        corpus.wordnet = types.ModuleType("nltk.corpus.wordnet")
+        nltk.corpus = corpus
+        sys.modules["nltk"], sys.modules["nltk.corpus"], sys.modules["nltk.corpus.wordnet"] = nltk, corpus, corpus.wordnet
+    return ref_import.load("ObjectLanguageStrategy")
+
+
+def g7_relsize():
+    from objcavit_amd import objects
+    mod = _reference_object_language_strategy()
+    args = make_args(language="clip")
+    args.graphbins.objcavit.obj_language_strategy = "name_synset_def_wn_rel_sz"
+    args.graphbins.yolov7_chkpt = "lvis"
+    strat = mod.ObjectLanguageStrategy(args)
+    scale = list(strat.rel_size_scale)
+    assert tuple(scale) == objects.REL_SIZE_SCALE
+    rs = np.random.RandomState(71)
+    e = np.e
+    images = [
+        rs.uniform(4, 400, (12, 4)),                                                  # random boxes
+        np.array([[10, 10, 20, 30], [50, 50, 30, 20], [5, 5, 60, 10]], dtype=np.float64),            # equal areas
+        # consecutive area ratios e^t AT the half-way points of the rounding, 2 (t + 1) = m + 0.5, i.e. t = -1.25 ... 1.75
+        # (which side fp32 rounding lands on is part of what is pinned), then wrapping back to the first
+        np.array([[0, 0, float(np.exp(5.0 - c)), 1.0] for c in np.concatenate([[0.0], np.cumsum(
+            [-1.25, -0.75, -0.25, 0.25, 0.75, 1.25, 1.75, -1.75, 0.2501, 0.2499, -0.2501, -0.2499])])]),
+        np.array([[0, 0, 1.0, 1.0], [0, 0, 1e4, 1e4]]),                               # beyond both ends of the scale
+        np.array([[1, 2, 3, 4]], dtype=np.float64),                                   # a single object: no clause
+        rs.uniform(4, 400, (2, 4)),
+        None,                                                                         # no detections
+    ]
+    xywh = [None if a is None else torch.from_numpy(a.astype(np.float32)) for a in images]
+    names = [None if a is None else [f"thing{j}.n.01" for j in range(a.shape[0])] for a in images]
+    clauses = strat.get_single_relative_size_clause(xywh, None, None, None, names)
+    idx, flat = [], []
+    for c_img, b in zip(clauses, xywh):
+        row = []
+        for c in c_img:
+            if c == "":
+                continue
+            hits = [i for i, ph in enumerate(scale) if f" appears {ph} the " in c]
+            assert len(hits) == 1, c
+            row.append(hits[0])
+        idx.append(row)
+        mine = objects.relative_size_index(b)
+        print(f"G7 relsize: reference {row} restatement {mine}")
+        assert mine == row
+        flat.append(np.array(row, dtype=np.int64))
+    arrays = {f"xywh{i}": (np.zeros((0, 4), np.float32) if b is None else b.numpy()) for i, b in enumerate(xywh)}
+    arrays.update({f"idx{i}": r for i, r in enumerate(flat)})
+    _save("g7_relsize", dict(n_images=len(images), none=[b is None for b in xywh], scale=scale,
+                             clauses=[[c for c in ci] for ci in clauses]), **arrays)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
     for w in which:
-        {"g1": g1_mvit, "g2": g2_saca, "g3": g3_objcavit, "g4": g4_decoder, "g5": g5_adabins, "g6": g6_validation}[w]()
+        {"g1": g1_mvit, "g2": g2_saca, "g3": g3_objcavit, "g4": g4_decoder, "g5": g5_adabins, "g6": g6_validation, "g7": g7_relsize}[w]()

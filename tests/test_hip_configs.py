@@ -21,12 +21,19 @@ from util import max_rel, rel_dev
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 
+# Weight gains: gen.PEAKY makes the 256-way bin softmax peaky on the NYU range.  On KITTI the same gains
+# SATURATE it: with few objects the reference's cross-attention hands every query the same vector (Q1), the logits are
+# r(pixel) * sum_q W[k, q] + b[k], and a 6x gain on conv_out puts all the mass of every pixel on one bin (oracle: depth
+# 75.2734 +- 2e-5 over the whole map -- a parity check that could not fail).  configs[3] therefore keeps conv_out at
+# default scale (oracle: 65.6 .. 75.2 m, std 0.34).
+KITTI_GAINS = (("in_proj_weight", 2.0), ("conv_out", 1.0), ("conv3x3", 1.0), ("regressor.4", 3.0))
 CONFIGS = {
-    "configs[2]": dict(kw=dict(strategy="learned"), dataset="nyu", H=480, W=640, n_obj=32, B=16, oracle=(0, 5, 10, 15)),
+    "configs[2]": dict(kw=dict(strategy="learned"), dataset="nyu", H=480, W=640, n_obj=32, B=16, oracle=(0, 5, 10, 15),
+                       gains=gen.PEAKY, min_range=0.5),
     "configs[3]": dict(kw=dict(strategy="learned_bbox_wh", use_2_saca=True), dataset="kitti", H=352, W=1216, n_obj=24, B=8,
-                       oracle=(0, 3, 7)),
+                       oracle=(0, 3, 7), gains=KITTI_GAINS, min_range=1.0),
     "configs[4]": dict(kw=dict(strategy="grid_random_roi_align"), dataset="nyu", H=480, W=640, n_obj=64, B=16,
-                       oracle=(1, 6, 11, 15)),
+                       oracle=(1, 6, 11, 15), gains=gen.PEAKY, min_range=0.5),
 }
 
 
@@ -39,7 +46,7 @@ def test_baseline_config_full_size_every_image(tag):
     args = make_args(dataset=c["dataset"], language="clip", dimensions_train=[H, W], dimensions_test=[H, W], **kw)
     dmax = float(args[c["dataset"]].max_depth)
     m = GraphBins(args, object_provider=SyntheticObjectProvider(c["n_obj"], "clip", seed=9)).eval()
-    gen.load_into(m, 31, gen.PEAKY)
+    gen.load_into(m, 31, c["gains"])
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     m = m.cuda()
     img = gen.randn("img", (B, 3, H, W), 31).cuda()
@@ -52,7 +59,7 @@ def test_baseline_config_full_size_every_image(tag):
     assert bool((e[:, 1:] > e[:, :-1]).all())
     assert float((e[:, 0] - 0.001).abs().max()) < 1e-6 and float((e[:, -1] - dmax).abs().max()) < 1e-3 * dmax
     assert float(d.min()) >= 0.001 and float(d.max()) <= dmax
-    assert float(d.max() - d.min()) > 0.05                                              # not a constant answer
+    assert float(d.max() - d.min()) > c["min_range"]                                    # the map carries information
 
     # oracle, ORACLE_IMAGES of the batch (each alone: the oracle's cost is per image)
     feats, boxes, _ = m.object_provider(img)

@@ -220,32 +220,6 @@ def test_config2_full_size_properties():
     assert max_rel(d[3:4], ref) < 1e-3 and max_rel(solo, ref) < 1e-3
 
 
-@pytest.mark.parametrize("tag,kw,dataset,H,W,n_obj,B", [
-    ("configs[3] KITTI 2xSA/CA", dict(strategy="learned_bbox_wh", use_2_saca=True), "kitti", 352, 1216, 24, 2),
-    ("configs[4] NYU roi_align 64 objs", dict(strategy="grid_random_roi_align"), "nyu", 480, 640, 64, 2),
-])
-def test_baseline_configs_3_and_4_full_size_vs_oracle(tag, kw, dataset, H, W, n_obj, B):
-    """The other BASELINE configurations at their full image size (per-GPU shard of the batch): one image against the
-    CPU oracle, all of them finite / inside the bin range, bin edges monotone up to the dataset's max depth."""
-    from objcavit_amd.modules.GraphBins import GraphBins, SyntheticObjectProvider
-    args = make_args(dataset=dataset, language="clip", dimensions_train=[H, W], dimensions_test=[H, W], **kw)
-    dmax = float(args[dataset].max_depth)
-    m = GraphBins(args, object_provider=SyntheticObjectProvider(n_obj, "clip", seed=9)).eval()
-    gen.load_into(m, 31, gen.PEAKY)
-    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
-    m = m.cuda()
-    img = gen.randn("img", (B, 3, H, W), 31).cuda()
-    out = m(img)
-    d, e = out.depth_pred, out.bin_edges
-    assert tuple(d.shape) == (B, 1, H // 2, W // 2) and bool(torch.isfinite(d).all())
-    assert bool((e[:, 1:] > e[:, :-1]).all()) and abs(float(e[0, -1]) - dmax) < 1e-3 * dmax
-    assert float(d.min()) >= 0.001 and float(d.max()) <= dmax
-    feats, boxes, _ = m.object_provider(img)
-    ref, ref_e = restate.graphbins_forward(img[1:2].cpu(), [feats[1].cpu()], [boxes[1].cpu()], sd, 0.001, dmax, **kw)
-    assert rel_dev(e[1:2], ref_e) < 1e-4
-    assert max_rel(d[1:2], ref) < 1e-3, tag
-
-
 def test_encoder_fast_path_vs_oracle():
     """EfficientNet-B5 encoder inference plan (folded BN, HIP depthwise kernel) vs the oracle's functional
     restatement on identical weights: every one of the five skip activations."""
@@ -311,3 +285,37 @@ def test_folded_encoder_weights_follow_in_place_updates():
     sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
     ref = effnet_ref.encoder_features(img, sd, "encoder.original_model.")[11]
     assert rel_dev(after, ref) < 1e-4 and rel_dev(before, ref) > 1e-3
+
+
+def test_lightning_checkpoint_to_gpu_forward_equals_oracle(tmp_path):
+    """Row N3 end to end: a checkpoint laid out like the reference's Lightning .ckpt of a full GraphBins run -- every
+    model key under ``model.`` (the Q5 prototype-layer keys included), next to metric / loss states, hyper-parameters
+    and optimizer state -- is loaded through checkpoint.load_reference_checkpoint into a FRESH drop-in model, and the
+    HIP forward of that model equals the oracle's forward on the checkpoint's own tensors."""
+    from objcavit_amd.checkpoint import load_reference_checkpoint
+    from objcavit_amd.modules.GraphBins import GraphBins
+    H, W, seed = 352, 384, 83
+    kw = dict(strategy="learned_bbox_wh", use_2_saca=True)
+    args = make_args(dimensions_train=[H, W], dimensions_test=[H, W], language="clip", **kw)
+    src = GraphBins(args).eval()
+    sd = gen.load_into(src, seed, gen.PEAKY)
+    assert any(k.startswith("objcavit.saca_1.image_encoder_layers.") for k in sd)            # Q5 prototype keys
+    lightning = {"model." + k: v.clone() for k, v in sd.items()}
+    lightning.update({"abs_rel.normed_abs_diff_total": torch.tensor(3.0), "abs_rel.total_pixels": torch.tensor(7.0),
+                      "loss_fn.silog_loss.dummy": torch.zeros(1)})
+    path = tmp_path / "epoch=24-step=37875-last.ckpt"
+    torch.save({"epoch": 24, "global_step": 37875, "pytorch-lightning_version": "1.7.7", "state_dict": lightning,
+                "optimizer_states": [{"state": {}, "param_groups": []}], "lr_schedulers": [{}],
+                "hyper_parameters": {"args": {"model": {"name": "graphbins"}}}}, str(path))
+    dst = GraphBins(args).eval()
+    gen.load_into(dst, seed + 1)                                                              # different weights first
+    missing, unexpected = load_reference_checkpoint(dst, str(path), strict=True)
+    assert missing == [] and unexpected == []                  # metric / loss states never reach the model
+    dst = dst.cuda()
+    img = gen.randn("img", (2, 3, H, W), seed)
+    feats = [gen.randn(f"f{i}", (12, 512), seed, 10.0 / np.sqrt(512)) for i in range(2)]
+    xywh = [gen.boxes(f"b{i}", 12, seed, H, W) for i in range(2)]
+    out = dst(img.cuda(), [f.cuda() for f in feats], [b.cuda() for b in xywh])
+    ref_depth, ref_edges = restate.graphbins_forward(img, feats, xywh, sd, 0.001, 10, **kw)
+    assert rel_dev(out.bin_edges, ref_edges) < 1e-4
+    assert max_rel(out.depth_pred, ref_depth) < 1e-3

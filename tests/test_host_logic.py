@@ -210,3 +210,23 @@ def test_table_object_provider_formats():
         TableObjectProvider(lambda img: dets)
     with pytest.raises(ValueError):
         TableObjectProvider(lambda img: ([torch.zeros(1, 4)], [torch.tensor([9])]), class_table=table)(torch.zeros(1, 3, 8, 8))
+
+
+def test_relative_size_index_vs_reference_golden():
+    """Row N4: objects.relative_size_index against the relation indices produced by the reference's own
+    ObjectLanguageStrategy.get_single_relative_size_clause (tests/golden/g7_relsize.npz): random boxes, equal areas, the
+    half-way points of the rounding, both ends of the 7-point scale, a single object, no detections."""
+    from objcavit_amd import objects
+    meta, z = load_golden("g7_relsize")
+    assert tuple(meta["scale"]) == objects.REL_SIZE_SCALE
+    seen = set()
+    for i in range(meta["n_images"]):
+        xywh = None if meta["none"][i] else torch.from_numpy(z[f"xywh{i}"])
+        got = objects.relative_size_index(xywh)
+        assert got == z[f"idx{i}"].tolist(), i
+        seen.update(got)
+        clauses = [c for c in meta["clauses"][i] if c]
+        assert len(clauses) == len(got)
+        for c, r in zip(clauses, got):
+            assert f" appears {objects.REL_SIZE_SCALE[r]} the " in c          # the phrase the reference handed to CLIP
+    assert seen == set(range(7))                                              # every entry of the scale is exercised
