@@ -70,11 +70,7 @@ struct ConvArgs {
 // An earlier version issued these from inline asm with hand-counted waits to keep two register stages in flight;
 // the register allocator is free to COPY such a destination register before the load has landed (it did, at the loop
 // back-edge), which reads stale data -- a silent, history-dependent corruption.  Never hide an in-flight load.
-#ifdef OCV_ABL_NOLOAD
-__device__ __forceinline__ f32x4 gload16(const void* p) { const float v = (float)(((unsigned long)p >> 4) & 1); return f32x4{v, v, v, v}; }
-#else
 __device__ __forceinline__ f32x4 gload16(const void* p) { return *reinterpret_cast<const f32x4*>(p); }
-#endif
 
 __device__ __forceinline__ void split4(const f32x4 v, __bf16* hi, __bf16* lo) {
   const float f[4] = {v[0], v[1], v[2], v[3]};
@@ -96,20 +92,7 @@ __device__ __forceinline__ void split4(const f32x4 v, __bf16* hi, __bf16* lo) {
 __device__ __forceinline__ long hl_index(long m, int c, int Cp) { return m * 2 * Cp + (c >> 5) * 64 + (c & 31); }
 
 __device__ __attribute__((aligned(256))) float ocv_zero_page[64];      // zero-initialised: source of padded taps
-#ifdef OCV_ABL_KXRAND
-__device__ __attribute__((aligned(256))) unsigned short ocv_rand_page[256 * 64];   // diagnostic build: 32 KB of random bf16
-#endif
 
-// Diagnostic build only (-DOCV_STAMPS): per-phase cycle sums of workgroup 0 (s_memtime), never in the product build.
-#ifdef OCV_STAMPS
-__device__ unsigned long long ocv_conv_stamps[16];
-#define STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
-#define OCV_STAMP_BLOCK ((gridDim.x >> 4) << 3)      // a workgroup from the middle of the launch (steady state, not the cold first round)
-#define STAMP_ADD(slot, t0, t1) do { if (blockIdx.x == OCV_STAMP_BLOCK && lane == 0) stamp_acc[slot] += (t1) - (t0); } while (0)
-#else
-#define STAMP(var)
-#define STAMP_ADD(slot, t0, t1)
-#endif
 
 template <bool IN_SPLIT>   /* always false: pre-split inputs take conv_split_dma_kernel */
 __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
@@ -140,12 +123,8 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0};
 
-#ifdef OCV_STAMPS
-    unsigned long long stamp_acc[4] = {0, 0, 0, 0};
-#endif
     __syncthreads();                                   // buffer 0 written by the producers' prologue
     for (int step = 0; step < nsteps; ++step) {
-      STAMP(tc0);
       const unsigned char* base = lds + (step & 1) * BUF_BYTES;
       const unsigned char* pa = base + (wm * 128 + l31) * ROWB + hh * 16;
       const unsigned char* pb = base + 2 * A_BYTES + (wn * 64 + l31) * ROWB + hh * 16;
@@ -175,15 +154,8 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk][i], bl[kk][j], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kk][i], bh[kk][j], acc[i][j], 0, 0, 0);
           }
-      STAMP(tc1);
       __syncthreads();
-      STAMP(tc2);
-      STAMP_ADD(0, tc0, tc1);       // consumer: reads + MFMAs
-      STAMP_ADD(1, tc1, tc2);       // consumer: barrier wait
     }
-#ifdef OCV_STAMPS
-    if (blockIdx.x == OCV_STAMP_BLOCK && tid == 0) { ocv_conv_stamps[0] = stamp_acc[0]; ocv_conv_stamps[1] = stamp_acc[1]; ocv_conv_stamps[7] = nsteps; }
-#endif
 
     // ---- epilogue: bias, activation, optional residual, NHWC store (128-byte runs per half-wave)
 #pragma unroll
@@ -277,11 +249,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const bool ok = ((tapmask[i] >> tap) & 1u);
-#ifdef OCV_ABL_SMALLFOOT
-        const unsigned off = (rb1[i] + (unsigned)soff) & 0x3FF0u;          // diagnostic: every load hits a 16 KB window
-#else
         const unsigned off = rb1[i] + (unsigned)soff;
-#endif
         st.a[2 * i + 0] = gload16(ok ? (const void*)((const char*)p.xhl + off) : (const void*)ocv_zero_page);
         st.a[2 * i + 1] = gload16(ok ? (const void*)((const char*)p.xhl + off + 64) : (const void*)ocv_zero_page);
       }
@@ -301,11 +269,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
       st.a[2 * i + 1] = gload16((inb && cok1) ? (const void*)(src + 16) : (const void*)ocv_zero_page);
     }
     }
-#ifdef OCV_ABL_SMALLFOOT
-    const unsigned woff = ((unsigned)tap * wtap + wrow + (unsigned)c0 * 2) & 0x3FF0u;
-#else
     const unsigned woff = (unsigned)tap * wtap + wrow + (unsigned)c0 * 2;
-#endif
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       st.bh[e] = gload16((const char*)p.whi + woff + 16 * e);
@@ -328,10 +292,6 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
     }
   };
   auto write_lds = [&](int buf, const Raw& st, const Cvt& cv) {
-#ifdef OCV_ABL_NOWRITE
-    asm volatile("" :: "v"(cv.ahi[0]), "v"(cv.alo[7]), "v"(st.bh[0]), "v"(st.bl[3]), "v"(cv.ahi[3]), "v"(cv.alo[2]));
-    return;
-#endif
     unsigned char* base = lds + buf * BUF_BYTES;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -357,47 +317,22 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
   }
   if (g == 0 && 2 < nsteps) issue_loads(raw);
   __syncthreads();
-#ifdef OCV_STAMPS
-  unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
-#endif
   for (int t = 0; t < nsteps; ++t) {                   // interval t: the consumers multiply buffer t & 1
-    STAMP(tp0);
     if ((t & 1) == g) {
       // convert interval: the loads of step t+2 (issued one interval ago) land and are split; B stays as loaded
       if (t + 2 < nsteps) convert(raw, cvt);
-#ifdef OCV_STAMPS
-      asm volatile("" :: "v"(cvt.ahi[0]), "v"(cvt.alo[7]), "v"(raw.bl[3]));
-#endif
-      STAMP(tp1);
-      STAMP_ADD(0, tp0, tp1);                          // wait for loads + convert
       __syncthreads();
-      STAMP(tp2);
-      STAMP_ADD(1, tp1, tp2);                          // barrier wait (convert interval)
     } else {
       // write interval: step t+1 goes to buffer (t+1) & 1 (free since the last barrier), then fetch step t+3
       if (t + 1 >= 2 && t + 1 < nsteps) write_lds((t + 1) & 1, raw, cvt);
-      STAMP(tp1);
       if (t + 3 < nsteps) issue_loads(raw);
-      STAMP(tp2);
-      STAMP_ADD(2, tp0, tp1);                          // LDS writes
-      STAMP_ADD(3, tp1, tp2);                          // address math + load issue
       __syncthreads();
-      STAMP(tp3);
-      STAMP_ADD(4, tp2, tp3);                          // barrier wait (write interval)
     }
   }
-#ifdef OCV_STAMPS
-  if (blockIdx.x == OCV_STAMP_BLOCK && tid == 256) { for (int i = 0; i < 5; ++i) ocv_conv_stamps[2 + i] = stamp_acc[i]; }
-#endif
 }
 
 }  // namespace
 
-#ifdef OCV_STAMPS
-extern "C" int ocv_conv_read_stamps(unsigned long long* out16) {
-  return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(ocv_conv_stamps), 16 * sizeof(unsigned long long));
-}
-#endif
 
 namespace {
 
@@ -514,14 +449,8 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#ifdef OCV_STAMPS
-    unsigned long long stamp_acc[4] = {0, 0, 0, 0};
-#endif
-    STAMP(tk0);
     __syncthreads();
-    STAMP(tk1);
     for (int step = 0; step < nsteps; ++step) {
-      STAMP(tc0);
       const unsigned char* base = lds + (step % DNBUF) * DBUF;
       const unsigned char* pa = base + (wm * 128 + l15) * DROW + co;
       const unsigned char* pb = base + 2 * DA + (wn * 64 + l15) * DROW + co;
@@ -544,13 +473,8 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
         }
-      STAMP(tc1);
       __syncthreads();
-      STAMP(tc2);
-      STAMP_ADD(0, tc0, tc1);       // reads + MFMA issue
-      STAMP_ADD(1, tc1, tc2);       // barrier wait
     }
-    STAMP(te0);
 
     // ---- epilogue.  accumulator (i, j): register r of lane l is output row 16 i + 4 (l >> 4) + r, column 16 j + (l & 15)
     // Storing straight from that layout costs 384 two- and four-byte store instructions per wavefront in 32- / 64-byte
@@ -566,16 +490,7 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) tile[(16 * i + 4 * q4 + r) * ERS + 16 * j + l15] = acc[i][j][r];
       __syncthreads();
-      STAMP(te05);
       conv_store_rows(p, lds, wave, lane, m0, n0, yoff);
-#ifdef OCV_STAMPS
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      STAMP(te1);
-      if (blockIdx.x == OCV_STAMP_BLOCK && tid == 0) {
-        ocv_conv_stamps[0] = stamp_acc[0]; ocv_conv_stamps[1] = stamp_acc[1]; ocv_conv_stamps[7] = nsteps;
-        ocv_conv_stamps[8] = tk1 - tk0; ocv_conv_stamps[9] = te1 - te0; ocv_conv_stamps[10] = te1 - tk0; ocv_conv_stamps[11] = te05 - te0;
-      }
-#endif
       return;
     }
     // Cout not a multiple of 8: element-wise stores
@@ -651,20 +566,10 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
     unsigned char* base = lds + buf * DBUF;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-#if defined(OCV_ABL_KXSHARE) || defined(OCV_ABL_KXRAND)   // diagnostic builds: only the centre column of taps fetches real data (wrong values; timing of a 3x smaller A stream)
-      const bool ok = ((tapmask[i] >> tap) & 1u) && kx == 1;
-#else
       const bool ok = ((tapmask[i] >> tap) & 1u);               // pad channels are zeros in memory: no channel check
-#endif
       const unsigned off = rbA[i] + (unsigned)soff;
-#ifdef OCV_ABL_KXRAND             // ... the other taps read RANDOM (L1-resident) rows, so that the matrix pipe toggles as with real data
-      const char* rp = (const char*)ocv_rand_page + (64 * pw + 16 * i + lrow) * 128 + lchunk * 16;
-      const void* sh = ok ? (const void*)((const char*)p.xhl + off) : (const void*)rp;
-      const void* sl = ok ? (const void*)((const char*)p.xhl + off + 64) : (const void*)(rp + 64);
-#else
       const void* sh = ok ? (const void*)((const char*)p.xhl + off) : (const void*)ocv_zero_page;
       const void* sl = ok ? (const void*)((const char*)p.xhl + off + 64) : (const void*)ocv_zero_page;   // same 128-B line
-#endif
       unsigned char* dst = base + (64 * pw + 16 * i) * DROW;
       __builtin_amdgcn_global_load_lds((gptr_t)sh, (lptr_t)dst, 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)sl, (lptr_t)(dst + DA), 16, 0, 0);
@@ -779,18 +684,6 @@ int launch_conv(ConvArgs& a, int B, bool in_split, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-#ifdef OCV_ABL_KXRAND
-  {
-    static bool filled = false;
-    if (!filled) {
-      static unsigned short hostbuf[256 * 64];
-      unsigned x = 12345u;
-      for (int i = 0; i < 256 * 64; ++i) { x = x * 1664525u + 1013904223u; hostbuf[i] = (unsigned short)(0x3c00u + ((x >> 16) & 0x3ffu) + (((x >> 8) & 1u) << 15)); }   // |v| in [~0.008, ~0.03], random sign
-      (void)hipMemcpyToSymbol(HIP_SYMBOL(ocv_rand_page), hostbuf, sizeof(hostbuf));
-      filled = true;
-    }
-  }
-#endif
   static const bool use_dma = getenv("OCV_CONV_NO_DMA") == nullptr;
   if (in_split && use_dma) {
     static bool attr2 = false;

@@ -70,22 +70,9 @@ __device__ __forceinline__ float4 mul4(float4 a, const float4 g) {
   return a;
 }
 
-// Diagnostic builds only (-DPW_ABL_*): knock out one stream at a time to find what bounds a kernel.
-#ifdef PW_ABL_NOW
-__device__ __forceinline__ bf16x8 ldb8(const __bf16* p) { const __bf16 v = (__bf16)(float)(((unsigned long)p >> 4) & 3); return bf16x8{v, v, v, v, v, v, v, v}; }
-#else
 __device__ __forceinline__ bf16x8 ldb8(const __bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
-#endif
-#ifdef PW_ABL_NOA
-__device__ __forceinline__ float4 lda4(const float* p) { const float v = (float)(((unsigned long)p >> 4) & 3); return make_float4(v, v, v, v); }
-#else
 __device__ __forceinline__ float4 lda4(const float* p) { return ld4(p); }
-#endif
-#ifdef PW_ABL_NOGATE
-__device__ __forceinline__ float4 ldg4(const float* p) { const float v = (float)(((unsigned long)p >> 4) & 3); return make_float4(v, v, v, v); }
-#else
 __device__ __forceinline__ float4 ldg4(const float* p) { return ld4(p); }
-#endif
 
 // Weight layout ("packed", built once on the host side of the C ABI): the B operand of v_mfma_f32_32x32x16_bf16 for
 // channel tile jt (32 channels) and K step s (16 inputs) is ONE contiguous 1 KB fragment -- lane l = 32 hh + l31
@@ -98,13 +85,9 @@ __device__ __forceinline__ const __bf16* w_frag(const PSArgs& p, int jt, int s, 
 }
 
 __device__ __forceinline__ f32x16 mfma3(const bf16x8 ah, const bf16x8 al, const bf16x8 bh, const bf16x8 bl, f32x16 acc) {
-#ifdef PW_ABL_NOMFMA
-  acc[0] += (float)ah[0] + (float)al[1] + (float)bh[2] + (float)bl[3];
-#else
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-#endif
   return acc;
 }
 
@@ -167,9 +150,6 @@ __device__ __forceinline__ void store_tile_lds(const PSArgs& p, const f32x16& ac
         const float4 q = ld4(p.res + m * p.N + ncol);
         v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
       }
-#ifdef PW_ABL_NOSTORE            // diagnostic build: (almost) no stores
-      if (v.x == 123456.f)
-#endif
       *reinterpret_cast<float4*>(p.y + m * p.N + ncol) = v;
     }
   }

@@ -504,6 +504,8 @@ def pos_grid_sample(table: torch.Tensor, gh: int, gw: int, coords: torch.Tensor,
         if addend.shape != (n, E):
             raise ValueError(f"pos_grid_sample: addend must be {(n, E)}, got {tuple(addend.shape)}")
     out = torch.empty(n, E, dtype=torch.float32, device=table.device)
+    if n == 0:
+        return out
     with timed("pos_grid_sample"):
         check(lib.ocv_pos_grid_sample_fwd(table.data_ptr(), gh, gw, E, coords.data_ptr(), ld, n, mode, float(p0), float(p1),
                                           int(rows_per_image), _ptr(addend), out.data_ptr(), _stream()),

@@ -6,7 +6,9 @@
 kt/        : rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py ...
 pmc_fetch/ : rocprofv3 --kernel-trace --pmc FETCH_SIZE ...      (separate pass, no other trace domains)
 pmc_write/ : rocprofv3 --kernel-trace --pmc WRITE_SIZE ...
-Writes <tag>_kernel_stats.csv (rocprof's own per-kernel stats for the whole process, MIOpen's first-call
+sq_a/, sq_b/ : rocprofv3 --kernel-trace --pmc <8 SQ counters> ... (tools/profile_round.sh)
+Writes <tag>_sq.json (matrix-pipe busy, LDS bank conflicts, instruction mix per hand-written kernel),
+<tag>_kernel_stats.csv (rocprof's own per-kernel stats for the whole process, MIOpen's first-call
 solver search included), <tag>_step_breakdown.txt (the fastest bench step, from the kernel trace) and
 <tag>_pmc.json (+ roofline_traffic.json, which bench.py reads for roofline.traffic).
 """
@@ -24,11 +26,88 @@ OURS = ("bin_head_kernel", "pixel_dot_kernel", "patch_embed_partial_kernel", "pa
         "channel_sum_kernel", "channel_mean_finish_kernel", "se_hidden_kernel", "se_gate_kernel",
         "conv_split_dma_kernel", "upsample_concat_split_kernel", "pw_rows_kernel", "pw_tile_kernel", "pw_stream_kernel",
         "bin_head_split_kernel", "cross_attn_fused_kernel", "depth_metrics_partial_kernel", "depth_metrics_finish_kernel", "dw_slide_kernel", "se_hidden_partials_kernel", "se_gate_hid_kernel", "stem_conv_kernel",
-        "mbconv_expand_dw_kernel", "upsample_concat_split8_kernel", "upsample_concat_split_2x2_kernel", "conv_splitk_finish_kernel", "ffn_finish_kernel", "upsample_concat_split_lds_kernel")
+        "mbconv_expand_dw_kernel", "pos_sample_kernel", "pw_big_kernel", "encoder_stack_kernel", "upsample_concat_split8_kernel", "upsample_concat_split_2x2_kernel", "conv_splitk_finish_kernel", "ffn_finish_kernel", "upsample_concat_split_lds_kernel")
 
 
 def short(name):
     return name.replace("(anonymous namespace)::", "").replace("void ", "")[:110]
+
+
+# kernels that run several problem shapes per step: one row per launch grid (the grid identifies the shape)
+PER_SHAPE = ("conv_split_dma_kernel", "conv_splitk_finish_kernel", "pw_tile_kernel", "pw_rows_kernel", "pw_stream_kernel",
+             "pw_big_kernel", "upsample_concat_split", "dw_slide_kernel", "mbconv_expand_dw_kernel")
+
+
+def grid_of(r):
+    if "Grid_Size_X" in r:
+        return int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]), \
+            int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
+    return int(r.get("Grid_Size", 0) or 0), int(r.get("Workgroup_Size", 0) or 0)
+
+
+def shape_key(r):
+    k = short(r["Kernel_Name"])
+    if any(p in k for p in PER_SHAPE):
+        g, w = grid_of(r)
+        return f"{k.split('(')[0][:84]} [wgs={g // max(w, 1)}x{w}]"
+    return k
+
+
+SQ_KERNELS = ("conv_split_dma_kernel", "pw_tile_kernel", "pw_big_kernel", "pw_rows_kernel", "patch_embed_partial_kernel", "bin_head_kernel",
+              "bin_head_split_kernel", "attention_kernel", "cross_attn_fused_kernel", "ffn_fused_kernel", "linear_stream_kernel",
+              "dw_slide_kernel", "mbconv_expand_dw_kernel", "upsample_concat_split_lds_kernel", "encoder_stack_kernel")
+N_SIMD = 1024            # 256 CUs x 4 SIMDs
+
+
+def sq_summary(src, newest):
+    """Per hand-written kernel (and per launch grid): counter sums over the launches of the run's LAST bench step, the
+    launch duration from the same pass, and the derived ratios the north star asks for.  Units (MI355X_MICROARCH.md):
+    SQ_VALU_MFMA_BUSY_CYCLES counts matrix-pipe cycles summed over all SIMDs; SQ_*_CYCLES / SQ_WAIT / SQ_ACTIVE_INST
+    count quad-cycles; SQ_LDS_BANK_CONFLICT = extra LDS cycles."""
+    out = {}
+    for d in ("sq_a", "sq_b"):
+        fs = newest(os.path.join(src, d, "*", "*_counter_collection.csv"))
+        if not fs:
+            continue
+        rows = [r for r in csv.DictReader(open(fs[0])) if any(k in r["Kernel_Name"] for k in SQ_KERNELS)]
+        if not rows:
+            continue
+        # last step = launches after the second-to-last bin-head dispatch
+        heads = sorted({int(r["Dispatch_Id"]) for r in rows if "bin_head" in r["Kernel_Name"]})
+        lo = heads[-2] if len(heads) >= 2 else 0
+        per = collections.defaultdict(lambda: collections.defaultdict(float))
+        seen = collections.defaultdict(set)
+        for r in rows:
+            did = int(r["Dispatch_Id"])
+            if did <= lo:
+                continue
+            key = shape_key(r)
+            per[key][r["Counter_Name"]] += float(r["Counter_Value"])
+            if did not in seen[key]:
+                seen[key].add(did)
+                per[key]["_ns_" + d] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+                per[key]["_launches_" + d] += 1
+        for k, v in per.items():
+            out.setdefault(k, {}).update(v)
+    res = {}
+    for k, v in out.items():
+        e = {c: int(x) for c, x in v.items() if not c.startswith("_")}
+        la = max(v.get("_launches_sq_a", 0), v.get("_launches_sq_b", 0))
+        e["launches"] = int(la)
+        ns = v.get("_ns_sq_a") or v.get("_ns_sq_b") or 0
+        e["total_us_under_pmc"] = round(ns / 1e3, 1)
+        if v.get("SQ_VALU_MFMA_BUSY_CYCLES") and v.get("_ns_sq_a"):
+            e["mfma_busy_frac_at_2.1GHz"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["_ns_sq_a"] * 2.1 * N_SIMD), 4)
+        if v.get("SQ_VALU_MFMA_BUSY_CYCLES") and v.get("SQ_BUSY_CYCLES"):
+            e["mfma_busy_over_sq_busy"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / v["SQ_BUSY_CYCLES"], 4)
+        if v.get("SQ_INSTS_MFMA"):
+            e["valu_per_mfma"] = round(v.get("SQ_INSTS_VALU", 0) / v["SQ_INSTS_MFMA"], 2)
+            e["salu_per_mfma"] = round(v.get("SQ_INSTS_SALU", 0) / v["SQ_INSTS_MFMA"], 2)
+        if v.get("SQ_WAVE_CYCLES"):
+            e["wait_inst_frac"] = round(v.get("SQ_WAIT_INST_ANY", 0) / v["SQ_WAVE_CYCLES"], 4)
+            e["lds_wait_frac"] = round(v.get("SQ_WAIT_INST_LDS", 0) / v["SQ_WAVE_CYCLES"], 4)
+        res[k] = e
+    return res
 
 
 def main(src, tag):
@@ -52,7 +131,7 @@ def main(src, tag):
         t0, t1 = int(step[0]["Start_Timestamp"]), int(step[-1]["End_Timestamp"])
         agg = collections.defaultdict(lambda: [0, 0])
         for r in step:
-            a = agg[short(r["Kernel_Name"])]
+            a = agg[shape_key(r)]
             a[0] += 1
             a[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         tot = sum(v[1] for v in agg.values())
@@ -105,6 +184,9 @@ def main(src, tag):
                 top = [t for t in tot if t >= 0.95 * tot[-1]]
                 traffic[key] = int(top[len(top) // 2] * 1024)
         json.dump(traffic, open(os.path.join(out, "roofline_traffic.json"), "w"), indent=1, sort_keys=True)
+    sq = sq_summary(src, newest)
+    if sq:
+        json.dump(sq, open(os.path.join(out, f"{tag}_sq.json"), "w"), indent=1, sort_keys=True)
     print("wrote summaries to", out)
 
 

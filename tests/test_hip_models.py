@@ -278,9 +278,10 @@ def test_folded_encoder_weights_follow_in_place_updates():
     m = m.cuda()
     img = gen.randn("img", (1, 3, 96, 128), 9)
     before = m.encoder(img.cuda())[11].clone()
-    blk = m.encoder.original_model.blocks[2][1]
+    blk = m.encoder.original_model.blocks[6][2]              # last block in front of conv_head (activation 11)
     blk.bn2.running_var.mul_(4.0)                            # in place, eval mode, no load_state_dict / train()
-    blk.conv_pwl.weight.data.mul_(0.5)
+    blk.conv_pwl.weight.data.mul_(-3.0)
+    blk.se.conv_expand.bias.data.add_(1.0)
     after = m.encoder(img.cuda())[11]
     sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
     ref = effnet_ref.encoder_features(img, sd, "encoder.original_model.")[11]

@@ -1,10 +1,21 @@
 #!/bin/bash
 # tools/build_variant.sh NAME "-DFLAG ..." : diagnostic build of the library into objcavit_amd/lib/variants/NAME.so
+#
+# The product sources under objcavit_amd/csrc carry no diagnostic code.  The ablation switches (-DOCV_ABL_NOLOAD,
+# -DOCV_ABL_KXSHARE, -DOCV_ABL_KXRAND, -DOCV_ABL_SMALLFOOT, -DOCV_ABL_NOWRITE, -DPW_ABL_NOW / NOA / NOGATE / NOMFMA /
+# NOSTORE) and the in-kernel cycle stamps (-DOCV_STAMPS) live in tools/diag/*.patch; this script applies them to a
+# scratch copy of csrc/ and builds THAT, so a variant can never leak into the product library.
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p objcavit_amd/lib/variants
+scratch=$(mktemp -d /tmp/ocv_csrc.XXXXXX)
+mkdir -p "$scratch/objcavit_amd/csrc" "$scratch/include"
+cp objcavit_amd/csrc/* "$scratch/objcavit_amd/csrc/"
+cp include/objcavit_hip.h "$scratch/include/"
+for p in tools/diag/*.patch; do patch -s -d "$scratch/objcavit_amd/csrc" -p1 < "$p"; done
 cp objcavit_amd/lib/libobjcavit_hip.so /tmp/ocv_keep.so 2>/dev/null || true
-OCV_EXTRA_HIPCC_FLAGS="$2" python -m objcavit_amd.build --force > /dev/null
+OCV_CSRC_DIR="$scratch/objcavit_amd/csrc" OCV_EXTRA_HIPCC_FLAGS="$2" python -m objcavit_amd.build --force > /dev/null
 mv objcavit_amd/lib/libobjcavit_hip.so objcavit_amd/lib/variants/$1.so
 [ -f /tmp/ocv_keep.so ] && mv /tmp/ocv_keep.so objcavit_amd/lib/libobjcavit_hip.so
+rm -rf "$scratch"
 echo built objcavit_amd/lib/variants/$1.so
