@@ -183,6 +183,11 @@ int ocv_pointwise_conv_nhwc_fwd(const float* x, const float* gate, int rows_per_
  * (part 0 = hi, 1 = lo; bf16; ocv_pointwise_packed_weight_elems() elements).  The exact-fp32 entry point above is
  * MFMA-bound from stage 4 of the encoder on (47 TFLOP/s of 157); this one is the encoder's default. */
 size_t ocv_pointwise_packed_weight_elems(int Cin, int Cout);
+/* Diagnostics / tests: pin the kernel family ocv_pointwise_conv_nhwc_split_fwd dispatches to, for every later call of
+ * this process: 0 = automatic (default), 1 = rows, 2 = stream, 3 = 32-row tile (a = wavefronts across channels 2|4 or 0,
+ * b = K groups 1|2 or 0).  A family that cannot run a shape falls back to the automatic choice for that call.  Results
+ * do not depend on it beyond fp32 summation order. */
+int ocv_pointwise_split_set_dispatch(int family, int a, int b);
 int ocv_pointwise_conv_nhwc_split_fwd(const float* x, const float* gate, int rows_per_image, const void* w_packed,
                                       const float* bias, const float* residual, float* y, long M, int Cin, int Cout,
                                       int act, ocv_stream_t stream);

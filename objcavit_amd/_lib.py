@@ -61,6 +61,7 @@ PROTOTYPES = {
                               [C.c_long, _f32p, C.c_int, C.c_void_p, C.c_size_t, _stream]),
     "ocv_stem_conv_fwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p] + [C.c_int] * 12 + [_stream]),
     "ocv_pointwise_packed_weight_elems": (C.c_size_t, [C.c_int, C.c_int]),
+    "ocv_pointwise_split_set_dispatch": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "ocv_pointwise_conv_nhwc_split_fwd": (C.c_int, [_f32p, _f32p, C.c_int, C.c_void_p, _f32p, _f32p, _f32p,
                                                     C.c_long, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ocv_pointwise_conv_nhwc_fwd": (C.c_int, [_f32p, _f32p, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_long, C.c_int, C.c_int,

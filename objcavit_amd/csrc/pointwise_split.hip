@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(PSArgs p) {
 
 // diagnostic override of the dispatch: OCV_PW_CFG = "rows" | "stream" | "tile" | "wn,wk" (tile kernel with that shape)
 struct PwCfg { int wn = 0, wk = 0, family = 0; };
-const PwCfg& pw_cfg() {
+PwCfg& pw_cfg() {
   static PwCfg c = [] {
     PwCfg v;
     const char* e = getenv("OCV_PW_CFG");
@@ -484,6 +484,15 @@ const PwCfg& pw_cfg() {
 }
 
 }  // namespace
+
+extern "C" int ocv_pointwise_split_set_dispatch(int family, int a, int b) {
+  OCV_CHECK_ARG(family >= 0 && family <= 3, "ocv_pointwise_split_set_dispatch: family must be 0 (automatic) .. 3");
+  PwCfg& c = pw_cfg();
+  c.family = family;
+  c.wn = a;
+  c.wk = b;
+  return 0;
+}
 
 extern "C" size_t ocv_pointwise_packed_weight_elems(int Cin, int Cout) {
   if (Cin < 1 || Cout < 1) return 0;

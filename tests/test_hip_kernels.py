@@ -426,6 +426,42 @@ def test_pointwise_nhwc_split(ops, B, H, W, Cin, Cout, act, use_gate, use_res):
     assert torch.equal(got, ops.pointwise_nhwc(xg, sw, dev(b), act, **kw))      # fixed-order K-group reduction
 
 
+@pytest.mark.parametrize("cfg", [(3, 4, 1), (3, 4, 2), (3, 2, 1), (3, 2, 2)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,act,use_gate,use_res", [
+    (2, 30, 40, 176, 1056, 3, False, False),    # stage-5 expand: 11 K steps, 33 channel tiles
+    (2, 30, 40, 1056, 176, 0, True, True),      # stage-5 project: ragged channel block, rows spanning two images per tile
+    (1, 15, 20, 1824, 304, 0, True, True),      # 300 rows, K = 114 steps
+    (2, 9, 11, 136, 200, 4, False, True),       # Kp = 144, 198 rows, ragged everything, sigmoid
+    (1, 4, 5, 128, 102, 1, False, True),        # N % 4 != 0: the per-element store path
+])
+def test_pointwise_nhwc_split_pinned_tile_shapes(ops, cfg, B, H, W, Cin, Cout, act, use_gate, use_res):
+    """Every shape of the 32-row tile kernel (2 | 4 wavefronts across channels x 1 | 2 K groups), pinned through
+    ocv_pointwise_split_set_dispatch instead of left to the automatic choice, on late-stage layer shapes and ragged
+    M / N / K; the automatic dispatch must agree with each of them to fp32 summation order."""
+    x, w, b = rnd("x", (B, Cin, H, W), 1), rnd("w", (Cout, Cin, 1, 1), 2, 1 / math.sqrt(Cin)), rnd("b", (Cout,), 3, 0.2)
+    gate = torch.sigmoid(rnd("g", (B, Cin), 4)) if use_gate else None
+    res = rnd("r", (B, Cout, H, W), 5) if use_res else None
+    xin = x if gate is None else x * gate[:, :, None, None]
+    ref = F.conv2d(xin.double(), w.double(), b.double())
+    ref = [ref, torch.relu(ref), F.leaky_relu(ref, 0.01), F.silu(ref), torch.sigmoid(ref)][act]
+    if res is not None:
+        ref = ref + res
+    cl = torch.channels_last
+    sw = ops.SplitWeight(dev(w))
+    xg = dev(x).contiguous(memory_format=cl)
+    kw = dict(gate=None if gate is None else dev(gate), residual=None if res is None else dev(res).contiguous(memory_format=cl))
+    lib = ops._lib.load()
+    try:
+        assert lib.ocv_pointwise_split_set_dispatch(*cfg) == 0
+        got = ops.pointwise_nhwc(xg, sw, dev(b), act, **kw)
+        again = ops.pointwise_nhwc(xg, sw, dev(b), act, **kw)
+    finally:
+        lib.ocv_pointwise_split_set_dispatch(0, 0, 0)
+    assert rel_dev(got, ref) < SPLIT_TOL and torch.equal(got, again)
+    assert rel_dev(ops.pointwise_nhwc(xg, sw, dev(b), act, **kw), got) < SPLIT_TOL
+    assert lib.ocv_pointwise_split_set_dispatch(9, 0, 0) == -1
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,gate", [(16, 120, 160, 40, 240, False), (16, 240, 320, 48, 24, True), (16, 120, 160, 240, 40, True)])
 def test_pointwise_nhwc_split_many_rows(ops, B, H, W, Cin, Cout, gate):
     """Full-size stage-1/2 shapes: these take the rows (Cin <= 128) / stream (<= 32 channels) / tile kernels."""
