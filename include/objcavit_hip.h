@@ -282,6 +282,21 @@ int ocv_conv_nhwc_split_ws_fwd(const void* x_hl, int Cin, const void* w_hi, cons
                                const float* residual, float* y, void* y_hl, int B, int H, int W, int Cout, int ksize,
                                int act, void* workspace, size_t workspace_bytes, ocv_stream_t stream);
 
+/* The same 3 x 3 convolution (stride 1, zero padding 1) in Winograd F(2x2, 3x3) form, for shapes where the arithmetic
+ * dominates the transforms' traffic (Cin, Cout in the thousands at <= ~30 x 40 pixels: the two deepest decoder stages):
+ *   y = act( A^T [ U (.) (B^T d B) ] A + bias ),  U[xi][co][ci] = (G g G^T)[xi] for the 16 positions xi = 4 i + j
+ * (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1], G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], A^T = [1 1 1 0; 0 1 -1 -1]).
+ * x_hl: the input in the hl32 split layout (as ocv_conv_nhwc_split_fwd); u_hi / u_lo: the TRANSFORMED weights split in
+ * bf16, [16][Cout][Cin rounded up to 32] (zero padded), built once per weight version by the caller; y (fp32 NHWC) and /
+ * or y_hl (hl32) outputs; Cout a multiple of 8.  Input transform (exact re-join, fp32 four-term sums, re-split), 16
+ * batched split-bf16 GEMMs on the matrix cores, output transform + bias + activation: three launches, 2.25x fewer
+ * matrix-core operations than the direct form.  Scratch: ocv_conv3x3_winograd_workspace_bytes (256-byte aligned).
+ * Replaces the same nn.Conv2d(k = 3) + BatchNorm2d + LeakyReLU of UpSampleWithSkip (modules/DenseFeatureExtractor.py:37-42). */
+size_t ocv_conv3x3_winograd_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int ocv_conv3x3_winograd_split_fwd(const void* x_hl, int Cin, const void* u_hi, const void* u_lo, const float* bias, float* y,
+                                   void* y_hl, int B, int H, int W, int Cout, int act, void* workspace,
+                                   size_t workspace_bytes, ocv_stream_t stream);
+
 /* Bilinear resize of x [B,h,w,C1] (NHWC fp32) to H x W with align_corners = True, concatenated along channels with
  * skip [B,H,W,C2] (nullable, then C2 = 0), written in the hl32 split layout for C1+C2 channels (out_hl,
  * ocv_split_act_elems(B,H,W,C1+C2) bf16 elements, 16-byte aligned; pad channels zeroed).  C1, C2 multiples of 4.

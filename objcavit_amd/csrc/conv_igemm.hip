@@ -64,6 +64,9 @@ struct ConvArgs {
   int ksplit;                           // conv_split_dma_kernel: 1, or 2 = the channel chunks are halved between two workgroups
                                         // per tile, each writing raw fp32 partial sums to y + khalf * M * Cout (bias / act /
                                         // residual / split output then belong to conv_splitk_finish_kernel)
+  int zbatch;                           // conv_split_dma_kernel: > 1 = that many independent GEMMs in one launch (the 16
+  long xz_bytes, wz_bytes;              // Winograd positions): operand z at xhl + z xz_bytes / whi, wlo + z wz_bytes, raw fp32
+                                        // result at y + (z ksplit + khalf) * M * Cout
 };
 
 // 16-byte global load (compiler-visible: hipcc tracks it and inserts the s_waitcnt before the first use).
@@ -414,14 +417,18 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
 
-  const int ntile = p.mtiles * p.ntiles, nwg = ntile * p.ksplit;
+  const int ntile = p.mtiles * p.ntiles, nwg = ntile * p.ksplit * p.zbatch;
   int wg = blockIdx.x;
   {
     const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int kh = wg / ntile;                                     // K part of this workgroup (0 unless ksplit == 2)
-  wg -= kh * ntile;
+  const int kz = wg / ntile;                                     // (GEMM of the batch, K part) of this workgroup
+  wg -= kz * ntile;
+  const int zb = kz / p.ksplit, kh = kz - zb * p.ksplit;         // kh: 0 unless ksplit == 2; zb: 0 unless zbatch > 1
+  const char* const xz = (const char*)p.xhl + (long)zb * p.xz_bytes;
+  const char* const whz = (const char*)p.whi + (long)zb * p.wz_bytes;
+  const char* const wlz = (const char*)p.wlo + (long)zb * p.wz_bytes;
   const int mt = wg / p.ntiles, nt = wg - mt * p.ntiles;
   const long m0 = (long)mt * CBM;
   const int n0 = nt * CBN;
@@ -429,7 +436,7 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
   const int nchunk = p.Cp / CBK;
   const int ch0 = nchunk * kh / p.ksplit, ch1 = nchunk * (kh + 1) / p.ksplit;      // channel chunks [ch0, ch1)
   const int nsteps = taps * (ch1 - ch0);
-  const long yoff = (long)kh * p.M * p.Cout;
+  const long yoff = (long)kz * p.M * p.Cout;
 
   if (wave < 4) {
     // =========================== CONSUMERS, v_mfma_f32_16x16x32_bf16 ===========================
@@ -568,8 +575,8 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
     for (int i = 0; i < 4; ++i) {
       const bool ok = ((tapmask[i] >> tap) & 1u);               // pad channels are zeros in memory: no channel check
       const unsigned off = rbA[i] + (unsigned)soff;
-      const void* sh = ok ? (const void*)((const char*)p.xhl + off) : (const void*)ocv_zero_page;
-      const void* sl = ok ? (const void*)((const char*)p.xhl + off + 64) : (const void*)ocv_zero_page;   // same 128-B line
+      const void* sh = ok ? (const void*)(xz + off) : (const void*)ocv_zero_page;
+      const void* sl = ok ? (const void*)(xz + off + 64) : (const void*)ocv_zero_page;   // same 128-B line
       unsigned char* dst = base + (64 * pw + 16 * i) * DROW;
       __builtin_amdgcn_global_load_lds((gptr_t)sh, (lptr_t)dst, 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)sl, (lptr_t)(dst + DA), 16, 0, 0);
@@ -578,8 +585,8 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       unsigned char* dst = base + 2 * DA + (32 * pw + 16 * i) * DROW;
-      __builtin_amdgcn_global_load_lds((gptr_t)((const char*)p.whi + woff + rbB[i]), (lptr_t)dst, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)((const char*)p.wlo + woff + rbB[i]), (lptr_t)(dst + DB), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(whz + woff + rbB[i]), (lptr_t)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(wlz + woff + rbB[i]), (lptr_t)(dst + DB), 16, 0, 0);
     }
   };
 
@@ -692,7 +699,8 @@ int launch_conv(ConvArgs& a, int B, bool in_split, hipStream_t st) {
       attr2 = true;
     }
     if (a.ksplit < 1) a.ksplit = 1;
-    hipLaunchKernelGGL(conv_split_dma_kernel, dim3(a.mtiles * a.ntiles * a.ksplit), dim3(512), DNBUF * DBUF, st, a);
+    if (a.zbatch < 1) a.zbatch = 1;
+    hipLaunchKernelGGL(conv_split_dma_kernel, dim3(a.mtiles * a.ntiles * a.ksplit * a.zbatch), dim3(512), DNBUF * DBUF, st, a);
   } else if (in_split) hipLaunchKernelGGL(conv_igemm_kernel<true>, dim3(a.mtiles * a.ntiles), dim3(512), 2 * BUF_BYTES, st, a);
   else hipLaunchKernelGGL(conv_igemm_kernel<false>, dim3(a.mtiles * a.ntiles), dim3(512), 2 * BUF_BYTES, st, a);
   OCV_CHECK_LAUNCH("ocv_conv_nhwc");
@@ -773,4 +781,206 @@ extern "C" int ocv_conv_nhwc_fwd(const float* x1, int C1, const float* x2, int C
   a.C1 = C1; a.C2 = x2 ? C2 : 0; a.Cin = a.C1 + a.C2;
   a.Cout = Cout; a.H = H; a.W = W; a.ks = ksize; a.act = act;
   return launch_conv(a, B, false, (hipStream_t)stream);
+}
+
+// =====================================================================================================================
+// Winograd F(2x2, 3x3) form of the 3x3 convolution for the deep decoder stages (row N1 of SURVEY.md section 8; reference
+// modules/DenseFeatureExtractor.py:37-42,104-116).
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A        per 2 x 2 output tile, 4 x 4 input patch d, 3 x 3 filter g
+//
+// 16 multiplies per 4 outputs instead of 36: 2.25x fewer matrix-core operations, on a convolution kernel that runs at
+// the package power cap with its matrix pipe ~95 % busy, i.e. where nothing but fewer MFMAs helps.
+// The three stages:
+//   1. wino_input_kernel     V[xi][tile][c] = (B^T d B)[xi]: the split input is re-joined (hi + lo, exact), transformed
+//                            in fp32 (B has entries 0, +-1: four-term sums) and split again, one hl32 "image" of
+//                            T = B * ceil(H/2) * ceil(W/2) rows per position xi = 4 i + j;
+//   2. conv_split_dma_kernel as a BATCH of 16 independent 1 x 1 GEMMs (zbatch): M[xi] = V[xi] . U[xi]^T with
+//                            U[xi] = (G g G^T)[xi] transformed and split once on the host; raw fp32 slabs;
+//   3. wino_output_kernel    Y = A^T M A + bias, activation, fp32 and / or hl32 split stores.
+// V is 4x the activation and M 4x the output, so this pays only where both are small next to the arithmetic: the two
+// 30 x 40 stages (Cin 2224 / 1024, Cout 1024) -- measured 16 GEMMs 0.87 / 0.45 ms against 1.85 / 0.87 ms direct
+// (tools/exp_winograd_gemm.py); from 60 x 80 on the transforms' HBM traffic eats the gain and the direct kernel stays.
+// Numerics: the transforms are sums of at most four terms in fp32, the products keep the 2^-17 split-bf16 contract;
+// measured against fp64 the result is within 1.6x of the direct split-bf16 kernel's error (tests: 2e-5 of max |y|).
+// =====================================================================================================================
+namespace {
+
+struct WinoInArgs {
+  const __bf16* xhl;      // [B][H][W][2 Cp] hl32
+  __bf16* v;              // [16][T][2 Cp] hl32 rows
+  int B, H, W, Cp, th, tw;
+  long T, items;          // items = T * Cp / 8
+};
+
+// one thread = (tile, channel octet): 16 pixels x (8 hi + 8 lo) in, 16 positions x (8 hi + 8 lo) out
+__global__ __launch_bounds__(256) void wino_input_kernel(WinoInArgs p) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.items) return;
+  const int noct = p.Cp >> 3;
+  const long t = i / noct;
+  const int oc = (int)(i - t * noct);
+  const int c = oc * 8;
+  const int tx = (int)(t % p.tw);
+  const long r = t / p.tw;
+  const int ty = (int)(r % p.th), b = (int)(r / p.th);
+  const long coff = (long)(c >> 5) * 64 + (c & 31);                       // hi octet; lo octet at + 32
+  float d[4][4][8];
+#pragma unroll
+  for (int yy = 0; yy < 4; ++yy) {
+    const int y = 2 * ty - 1 + yy;
+#pragma unroll
+    for (int xx = 0; xx < 4; ++xx) {
+      const int x = 2 * tx - 1 + xx;
+      const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+      const __bf16* src = ok ? p.xhl + (((long)b * p.H + y) * p.W + x) * 2 * p.Cp + coff
+                             : reinterpret_cast<const __bf16*>(ocv_zero_page);
+      const bf16x8 h = *reinterpret_cast<const bf16x8*>(src);
+      const bf16x8 l = *reinterpret_cast<const bf16x8*>(src + (ok ? 32 : 8));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d[yy][xx][e] = (float)h[e] + (float)l[e];
+    }
+  }
+  // rows: B^T d   (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1])
+  float w[4][4][8];
+#pragma unroll
+  for (int xx = 0; xx < 4; ++xx)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      w[0][xx][e] = d[0][xx][e] - d[2][xx][e];
+      w[1][xx][e] = d[1][xx][e] + d[2][xx][e];
+      w[2][xx][e] = d[2][xx][e] - d[1][xx][e];
+      w[3][xx][e] = d[1][xx][e] - d[3][xx][e];
+    }
+  // columns: (B^T d) B, split, store position xi = 4 i + j
+#pragma unroll
+  for (int ii = 0; ii < 4; ++ii) {
+    float v4[4][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v4[0][e] = w[ii][0][e] - w[ii][2][e];
+      v4[1][e] = w[ii][1][e] + w[ii][2][e];
+      v4[2][e] = w[ii][2][e] - w[ii][1][e];
+      v4[3][e] = w[ii][1][e] - w[ii][3][e];
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      __bf16 hi[8], lo[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const __bf16 hb = (__bf16)v4[jj][e];
+        hi[e] = hb;
+        lo[e] = (__bf16)(v4[jj][e] - (float)hb);
+      }
+      __bf16* dst = p.v + (((long)(4 * ii + jj) * p.T + t) * 2 * p.Cp) + coff;
+      *reinterpret_cast<bf16x8*>(dst) = *reinterpret_cast<bf16x8*>(hi);
+      *reinterpret_cast<bf16x8*>(dst + 32) = *reinterpret_cast<bf16x8*>(lo);
+    }
+  }
+}
+
+struct WinoOutArgs {
+  const float* m;         // [16][T][Cout] raw GEMM results
+  const float* bias;
+  float* y;               // [B][H][W][Cout] fp32 (nullable)
+  __bf16* yhl;            // hl32 split copy (nullable)
+  int B, H, W, Cout, Cpo, th, tw, act;
+  long T, items;          // items = T * Cout / 4
+};
+
+// one thread = (tile, 4 channels): Y = A^T M A   (A^T = [1 1 1 0; 0 1 -1 -1]), bias, activation, up to 2 x 2 pixel stores
+__global__ __launch_bounds__(256) void wino_output_kernel(WinoOutArgs p) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.items) return;
+  const int nq = p.Cout >> 2;
+  const long t = i / nq;
+  const int n = (int)(i - t * nq) * 4;
+  const int tx = (int)(t % p.tw);
+  const long r = t / p.tw;
+  const int ty = (int)(r % p.th), b = (int)(r / p.th);
+  f32x4 m[4][4];
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi) m[xi >> 2][xi & 3] = *reinterpret_cast<const f32x4*>(p.m + ((long)xi * p.T + t) * p.Cout + n);
+  f32x4 s[2][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    s[0][j] = m[0][j] + m[1][j] + m[2][j];
+    s[1][j] = m[1][j] - m[2][j] - m[3][j];
+  }
+  const f32x4 bv = p.bias != nullptr ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy) {
+    const int y = 2 * ty + dy;
+    if (y >= p.H) continue;
+    f32x4 o[2];
+    o[0] = s[dy][0] + s[dy][1] + s[dy][2] + bv;
+    o[1] = s[dy][1] - s[dy][2] - s[dy][3] + bv;
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const int x = 2 * tx + dx;
+      if (x >= p.W) continue;
+      f32x4 v = o[dx];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = conv_act(v[e], p.act);
+      const long px = ((long)b * p.H + y) * p.W + x;
+      if (p.y != nullptr) *reinterpret_cast<f32x4*>(p.y + px * p.Cout + n) = v;
+      if (p.yhl != nullptr) {
+        __bf16 hi[4], lo[4];
+        split4(v, hi, lo);
+        const long oh = hl_index(px, n, p.Cpo);
+        *reinterpret_cast<uint2*>(p.yhl + oh) = *reinterpret_cast<uint2*>(hi);
+        *reinterpret_cast<uint2*>(p.yhl + oh + 32) = *reinterpret_cast<uint2*>(lo);
+      }
+    }
+  }
+}
+
+inline size_t wino_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" size_t ocv_conv3x3_winograd_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+  if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return 0;
+  const long T = (long)B * ((H + 1) / 2) * ((W + 1) / 2);
+  const int Cp = (Cin + 31) / 32 * 32;
+  return wino_align((size_t)16 * T * 2 * Cp * sizeof(__bf16)) + wino_align((size_t)16 * T * Cout * sizeof(float));
+}
+
+extern "C" int ocv_conv3x3_winograd_split_fwd(const void* x_hl, int Cin, const void* u_hi, const void* u_lo,
+                                              const float* bias, float* y, void* y_hl, int B, int H, int W, int Cout,
+                                              int act, void* workspace, size_t workspace_bytes, ocv_stream_t stream) {
+  OCV_CHECK_ARG(x_hl && u_hi && u_lo && (y || y_hl) && workspace, "ocv_conv3x3_winograd_split_fwd: null pointer");
+  OCV_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 8 && Cout % 8 == 0,
+                "ocv_conv3x3_winograd_split_fwd: bad sizes (Cout must be a multiple of 8, got %d)", Cout);
+  OCV_CHECK_ARG(act >= 0 && act <= 3, "ocv_conv3x3_winograd_split_fwd: unknown activation %d", act);
+  OCV_CHECK_ARG((reinterpret_cast<uintptr_t>(x_hl) & 127) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0 &&
+                    ocv_aligned16(u_hi) && ocv_aligned16(u_lo) && ocv_aligned16(y) && ocv_aligned16(y_hl) && ocv_aligned16(bias),
+                "ocv_conv3x3_winograd_split_fwd: x_hl must be 128-byte, workspace 256-byte, the rest 16-byte aligned");
+  OCV_CHECK_ARG(workspace_bytes >= ocv_conv3x3_winograd_workspace_bytes(B, H, W, Cin, Cout),
+                "ocv_conv3x3_winograd_split_fwd: workspace too small");
+  const int th = (H + 1) / 2, tw = (W + 1) / 2, Cp = (Cin + 31) / 32 * 32;
+  const long T = (long)B * th * tw;
+  OCV_CHECK_ARG(T * (Cin + 32) * 4 < (1L << 32) && (long)Cout * (Cin + 32) * 2 < (1L << 32),
+                "ocv_conv3x3_winograd_split_fwd: one transformed operand must stay below 4 GiB");
+  hipStream_t st = (hipStream_t)stream;
+  __bf16* v = (__bf16*)workspace;
+  float* m = (float*)((char*)workspace + wino_align((size_t)16 * T * 2 * Cp * sizeof(__bf16)));
+  if (y_hl != nullptr && Cout % 32 != 0) {
+    const hipError_t e = hipMemsetAsync(y_hl, 0, ocv_split_act_elems(B, H, W, Cout) * sizeof(__bf16), st);
+    OCV_CHECK_ARG(e == hipSuccess, "ocv_conv3x3_winograd_split_fwd: hipMemsetAsync failed: %s", hipGetErrorString(e));
+  }
+  WinoInArgs wi{(const __bf16*)x_hl, v, B, H, W, Cp, th, tw, T, T * (Cp / 8)};
+  hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((wi.items + 255) / 256)), dim3(256), 0, st, wi);
+  OCV_CHECK_LAUNCH("ocv_conv3x3_winograd_split_fwd(input transform)");
+  ConvArgs a{};
+  a.xhl = v; a.whi = (const __bf16*)u_hi; a.wlo = (const __bf16*)u_lo; a.y = m;
+  a.C1 = Cin; a.Cin = Cin; a.Cout = Cout; a.H = 1; a.W = (int)T; a.ks = 1; a.act = OCV_ACT_NONE; a.ksplit = 1;
+  a.zbatch = 16; a.xz_bytes = T * 2 * Cp * (long)sizeof(__bf16); a.wz_bytes = (long)Cout * Cp * (long)sizeof(__bf16);
+  a.Cpo = (Cout + 31) / 32 * 32;
+  const int rc = launch_conv(a, 1, true, st);
+  if (rc != 0) return rc;
+  WinoOutArgs wo{m, bias, y, (__bf16*)y_hl, B, H, W, Cout, a.Cpo, th, tw, act, T, T * (Cout / 4)};
+  hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)((wo.items + 255) / 256)), dim3(256), 0, st, wo);
+  OCV_CHECK_LAUNCH("ocv_conv3x3_winograd_split_fwd(output transform)");
+  return 0;
 }
