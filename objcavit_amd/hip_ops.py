@@ -558,6 +558,76 @@ def prep_conv_weight(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return hi.contiguous(), lo.contiguous()
 
 
+_WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
+
+
+def prep_winograd_weight(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[Cout, Cin, 3, 3] fp32 -> (u_hi, u_lo) bf16 [16, Cout, Cp]: the Winograd F(2x2, 3x3) filter transform
+    U[4 i + j] = (G g G^T)[i][j] (computed in fp64, rounded once to fp32), split like prep_conv_weight, Cp = Cin rounded
+    up to 32.  Done once per weight version by the callers (cached there)."""
+    Cout, Cin, kh, kw = weight.shape
+    if (kh, kw) != (3, 3):
+        raise ValueError("prep_winograd_weight: kernel must be 3x3")
+    G = torch.tensor(_WINO_G, dtype=torch.float64, device=weight.device)
+    u = torch.einsum("ia,ocab,jb->ijoc", G, weight.detach().double(), G).reshape(16, Cout, Cin).float()
+    Cp = (Cin + 31) // 32 * 32
+    if Cp != Cin:
+        u = torch.nn.functional.pad(u, (0, Cp - Cin))
+    hi = u.to(torch.bfloat16)
+    lo = (u - hi.float()).to(torch.bfloat16)
+    return hi.contiguous(), lo.contiguous()
+
+
+def winograd_pays(B: int, H: int, W: int, Cin: int, Cout: int) -> bool:
+    """Where the Winograd form of a 3x3 convolution beats the direct split-bf16 kernel: its transformed input is 4x the
+    activation and its raw result 4x the output, both through HBM, so the arithmetic must dominate -- the decoder's two
+    30 x 40 stages (2224 / 1024 -> 1024 at bs = 16: 16 GEMMs 0.87 / 0.45 ms + transforms against 1.85 / 0.87 ms direct,
+    tools/exp_winograd_gemm.py); at 60 x 80 (1088 / 512 -> 512) the transforms' traffic already eats the gain.
+    OCV_CONV_WINOGRAD=0 / =1 in the environment forces never / whenever the kernel supports the shape."""
+    mode = os.environ.get("OCV_CONV_WINOGRAD", "auto")
+    if mode == "0" or Cout % 8 != 0:
+        return False
+    if mode == "1":
+        return True
+    return Cin >= 768 and Cout >= 512 and B * H * W <= 32768
+
+
+def conv3x3_winograd_split(x: "SplitAct", u_hi: torch.Tensor, u_lo: torch.Tensor, bias: Optional[torch.Tensor],
+                           act: int = ACT_NONE, out_fp32: bool = True, out_split: bool = False):
+    """3x3 convolution (stride 1, padding 1) of a pre-split activation in Winograd F(2x2, 3x3) form
+    (ocv_conv3x3_winograd_split_fwd).  Returns fp32 tensor, SplitAct, or (fp32, SplitAct) like conv_nhwc_split."""
+    lib = _lib.load()
+    if not (out_fp32 or out_split):
+        raise ValueError("conv3x3_winograd_split: nothing to output")
+    _req(x.hl, "x.hl", torch.bfloat16)
+    B, Cin, H, W = x.shape
+    Cp = (Cin + 31) // 32 * 32
+    if x.hl.dim() != 4 or x.hl.shape[3] != 2 * Cp:
+        raise ValueError("conv3x3_winograd_split: x.hl must be [B, H, W, 2 * ceil32(C)] bf16")
+    for n, t in (("u_hi", u_hi), ("u_lo", u_lo)):
+        _req(t, n, torch.bfloat16)
+    if u_hi.dim() != 3 or u_hi.shape[0] != 16 or u_hi.shape[2] != Cp or u_lo.shape != u_hi.shape:
+        raise ValueError(f"conv3x3_winograd_split: transformed weights {tuple(u_hi.shape)} do not match {Cin} input channels")
+    Cout = u_hi.shape[1]
+    if Cout % 8 != 0:
+        raise ValueError("conv3x3_winograd_split: Cout must be a multiple of 8")
+    if bias is not None:
+        _req(bias, "bias")
+        if bias.numel() != Cout:
+            raise ValueError("conv3x3_winograd_split: bias size mismatch")
+    y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.hl.device, memory_format=torch.channels_last) if out_fp32 else None
+    ys = SplitAct.empty(B, Cout, H, W, x.hl.device) if out_split else None
+    nws = int(lib.ocv_conv3x3_winograd_workspace_bytes(B, H, W, Cin, Cout))
+    ws = workspace(nws, x.hl.device, "conv_winograd")
+    with timed(f"conv3x3w|{B},{H},{W},{Cin},{Cout}"):
+        check(lib.ocv_conv3x3_winograd_split_fwd(x.hl.data_ptr(), Cin, u_hi.data_ptr(), u_lo.data_ptr(), _ptr(bias), _ptr(y),
+                                                 ys.hl.data_ptr() if out_split else None, B, H, W, Cout, act,
+                                                 ws.data_ptr(), ws.numel(), _stream()), "ocv_conv3x3_winograd_split_fwd")
+    if out_fp32 and out_split:
+        return y, ys
+    return y if out_fp32 else ys
+
+
 def _nhwc(t: torch.Tensor, name: str) -> torch.Tensor:
     _req(t, name, contiguous=False)
     if t.dim() != 4:

@@ -58,6 +58,8 @@ class SplitConv3x3:
         self.conv, self.bn = conv, bn
         self._key = None
         self._prep = None
+        self._wino = None
+        self._w_folded = None
 
     def usable(self, c1: int, c2: int = 0) -> bool:
         k = self.conv.kernel_size
@@ -85,12 +87,22 @@ class SplitConv3x3:
                     w, b = self.conv.weight, self.conv.bias
                 hi, lo = hip_ops.prep_conv_weight(w)
                 self._prep = (hi, lo, None if b is None else b.detach().float().contiguous())
+                self._wino = None                                      # transformed weights: built on first use
+                self._w_folded = w.detach() if w.shape[-1] == 3 else None
             self._key = key
 
     def run_split(self, x: "hip_ops.SplitAct", act=hip_ops.ACT_NONE, out_fp32=True, out_split=False):
         """Same convolution on a pre-split activation (no per-tap fp32 -> bf16 work in the kernel)."""
         self._ensure_prepared()
         hi, lo, b = self._prep
+        B, Cin, H, W = x.shape
+        if self.conv.kernel_size[0] == 3 and hip_ops.winograd_pays(B, H, W, Cin, self.conv.out_channels):
+            # the deep stages: Winograd F(2x2, 3x3), 2.25x fewer matrix-core operations (csrc/conv_igemm.hip)
+            if self._wino is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("weight preparation during graph capture: run one eager warm-up call first")
+                self._wino = hip_ops.prep_winograd_weight(self._w_folded)
+            return hip_ops.conv3x3_winograd_split(x, self._wino[0], self._wino[1], b, act, out_fp32=out_fp32, out_split=out_split)
         return hip_ops.conv_nhwc_split(x, hi, lo, b, self.conv.kernel_size[0], act, out_fp32=out_fp32, out_split=out_split)
 
 # skip-connection table: encoder-name fragment -> (feature_select, skip channels 3..0)

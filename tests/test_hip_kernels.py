@@ -634,6 +634,55 @@ def test_conv_nhwc_split_in_and_out(ops, B, H, W, Cin, Cout, k, act):
     assert rel_dev(y, y3) < 1e-5
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,act", [
+    (2, 30, 40, 96, 64, 2),        # even sizes, LeakyReLU
+    (1, 7, 9, 40, 72, 0),          # odd H and W (last tile row / column half outside), Cin % 32 != 0, Cout % 32 != 0
+    (3, 1, 1, 32, 8, 1),           # a single pixel: every tap but the centre is padding
+    (1, 2, 2, 8, 16, 3),           # one tile, SiLU
+    (1, 15, 20, 1024, 512, 2),     # long K: 32 channel chunks per position
+    (2, 13, 16, 300, 136, 2),      # ragged everything (300 rows of tiles are not a multiple of the 256-row GEMM tile)
+])
+def test_conv3x3_winograd_split(ops, B, H, W, Cin, Cout, act):
+    """ocv_conv3x3_winograd_split_fwd (input transform, 16 batched split-bf16 GEMMs, output transform) against an fp64
+    convolution at the SAME bar as the direct kernel (2e-5 of max |y|), and against the direct kernel itself."""
+    x = rnd("x", (B, Cin, H, W), 1)
+    w, b = rnd("w", (Cout, Cin, 3, 3), 3, 1 / math.sqrt(Cin * 9)), rnd("b", (Cout,), 4, 0.2)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    ref = [ref, torch.relu(ref), F.leaky_relu(ref, 0.01), F.silu(ref)][act]
+    u_hi, u_lo = ops.prep_winograd_weight(dev(w))
+    assert tuple(u_hi.shape) == (16, Cout, (Cin + 31) // 32 * 32)
+    xs = ops.upsample_concat_split(dev(x), None, (H, W))
+    poison = [torch.full((1 << 22,), float("nan"), device="cuda") for _ in range(8)]
+    del poison                                                  # workspace and outputs come out of NaN-filled memory
+    y, ys = ops.conv3x3_winograd_split(xs, u_hi, u_lo, dev(b), act, out_fp32=True, out_split=True)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    assert rel_dev(y, ref) < SPLIT_TOL
+    assert rel_dev(ys.float(), y) < 1e-5
+    Cpo = (Cout + 31) // 32 * 32
+    blocks = ys.hl.view(B, H, W, Cpo // 32, 2, 32).permute(0, 1, 2, 4, 3, 5).reshape(B, H, W, 2, Cpo)
+    assert not bool(blocks[..., Cout:].any())                  # pad channels of the split output are zero
+    y2 = ops.conv3x3_winograd_split(xs, u_hi, u_lo, dev(b), act, out_fp32=True, out_split=False)
+    assert torch.equal(y, y2)
+    hi, lo = ops.prep_conv_weight(dev(w))
+    direct = ops.conv_nhwc_split(xs, hi, lo, dev(b), 3, act)
+    assert rel_dev(y, direct) < SPLIT_TOL
+
+
+def test_conv3x3_winograd_keeps_fp32_range_and_rejects_bad_operands(ops):
+    x = rnd("x", (1, 64, 12, 12), 1) * torch.logspace(-3, 3, 64).view(1, 64, 1, 1)
+    w = rnd("w", (32, 64, 3, 3), 2, 0.05) / torch.logspace(-3, 3, 64).view(1, 64, 1, 1)
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    u_hi, u_lo = ops.prep_winograd_weight(dev(w))
+    xs = ops.upsample_concat_split(dev(x), None, (12, 12))
+    assert rel_dev(ops.conv3x3_winograd_split(xs, u_hi, u_lo, None), ref) < SPLIT_TOL
+    with pytest.raises(ValueError):
+        ops.conv3x3_winograd_split(xs, u_hi[:, :, :32].contiguous(), u_lo[:, :, :32].contiguous(), None)     # wrong Cin
+    with pytest.raises(ValueError):
+        ops.prep_winograd_weight(dev(rnd("w1", (8, 8, 1, 1), 1)))
+    assert ops.winograd_pays(16, 30, 40, 2224, 1024) and ops.winograd_pays(16, 30, 40, 1024, 1024)
+    assert not ops.winograd_pays(16, 60, 80, 1088, 512) and not ops.winograd_pays(16, 240, 320, 280, 128)
+
+
 @pytest.mark.parametrize("out_fp32,out_split", [(True, False), (False, True), (True, True)])
 def test_conv_nhwc_split_k_halves(ops, out_fp32, out_split):
     """300 tiles on 256 CUs: the launcher halves the channel chunks between two workgroups per tile (fp32 partial
