@@ -151,6 +151,15 @@ int ocv_bin_head_fold_fwd(const float* queries, long q_bs, int q_ld, const float
                           int n_bins, ocv_stream_t stream);
 int ocv_bin_head_folded_fwd(const float* feat, int channels_last, const float* Wf, const float* bout,
                             const float* centers, float* depth, int B, int C, int n_bins, int P, ocv_stream_t stream);
+/* The same with scratch for the per-half softmax states: for a channels_last map (channels_last == 1) the logits then run
+ * as a THREE-term bf16 split (v = h + m + l, six matrix-core products per product, dropped terms <= 2^-24: fp32-faithful)
+ * at 2.7x the matrix rate of the exact fp32 kernel -- 256 bins in two halves of 128 (three parts of a half's folded
+ * matrix fill 96 KB of LDS), merged per pixel by a second launch.  partials: ocv_bin_head_partials_bytes(B, P) bytes,
+ * 16-byte aligned (NULL, or OCV_BINHEAD=exact in the environment: the exact kernel of ocv_bin_head_folded_fwd). */
+size_t ocv_bin_head_partials_bytes(int B, int P);
+int ocv_bin_head_folded_ws_fwd(const float* feat, int channels_last, const float* Wf, const float* bout, const float* centers,
+                               float* depth, int B, int C, int n_bins, int P, void* partials, size_t partials_bytes,
+                               ocv_stream_t stream);
 int ocv_bin_head_fwd(const float* feat, int channels_last, const float* queries, long q_bs, int q_ld, const float* Wout,
                      const float* bout, const float* centers, float* depth, int B, int C, int Q, int n_bins, int P,
                      void* workspace, size_t workspace_bytes, ocv_stream_t stream);

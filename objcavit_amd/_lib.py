@@ -49,6 +49,9 @@ PROTOTYPES = {
     "ocv_bin_head_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "ocv_bin_head_fold_fwd": (C.c_int, [_f32p, C.c_long, C.c_int, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
     "ocv_bin_head_folded_fwd": (C.c_int, [_f32p, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
+    "ocv_bin_head_partials_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "ocv_bin_head_folded_ws_fwd": (C.c_int, [_f32p, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_void_p, C.c_size_t, _stream]),
     "ocv_bin_head_fwd": (C.c_int, [_f32p, C.c_int, _f32p, C.c_long, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, _stream]),
     "ocv_depthwise_conv_fwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p] + [C.c_int] * 11 + [_stream]),

@@ -245,6 +245,144 @@ __global__ __launch_bounds__(256) void bin_head_split_kernel(const float* __rest
   }
 }
 
+// ---------------------------------------------------------------------------
+// THREE-term split bin head (NHWC map): fp32-faithful logits at the bf16 matrix rate.  Every operand is written as
+// v = h + m + l with h = bf16(v), m = bf16(v - h), l = bf16(v - h - m) (24 significant bits: the two subtractions are
+// exact in fp32), every product as the six terms h h + h m + m h + m m + h l + l h on v_mfma_f32_32x32x16_bf16 with
+// fp32 accumulation -- the dropped terms are <= 2^-24 of the product, i.e. below fp32's own rounding of it -- at
+// 6 x 32 = 192 matrix-pipe cycles per 32 x 32 x 16 block against 8 x 64 = 512 for the exact v_mfma_f32_32x32x2_f32
+// kernel above (which runs at 70 % of the fp32 matrix peak and is bound by it).  The two-term kernel below cannot
+// replace it: a near-one-hot bin softmax passes logit error straight into depth.
+// Wf[b] in three parts is 192 KB, more than a CU's LDS, so the 256 bins are cut in two HALVES: a workgroup (8 wavefronts,
+// two per SIMD: one's softmax arithmetic runs under the other's MFMAs) stages the three parts of its 128 bins once
+// (96 KB, A-operand fragment order) and walks pixel tiles like the kernels above; it leaves the online-softmax state of
+// its half per pixel -- (running max, sum of exponentials, sum of exponentials x centre) -- and
+// bin_head_combine_kernel merges the two halves (fixed order) into depth.  The map is read twice (the second time
+// mostly from L2 / Infinity Cache when the two halves of a tile run together).
+// ---------------------------------------------------------------------------
+constexpr int HB = NB / 2;         // bins per half
+constexpr int TP3 = 256;           // pixels per workgroup tile (8 wavefronts x 32)
+
+__device__ __forceinline__ void bh_split8x3(const float4 u, const float4 v, bh_bf16x8& h, bh_bf16x8& m, bh_bf16x8& l) {
+  const float f[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 a = (__bf16)f[i];
+    const float r1 = f[i] - (float)a;
+    const __bf16 b = (__bf16)r1;
+    h[i] = a;
+    m[i] = b;
+    l[i] = (__bf16)(r1 - (float)b);
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void bin_head_split3_kernel(const float* __restrict__ feat, const float* __restrict__ Wf,
+                                                                 const float* __restrict__ bout,
+                                                                 const float* __restrict__ centers, float* __restrict__ part,
+                                                                 long P, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __bf16* wfrag = reinterpret_cast<__bf16*>(lds);           // [4 bin tiles][8 K steps][h, m, l][64 lanes][8]
+  float* bl = lds + (HB * CH * 3 * 2) / 4;                   // [128]
+  float* cl = bl + HB;                                       // [128]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.z, half = blockIdx.y;
+  const float* fb = feat + (long)b * CH * P;
+  const float* wb = Wf + ((long)b * NB + half * HB) * CH;
+
+  for (int idx = tid; idx < HB * CH / 8; idx += 512) {
+    const int k = idx >> 4, o = idx & 15;                    // bin of the half, K octet
+    bh_bf16x8 h, m, l;
+    bh_split8x3(ld4(wb + (long)k * CH + 8 * o), ld4(wb + (long)k * CH + 8 * o + 4), h, m, l);
+    __bf16* d = wfrag + ((((k >> 5) * 8 + (o >> 1)) * 3) * 64 + (o & 1) * 32 + (k & 31)) * 8;
+    *reinterpret_cast<bh_bf16x8*>(d) = h;
+    *reinterpret_cast<bh_bf16x8*>(d + 512) = m;
+    *reinterpret_cast<bh_bf16x8*>(d + 1024) = l;
+  }
+  if (tid < HB) {
+    bl[tid] = bout[half * HB + tid];
+    cl[tid] = centers[(long)b * NB + half * HB + tid];
+  }
+  __syncthreads();
+
+  float4 nxt[16];
+  auto load_px = [&](float4 (&dst)[16], long pix) {
+    const float* src = fb + (pix < P ? pix : 0) * CH + 8 * hh;        // rows past P re-read pixel 0 (never stored)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      dst[2 * s] = ld4(src + 16 * s);
+      dst[2 * s + 1] = ld4(src + 16 * s + 4);
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) load_px(nxt, (long)tile * TP3 + wave * 32 + l31);
+  for (; tile < ntiles; tile += gridDim.x) {
+    const long pix = (long)tile * TP3 + wave * 32 + l31;
+    bh_bf16x8 ph[8], pm[8], pl[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) bh_split8x3(nxt[2 * s], nxt[2 * s + 1], ph[s], pm[s], pl[s]);
+    const int tn = tile + gridDim.x;
+    if (tn < ntiles) load_px(nxt, (long)tn * TP3 + wave * 32 + l31);   // in flight under this tile's 192 MFMAs
+
+    float m_run = -__builtin_inff(), l_half = 0.f, d_half = 0.f;
+#pragma unroll 1
+    for (int t = 0; t < HB / 32; ++t) {
+      f32x16 acc = {0};
+      const __bf16* wf = wfrag + (t * 8 * 3) * 512 + lane * 8;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const bh_bf16x8 ah = *reinterpret_cast<const bh_bf16x8*>(wf + s * 1536);
+        const bh_bf16x8 am = *reinterpret_cast<const bh_bf16x8*>(wf + s * 1536 + 512);
+        const bh_bf16x8 al = *reinterpret_cast<const bh_bf16x8*>(wf + s * 1536 + 1024);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ph[s], acc, 0, 0, 0);      // small terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, pl[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, pm[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, ph[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, pm[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ph[s], acc, 0, 0, 0);
+      }
+      float tmax = -__builtin_inff();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[r] += bl[t * 32 + acc_row(r, hh)];
+        tmax = fmaxf(tmax, acc[r]);
+      }
+      tmax = xor32_max(tmax);
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = fast_exp(m_run - m_new);
+      float ps = 0.f, ds = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pr = fast_exp(acc[r] - m_new);
+        ps += pr;
+        ds += pr * cl[t * 32 + acc_row(r, hh)];
+      }
+      l_half = l_half * alpha + ps;
+      d_half = d_half * alpha + ds;
+      m_run = m_new;
+    }
+    const float l = xor32_sum(l_half), d = xor32_sum(d_half);
+    if (hh == 0 && pix < P) {
+      float* o = part + (((long)b * 2 + half) * P + pix) * 4;
+      *reinterpret_cast<float4*>(o) = make_float4(m_run, l, d, 0.f);
+    }
+  }
+}
+
+// depth = (d0 e0 + d1 e1) / (l0 e0 + l1 e1),  e_i = exp(m_i - max(m0, m1)): the online-softmax merge of the two halves
+__global__ __launch_bounds__(256) void bin_head_combine_kernel(const float* __restrict__ part, float* __restrict__ depth, long P,
+                                                               long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;     // b * P + pixel
+  if (i >= total) return;
+  const long b = i / P, px = i - b * P;
+  const float4 a = *reinterpret_cast<const float4*>(part + ((b * 2 + 0) * P + px) * 4);
+  const float4 c = *reinterpret_cast<const float4*>(part + ((b * 2 + 1) * P + px) * 4);
+  const float m = fmaxf(a.x, c.x);
+  const float ea = fast_exp(a.x - m), ec = fast_exp(c.x - m);
+  depth[i] = (a.z * ea + c.z * ec) / (a.y * ea + c.y * ec);
+}
+
 // ram[b][q][p] = sum_c queries[b][q][c] * feat[b][c][p]
 template <bool NHWC>
 __global__ __launch_bounds__(256) void pixel_dot_kernel(const float* __restrict__ feat, const float* __restrict__ qm,
@@ -296,6 +434,11 @@ int blocks_per_image(int B, int ntiles) {
 extern "C" size_t ocv_bin_head_workspace_bytes(int B, int n_bins, int C) {
   if (B < 1 || n_bins != NB || C != CH) return 0;
   return (size_t)B * NB * CH * sizeof(float);
+}
+
+extern "C" size_t ocv_bin_head_partials_bytes(int B, int P) {
+  if (B < 1 || P < 1) return 0;
+  return (size_t)B * 2 * P * 4 * sizeof(float);
 }
 
 extern "C" int ocv_pixel_dot_fwd(const float* feat, int channels_last, const float* queries, long q_bs, int q_ld,
@@ -371,6 +514,40 @@ extern "C" int ocv_bin_head_folded_fwd(const float* feat, int channels_last, con
     hipLaunchKernelGGL(bin_head_kernel<false>, dim3(per, B), dim3(256), lds, (hipStream_t)stream, feat, Wf, bout,
                        centers, depth, (long)P, ntiles);
   OCV_CHECK_LAUNCH("ocv_bin_head_folded_fwd");
+  return 0;
+}
+
+extern "C" int ocv_bin_head_folded_ws_fwd(const float* feat, int channels_last, const float* Wf, const float* bout,
+                                          const float* centers, float* depth, int B, int C, int n_bins, int P, void* partials,
+                                          size_t partials_bytes, ocv_stream_t stream) {
+  static const int forced = [] {
+    const char* e = getenv("OCV_BINHEAD");
+    return e == nullptr ? 0 : (strcmp(e, "exact") == 0 ? 1 : (strcmp(e, "split") == 0 ? 2 : 0));
+  }();
+  if (channels_last != 1 || forced != 0 || partials == nullptr)
+    return ocv_bin_head_folded_fwd(feat, channels_last, Wf, bout, centers, depth, B, C, n_bins, P, stream);
+  OCV_CHECK_ARG(feat && Wf && bout && centers && depth, "ocv_bin_head_folded_ws_fwd: null pointer");
+  OCV_CHECK_ARG(C == CH && n_bins == NB, "ocv_bin_head_folded_ws_fwd: needs C = %d, n_bins = %d", CH, NB);
+  OCV_CHECK_ARG(B >= 1 && B <= 65535 && P >= 1 && ocv_aligned16(Wf) && ocv_aligned16(feat) && ocv_aligned16(partials),
+                "ocv_bin_head_folded_ws_fwd: bad sizes / alignment");
+  OCV_CHECK_ARG(partials_bytes >= ocv_bin_head_partials_bytes(B, P), "ocv_bin_head_folded_ws_fwd: partials buffer too small");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)bin_head_split3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  const int ntiles = ocv_cdiv(P, TP3);
+  int per = (256 + 2 * B - 1) / (2 * B);          // persistent grid: about one workgroup per CU over (halves x images)
+  if (per > ntiles) per = ntiles;
+  if (per < 1) per = 1;
+  const size_t lds3 = (size_t)HB * CH * 3 * 2 + 2 * HB * sizeof(float);
+  hipLaunchKernelGGL(bin_head_split3_kernel, dim3(per, 2, B), dim3(512), lds3, (hipStream_t)stream, feat, Wf, bout, centers,
+                     (float*)partials, (long)P, ntiles);
+  OCV_CHECK_LAUNCH("ocv_bin_head_folded_ws_fwd(halves)");
+  const long total = (long)B * P;
+  hipLaunchKernelGGL(bin_head_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)partials, depth, (long)P, total);
+  OCV_CHECK_LAUNCH("ocv_bin_head_folded_ws_fwd(combine)");
   return 0;
 }
 

@@ -447,10 +447,11 @@ def pixel_dot(feat: torch.Tensor, queries: torch.Tensor) -> torch.Tensor:
 
 
 def bin_head(feat: torch.Tensor, queries: torch.Tensor, w_out: torch.Tensor, b_out: torch.Tensor,
-             centers: torch.Tensor, split: bool = False) -> torch.Tensor:
+             centers: torch.Tensor, split: bool = False, exact: bool = False) -> torch.Tensor:
     """depth [B,1,h,w] = sum_k softmax_k(conv1x1(pixel_dot(feat, queries)))_k * centers_k, fused.
-    feat may be NCHW-contiguous or channels_last (exact fp32 MFMA either way); ``split=True`` (channels_last only)
-    computes the logits in split bf16 -- 2x faster, ~3x the depth error under near-one-hot softmaxes."""
+    feat NCHW-contiguous: exact fp32 MFMA.  feat channels_last: logits as a THREE-term bf16 split (fp32-faithful: dropped
+    terms <= 2^-24 of a product; 2.7x the matrix rate), or the exact fp32 MFMA kernel with ``exact=True``; ``split=True``
+    computes them in the TWO-term split -- faster still, ~3x the depth error under near-one-hot softmaxes (opt-in)."""
     lib = _lib.load()
     feat, cl = _map4(feat, "feat")
     _req(b_out, "b_out"); _req(centers, "centers")
@@ -469,9 +470,12 @@ def bin_head(feat: torch.Tensor, queries: torch.Tensor, w_out: torch.Tensor, b_o
     wf = ws.view(torch.float32)
     check(lib.ocv_bin_head_fold_fwd(queries.data_ptr(), queries.stride(0), queries.stride(1), w2.data_ptr(), wf.data_ptr(), B,
                                     Cc, Q, nbins, _stream()), "ocv_bin_head_fold_fwd")
-    with timed("bin_head"):          # brackets exactly one launch of bin_head_kernel
-        check(lib.ocv_bin_head_folded_fwd(feat.data_ptr(), 2 if (cl and split) else cl, wf.data_ptr(), b_out.data_ptr(), centers.data_ptr(),
-                                          depth.data_ptr(), B, Cc, nbins, h * w, _stream()), "ocv_bin_head_folded_fwd")
+    npart = int(lib.ocv_bin_head_partials_bytes(B, h * w)) if (cl and not exact and not split) else 0
+    part = workspace(npart, feat.device, "bin_head_partials") if npart else None
+    with timed("bin_head"):          # the logit / softmax / depth launch(es): split-3 halves + merge, or the exact kernel
+        check(lib.ocv_bin_head_folded_ws_fwd(feat.data_ptr(), 2 if (cl and split) else cl, wf.data_ptr(), b_out.data_ptr(),
+                                             centers.data_ptr(), depth.data_ptr(), B, Cc, nbins, h * w, _ptr(part), npart,
+                                             _stream()), "ocv_bin_head_folded_ws_fwd")
     return depth
 
 

@@ -288,8 +288,17 @@ def test_pixel_dot_and_bin_head_channels_last(ops, B, h, w):
     assert got_ram.is_contiguous() and rel_dev(got_ram, ram) < TOL
     ref_depth, _ = restate.bin_head(widths, ram, wout, bout, 0.001, 10.0)
     _, centers = bin_edges_and_centers(dev(widths), 0.001, 10.0)
-    got = ops.bin_head(fg, qg, dev(wout), dev(bout), centers)
+    got = ops.bin_head(fg, qg, dev(wout), dev(bout), centers)          # NHWC default: three-term split, 256 bins in two halves
     assert float(((got.cpu() - ref_depth).abs() / ref_depth).max()) < 1e-4
+    # ... which is fp32-faithful: against an fp64 evaluation of the same folded logits its error is that of the exact
+    # v_mfma_f32_32x32x2_f32 kernel (this input is the stress case: logit gain 6, near-one-hot softmax over 256 bins)
+    d64, _ = restate.bin_head(widths.double(), restate.pixel_wise_dot_product(feat.double(), q[:, 1:129, :].double()),
+                              wout.double(), bout.double(), 0.001, 10.0)
+    exact = ops.bin_head(fg, qg, dev(wout), dev(bout), centers, exact=True)
+    e3 = float(((got.cpu().double() - d64).abs() / d64).max())
+    ex = float(((exact.cpu().double() - d64).abs() / d64).max())
+    assert e3 < 1e-4 and e3 <= 2.0 * ex + 2e-6, (e3, ex)
+    assert torch.equal(got, ops.bin_head(fg, qg, dev(wout), dev(bout), centers))
     # NCHW and NHWC paths agree to rounding
     got_nchw = ops.bin_head(dev(feat), qg, dev(wout), dev(bout), centers)
     assert float(((got - got_nchw).abs() / got_nchw).max()) < 1e-4      # different K order inside the MFMA chains
