@@ -1,0 +1,27 @@
+"""Cross-attention #1 (image <- objects, reference modules/ObjCAViT.py:195-201) against the HBM roofline at growing batch:
+algorithmic bytes per SURVEY.md section 8d (3 S E 4 + S per image + the projection weights once per launch) / HIP-event
+duration of ocv_mha_fwd, for S = 300 (NYU) and 418 (KITTI), 32 objects per image.  The north star asks for >= 40 % of
+the HBM roofline for this kernel: the table says at which batch, if any, a launch gets there."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from objcavit_amd import hip_ops
+E, H, N = 128, 4, 32
+torch.manual_seed(0)
+w = torch.randn(3 * E, E, device="cuda") * 0.1; b = torch.randn(3 * E, device="cuda") * 0.1
+wo = torch.randn(E, E, device="cuda") * 0.1; bo = torch.randn(E, device="cuda") * 0.1
+print(f"{'S':>4s} {'B':>5s} {'us':>8s} {'alg MB':>8s} {'GB/s':>8s} {'% of 8 TB/s':>12s} {'MFLOP':>8s} {'TFLOP/s':>8s}")
+for S in (300, 418):
+    for B in (16, 64, 128, 512, 2048):
+        x = torch.randn(B, S, E, device="cuda")
+        k = torch.full((B, S, E), 1e-4, device="cuda"); k[:, S - N:, :] = torch.randn(B, N, E, device="cuda")
+        mask = torch.ones(B, S, dtype=torch.bool, device="cuda"); mask[:, :N] = False
+        for _ in range(3): hip_ops.mha(x, k, x, w, b, wo, bo, mask, H, kv_limit=N)
+        torch.cuda.synchronize()
+        hip_ops.enable_timing(True)
+        for _ in range(20): hip_ops.mha(x, k, x, w, b, wo, bo, mask, H, kv_limit=N)
+        us = hip_ops.timing_results()["mha_cross"][1] * 1e3
+        hip_ops.enable_timing(False)
+        byts = B * (3 * S * E * 4 + S) + 4 * E * E * 4 + 4 * E * 4
+        flops = B * (4 * 2 * S * E * E + 2 * 2 * S * S * E)            # the reference's full-length form
+        print(f"{S:4d} {B:5d} {us:8.1f} {byts / 1e6:8.2f} {byts / us / 1e3:8.1f} {100 * byts / us / 1e3 / 8000:11.1f}% {flops / 1e6:8.0f} {flops / us / 1e6:8.2f}")
