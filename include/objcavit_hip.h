@@ -251,6 +251,13 @@ int ocv_se_gate_fwd(const float* mean, const float* w1, const float* b1, const f
 int ocv_conv_nhwc_fwd(const float* x1, int C1, const float* x2, int C2, const void* w_hi, const void* w_lo,
                       const float* bias, const float* residual, float* y, int B, int H, int W, int Cout, int ksize,
                       int act, ocv_stream_t stream);
+/* The same convolution in EXACT fp32 (v_mfma_f32_32x32x2_f32: bit-for-bit a k-ordered fp32 fma chain, no split
+ * operands), any odd k <= 7, any channel counts: the hand-written exact route for A/B numerics and for shapes the
+ * split-bf16 kernels do not take (5x slower by construction; not on any default path).  w_tap_major: fp32
+ * [k*k][Cout][C1+C2].  Replaces the same reference lines as ocv_conv_nhwc_fwd. */
+int ocv_conv_nhwc_exact_fwd(const float* x1, int C1, const float* x2, int C2, const float* w_tap_major, const float* bias,
+                            const float* residual, float* y, int B, int H, int W, int Cout, int ksize, int act,
+                            ocv_stream_t stream);
 
 /* Expand 1x1 convolution (+ bias = folded BN, SiLU) and the depthwise k x k convolution (+ bias, SiLU) behind it, fused:
  * the expanded tensor is never written to memory.  x [B,H,W,Cin] NHWC fp32, Cin a multiple of 8 in [24, 64];

@@ -75,6 +75,7 @@ PROTOTYPES = {
     "ocv_se_gate_fwd": (C.c_int, [_f32p] * 7 + [C.c_int] * 3 + [_stream]),
     "ocv_conv_nhwc_fwd": (C.c_int, [_f32p, C.c_int, _f32p, C.c_int, C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p] +
                           [C.c_int] * 6 + [_stream]),
+    "ocv_conv_nhwc_exact_fwd": (C.c_int, [_f32p, C.c_int, _f32p, C.c_int, _f32p, _f32p, _f32p, _f32p] + [C.c_int] * 6 + [_stream]),
     "ocv_mbconv_expand_dw_tiles": (C.c_int, [C.c_int] * 4),
     "ocv_mbconv_expand_dw_fwd": (C.c_int, [_f32p, C.c_void_p, _f32p, _f32p, _f32p, _f32p, _f32p] + [C.c_int] * 11 + [_stream]),
     "ocv_split_act_elems": (C.c_size_t, [C.c_int] * 4),

@@ -562,6 +562,38 @@ def prep_conv_weight(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return hi.contiguous(), lo.contiguous()
 
 
+def conv_nhwc_exact(x1: torch.Tensor, x2: Optional[torch.Tensor], w_tap_major: torch.Tensor, bias: Optional[torch.Tensor],
+                    ksize: int, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(conv_kxk(cat([x1, x2], 1)) + bias) (+ residual) in exact fp32 (ocv_conv_nhwc_exact_fwd); logical shapes
+    [B, C, H, W], storage channels_last; w_tap_major fp32 [k*k, Cout, C1+C2] = weight.permute(2, 3, 0, 1)."""
+    lib = _lib.load()
+    x1 = _nhwc(x1, "x1")
+    B, C1, H, W = x1.shape
+    C2 = 0
+    if x2 is not None:
+        x2 = _nhwc(x2, "x2")
+        if x2.shape[0] != B or x2.shape[2:] != x1.shape[2:]:
+            raise ValueError("conv_nhwc_exact: x2 must match x1 in batch and spatial size")
+        C2 = x2.shape[1]
+    _req(w_tap_major, "w_tap_major")
+    if w_tap_major.dim() != 3 or w_tap_major.shape[0] != ksize * ksize or w_tap_major.shape[2] != C1 + C2:
+        raise ValueError(f"conv_nhwc_exact: weights {tuple(w_tap_major.shape)} do not match {C1}+{C2} input channels, k={ksize}")
+    Cout = w_tap_major.shape[1]
+    if bias is not None:
+        _req(bias, "bias")
+        if bias.numel() != Cout:
+            raise ValueError("conv_nhwc_exact: bias size mismatch")
+    y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x1.device, memory_format=torch.channels_last)
+    if residual is not None:
+        residual = _nhwc(residual, "residual")
+        if residual.shape != y.shape:
+            raise ValueError("conv_nhwc_exact: residual shape mismatch")
+    with timed(f"conv{ksize}x{ksize}x|{B},{H},{W},{C1 + C2},{Cout}"):
+        check(lib.ocv_conv_nhwc_exact_fwd(x1.data_ptr(), C1, _ptr(x2), C2, w_tap_major.data_ptr(), _ptr(bias), _ptr(residual),
+                                          y.data_ptr(), B, H, W, Cout, ksize, act, _stream()), "ocv_conv_nhwc_exact_fwd")
+    return y
+
+
 _WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
 
 

@@ -8,9 +8,11 @@ into a single biased convolution (cached per parameter version); resize +
 concat + fp32 -> split-bf16 is one kernel (ocv_upsample_concat_split_fwd) and
 the 3x3 convolutions run on pre-split activations (ocv_conv_nhwc_split_ws_fwd);
 the encoder keeps only the five activations the decoder reads instead of all
-sixteen.  PyTorch-ROCm / MIOpen convolutions run only on request
-(OCV_CONV=miopen, ``third_party_conv``) and in training / on the CPU, where the
-plain module graph is what the golden generator wraps.
+sixteen.  OCV_CONV=exact routes the 3x3 convolutions through the hand-written
+exact-fp32 implicit GEMM instead (csrc/conv_exact.hip; A/B numerics), which
+also takes the channel counts the split kernel does not.  PyTorch convolutions
+run only in training / on the CPU, where the plain module graph is what the
+golden generator wraps.
 """
 from __future__ import annotations
 
@@ -27,27 +29,14 @@ from .efficientnet import tf_efficientnet_b5_ap
 
 
 def split_bf16_convs_enabled() -> bool:
-    """3x3 convolutions of the decoder / heads: hand-written split-bf16 implicit GEMM (default) or MIOpen fp32
-    (OCV_CONV=miopen).  Both are checked against the CPU oracle by the parity tests."""
+    """Dense convolutions of the decoder / heads on the GPU inference path: the hand-written split-bf16 implicit GEMM
+    (default) or, with OCV_CONV=exact, the hand-written EXACT-fp32 implicit GEMM (csrc/conv_exact.hip, 5x slower: the
+    A/B numerics route -- round 1 used MIOpen for it).  Either way nothing but libobjcavit_hip.so computes them."""
     import os
-    return os.environ.get("OCV_CONV", "split_bf16") != "miopen"
-
-
-_warned_third_party = set()
-
-
-def third_party_conv(what: str) -> None:
-    """Gate in front of every place where the GPU inference path would hand a convolution to PyTorch-ROCm / MIOpen
-    instead of a kernel of libobjcavit_hip.so.  That only happens on request (OCV_CONV=miopen: the exact-fp32
-    third-party route, kept for A/B numerics) -- a shape our kernels do not cover raises instead of silently running
-    somebody else's kernels."""
-    if split_bf16_convs_enabled():
-        from .._lib import HipLibraryError
-        raise HipLibraryError(f"{what}: no hand-written kernel covers this configuration; set OCV_CONV=miopen to route the "
-                              "dense convolutions through PyTorch-ROCm / MIOpen explicitly")
-    if what not in _warned_third_party:
-        _warned_third_party.add(what)
-        logging.getLogger(__name__).warning("OCV_CONV=miopen: %s runs on PyTorch-ROCm / MIOpen, not on libobjcavit_hip.so", what)
+    mode = os.environ.get("OCV_CONV", "split_bf16")
+    if mode not in ("split_bf16", "exact"):
+        raise ValueError(f"OCV_CONV={mode!r}: expected 'split_bf16' (default) or 'exact'")
+    return mode != "exact"
 
 
 class SplitConv3x3:
@@ -60,6 +49,7 @@ class SplitConv3x3:
         self._prep = None
         self._wino = None
         self._w_folded = None
+        self._w_exact = None
 
     def usable(self, c1: int, c2: int = 0) -> bool:
         k = self.conv.kernel_size
@@ -71,6 +61,23 @@ class SplitConv3x3:
         self._ensure_prepared()
         hi, lo, b = self._prep
         return hip_ops.conv_nhwc(x1, x2, hi, lo, b, self.conv.kernel_size[0], act)
+
+    def exact(self, x1, x2=None, act=hip_ops.ACT_NONE):
+        """The same convolution (any odd kernel size <= 7, "same" padding, stride 1, any channel counts) on the exact-fp32
+        kernel: OCV_CONV=exact, and the shapes the split-bf16 kernels do not take."""
+        c = self.conv
+        k = c.kernel_size[0]
+        if not (c.kernel_size == (k, k) and k % 2 == 1 and k <= 7 and c.stride == (1, 1) and c.padding == (k // 2, k // 2)
+                and c.groups == 1 and c.dilation == (1, 1)):
+            from .._lib import HipLibraryError
+            raise HipLibraryError(f"no hand-written kernel for this convolution: {c}")
+        self._ensure_prepared()
+        if self._w_exact is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("weight preparation during graph capture: run one eager warm-up call first")
+            w = self._w_folded
+            self._w_exact = w.float().permute(2, 3, 0, 1).reshape(k * k, w.shape[0], w.shape[1]).contiguous()
+        return hip_ops.conv_nhwc_exact(x1, x2, self._w_exact, self._prep[2], k, act)
 
     def _ensure_prepared(self):
         ps = [self.conv.weight] + ([self.conv.bias] if self.conv.bias is not None else [])
@@ -85,10 +92,12 @@ class SplitConv3x3:
                     w, b = _fold_conv_bn(self.conv, self.bn)
                 else:
                     w, b = self.conv.weight, self.conv.bias
-                hi, lo = hip_ops.prep_conv_weight(w)
+                k = w.shape[-1]
+                hi, lo = hip_ops.prep_conv_weight(w) if k in (1, 3) else (None, None)
                 self._prep = (hi, lo, None if b is None else b.detach().float().contiguous())
-                self._wino = None                                      # transformed weights: built on first use
-                self._w_folded = w.detach() if w.shape[-1] == 3 else None
+                self._wino = None                                      # transformed / tap-major weights: built on first use
+                self._w_exact = None
+                self._w_folded = w.detach()
             self._key = key
 
     def run_split(self, x: "hip_ops.SplitAct", act=hip_ops.ACT_NONE, out_fp32=True, out_split=False):
@@ -199,7 +208,6 @@ class UpSampleWithSkip(nn.Module):
             nn.BatchNorm2d(output_features),
             nn.LeakyReLU())
         self._folded = None
-        self._folded_cl = False
         self._split1 = SplitConv3x3(self._net[0], self._net[1])
         self._split2 = SplitConv3x3(self._net[3], self._net[4])
 
@@ -227,23 +235,24 @@ class UpSampleWithSkip(nn.Module):
         if self.split_ready(x, skip_features):
             return self.forward_split(x, skip_features)
         up = F.interpolate(x, size=skip_features.shape[-2:], mode="bilinear", align_corners=True)
-        if (not self.training and not torch.is_grad_enabled() and up.device.type == "cuda"
-                and self._split1.usable(up.shape[1], skip_features.shape[1])):
-            # hand-written path: the channel concat is virtual (two A-operand sources), BN is folded, LeakyReLU fused
-            f = self._split1(up, skip_features, hip_ops.ACT_LEAKY_RELU)
-            return self._split2(f, None, hip_ops.ACT_LEAKY_RELU)
+        if not self.training and not torch.is_grad_enabled() and up.device.type == "cuda":
+            # hand-written convolutions on fp32 operands: the channel concat is virtual (two A-operand sources), BN is
+            # folded, LeakyReLU fused -- split-bf16, or exact fp32 (OCV_CONV=exact / channel counts the split kernel
+            # does not take); only the resize above is an ATen element-wise kernel here
+            if self._split1.usable(up.shape[1], skip_features.shape[1]):
+                f = self._split1(up, skip_features, hip_ops.ACT_LEAKY_RELU)
+            else:
+                f = self._split1.exact(up, skip_features, hip_ops.ACT_LEAKY_RELU)
+            if self._split2.usable(f.shape[1]):
+                return self._split2(f, None, hip_ops.ACT_LEAKY_RELU)
+            return self._split2.exact(f, None, hip_ops.ACT_LEAKY_RELU)
         f = torch.cat([up, skip_features], dim=1)
         if self.training or torch.is_grad_enabled():
             return self._net(f)
-        if f.device.type == "cuda":
-            third_party_conv(f"UpSampleWithSkip {tuple(f.shape)}")
-        cl = f.device.type == "cuda" and f.is_contiguous(memory_format=torch.channels_last)
-        if self._folded is None or self._folded[0].device != f.device or self._folded_cl != cl:
+        # CPU, eval: plain PyTorch with folded BatchNorm (what the golden generator wraps; never the GPU path)
+        if self._folded is None or self._folded[0].device != f.device:
             with torch.no_grad():
-                ws = (*_fold_conv_bn(self._net[0], self._net[1]), *_fold_conv_bn(self._net[3], self._net[4]))
-                if cl:      # MIOpen's fp32 implicit-GEMM convolutions are NHWC-native: keep weights in that layout too
-                    ws = tuple(t.contiguous(memory_format=torch.channels_last) if t.dim() == 4 else t for t in ws)
-                self._folded, self._folded_cl = ws, cl
+                self._folded = (*_fold_conv_bn(self._net[0], self._net[1]), *_fold_conv_bn(self._net[3], self._net[4]))
         w1, b1, w2, b2 = self._folded
         f = F.leaky_relu(F.conv2d(f, w1, b1, padding=1), 0.01)
         return F.leaky_relu(F.conv2d(f, w2, b2, padding=1), 0.01)
@@ -277,13 +286,14 @@ class Decoder(nn.Module):
     def _conv2_padded_1x1(self, b4):
         """conv2 is a 1x1 convolution with padding=1 (reference :57): the output grows by a border that only ever
         sees zero padding, i.e. equals the bias.  On the inference fast path the interior runs as the split-bf16
-        pointwise kernel (MIOpen's fp32 implicit GEMM needs 0.79 ms for it at bs = 16) and the border is filled."""
+        pointwise kernel and the border is filled."""
         c = self.conv2
         if not (b4.device.type == "cuda" and not self.training and not torch.is_grad_enabled()
                 and c.kernel_size == (1, 1) and c.padding == (1, 1) and c.stride == (1, 1) and c.groups == 1
                 and c.in_channels % 8 == 0 and b4.dtype == torch.float32):
             if b4.device.type == "cuda" and not self.training and not torch.is_grad_enabled():
-                third_party_conv(f"Decoder.conv2 {tuple(b4.shape)}")
+                from .._lib import HipLibraryError
+                raise HipLibraryError(f"Decoder.conv2: no hand-written kernel for {c} on {tuple(b4.shape)}")
             return c(b4)
         key = (b4.device, c.weight._version, c.weight.data_ptr(), None if c.bias is None else c.bias._version)
         cache = self.__dict__.get("_conv2_cache")
@@ -305,14 +315,9 @@ class Decoder(nn.Module):
     def forward(self, features):
         b0, b1, b2, b3, b4 = (features[i] for i in self.feature_select)
         if b4.device.type == "cuda" and not self.training and not torch.is_grad_enabled():
-            # inference on the GPU: run the decoder in channels_last.  MIOpen's fp32 NHWC implicit-GEMM solvers reach
-            # ~85 % of the fp32 matrix peak on these 3x3 convolutions and ATen's NHWC bilinear resize is 10x faster
-            # than its NCHW one (profiles/r01a: 73 ms -> 45 ms at bs = 16); our kernels read either layout.
+            # inference on the GPU: the decoder runs in channels_last (NHWC), the layout of every kernel of the path
             cl = torch.channels_last
             b0, b1, b2, b3, b4 = (t.contiguous(memory_format=cl) for t in (b0, b1, b2, b3, b4))
-            if not self.conv2.weight.is_contiguous(memory_format=cl) or not self.conv3.weight.is_contiguous(memory_format=cl):
-                self.conv2.to(memory_format=cl)
-                self.conv3.to(memory_format=cl)
         x = self._conv2_padded_1x1(b4)
         stages = ((self.up1, b3), (self.up2, b2), (self.up3, b1), (self.up4, b0))
         if (self.final_upscale is None and all(up.split_ready(x, skip) for up, skip in stages[:1])
@@ -330,9 +335,7 @@ class Decoder(nn.Module):
         if self.final_upscale is not None:
             x = self.final_upscale(x, features[0])
         if x.device.type == "cuda" and not self.training and not torch.is_grad_enabled():
-            if self._split3.usable(x.shape[1]):
-                return self._split3(x)
-            third_party_conv(f"Decoder.conv3 {tuple(x.shape)}")
+            return self._split3(x) if self._split3.usable(x.shape[1]) else self._split3.exact(x)
         return self.conv3(x)
 
 

@@ -344,12 +344,7 @@ class ObjCAViT(nn.Module):
             if pre is not None and tuple(pre.shape) == tuple(x.shape):
                 return plan.run_split(pre)
             return plan(x)                                            # split-bf16 implicit GEMM, NHWC in / out
-        from .DenseFeatureExtractor import third_party_conv
-        third_party_conv(f"conv3x3 {tuple(x.shape)}")                 # raises unless OCV_CONV=miopen was asked for
-        if x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous() \
-                and not self.conv3x3.weight.is_contiguous(memory_format=torch.channels_last):
-            self.conv3x3.to(memory_format=torch.channels_last)
-        return self.conv3x3(x)
+        return plan.exact(x)                                          # OCV_CONV=exact, or channels not a multiple of 4
 
     def forward(self, image_features, object_features, object_xywh_list):
         y, feat, queries = self.forward_parts(image_features, object_features, object_xywh_list)

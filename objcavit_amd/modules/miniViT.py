@@ -2,8 +2,8 @@
 constructor, forward signature, return values and state_dict keys; the
 patch-embedding convolution, the four transformer layers, the regressor and
 the pixel-wise dot product run as HIP kernels, the 3x3 convolution as the
-split-bf16 implicit GEMM of csrc/conv_igemm.hip (MIOpen only on request:
-OCV_CONV=miopen).
+split-bf16 implicit GEMM of csrc/conv_igemm.hip (exact fp32 on request:
+OCV_CONV=exact).
 """
 from __future__ import annotations
 
@@ -64,12 +64,7 @@ class mViT(nn.Module):
             if pre is not None and tuple(pre.shape) == tuple(x.shape):
                 return plan.run_split(pre)
             return plan(x)                                            # split-bf16 implicit GEMM, NHWC in / out
-        from .DenseFeatureExtractor import third_party_conv
-        third_party_conv(f"conv3x3 {tuple(x.shape)}")                 # raises unless OCV_CONV=miopen was asked for
-        if x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous() \
-                and not self.conv3x3.weight.is_contiguous(memory_format=torch.channels_last):
-            self.conv3x3.to(memory_format=torch.channels_last)
-        return self.conv3x3(x)
+        return plan.exact(x)                                          # OCV_CONV=exact, or channels not a multiple of 4
 
     def forward(self, x):
         y, feat, queries = self.forward_parts(x)

@@ -692,6 +692,30 @@ def test_conv3x3_winograd_keeps_fp32_range_and_rejects_bad_operands(ops):
     assert not ops.winograd_pays(16, 60, 80, 1088, 512) and not ops.winograd_pays(16, 240, 320, 280, 128)
 
 
+@pytest.mark.parametrize("B,H,W,C1,C2,Cout,k,act", [
+    (2, 13, 17, 40, 0, 72, 3, 2),        # ragged rows / channels
+    (1, 9, 11, 128, 3, 128, 3, 2),       # the final_upscale stage's 131 input channels (virtual concat with the image)
+    (1, 7, 5, 5, 0, 3, 5, 0),            # 5 x 5, tiny odd channel counts
+    (2, 6, 6, 32, 16, 33, 1, 3),         # 1 x 1, concat, SiLU
+    (1, 30, 40, 256, 0, 128, 3, 1),      # several K chunks, ReLU
+])
+def test_conv_nhwc_exact(ops, B, H, W, C1, C2, Cout, k, act):
+    """ocv_conv_nhwc_exact_fwd: the hand-written exact-fp32 implicit GEMM (OCV_CONV=exact and shapes the split-bf16
+    kernels do not take) against an fp64 convolution, at fp32 accumulation-order noise."""
+    x1 = rnd("x1", (B, C1, H, W), 1)
+    x2 = rnd("x2", (B, C2, H, W), 2) if C2 else None
+    w, b = rnd("w", (Cout, C1 + C2, k, k), 3, 1 / math.sqrt((C1 + C2) * k * k)), rnd("b", (Cout,), 4, 0.2)
+    res = rnd("r", (B, Cout, H, W), 5)
+    xin = x1 if x2 is None else torch.cat([x1, x2], 1)
+    ref = F.conv2d(xin.double(), w.double(), b.double(), padding=k // 2)
+    ref = [ref, torch.relu(ref), F.leaky_relu(ref, 0.01), F.silu(ref)][act] + res
+    wt = dev(w).permute(2, 3, 0, 1).reshape(k * k, Cout, C1 + C2).contiguous()
+    cl = torch.channels_last
+    got = ops.conv_nhwc_exact(dev(x1).contiguous(memory_format=cl), None if x2 is None else dev(x2).contiguous(memory_format=cl),
+                              wt, dev(b), k, act, residual=dev(res).contiguous(memory_format=cl))
+    assert got.is_contiguous(memory_format=cl) and rel_dev(got, ref) < 2e-6
+
+
 @pytest.mark.parametrize("out_fp32,out_split", [(True, False), (False, True), (True, True)])
 def test_conv_nhwc_split_k_halves(ops, out_fp32, out_split):
     """300 tiles on 256 CUs: the launcher halves the channel chunks between two workgroups per tile (fp32 partial

@@ -320,3 +320,29 @@ def test_lightning_checkpoint_to_gpu_forward_equals_oracle(tmp_path):
     ref_depth, ref_edges = restate.graphbins_forward(img, feats, xywh, sd, 0.001, 10, **kw)
     assert rel_dev(out.bin_edges, ref_edges) < 1e-4
     assert max_rel(out.depth_pred, ref_depth) < 1e-3
+
+
+def test_ocv_conv_exact_routes_every_dense_convolution_through_the_exact_kernel(monkeypatch):
+    """OCV_CONV=exact (+ OCV_PW=fp32 for the 1x1 layers): the hand-written exact-fp32 route for A/B numerics -- round 1
+    needed MIOpen for it.  Same model, same inputs: both routes meet the north-star bar against the oracle, and the
+    exact one is closer."""
+    from objcavit_amd.modules.GraphBins import GraphBins
+    H, W, seed = 176, 192, 41
+    args = make_args(dimensions_train=[H, W], dimensions_test=[H, W], language="clip")
+    img = gen.randn("img", (1, 3, H, W), seed)
+    feats = [gen.randn("f0", (7, 512), seed, 10.0 / np.sqrt(512))]
+    xywh = [gen.boxes("b0", 7, seed, H, W)]
+    errs = {}
+    for mode in ("split_bf16", "exact"):
+        monkeypatch.setenv("OCV_CONV", mode)
+        monkeypatch.setenv("OCV_PW", "split" if mode == "split_bf16" else "fp32")
+        m = GraphBins(args).eval()
+        sd = gen.load_into(m, seed, gen.PEAKY)
+        out = m.cuda()(img.cuda(), [f.cuda() for f in feats], [b.cuda() for b in xywh])
+        ref_depth, _ = restate.graphbins_forward(img, feats, xywh, sd, 0.001, 10)
+        errs[mode] = max_rel(out.depth_pred, ref_depth)
+    assert errs["split_bf16"] < 1e-3 and errs["exact"] < 1e-3
+    assert errs["exact"] <= errs["split_bf16"] * 1.5 + 1e-6, errs
+    monkeypatch.setenv("OCV_CONV", "miopen")
+    with pytest.raises(ValueError):
+        GraphBins(args).eval().cuda()(img.cuda(), [f.cuda() for f in feats], [b.cuda() for b in xywh])
