@@ -56,6 +56,11 @@ def enable_timing(on: bool = True) -> None:
     _Timing.events = {}
 
 
+def pause_timing(paused: bool = True) -> None:
+    """Stop (or resume) recording event pairs WITHOUT dropping the ones already recorded."""
+    _Timing.enabled = not paused
+
+
 def timing_results() -> Dict[str, Tuple[int, float]]:
     """name -> (launch count, mean milliseconds); synchronises the device."""
     torch.cuda.synchronize()

@@ -327,7 +327,7 @@ def test_ocv_conv_exact_routes_every_dense_convolution_through_the_exact_kernel(
     needed MIOpen for it.  Same model, same inputs: both routes meet the north-star bar against the oracle, and the
     exact one is closer."""
     from objcavit_amd.modules.GraphBins import GraphBins
-    H, W, seed = 176, 192, 41
+    H, W, seed = 352, 384, 41
     args = make_args(dimensions_train=[H, W], dimensions_test=[H, W], language="clip")
     img = gen.randn("img", (1, 3, H, W), seed)
     feats = [gen.randn("f0", (7, 512), seed, 10.0 / np.sqrt(512))]
@@ -346,3 +346,31 @@ def test_ocv_conv_exact_routes_every_dense_convolution_through_the_exact_kernel(
     monkeypatch.setenv("OCV_CONV", "miopen")
     with pytest.raises(ValueError):
         GraphBins(args).eval().cuda()(img.cuda(), [f.cuda() for f in feats], [b.cuda() for b in xywh])
+
+
+def test_two_batches_in_flight_give_the_same_bits():
+    """bench.py's default keeps two batches in flight: one GraphedGraphBins per slot (own static input, own scratch
+    store), each replayed on its own stream.  Interleaved replays of two slots on two streams must give, for every
+    step, exactly the depth of a lone replay -- nothing is shared between slots but read-only weights."""
+    from objcavit_amd.graph import GraphedGraphBins
+    from objcavit_amd.modules.GraphBins import GraphBins, SyntheticObjectProvider
+    H, W = 352, 384
+    args = make_args(dimensions_train=[H, W], dimensions_test=[H, W], language="clip")
+    m = GraphBins(args, object_provider=SyntheticObjectProvider(8, "clip", seed=3)).eval()
+    gen.load_into(m, 61, gen.PEAKY)
+    m = m.cuda()
+    imgs = [gen.randn(f"img{i}", (2, 3, H, W), 61 + i).cuda() for i in range(4)]
+    refs = [m(im).depth_pred.clone() for im in imgs]
+    slots = [GraphedGraphBins(m, imgs[0]) for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    assert not (set(v.data_ptr() for v in slots[0].scratch.values()) & set(v.data_ptr() for v in slots[1].scratch.values()))
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(3):
+        for i, im in enumerate(imgs):
+            k = i % 2
+            with torch.cuda.stream(streams[k]):
+                outs.append((i, slots[k](im).depth_pred.clone()))
+    torch.cuda.synchronize()
+    for i, d in outs:
+        assert torch.equal(d, refs[i]), i
