@@ -119,6 +119,9 @@ def main(src, tag):
     ks = newest(os.path.join(src, "kt", "*", "*_kernel_stats.csv"))
     if ks:
         shutil.copy(ks[0], os.path.join(out, f"{tag}_kernel_stats.csv"))
+    ksd = newest(os.path.join(src, "kt_default", "*", "*_kernel_stats.csv"))     # the default (pipelined) command
+    if ksd:
+        shutil.copy(ksd[0], os.path.join(out, f"{tag}_kernel_stats_default_inflight.csv"))
     kt = newest(os.path.join(src, "kt", "*", "*_kernel_trace.csv"))
     if kt:
         rows = list(csv.DictReader(open(kt[0])))
