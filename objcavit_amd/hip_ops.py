@@ -630,7 +630,8 @@ def winograd_pays(B: int, H: int, W: int, Cin: int, Cout: int) -> bool:
         return False
     if mode == "1":
         return True
-    return Cin >= 768 and Cout >= 512 and B * H * W <= 32768
+    return Cin >= int(os.environ.get("OCV_WINO_MIN_CIN", "768")) and Cout >= int(os.environ.get("OCV_WINO_MIN_COUT", "512")) \
+        and B * H * W <= int(os.environ.get("OCV_WINO_MAX_PIX", "32768"))
 
 
 def conv3x3_winograd_split(x: "SplitAct", u_hi: torch.Tensor, u_lo: torch.Tensor, bias: Optional[torch.Tensor],
