@@ -25,8 +25,13 @@ OURS = ("bin_head_kernel", "pixel_dot_kernel", "patch_embed_partial_kernel", "pa
         "conv_igemm_kernel", "pointwise_kernel", "pointwise_smallk_kernel", "depthwise_kernel", "depthwise_nhwc_kernel",
         "channel_sum_kernel", "channel_mean_finish_kernel", "se_hidden_kernel", "se_gate_kernel",
         "conv_split_dma_kernel", "upsample_concat_split_kernel", "pw_rows_kernel", "pw_tile_kernel", "pw_stream_kernel",
-        "bin_head_split_kernel", "cross_attn_fused_kernel", "depth_metrics_partial_kernel", "depth_metrics_finish_kernel", "dw_slide_kernel", "se_hidden_partials_kernel", "se_gate_hid_kernel", "stem_conv_kernel",
+        "bin_head_split_kernel", "bin_head_split3_kernel", "bin_head_combine_kernel", "wino_input_kernel", "wino_output_kernel", "conv_exact_kernel", "cross_attn_fused_kernel", "depth_metrics_partial_kernel", "depth_metrics_finish_kernel", "dw_slide_kernel", "se_hidden_partials_kernel", "se_gate_hid_kernel", "stem_conv_kernel",
         "mbconv_expand_dw_kernel", "pos_sample_kernel", "pw_big_kernel", "encoder_stack_kernel", "upsample_concat_split8_kernel", "upsample_concat_split_2x2_kernel", "conv_splitk_finish_kernel", "ffn_finish_kernel", "upsample_concat_split_lds_kernel")
+
+
+def is_step_end(name):
+    """The launch that ends a bench step's forward: the bin head (its merge pass when it runs in two halves)."""
+    return "bin_head_combine_kernel" in name or "bin_head_kernel<" in name or "bin_head_split_kernel" in name
 
 
 def short(name):
@@ -53,7 +58,7 @@ def shape_key(r):
     return k
 
 
-SQ_KERNELS = ("conv_split_dma_kernel", "pw_tile_kernel", "pw_big_kernel", "pw_rows_kernel", "patch_embed_partial_kernel", "bin_head_kernel",
+SQ_KERNELS = ("conv_split_dma_kernel", "wino_input_kernel", "wino_output_kernel", "bin_head_split3_kernel", "bin_head_combine_kernel", "pw_tile_kernel", "pw_big_kernel", "pw_rows_kernel", "patch_embed_partial_kernel", "bin_head_kernel",
               "bin_head_split_kernel", "attention_kernel", "cross_attn_fused_kernel", "ffn_fused_kernel", "linear_stream_kernel",
               "dw_slide_kernel", "mbconv_expand_dw_kernel", "upsample_concat_split_lds_kernel", "encoder_stack_kernel")
 N_SIMD = 1024            # 256 CUs x 4 SIMDs
@@ -73,7 +78,7 @@ def sq_summary(src, newest):
         if not rows:
             continue
         # last step = launches after the second-to-last bin-head dispatch
-        heads = sorted({int(r["Dispatch_Id"]) for r in rows if "bin_head" in r["Kernel_Name"]})
+        heads = sorted({int(r["Dispatch_Id"]) for r in rows if is_step_end(r["Kernel_Name"])})
         lo = heads[-2] if len(heads) >= 2 else 0
         per = collections.defaultdict(lambda: collections.defaultdict(float))
         seen = collections.defaultdict(set)
@@ -126,7 +131,7 @@ def main(src, tag):
     if kt:
         rows = list(csv.DictReader(open(kt[0])))
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-        idx = [i for i, r in enumerate(rows) if "bin_head_kernel" in r["Kernel_Name"] or "bin_head_split_kernel" in r["Kernel_Name"]]
+        idx = [i for i, r in enumerate(rows) if is_step_end(r["Kernel_Name"])]
         # a bench step = the launches between two bin-head launches; take the step with the shortest wall time (the
         # first steps still load code objects lazily and the last one is disturbed by the profiler's buffer flush)
         steps = [rows[a + 1: b + 1] for a, b in zip(idx[:-1], idx[1:])]
@@ -164,7 +169,7 @@ def main(src, tag):
     if pmc:
         json.dump(pmc, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
         traffic = {}
-        for key, prefixes in (("bin_head", ("bin_head_split_kernel", "bin_head_kernel")), ("patch_embed", ("patch_embed_partial_kernel",)),
+        for key, prefixes in (("bin_head", ("bin_head_split3_kernel", "bin_head_split_kernel", "bin_head_kernel")), ("patch_embed", ("patch_embed_partial_kernel",)),
                               ("conv3x3", ("conv_split_dma_kernel", "conv_igemm_kernel"))):
             names = [n for n in series if n.startswith(prefixes) and len(series[n]) == 2
                      and len(series[n]["FETCH_SIZE"]) == len(series[n]["WRITE_SIZE"])]
