@@ -110,11 +110,37 @@ int ocv_mha_fwd(const float* q_src, const float* k_src, const float* v_src, cons
 typedef struct {
   const float *in_proj_w, *in_proj_b, *out_proj_w, *out_proj_b;
   const float *norm1_w, *norm1_b, *linear1_w, *linear1_b, *linear2_w, *linear2_b, *norm2_w, *norm2_b;
+  /* optional: the four weight matrices packed by ocv_pack_split3_fwd (all four or none).  With them the projections and
+   * the feed-forward block run as the three-term bf16 split (fp32-faithful, 2.7x the matrix rate); NULL = exact fp32. */
+  const void *in_proj_p3, *out_proj_p3, *linear1_p3, *linear2_p3;
 } ocv_encoder_layer_params;
 size_t ocv_encoder_layer_workspace_bytes(int B, int S, int E, int FF);
 int ocv_encoder_layer_fwd(const float* x, const ocv_encoder_layer_params* p, const uint8_t* key_padding_mask,
                           int zero_padded_rows, float* out, int B, int S, int E, int H, int FF, float eps,
                           void* workspace, size_t workspace_bytes, ocv_stream_t stream);
+
+/* Three-term bf16 split ("split3") forms of the token-path linear layers: every operand v = h + m + l (h = bf16(v),
+ * m = bf16(v - h), l = bf16(v - h - m): 24 significant bits), every product as the six terms whose magnitude exceeds
+ * 2^-24 of it, on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- results equal to the exact-fp32 kernels' to fp32
+ * rounding at 2.7x their matrix rate (and ~1/2.7 of their matrix-core energy).  The static weight W [N][K] (nn.Linear
+ * layout, row stride ldw) is split and packed once per weight version by ocv_pack_split3_fwd into MFMA B-operand
+ * fragments, ocv_split3_packed_elems(N, K) bf16 elements:
+ *   packed[((jt * ceil(K/16) + s) * 3 + part) * 512 + lane * 8 + e] = part of W[32 jt + (lane & 31)][16 s + 8 (lane >> 5) + e]
+ * (zero beyond N / K).  K a multiple of 8.  Same reference lines as ocv_linear_fwd /
+ * ocv_linear_residual_layernorm_fwd / ocv_ffn_residual_layernorm_fwd. */
+size_t ocv_split3_packed_elems(int N, int K);
+int ocv_pack_split3_fwd(const float* W, int ldw, int N, int K, void* packed, ocv_stream_t stream);
+int ocv_linear_split3_fwd(const float* A, int lda, const void* w_packed, const float* bias, float* out, int ldo, int M, int N,
+                          int K, int act, ocv_stream_t stream);
+int ocv_linear_residual_layernorm_split3_fwd(const float* A, int lda, const void* w_packed, const float* bias,
+                                             const float* residual, int ldres, const float* gamma, const float* beta,
+                                             float eps, const uint8_t* zero_row_mask, float* out, int ldo, int M, int N,
+                                             int K, ocv_stream_t stream);
+size_t ocv_ffn_split3_workspace_bytes(int M, int FF);
+int ocv_ffn_residual_layernorm_split3_fwd(const float* x, const void* w1_packed, const float* b1, const void* w2_packed,
+                                          const float* b2, const float* gamma, const float* beta, float eps,
+                                          const uint8_t* zero_row_mask, float* out, int M, int E, int FF, void* workspace,
+                                          size_t workspace_bytes, ocv_stream_t stream);
 
 /* Patch embedding: Conv2d(C -> E, kernel = stride = 16, no padding) on fmap [B,C,h,w] (NCHW), flattened to tokens,
  * plus bias and positional embedding, written token-major:

@@ -21,7 +21,8 @@ class EncoderLayerParams(C.Structure):
     """ocv_encoder_layer_params"""
     _fields_ = [(n, C.c_void_p) for n in (
         "in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "norm1_w", "norm1_b",
-        "linear1_w", "linear1_b", "linear2_w", "linear2_b", "norm2_w", "norm2_b")]
+        "linear1_w", "linear1_b", "linear2_w", "linear2_b", "norm2_w", "norm2_b",
+        "in_proj_p3", "out_proj_p3", "linear1_p3", "linear2_p3")]
 
 
 # name -> (restype, argtypes); every symbol declared in include/objcavit_hip.h
@@ -39,6 +40,14 @@ PROTOTYPES = {
     "ocv_mha_fwd": (C.c_int, [_f32p, _f32p, _f32p, _u8p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int,
                               C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, _stream]),
     "ocv_ffn_residual_layernorm_fwd": (C.c_int, [_f32p] * 7 + [C.c_float, _u8p, _f32p, C.c_int, C.c_int, C.c_int, _stream]),
+    "ocv_split3_packed_elems": (C.c_size_t, [C.c_int, C.c_int]),
+    "ocv_pack_split3_fwd": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, C.c_void_p, _stream]),
+    "ocv_linear_split3_fwd": (C.c_int, [_f32p, C.c_int, C.c_void_p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
+    "ocv_linear_residual_layernorm_split3_fwd": (C.c_int, [_f32p, C.c_int, C.c_void_p, _f32p, _f32p, C.c_int, _f32p, _f32p, C.c_float,
+                                                           _u8p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
+    "ocv_ffn_split3_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "ocv_ffn_residual_layernorm_split3_fwd": (C.c_int, [_f32p, C.c_void_p, _f32p, C.c_void_p, _f32p, _f32p, _f32p, C.c_float, _u8p, _f32p,
+                                                        C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, _stream]),
     "ocv_encoder_layer_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "ocv_encoder_layer_fwd": (C.c_int, [_f32p, C.POINTER(EncoderLayerParams), _u8p, C.c_int, _f32p, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_size_t, _stream]),

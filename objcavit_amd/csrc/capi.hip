@@ -99,15 +99,28 @@ extern "C" int ocv_encoder_layer_fwd(const float* x, const ocv_encoder_layer_par
   ws += align_up((size_t)M * E * sizeof(float));
   float* hid = (float*)ws;
   int rc;
+  const uint8_t* zmask = (zero_padded_rows && key_padding_mask) ? key_padding_mask : nullptr;
+  const bool any3 = p->in_proj_p3 || p->out_proj_p3 || p->linear1_p3 || p->linear2_p3;
+  const bool all3 = p->in_proj_p3 && p->out_proj_p3 && p->linear1_p3 && p->linear2_p3;
+  OCV_CHECK_ARG(all3 || !any3, "ocv_encoder_layer_fwd: give all four packed split3 weights or none");
+  const bool s3 = all3 && FF % 128 == 0;
   // packed QKV projection
-  if ((rc = ocv_linear_fwd(x, E, 0, p->in_proj_w, E, 0, 0, p->in_proj_b, qkv, 3 * E, 0, 1, M, 3 * E, E, OCV_ACT_NONE, stream))) return rc;
+  if (s3) rc = ocv_linear_split3_fwd(x, E, p->in_proj_p3, p->in_proj_b, qkv, 3 * E, M, 3 * E, E, OCV_ACT_NONE, stream);
+  else rc = ocv_linear_fwd(x, E, 0, p->in_proj_w, E, 0, 0, p->in_proj_b, qkv, 3 * E, 0, 1, M, 3 * E, E, OCV_ACT_NONE, stream);
+  if (rc) return rc;
   if ((rc = ocv_attention_fwd(qkv, (long)S * 3 * E, 3 * E, qkv + E, (long)S * 3 * E, 3 * E, qkv + 2 * E,
                               (long)S * 3 * E, 3 * E, key_padding_mask, ctx, (long)S * E, E, B, H, S, S,
                               1.0f / sqrtf(32.0f), stream))) return rc;
   // x1 = LN1(x + ctx Wo^T + bo)
+  if (s3) {
+    if ((rc = ocv_linear_residual_layernorm_split3_fwd(ctx, E, p->out_proj_p3, p->out_proj_b, x, E, p->norm1_w, p->norm1_b, eps,
+                                                       nullptr, x1, E, M, E, E, stream))) return rc;
+    // out = LN2(x1 + W2 relu(W1 x1 + b1) + b2); split partials live in the (otherwise unused) hid region
+    return ocv_ffn_residual_layernorm_split3_fwd(x1, p->linear1_p3, p->linear1_b, p->linear2_p3, p->linear2_b, p->norm2_w,
+                                                 p->norm2_b, eps, zmask, out, M, E, FF, hid, (size_t)M * FF * sizeof(float), stream);
+  }
   if ((rc = ocv_linear_residual_layernorm_fwd(ctx, E, p->out_proj_w, E, p->out_proj_b, x, E, p->norm1_w, p->norm1_b,
                                               eps, nullptr, x1, E, M, E, E, stream))) return rc;
-  const uint8_t* zmask = (zero_padded_rows && key_padding_mask) ? key_padding_mask : nullptr;
   if (FF % 128 == 0) {
     // out = LN2(x1 + W2 relu(W1 x1 + b1) + b2), hidden activations stay in LDS
     const int ns = ocv_ffn_split_count(M, FF);       // partials live in the (otherwise unused) hid region: ns * 128 <= FF

@@ -1,0 +1,395 @@
+// Token-path linear layers on the bf16 matrix cores at fp32 accuracy: THREE-term split operands.
+//
+//   v = h + m + l,  h = bf16(v), m = bf16(v - h), l = bf16(v - h - m)      (24 significant bits; both subtractions exact)
+//   a b ~= ah bh + ah bm + am bh + am bm + ah bl + al bh                     (dropped terms <= 2^-24 of the product)
+//
+// Six v_mfma_f32_32x32x16_bf16 (192 matrix-pipe cycles per 32 x 32 x 16 block) against eight v_mfma_f32_32x32x2_f32
+// (512): the same results to fp32 rounding at 2.7x the matrix rate and ~1/2.7 of the matrix-core energy -- the forward
+// runs at the package power cap once batches are pipelined, so joules per image are what is left
+// to save.  The two-term split of the convolutions (2^-17 per product) is NOT used here: the token path feeds the
+// queries of a near-one-hot bin softmax.
+//
+// Operands: activation rows are split once per workgroup while they are staged into LDS (three bf16 planes, rows padded
+// to 272 bytes: conflict-free ds_read_b128 of 16 rows x one K octet); the static weights are split and packed ONCE on the
+// device by ocv_pack_split3_fwd into MFMA B-operand fragments,
+//   Wp[((jt * (K/16) + s) * 3 + part) * 512 + lane * 8 + e] = part of W[32 jt + (lane & 31)][16 s + 8 (lane >> 5) + e],
+// so a wavefront's weight load is one contiguous 1 KB run per (channel tile, K step, part), straight from L2 into VGPRs
+// (every weight element is used by exactly one wavefront of a workgroup).
+//   lin3_kernel<NT, EPI>   out = epi(A W^T + b): 32 rows x (128 NT) columns per workgroup; epi = none | residual + LayerNorm
+//   ffn3_kernel            out = LayerNorm(x + W2 relu(W1 x + b1) + b2), hidden units 128 at a time through LDS
+// Replace nn.Linear / nn.MultiheadAttention projections / linear1 + linear2 of nn.TransformerEncoderLayer at
+// modules/ObjCAViT.py:155-161,169,188 and modules/layers.py:8-9,23 (same lines as the fp32 kernels of csrc/linear.hip).
+#include "common.hpp"
+#include "../../include/objcavit_hip.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int TM = 32;               // rows per workgroup
+constexpr int KC = 128;              // K chunk staged at a time
+constexpr int PROW = KC + 8;         // bf16 per plane row (272 bytes)
+constexpr int PLANE = TM * PROW;     // bf16 per plane
+constexpr int E128 = 128;
+
+__device__ __forceinline__ void split8x3(const float4 u, const float4 v, bf16x8& h, bf16x8& m, bf16x8& l) {
+  const float f[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 a = (__bf16)f[i];
+    const float r1 = f[i] - (float)a;
+    const __bf16 b = (__bf16)r1;
+    h[i] = a;
+    m[i] = b;
+    l[i] = (__bf16)(r1 - (float)b);
+  }
+}
+
+// 256 threads stage rows [m0, m0 + 32) x columns [k0, k0 + kc) of a row-major fp32 matrix as three bf16 planes
+__device__ __forceinline__ void stage_rows3(__bf16* planes, const float* __restrict__ src, int ld, int m0, int M, int k0, int kc,
+                                            int tid) {
+  const int row = tid >> 3;
+  const bool ok = m0 + row < M;
+  const float* s = src + (long)(ok ? m0 + row : 0) * ld + k0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int o = (tid & 7) + 8 * i;                     // K octet of the chunk
+    float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = u;
+    if (ok && 8 * o < kc) {
+      u = ld4(s + 8 * o);
+      v = ld4(s + 8 * o + 4);
+    }
+    bf16x8 h, m, l;
+    split8x3(u, v, h, m, l);
+    __bf16* d = planes + row * PROW + 8 * o;
+    *reinterpret_cast<bf16x8*>(d) = h;
+    *reinterpret_cast<bf16x8*>(d + PLANE) = m;
+    *reinterpret_cast<bf16x8*>(d + 2 * PLANE) = l;
+  }
+}
+
+__device__ __forceinline__ f32x16 mfma6(const bf16x8 ah, const bf16x8 am, const bf16x8 al, const bf16x8 bh, const bf16x8 bm,
+                                        const bf16x8 bl, f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);      // small terms first
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+  return acc;
+}
+
+// acc[t] += planes[32 x (16 nsteps)] . Wp(channel tile jt[t], K steps s0 ..)^T  for NT channel tiles of this wavefront
+template <int NT>
+__device__ __forceinline__ void chunk_mfma3(f32x16 (&acc)[NT], const __bf16* planes, const __bf16* const (&wp)[NT], int nsteps,
+                                            int l31, int hh) {
+  const __bf16* pa = planes + l31 * PROW + 8 * hh;
+#pragma unroll
+  for (int s = 0; s < KC / 16; ++s) {
+    if (s < nsteps) {
+      const bf16x8 ah = *reinterpret_cast<const bf16x8*>(pa + 16 * s);
+      const bf16x8 am = *reinterpret_cast<const bf16x8*>(pa + 16 * s + PLANE);
+      const bf16x8 al = *reinterpret_cast<const bf16x8*>(pa + 16 * s + 2 * PLANE);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const __bf16* w = wp[t] + (long)s * 1536;
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(w);
+        const bf16x8 bm = *reinterpret_cast<const bf16x8*>(w + 512);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(w + 1024);
+        acc[t] = mfma6(ah, am, al, bh, bm, bl, acc[t]);
+      }
+    }
+  }
+}
+
+// residual + LayerNorm over the 128 columns of a 32-row tile held in Cs (one wavefront per 8 rows)
+__device__ __forceinline__ void ln_rows3(const float (*Cs)[E128 + 1], const float* gamma, const float* beta, float eps,
+                                         const uint8_t* zero_mask, float* out, int ldo, int m0, int M, int lane, int wave) {
+  const float g0 = gamma[lane], g1 = gamma[lane + 64];
+  const float b0 = beta[lane], b1 = beta[lane + 64];
+#pragma unroll
+  for (int i = 0; i < TM / 4; ++i) {
+    const int row = wave * (TM / 4) + i, m = m0 + row;
+    const float x0 = Cs[row][lane], x1 = Cs[row][lane + 64];
+    const float mean = wave_sum(x0 + x1) * (1.0f / E128);
+    const float d0 = x0 - mean, d1 = x1 - mean;
+    const float var = wave_sum(d0 * d0 + d1 * d1) * (1.0f / E128);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (m < M) {
+      const bool z = zero_mask != nullptr && zero_mask[m] != 0;
+      out[(long)m * ldo + lane] = z ? 0.f : d0 * rstd * g0 + b0;
+      out[(long)m * ldo + lane + 64] = z ? 0.f : d1 * rstd * g1 + b1;
+    }
+  }
+}
+
+enum { L3_NONE = 0, L3_RELU = 1, L3_LEAKY = 2, L3_RES_LN = 3 };
+
+struct L3Args {
+  const float* A; int lda;
+  const __bf16* Wp;
+  const float* bias;
+  float* out; int ldo;
+  int M, N, K;
+  const float* res; int ldres;
+  const float *gamma, *beta; float eps;
+  const uint8_t* zero_mask;
+};
+
+template <int NT, int EPI>
+__global__ __launch_bounds__(256) void lin3_kernel(L3Args p) {
+  __shared__ __attribute__((aligned(16))) __bf16 planes[3 * PLANE];
+  __shared__ float Cs[EPI == L3_RES_LN ? TM : 1][E128 + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int m0 = blockIdx.x * TM;
+  const int nsteps_all = (p.K + 15) >> 4, ntl = (p.N + 31) >> 5;
+  int jt[NT];
+  const __bf16* wp[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    jt[t] = (blockIdx.y * 4 + wave) * NT + t;
+    wp[t] = p.Wp + ((long)min(jt[t], ntl - 1) * nsteps_all * 3) * 512 + lane * 8;
+  }
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x16{0};
+  for (int k0 = 0; k0 < p.K; k0 += KC) {
+    const int kc = min(KC, p.K - k0);
+    __syncthreads();
+    stage_rows3(planes, p.A, p.lda, m0, p.M, k0, kc, tid);
+    __syncthreads();
+    const __bf16* wk[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wk[t] = wp[t] + (long)(k0 >> 4) * 1536;
+    chunk_mfma3<NT>(acc, planes, wk, (kc + 15) >> 4, l31, hh);
+  }
+  if (EPI != L3_RES_LN) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n = jt[t] * 32 + l31;
+      if (n >= p.N) continue;
+      const float bn = p.bias != nullptr ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + acc_row(r, hh);
+        float v = acc[t][r] + bn;
+        if (EPI == L3_RELU) v = fmaxf(v, 0.f);
+        if (EPI == L3_LEAKY) v = v > 0.f ? v : 0.01f * v;
+        if (m < p.M) p.out[(long)m * p.ldo + n] = v;
+      }
+    }
+  } else {
+    const int n = wave * 32 + l31;                       // N == 128, NT == 1, gridDim.y == 1
+    const float bn = p.bias != nullptr ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = acc_row(r, hh), m = m0 + row;
+      float v = acc[0][r] + bn;
+      if (m < p.M) v += p.res[(long)m * p.ldres + n];
+      Cs[row][n] = v;
+    }
+    __syncthreads();
+    ln_rows3(Cs, p.gamma, p.beta, p.eps, p.zero_mask, p.out, p.ldo, m0, p.M, lane, wave);
+  }
+}
+
+struct F3Args {
+  const float* x;
+  const __bf16 *w1p, *w2p;
+  const float *b1, *b2, *gamma, *beta;
+  float eps;
+  const uint8_t* zero_mask;
+  float* out;
+  int M, FF;
+  float* part;           // nsplit > 1: raw partial outputs [nsplit][M][128]
+  int nsplit;
+};
+
+__global__ __launch_bounds__(256) void ffn3_kernel(F3Args p) {
+  __shared__ __attribute__((aligned(16))) __bf16 xp[3 * PLANE];
+  __shared__ __attribute__((aligned(16))) __bf16 hp[3 * PLANE];
+  __shared__ float Cs[TM][E128 + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int m0 = blockIdx.x * TM;
+  const int col = wave * 32 + l31;
+  const int nchunk_all = p.FF / KC;
+  const int cbeg = nchunk_all * (int)blockIdx.y / p.nsplit, cend = nchunk_all * ((int)blockIdx.y + 1) / p.nsplit;
+  const int ksteps2 = p.FF >> 4;                         // K steps of W2 (K = FF)
+
+  stage_rows3(xp, p.x, E128, m0, p.M, 0, E128, tid);
+  f32x16 acc[1] = {f32x16{0}};
+  __syncthreads();
+  for (int c = cbeg; c < cend; ++c) {
+    // phase 1: hidden units [128 c + 32 wave, + 32) of the tile's rows
+    f32x16 h[1] = {f32x16{0}};
+    const __bf16* const w1[1] = {p.w1p + ((long)(c * 4 + wave) * (E128 / 16) * 3) * 512 + lane * 8};
+    chunk_mfma3<1>(h, xp, w1, E128 / 16, l31, hh);
+    const float b1 = p.b1[c * KC + col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = fmaxf(h[0][r] + b1, 0.f);
+      const __bf16 a = (__bf16)v;
+      const float r1 = v - (float)a;
+      const __bf16 b = (__bf16)r1;
+      __bf16* d = hp + acc_row(r, hh) * PROW + col;
+      d[0] = a;
+      d[PLANE] = b;
+      d[2 * PLANE] = (__bf16)(r1 - (float)b);
+    }
+    __syncthreads();
+    // phase 2: out[:, 32 wave ..] += H_chunk . W2[:, 128 c ..]^T
+    const __bf16* const w2[1] = {p.w2p + (((long)wave * ksteps2 + c * (KC / 16)) * 3) * 512 + lane * 8};
+    chunk_mfma3<1>(acc, hp, w2, KC / 16, l31, hh);
+    __syncthreads();
+  }
+  if (p.nsplit > 1) {
+    float* dst = p.part + ((long)blockIdx.y * p.M + m0) * E128 + col;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = acc_row(r, hh);
+      if (m0 + row < p.M) dst[(long)row * E128] = acc[0][r];
+    }
+    return;
+  }
+  const float b2 = p.b2[col];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = acc_row(r, hh), m = m0 + row;
+    Cs[row][col] = acc[0][r] + b2 + (m < p.M ? p.x[(long)m * E128 + col] : 0.f);
+  }
+  __syncthreads();
+  ln_rows3(Cs, p.gamma, p.beta, p.eps, p.zero_mask, p.out, E128, m0, p.M, lane, wave);
+}
+
+// out = LayerNorm(x + sum_s part[s] + b2), partials added in split order (second pass of a split FFN)
+__global__ __launch_bounds__(256) void ffn3_finish_kernel(F3Args p) {
+  __shared__ float Cs[TM][E128 + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * TM;
+  for (int i = tid; i < TM * E128; i += 256) {
+    const int row = i / E128, col = i % E128;
+    const long m = m0 + row;
+    float v = 0.f;
+    if (m < p.M) {
+      v = p.part[m * E128 + col];
+      for (int sidx = 1; sidx < p.nsplit; ++sidx) v += p.part[((long)sidx * p.M + m) * E128 + col];
+      v += p.b2[col] + p.x[m * E128 + col];
+    }
+    Cs[row][col] = v;
+  }
+  __syncthreads();
+  ln_rows3(Cs, p.gamma, p.beta, p.eps, p.zero_mask, p.out, E128, m0, p.M, lane, wave);
+}
+
+// W [N][K] fp32 (row stride ldw) -> packed three-term fragments; one thread per (jt, s, lane)
+__global__ __launch_bounds__(256) void pack3_kernel(const float* __restrict__ W, int ldw, int N, int K, __bf16* __restrict__ out,
+                                                    long items) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= items) return;
+  const int lane = (int)(i & 63);
+  const long js = i >> 6;
+  const int nsteps = (K + 15) >> 4;
+  const int s = (int)(js % nsteps), jt = (int)(js / nsteps);
+  const int n = jt * 32 + (lane & 31), k0 = 16 * s + 8 * (lane >> 5);
+  float f[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = (n < N && k0 + e < K) ? W[(long)n * ldw + k0 + e] : 0.f;
+  bf16x8 h, m, l;
+  split8x3(make_float4(f[0], f[1], f[2], f[3]), make_float4(f[4], f[5], f[6], f[7]), h, m, l);
+  __bf16* d = out + (js * 3) * 512 + lane * 8;
+  *reinterpret_cast<bf16x8*>(d) = h;
+  *reinterpret_cast<bf16x8*>(d + 512) = m;
+  *reinterpret_cast<bf16x8*>(d + 1024) = l;
+}
+
+template <int NT>
+int launch_lin3(const L3Args& a, int act, hipStream_t st) {
+  dim3 grid(ocv_cdiv(a.M, TM), ocv_cdiv(a.N, 128 * NT)), block(256);
+  switch (act) {
+    case OCV_ACT_RELU: hipLaunchKernelGGL((lin3_kernel<NT, L3_RELU>), grid, block, 0, st, a); break;
+    case OCV_ACT_LEAKY_RELU: hipLaunchKernelGGL((lin3_kernel<NT, L3_LEAKY>), grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL((lin3_kernel<NT, L3_NONE>), grid, block, 0, st, a); break;
+  }
+  OCV_CHECK_LAUNCH("ocv_linear_split3_fwd");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" size_t ocv_split3_packed_elems(int N, int K) {
+  if (N < 1 || K < 1) return 0;
+  return (size_t)((N + 31) / 32) * ((K + 15) / 16) * 3 * 512;
+}
+
+extern "C" int ocv_pack_split3_fwd(const float* W, int ldw, int N, int K, void* packed, ocv_stream_t stream) {
+  OCV_CHECK_ARG(W && packed, "ocv_pack_split3_fwd: null pointer");
+  OCV_CHECK_ARG(N >= 1 && K >= 1 && ldw >= K, "ocv_pack_split3_fwd: bad sizes N=%d K=%d ldw=%d", N, K, ldw);
+  OCV_CHECK_ARG(ocv_aligned16(packed), "ocv_pack_split3_fwd: packed must be 16-byte aligned");
+  const long items = (long)((N + 31) / 32) * ((K + 15) / 16) * 64;
+  hipLaunchKernelGGL(pack3_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, ldw, N, K,
+                     (__bf16*)packed, items);
+  OCV_CHECK_LAUNCH("ocv_pack_split3_fwd");
+  return 0;
+}
+
+extern "C" int ocv_linear_split3_fwd(const float* A, int lda, const void* w_packed, const float* bias, float* out, int ldo,
+                                     int M, int N, int K, int act, ocv_stream_t stream) {
+  OCV_CHECK_ARG(A && w_packed && out, "ocv_linear_split3_fwd: null pointer");
+  OCV_CHECK_ARG(M >= 0 && N >= 1 && K >= 8 && K % 8 == 0 && lda >= K && ldo >= N && lda % 4 == 0,
+                "ocv_linear_split3_fwd: bad sizes (K and lda must be multiples of 8 / 4; M=%d N=%d K=%d)", M, N, K);
+  OCV_CHECK_ARG(act >= 0 && act <= 2, "ocv_linear_split3_fwd: unknown activation %d", act);
+  OCV_CHECK_ARG(ocv_aligned16(A) && ocv_aligned16(w_packed), "ocv_linear_split3_fwd: A / w_packed must be 16-byte aligned");
+  if (M == 0) return 0;
+  L3Args a{A, lda, (const __bf16*)w_packed, bias, out, ldo, M, N, K, nullptr, 0, nullptr, nullptr, 0.f, nullptr};
+  hipStream_t st = (hipStream_t)stream;
+  const int ntl = (N + 31) / 32;
+  if (ntl % 12 == 0 || ntl > 8) return launch_lin3<3>(a, act, st);       // 384 columns per workgroup (packed QKV)
+  if (ntl > 4) return launch_lin3<2>(a, act, st);
+  return launch_lin3<1>(a, act, st);
+}
+
+extern "C" int ocv_linear_residual_layernorm_split3_fwd(const float* A, int lda, const void* w_packed, const float* bias,
+                                                        const float* residual, int ldres, const float* gamma,
+                                                        const float* beta, float eps, const uint8_t* zero_row_mask,
+                                                        float* out, int ldo, int M, int N, int K, ocv_stream_t stream) {
+  OCV_CHECK_ARG(A && w_packed && residual && gamma && beta && out, "ocv_linear_residual_layernorm_split3_fwd: null pointer");
+  OCV_CHECK_ARG(N == E128, "ocv_linear_residual_layernorm_split3_fwd: N must be %d (got %d)", E128, N);
+  OCV_CHECK_ARG(M >= 0 && K >= 8 && K % 8 == 0 && lda >= K && lda % 4 == 0 && ldo >= N && ldres >= N,
+                "ocv_linear_residual_layernorm_split3_fwd: bad sizes");
+  OCV_CHECK_ARG(ocv_aligned16(A) && ocv_aligned16(w_packed), "ocv_linear_residual_layernorm_split3_fwd: A / w_packed must be 16-byte aligned");
+  if (M == 0) return 0;
+  L3Args a{A, lda, (const __bf16*)w_packed, bias, out, ldo, M, N, K, residual, ldres, gamma, beta, eps, zero_row_mask};
+  hipLaunchKernelGGL((lin3_kernel<1, L3_RES_LN>), dim3(ocv_cdiv(M, TM), 1), dim3(256), 0, (hipStream_t)stream, a);
+  OCV_CHECK_LAUNCH("ocv_linear_residual_layernorm_split3_fwd");
+  return 0;
+}
+
+extern "C" size_t ocv_ffn_split3_workspace_bytes(int M, int FF) {
+  if (M < 1 || FF < KC || FF % KC != 0) return 0;
+  return (size_t)ocv_ffn_split_count(M, FF) * M * E128 * sizeof(float);
+}
+
+extern "C" int ocv_ffn_residual_layernorm_split3_fwd(const float* x, const void* w1_packed, const float* b1,
+                                                     const void* w2_packed, const float* b2, const float* gamma,
+                                                     const float* beta, float eps, const uint8_t* zero_row_mask, float* out,
+                                                     int M, int E, int FF, void* workspace, size_t workspace_bytes,
+                                                     ocv_stream_t stream) {
+  OCV_CHECK_ARG(x && w1_packed && b1 && w2_packed && b2 && gamma && beta && out, "ocv_ffn_residual_layernorm_split3_fwd: null pointer");
+  OCV_CHECK_ARG(E == E128 && FF >= KC && FF % KC == 0, "ocv_ffn_residual_layernorm_split3_fwd: needs E = %d and FF a multiple of %d (got %d, %d)", E128, KC, E, FF);
+  OCV_CHECK_ARG(M >= 0 && ocv_aligned16(x) && ocv_aligned16(w1_packed) && ocv_aligned16(w2_packed), "ocv_ffn_residual_layernorm_split3_fwd: bad M / alignment");
+  if (M == 0) return 0;
+  int ns = ocv_ffn_split_count(M, FF);
+  if (ns > 1 && (workspace == nullptr || workspace_bytes < (size_t)ns * M * E128 * sizeof(float))) ns = 1;
+  F3Args a{x, (const __bf16*)w1_packed, (const __bf16*)w2_packed, b1, b2, gamma, beta, eps, zero_row_mask, out, M, FF,
+           (float*)workspace, ns};
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ffn3_kernel, dim3(ocv_cdiv(M, TM), ns), dim3(256), 0, st, a);
+  OCV_CHECK_LAUNCH("ocv_ffn_residual_layernorm_split3_fwd");
+  if (ns > 1) {
+    hipLaunchKernelGGL(ffn3_finish_kernel, dim3(ocv_cdiv(M, TM)), dim3(256), 0, st, a);
+    OCV_CHECK_LAUNCH("ocv_ffn_residual_layernorm_split3_fwd(finish)");
+  }
+  return 0;
+}

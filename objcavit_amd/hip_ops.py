@@ -319,9 +319,81 @@ _LAYER_FIELDS = (("in_proj_w", "self_attn.in_proj_weight"), ("in_proj_b", "self_
                  ("norm2_w", "norm2.weight"), ("norm2_b", "norm2.bias"))
 
 
-def layer_params(layer: torch.nn.Module) -> Tuple[EncoderLayerParams, list]:
-    """Pointer table for one nn.TransformerEncoderLayer-shaped parameter holder.
-    Returns (struct, keep-alive list of tensors)."""
+class SplitWeight3:
+    """A static [N, K] matrix split into three bf16 terms (24 significant bits) and packed in matrix-core B-operand
+    order by the device (ocv_pack_split3_fwd; layout in include/objcavit_hip.h).  Built once per weight version by the
+    callers (cached next to the parameter)."""
+
+    def __init__(self, weight: torch.Tensor):
+        lib = _lib.load()
+        w = _req(weight.detach().reshape(weight.shape[0], -1).contiguous(), "weight")
+        self.n, self.k = int(w.shape[0]), int(w.shape[1])
+        if self.k % 8 != 0:
+            raise ValueError("SplitWeight3: K must be a multiple of 8")
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("weight packing during graph capture: run one eager warm-up call first")
+        self.packed = torch.empty(int(lib.ocv_split3_packed_elems(self.n, self.k)), dtype=torch.bfloat16, device=w.device)
+        check(lib.ocv_pack_split3_fwd(w.data_ptr(), self.k, self.n, self.k, self.packed.data_ptr(), _stream()), "ocv_pack_split3_fwd")
+
+
+def linear_split3(x: torch.Tensor, weight: SplitWeight3, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE) -> torch.Tensor:
+    """act(x @ W.T + bias) with three-term-split operands (fp32-faithful); x [..., K] contiguous."""
+    lib = _lib.load()
+    _req(x, "x")
+    K = x.shape[-1]
+    if K != weight.k:
+        raise ValueError(f"linear_split3: weight with K={weight.k} does not match x[..., {K}]")
+    if bias is not None:
+        _req(bias, "bias")
+        if bias.numel() != weight.n:
+            raise ValueError("linear_split3: bias size mismatch")
+    M = x.numel() // K
+    out = torch.empty(*x.shape[:-1], weight.n, dtype=torch.float32, device=x.device)
+    check(lib.ocv_linear_split3_fwd(x.data_ptr(), K, weight.packed.data_ptr(), _ptr(bias), out.data_ptr(), weight.n, M, weight.n, K,
+                                    act, _stream()), "ocv_linear_split3_fwd")
+    return out
+
+
+def ffn_residual_layernorm_split3(x: torch.Tensor, w1: SplitWeight3, b1: torch.Tensor, w2: SplitWeight3, b2: torch.Tensor,
+                                  gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
+                                  zero_row_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """LayerNorm(x + W2 relu(W1 x + b1) + b2) with three-term-split operands; x [..., 128]."""
+    lib = _lib.load()
+    for n, t in (("x", x), ("b1", b1), ("b2", b2), ("gamma", gamma), ("beta", beta)):
+        _req(t, n)
+    E = x.shape[-1]
+    FF = w1.n
+    M = x.numel() // E
+    if w1.k != E or w2.n != E or w2.k != FF or b1.numel() != FF or b2.numel() != E:
+        raise ValueError("ffn_residual_layernorm_split3: shape mismatch")
+    if zero_row_mask is not None:
+        _req(zero_row_mask, "zero_row_mask", torch.uint8)
+    nb = int(lib.ocv_ffn_split3_workspace_bytes(M, FF))
+    ws = workspace(nb, x.device, "ffn3") if nb else None
+    out = torch.empty_like(x)
+    check(lib.ocv_ffn_residual_layernorm_split3_fwd(x.data_ptr(), w1.packed.data_ptr(), b1.data_ptr(), w2.packed.data_ptr(), b2.data_ptr(),
+                                                    gamma.data_ptr(), beta.data_ptr(), eps, _ptr(zero_row_mask), out.data_ptr(), M, E, FF,
+                                                    _ptr(ws), nb, _stream()), "ocv_ffn_residual_layernorm_split3_fwd")
+    return out
+
+
+_P3_FIELDS = (("in_proj_p3", "self_attn.in_proj_weight"), ("out_proj_p3", "self_attn.out_proj.weight"),
+              ("linear1_p3", "linear1.weight"), ("linear2_p3", "linear2.weight"))
+
+
+def token_split3_enabled() -> bool:
+    """Projections and feed-forward blocks of the transformer layers as the three-term bf16 split (default) or on the
+    exact-fp32 MFMA kernels (OCV_TOKENS=fp32: the A/B numerics route)."""
+    mode = os.environ.get("OCV_TOKENS", "split3")
+    if mode not in ("split3", "fp32"):
+        raise ValueError(f"OCV_TOKENS={mode!r}: expected 'split3' (default) or 'fp32'")
+    return mode == "split3"
+
+
+def layer_params(layer: torch.nn.Module, packed: Optional[dict] = None) -> Tuple[EncoderLayerParams, list]:
+    """Pointer table for one nn.TransformerEncoderLayer-shaped parameter holder.  ``packed``: the caller's cache of
+    SplitWeight3 objects for this layer (filled / refreshed here, keyed on the parameters' identity and version);
+    None = exact-fp32 kernels.  Returns (struct, keep-alive list of tensors)."""
     sd = dict(layer.named_parameters())
     st = EncoderLayerParams()
     keep = []
@@ -329,6 +401,15 @@ def layer_params(layer: torch.nn.Module) -> Tuple[EncoderLayerParams, list]:
         t = _req(sd[key].detach(), key)
         keep.append(t)
         setattr(st, field, t.data_ptr())
+    if packed is not None:
+        for field, key in _P3_FIELDS:
+            w = sd[key]
+            ver = (w.data_ptr(), w._version)
+            hit = packed.get(field)
+            if hit is None or hit[0] != ver:
+                hit = packed[field] = (ver, SplitWeight3(w))
+            keep.append(hit[1].packed)
+            setattr(st, field, hit[1].packed.data_ptr())
     return st, keep
 
 

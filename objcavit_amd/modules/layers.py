@@ -31,6 +31,7 @@ class HipEncoderStack:
         self.eps = l0.norm1.eps
         if l0.norm_first:
             raise NotImplementedError("pre-norm transformer layers are not part of the reference path")
+        self._packed = [dict() for _ in encoder.layers]      # per layer: three-term-split weights, keyed on versions
 
     def __call__(self, x: torch.Tensor, key_padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         if self.encoder.training:
@@ -38,7 +39,7 @@ class HipEncoderStack:
         n = len(self.encoder.layers)
         cur = x
         for i, layer in enumerate(self.encoder.layers):
-            params, keep = hip_ops.layer_params(layer)
+            params, keep = hip_ops.layer_params(layer, self._packed[i] if hip_ops.token_split3_enabled() else None)
             cur = hip_ops.encoder_layer(cur, params, key_padding_mask,
                                         zero_padded_rows=(key_padding_mask is not None and i == n - 1),
                                         n_heads=self.n_heads, dim_ff=self.dim_ff, eps=self.eps)

@@ -79,6 +79,55 @@ def test_ffn_residual_layernorm_fused(ops, M, FF):
     assert rel_dev(got, ref.masked_fill(mask[:, None], 0.0)) < TOL
 
 
+# ------------------------------------------------------------------ three-term bf16 split ("split3") token kernels
+@pytest.mark.parametrize("M,N,K", [(1, 32, 8), (37, 64, 24), (300, 128, 128), (4800, 384, 128), (77, 1024, 128),
+                                   (130, 128, 1024), (33, 256, 520), (16, 130, 72), (512, 200, 512)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_linear_split3(ops, M, N, K, act):
+    """ocv_linear_split3_fwd against an fp64 reference AT THE EXACT KERNEL'S TOLERANCE (fp32 accumulation noise): the
+    three-term split is fp32-faithful, unlike the two-term split of the convolutions."""
+    x, w, b = rnd("x", (M, K), 1), rnd("w", (N, K), 2, 1 / math.sqrt(K)), rnd("b", (N,), 3, 0.1)
+    ref = x.double() @ w.double().T + b.double()
+    ref = [ref, torch.relu(ref), F.leaky_relu(ref, 0.01)][act]
+    sw = ops.SplitWeight3(dev(w))
+    assert sw.packed.numel() == ops._lib.load().ocv_split3_packed_elems(N, K)
+    got = ops.linear_split3(dev(x), sw, dev(b), act)
+    assert rel_dev(got, ref) < TOL
+    exact = ops.linear(dev(x), dev(w), dev(b), act)
+    e3, ex = rel_dev(got, ref), rel_dev(exact, ref)
+    assert e3 <= 3.0 * ex + 1e-7, (e3, ex)                  # as good as the exact-fp32 MFMA kernel
+
+
+def test_split3_keeps_fp32_range_and_24_bits(ops):
+    """Operands spanning 12 decades and values that differ in their last mantissa bits only."""
+    x = rnd("x", (64, 128), 1) * torch.logspace(-6, 6, 128).view(1, 128)
+    w = rnd("w", (96, 128), 2, 0.05) / torch.logspace(-6, 6, 128).view(1, 128)
+    got = ops.linear_split3(dev(x), ops.SplitWeight3(dev(w)))
+    assert rel_dev(got, x.double() @ w.double().T) < TOL
+    a = torch.full((32, 16), 1.0) + torch.arange(16).float() * 2.0 ** -23          # 1 + j ulp
+    eye = torch.eye(16)
+    got = ops.linear_split3(dev(a), ops.SplitWeight3(dev(eye)))
+    assert torch.equal(got.cpu(), a)                                              # every mantissa bit survives
+
+
+@pytest.mark.parametrize("M,FF", [(1, 128), (37, 1024), (512, 1024), (4800, 1024), (300, 256)])
+def test_ffn_residual_layernorm_split3(ops, M, FF):
+    x = rnd("x", (M, 128), 1)
+    w1, b1 = rnd("w1", (FF, 128), 2, 1 / math.sqrt(128)), rnd("b1", (FF,), 3, 0.1)
+    w2, b2 = rnd("w2", (128, FF), 4, 1 / math.sqrt(FF)), rnd("b2", (128,), 5, 0.1)
+    g, be = 1 + 0.1 * rnd("g", (128,), 6), rnd("be", (128,), 7)
+    ref = restate.layer_norm((x.double() + torch.relu(x.double() @ w1.double().T + b1.double()) @ w2.double().T + b2.double()).float(),
+                             g, be)
+    p1, p2 = ops.SplitWeight3(dev(w1)), ops.SplitWeight3(dev(w2))
+    got = ops.ffn_residual_layernorm_split3(dev(x), p1, dev(b1), p2, dev(b2), dev(g), dev(be))
+    assert rel_dev(got, ref) < TOL
+    assert torch.equal(got, ops.ffn_residual_layernorm_split3(dev(x), p1, dev(b1), p2, dev(b2), dev(g), dev(be)))
+    mask = (torch.arange(M) % 4 == 2)
+    got = ops.ffn_residual_layernorm_split3(dev(x), p1, dev(b1), p2, dev(b2), dev(g), dev(be),
+                                            zero_row_mask=dev(mask.to(torch.uint8)))
+    assert rel_dev(got, ref.masked_fill(mask[:, None], 0.0)) < TOL
+
+
 @pytest.mark.parametrize("rows,E", [(1, 128), (301, 128), (17, 96), (9, 300)])
 def test_layernorm(ops, rows, E):
     x, r = rnd("x", (rows, E), 1, 3.0), rnd("r", (rows, E), 2)
@@ -200,10 +249,20 @@ def test_transformer_encoder_stack(ops, B, S, counts):
     x = rnd("x", (B, S, 128), 12)
     mask = None if counts is None else (torch.arange(S)[None, :] >= torch.tensor(counts)[:, None])
     ref = restate.transformer_encoder(x, sd, "", mask)
-    got = HipEncoderStack(enc.cuda())(dev(x), None if mask is None else dev(mask))
+    stack = HipEncoderStack(enc.cuda())
+    got = stack(dev(x), None if mask is None else dev(mask))          # default: three-term-split projections / FFN
     assert rel_dev(got, ref) < 5e-5
     if mask is not None and bool(mask.any()):
         assert float(got[dev(mask)].abs().max()) == 0.0
+    import os
+    os.environ["OCV_TOKENS"] = "fp32"                                  # the exact-fp32 MFMA route: same answer to rounding
+    try:
+        exact = stack(dev(x), None if mask is None else dev(mask))
+    finally:
+        del os.environ["OCV_TOKENS"]
+    assert rel_dev(exact, ref) < 5e-5
+    ok = ~dev(mask) if mask is not None else torch.ones(B, S, dtype=torch.bool, device="cuda")
+    assert rel_dev(got[ok], exact[ok]) < 2e-5
 
 
 # ------------------------------------------------------------------ patch embedding
