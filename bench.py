@@ -448,7 +448,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     timing = {}
-    step_latency_ms = None
+    step_latency_ms = sequential_ips = None
     if not a.stub_cpu:
         timing = hip_ops.timing_results()          # graph mode: only the eager islands + bin head carry events here
         log(f"timed region done: {dt / a.steps * 1e3:.1f} ms/step")
@@ -461,6 +461,12 @@ def main():
             step(0, 0)
             torch.cuda.synchronize()
             step_latency_ms = (time.perf_counter() - t1) * 1e3          # one batch alone, submit -> metrics record
+            nseq = max(2, a.steps // 2)                                  # reference: the same steps strictly one after the other
+            t1 = time.perf_counter()
+            for _ in range(nseq):
+                step(0, 0)
+            torch.cuda.synchronize()
+            sequential_ips = nseq * B / (time.perf_counter() - t1)
             hip_ops.enable_timing(True)
             for _ in range(3):
                 model(img)
@@ -493,6 +499,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "stub" if a.stub_cpu else "synthetic",
             "launch": launch_mode.replace("ROOFLINE_STEPS", str(ROOFLINE_STEPS)), "inflight": nslot, "launcher": launcher,
             "ranks_seen": ranks_seen, "step_latency_ms": None if step_latency_ms is None else round(step_latency_ms, 3),
+            "sequential_images_per_s_this_rank": None if sequential_ips is None else round(sequential_ips, 1),
             "per_rank_images_per_s": {"min": round(min(rank_rates), 2), "max": round(max(rank_rates), 2)},
             "config": {"workload": "BASELINE configs[2]: ObjCAViT enet-b5 NYU 480x640, emb_dim=128, learned pos-MLP, "
                                    f"{N_OBJ} objs/img with random 512-d text features, bs={B} per GPU, random-init weights",
