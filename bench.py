@@ -63,6 +63,9 @@ def kernel_model(B):
                           flops=B * (4 * 2 * S * E * E + 2 * 2 * S * S * E)),
         "encoder_layer": dict(bytes=B * 2 * act + (4 * E * E + 2 * E * 1024) * 4,
                               flops=B * (4 * 2 * S * E * E + 2 * 2 * S * S * E + 2 * 2 * S * E * 1024)),
+        # the image-token stack: 4 layers in 9 launches (packed projection, then attention + layer tail per layer)
+        "encoder_stack": dict(bytes=4 * (B * 2 * act + (4 * E * E + 2 * E * 1024) * 4),
+                              flops=4 * B * (4 * 2 * S * E * E + 2 * 2 * S * S * E + 2 * 2 * S * E * 1024)),
     }
 
 

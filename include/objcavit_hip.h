@@ -142,6 +142,23 @@ int ocv_ffn_residual_layernorm_split3_fwd(const float* x, const void* w1_packed,
                                           const uint8_t* zero_row_mask, float* out, int M, int E, int FF, void* workspace,
                                           size_t workspace_bytes, ocv_stream_t stream);
 
+/* Everything of a post-norm transformer layer that is local to a token, one launch per 32-token tile (split3 arithmetic):
+ *   x1 = LayerNorm1(x + ctx Wo^T + bo);  out = LayerNorm2(x1 + W2 relu(W1 x1 + b1) + b2)   (rows with zero_row_mask != 0: 0)
+ *   qkv_next[M][3E] = out . Wqkv_next^T + bqkv_next      when next_in_proj_p3 / next_in_proj_b / qkv_next are given
+ * ctx = the attention output of the layer, x its input; p: the layer's parameters with the packed *_p3 weights set. */
+int ocv_layer_tail_split3_fwd(const float* ctx, const float* x, const ocv_encoder_layer_params* p, const void* next_in_proj_p3,
+                              const float* next_in_proj_b, float eps, const uint8_t* zero_row_mask, float* out,
+                              float* qkv_next, int M, int E, int FF, ocv_stream_t stream);
+/* nn.TransformerEncoder(layer, n_layers) forward (eval, post-norm, batch-first [B,S,E]) in 1 + 2 n_layers launches: the
+ * packed projection of layer 0, then per layer ocv_attention_fwd and ocv_layer_tail_split3_fwd.  Every layer needs its
+ * packed split3 weights.  Semantics of key_padding_mask / zero_padded_rows as in ocv_encoder_layer_fwd (the zeros are
+ * written by the last layer).  Replaces the nn.TransformerEncoder calls at modules/ObjCAViT.py:169,188 and
+ * modules/layers.py:23. */
+size_t ocv_encoder_stack_workspace_bytes(int B, int S, int E);
+int ocv_encoder_stack_fwd(const float* x, const ocv_encoder_layer_params* layers, int n_layers, const uint8_t* key_padding_mask,
+                          int zero_padded_rows, float* out, int B, int S, int E, int H, int FF, float eps, void* workspace,
+                          size_t workspace_bytes, ocv_stream_t stream);
+
 /* Patch embedding: Conv2d(C -> E, kernel = stride = 16, no padding) on fmap [B,C,h,w] (NCHW), flattened to tokens,
  * plus bias and positional embedding, written token-major:
  *   out[b][s][e] = bias[e] + pos[b*pos_bs + s*E + e] + sum_{c,i,j} W[e][c][i][j] * fmap[b][c][16*ph+i][16*pw+j]

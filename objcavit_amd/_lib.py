@@ -48,6 +48,11 @@ PROTOTYPES = {
     "ocv_ffn_split3_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "ocv_ffn_residual_layernorm_split3_fwd": (C.c_int, [_f32p, C.c_void_p, _f32p, C.c_void_p, _f32p, _f32p, _f32p, C.c_float, _u8p, _f32p,
                                                         C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, _stream]),
+    "ocv_layer_tail_split3_fwd": (C.c_int, [_f32p, _f32p, C.POINTER(EncoderLayerParams), C.c_void_p, _f32p, C.c_float, _u8p, _f32p, _f32p,
+                                            C.c_int, C.c_int, C.c_int, _stream]),
+    "ocv_encoder_stack_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "ocv_encoder_stack_fwd": (C.c_int, [_f32p, C.POINTER(EncoderLayerParams), C.c_int, _u8p, C.c_int, _f32p, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_size_t, _stream]),
     "ocv_encoder_layer_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "ocv_encoder_layer_fwd": (C.c_int, [_f32p, C.POINTER(EncoderLayerParams), _u8p, C.c_int, _f32p, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_size_t, _stream]),

@@ -135,3 +135,52 @@ extern "C" int ocv_encoder_layer_fwd(const float* x, const ocv_encoder_layer_par
   return ocv_linear_residual_layernorm_fwd(hid, FF, p->linear2_w, FF, p->linear2_b, x1, E, p->norm2_w, p->norm2_b, eps,
                                            zmask, out, E, M, E, FF, stream);
 }
+
+
+// ---------------------------------------------------------------------------
+// a whole nn.TransformerEncoder (L post-norm layers) in 1 + 2 L launches: packed projection of layer 0, then per layer
+// the attention kernel and ocv_layer_tail_split3_fwd (everything token-local + the next layer's projection).
+// workspace: qkv [M, 3E] | ctx [M, E] | xa [M, E] | xb [M, E]
+// ---------------------------------------------------------------------------
+extern "C" size_t ocv_encoder_stack_workspace_bytes(int B, int S, int E) {
+  if (B < 1 || S < 1 || E < 1) return 0;
+  const size_t M = (size_t)B * S;
+  return align_up(M * 3 * E * sizeof(float)) + 3 * align_up(M * E * sizeof(float));
+}
+
+extern "C" int ocv_encoder_stack_fwd(const float* x, const ocv_encoder_layer_params* layers, int n_layers,
+                                     const uint8_t* key_padding_mask, int zero_padded_rows, float* out, int B, int S, int E,
+                                     int H, int FF, float eps, void* workspace, size_t workspace_bytes, ocv_stream_t stream) {
+  OCV_CHECK_ARG(x && layers && out && workspace && n_layers >= 1, "ocv_encoder_stack_fwd: null pointer / no layers");
+  OCV_CHECK_ARG(E == 128 && H == 4 && FF >= 128 && FF % 128 == 0, "ocv_encoder_stack_fwd: built for E = 128, H = 4, FF a multiple of 128 (got %d, %d, %d)", E, H, FF);
+  OCV_CHECK_ARG(workspace_bytes >= ocv_encoder_stack_workspace_bytes(B, S, E), "ocv_encoder_stack_fwd: workspace too small");
+  for (int l = 0; l < n_layers; ++l)
+    OCV_CHECK_ARG(layers[l].in_proj_p3 && layers[l].out_proj_p3 && layers[l].linear1_p3 && layers[l].linear2_p3,
+                  "ocv_encoder_stack_fwd: layer %d lacks its packed split3 weights (ocv_pack_split3_fwd)", l);
+  const int M = B * S;
+  char* ws = (char*)workspace;
+  float* qkv = (float*)ws;
+  ws += align_up((size_t)M * 3 * E * sizeof(float));
+  float* ctx = (float*)ws;
+  ws += align_up((size_t)M * E * sizeof(float));
+  float* xa = (float*)ws;
+  ws += align_up((size_t)M * E * sizeof(float));
+  float* xb = (float*)ws;
+  int rc;
+  if ((rc = ocv_linear_split3_fwd(x, E, layers[0].in_proj_p3, layers[0].in_proj_b, qkv, 3 * E, M, 3 * E, E, OCV_ACT_NONE, stream))) return rc;
+  const float* cur = x;
+  for (int l = 0; l < n_layers; ++l) {
+    const bool last = l + 1 == n_layers;
+    if ((rc = ocv_attention_fwd(qkv, (long)S * 3 * E, 3 * E, qkv + E, (long)S * 3 * E, 3 * E, qkv + 2 * E, (long)S * 3 * E, 3 * E,
+                                key_padding_mask, ctx, (long)S * E, E, B, H, S, S, 1.0f / sqrtf(32.0f), stream))) return rc;
+    float* dst = last ? out : ((l & 1) ? xb : xa);
+    const uint8_t* zmask = (last && zero_padded_rows && key_padding_mask) ? key_padding_mask : nullptr;
+    // the tail of layer l writes the next layer's q | k | v into the buffer this layer's attention has just consumed:
+    // launches on one stream run in order, so the attention above has finished reading it
+    if ((rc = ocv_layer_tail_split3_fwd(ctx, cur, &layers[l], last ? nullptr : layers[l + 1].in_proj_p3,
+                                        last ? nullptr : layers[l + 1].in_proj_b, eps, zmask, dst, last ? nullptr : qkv, M, E, FF,
+                                        stream))) return rc;
+    cur = dst;
+  }
+  return 0;
+}

@@ -300,6 +300,159 @@ __global__ __launch_bounds__(256) void ffn3_finish_kernel(F3Args p) {
   ln_rows3(Cs, p.gamma, p.beta, p.eps, p.zero_mask, p.out, E128, m0, p.M, lane, wave);
 }
 
+// ---------------------------------------------------------------------------
+// Everything of a post-norm transformer layer that is LOCAL to a token, in one launch per 32-token tile:
+//   x1 = LayerNorm1(x + ctx Wo^T + bo)            (ctx = the attention kernel's output for these tokens)
+//   x2 = LayerNorm2(x1 + W2 relu(W1 x1 + b1) + b2)          -> out
+//   qkv_next = x2 Wqkv'^T + bqkv'                           -> the NEXT layer's packed q | k | v rows (if there is one)
+// so a layer is two launches -- attention, this -- instead of four, and the next layer's projection rides along.  The
+// four separate launches cost 13 - 17 us each for ~5 us of arithmetic (a cold start per launch: row staging, first
+// weight fragments, tail), 112 us per layer.  x1 and x2 never leave the workgroup between the phases (fp32 copy in LDS
+// for the residuals, three-term planes for the next contraction).  Same arithmetic, same order as lin3 + ffn3 + lin3.
+// ---------------------------------------------------------------------------
+struct TailArgs {
+  const float *ctx, *x;                 // [M][128]
+  const __bf16 *wo_p, *w1_p, *w2_p, *wqkv_p;     // wqkv_p: the next layer's packed in_proj (nullable)
+  const float *bo, *g1, *be1, *b1, *b2, *g2, *be2, *bqkv;
+  float eps;
+  const uint8_t* zero_mask;             // rows written as 0 in `out` (last layer of a masked stack), nullable
+  float* out;                           // [M][128]
+  float* qkv;                           // [M][384] (nullable with wqkv_p)
+  int M, FF;
+};
+
+// LayerNorm of the 32 x 128 tile in Cs, IN PLACE (one wavefront per 8 rows)
+__device__ __forceinline__ void ln_tile_inplace(float (*Cs)[E128 + 1], const float* gamma, const float* beta, float eps, int lane,
+                                                int wave) {
+  const float g0 = gamma[lane], g1 = gamma[lane + 64];
+  const float b0 = beta[lane], b1 = beta[lane + 64];
+#pragma unroll
+  for (int i = 0; i < TM / 4; ++i) {
+    const int row = wave * (TM / 4) + i;
+    const float x0 = Cs[row][lane], x1 = Cs[row][lane + 64];
+    const float mean = wave_sum(x0 + x1) * (1.0f / E128);
+    const float d0 = x0 - mean, d1 = x1 - mean;
+    const float var = wave_sum(d0 * d0 + d1 * d1) * (1.0f / E128);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    Cs[row][lane] = d0 * rstd * g0 + b0;
+    Cs[row][lane + 64] = d1 * rstd * g1 + b1;
+  }
+}
+
+// the 32 x 128 fp32 tile in Cs -> three bf16 planes (thread: row tid / 8, two K octets)
+__device__ __forceinline__ void tile_to_planes(__bf16* planes, const float (*Cs)[E128 + 1], int tid) {
+  const int row = tid >> 3;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int o = (tid & 7) + 8 * i;
+    const float* c = &Cs[row][8 * o];
+    bf16x8 h, m, l;
+    split8x3(make_float4(c[0], c[1], c[2], c[3]), make_float4(c[4], c[5], c[6], c[7]), h, m, l);
+    __bf16* d = planes + row * PROW + 8 * o;
+    *reinterpret_cast<bf16x8*>(d) = h;
+    *reinterpret_cast<bf16x8*>(d + PLANE) = m;
+    *reinterpret_cast<bf16x8*>(d + 2 * PLANE) = l;
+  }
+}
+
+__global__ __launch_bounds__(256) void layer_tail3_kernel(TailArgs p) {
+  __shared__ __attribute__((aligned(16))) __bf16 xp[3 * PLANE];      // ctx, then x1, then x2 as three-term planes
+  __shared__ __attribute__((aligned(16))) __bf16 hp[3 * PLANE];      // hidden chunk
+  __shared__ float Cs[TM][E128 + 1];                                  // fp32 tile: pre-LN sums, then x1, then x2
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int m0 = blockIdx.x * TM;
+  const int col = wave * 32 + l31;
+  const int ksteps2 = p.FF >> 4, nchunk = p.FF / KC;
+
+  // ---- x1 = LN1(x + ctx Wo^T + bo)
+  WFrag3 f1, f2;
+  load_w3(f1, p.wo_p + ((long)wave * (E128 / 16) * 3) * 512 + lane * 8, E128 / 16);
+  stage_rows3(xp, p.ctx, E128, m0, p.M, 0, E128, tid);
+  __syncthreads();
+  {
+    f32x16 a = {0};
+    a = chunk_mfma3(a, xp, f1, E128 / 16, l31, hh);
+    load_w3(f1, p.w1_p + ((long)wave * (E128 / 16) * 3) * 512 + lane * 8, E128 / 16);      // W1, first chunk: under LN1
+    const float bo = p.bo[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = acc_row(r, hh), m = m0 + row;
+      Cs[row][col] = a[r] + bo + (m < p.M ? p.x[(long)m * E128 + col] : 0.f);
+    }
+  }
+  __syncthreads();
+  ln_tile_inplace(Cs, p.g1, p.be1, p.eps, lane, wave);
+  __syncthreads();
+  tile_to_planes(xp, Cs, tid);                        // every wavefront is past its reads of the ctx planes
+  __syncthreads();
+
+  // ---- x2 = LN2(x1 + W2 relu(W1 x1 + b1) + b2)
+  f32x16 acc = {0};
+  for (int c = 0; c < nchunk; ++c) {
+    load_w3(f2, p.w2_p + (((long)wave * ksteps2 + c * (KC / 16)) * 3) * 512 + lane * 8, KC / 16);
+    f32x16 h = {0};
+    h = chunk_mfma3(h, xp, f1, E128 / 16, l31, hh);
+    const float b1 = p.b1[c * KC + col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = fmaxf(h[r] + b1, 0.f);
+      const __bf16 a = (__bf16)v;
+      const float r1 = v - (float)a;
+      const __bf16 b = (__bf16)r1;
+      __bf16* d = hp + acc_row(r, hh) * PROW + col;
+      d[0] = a;
+      d[PLANE] = b;
+      d[2 * PLANE] = (__bf16)(r1 - (float)b);
+    }
+    if (c + 1 < nchunk) load_w3(f1, p.w1_p + ((long)((c + 1) * 4 + wave) * (E128 / 16) * 3) * 512 + lane * 8, E128 / 16);
+    __syncthreads();
+    acc = chunk_mfma3(acc, hp, f2, KC / 16, l31, hh);
+    __syncthreads();
+  }
+  const bool next = p.wqkv_p != nullptr;
+  if (next) load_w3(f1, p.wqkv_p + ((long)(wave * 3) * (E128 / 16) * 3) * 512 + lane * 8, E128 / 16);     // under LN2
+  {
+    const float b2 = p.b2[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = acc_row(r, hh);
+      Cs[row][col] = acc[r] + b2 + Cs[row][col];        // residual = x1 (each element read and written by one lane)
+    }
+  }
+  __syncthreads();
+  ln_tile_inplace(Cs, p.g2, p.be2, p.eps, lane, wave);
+  __syncthreads();
+  for (int i = tid; i < TM * (E128 / 4); i += 256) {     // x2 -> out, 16-byte stores
+    const int row = i / (E128 / 4), c4 = (i % (E128 / 4)) * 4, m = m0 + row;
+    if (m < p.M) {
+      const bool z = p.zero_mask != nullptr && p.zero_mask[m] != 0;
+      const float4 v = z ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(Cs[row][c4], Cs[row][c4 + 1], Cs[row][c4 + 2], Cs[row][c4 + 3]);
+      *reinterpret_cast<float4*>(p.out + (long)m * E128 + c4) = v;
+    }
+  }
+  if (!next) return;
+
+  // ---- the next layer's packed projection: wavefront w -> channel tiles 3 w .. 3 w + 2 of the 12
+  tile_to_planes(xp, Cs, tid);
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    WFrag3& cur = (t & 1) ? f2 : f1;
+    WFrag3& nxt = (t & 1) ? f1 : f2;
+    if (t + 1 < 3) load_w3(nxt, p.wqkv_p + ((long)(wave * 3 + t + 1) * (E128 / 16) * 3) * 512 + lane * 8, E128 / 16);
+    f32x16 q = {0};
+    q = chunk_mfma3(q, xp, cur, E128 / 16, l31, hh);
+    const int n = (wave * 3 + t) * 32 + l31;
+    const float bn = p.bqkv[n];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + acc_row(r, hh);
+      if (m < p.M) p.qkv[(long)m * 3 * E128 + n] = q[r] + bn;
+    }
+  }
+}
+
 // W [N][K] fp32 (row stride ldw) -> packed three-term fragments; one thread per (jt, s, lane)
 __global__ __launch_bounds__(256) void pack3_kernel(const float* __restrict__ W, int ldw, int N, int K, __bf16* __restrict__ out,
                                                     long items) {
@@ -380,6 +533,26 @@ extern "C" int ocv_linear_residual_layernorm_split3_fwd(const float* A, int lda,
   L3Args a{A, lda, (const __bf16*)w_packed, bias, out, ldo, M, N, K, residual, ldres, gamma, beta, eps, zero_row_mask};
   hipLaunchKernelGGL((lin3_kernel<1, L3_RES_LN>), dim3(ocv_cdiv(M, TM), 1), dim3(256), 0, (hipStream_t)stream, a);
   OCV_CHECK_LAUNCH("ocv_linear_residual_layernorm_split3_fwd");
+  return 0;
+}
+
+extern "C" int ocv_layer_tail_split3_fwd(const float* ctx, const float* x, const ocv_encoder_layer_params* p,
+                                         const void* next_in_proj_p3, const float* next_in_proj_b, float eps,
+                                         const uint8_t* zero_row_mask, float* out, float* qkv_next, int M, int E, int FF,
+                                         ocv_stream_t stream) {
+  OCV_CHECK_ARG(ctx && x && p && out, "ocv_layer_tail_split3_fwd: null pointer");
+  OCV_CHECK_ARG(p->out_proj_p3 && p->linear1_p3 && p->linear2_p3, "ocv_layer_tail_split3_fwd: needs the packed split3 weights");
+  OCV_CHECK_ARG(E == E128 && FF >= KC && FF % KC == 0, "ocv_layer_tail_split3_fwd: needs E = %d and FF a multiple of %d (got %d, %d)", E128, KC, E, FF);
+  OCV_CHECK_ARG((next_in_proj_p3 == nullptr) == (qkv_next == nullptr) && (next_in_proj_p3 == nullptr || next_in_proj_b != nullptr),
+                "ocv_layer_tail_split3_fwd: next_in_proj_p3 / next_in_proj_b / qkv_next go together");
+  OCV_CHECK_ARG(M >= 0 && ocv_aligned16(ctx) && ocv_aligned16(x) && ocv_aligned16(out) && ocv_aligned16(qkv_next),
+                "ocv_layer_tail_split3_fwd: bad M / alignment");
+  if (M == 0) return 0;
+  TailArgs a{ctx, x, (const __bf16*)p->out_proj_p3, (const __bf16*)p->linear1_p3, (const __bf16*)p->linear2_p3,
+             (const __bf16*)next_in_proj_p3, p->out_proj_b, p->norm1_w, p->norm1_b, p->linear1_b, p->linear2_b, p->norm2_w,
+             p->norm2_b, next_in_proj_b, eps, zero_row_mask, out, qkv_next, M, FF};
+  hipLaunchKernelGGL(layer_tail3_kernel, dim3(ocv_cdiv(M, TM)), dim3(256), 0, (hipStream_t)stream, a);
+  OCV_CHECK_LAUNCH("ocv_layer_tail_split3_fwd");
   return 0;
 }
 

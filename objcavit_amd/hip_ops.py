@@ -432,6 +432,26 @@ def encoder_layer(x: torch.Tensor, params: EncoderLayerParams, key_padding_mask:
     return out
 
 
+def encoder_stack(x: torch.Tensor, params: Sequence[EncoderLayerParams], key_padding_mask: Optional[torch.Tensor] = None,
+                  zero_padded_rows: bool = False, n_heads: int = 4, dim_ff: int = 1024, eps: float = 1e-5) -> torch.Tensor:
+    """A whole nn.TransformerEncoder in 1 + 2 L launches (ocv_encoder_stack_fwd); every layer's params must carry the
+    packed split3 weights (layer_params(layer, packed_cache))."""
+    lib = _lib.load()
+    _req(x, "x")
+    if x.dim() != 3:
+        raise ValueError("encoder_stack: x must be [B, S, E]")
+    B, S, E = x.shape
+    m = _mask_u8(key_padding_mask, B, S)
+    arr = (EncoderLayerParams * len(params))(*params)
+    nb = lib.ocv_encoder_stack_workspace_bytes(B, S, E)
+    ws = workspace(nb, x.device, "encoder_stack")
+    out = torch.empty_like(x)
+    with timed("encoder_stack" if S > 64 else "encoder_stack_obj"):
+        check(lib.ocv_encoder_stack_fwd(x.data_ptr(), arr, len(params), _ptr(m), int(zero_padded_rows), out.data_ptr(), B, S, E,
+                                        n_heads, dim_ff, eps, ws.data_ptr(), ws.numel(), _stream()), "ocv_encoder_stack_fwd")
+    return out
+
+
 # ---------------------------------------------------------------------------
 # patch embedding / pixel-wise dot / bin head
 # ---------------------------------------------------------------------------

@@ -37,11 +37,22 @@ class HipEncoderStack:
         if self.encoder.training:
             raise RuntimeError("the HIP path implements inference (eval mode) only")
         n = len(self.encoder.layers)
-        cur = x
+        zero = key_padding_mask is not None
+        if hip_ops.token_split3_enabled() and self.dim_ff % 128 == 0:
+            # default: three-term-split projections / feed-forward, the whole stack in 1 + 2 n launches
+            params, keep = [], []
+            for i, layer in enumerate(self.encoder.layers):
+                st, k = hip_ops.layer_params(layer, self._packed[i])
+                params.append(st)
+                keep.append(k)
+            out = hip_ops.encoder_stack(x, params, key_padding_mask, zero_padded_rows=zero, n_heads=self.n_heads,
+                                        dim_ff=self.dim_ff, eps=self.eps)
+            del keep
+            return out
+        cur = x                                              # OCV_TOKENS=fp32: exact-fp32 kernels, four launches per layer
         for i, layer in enumerate(self.encoder.layers):
-            params, keep = hip_ops.layer_params(layer, self._packed[i] if hip_ops.token_split3_enabled() else None)
-            cur = hip_ops.encoder_layer(cur, params, key_padding_mask,
-                                        zero_padded_rows=(key_padding_mask is not None and i == n - 1),
+            params, keep = hip_ops.layer_params(layer, None)
+            cur = hip_ops.encoder_layer(cur, params, key_padding_mask, zero_padded_rows=(zero and i == n - 1),
                                         n_heads=self.n_heads, dim_ff=self.dim_ff, eps=self.eps)
             del keep
         return cur
