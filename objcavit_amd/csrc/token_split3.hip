@@ -321,14 +321,21 @@ struct TailArgs {
   int M, FF;
 };
 
-// LayerNorm of the 32 x 128 tile in Cs, IN PLACE (one wavefront per 8 rows)
+// Row tiles per workgroup.  RT = 2 (64 tokens: every streamed weight fragment serves two MFMA tiles, half the L2 traffic)
+// was measured SLOWER, 92 us against 60 us per launch: the launch is not bound by L2 bandwidth but by the chain of 2 x 8
+// phases per workgroup, each waiting ~2 - 3 us for weight fragments requested one phase (48 MFMAs, 0.75 us) earlier, and
+// doubling the rows doubles every phase's MFMA time without shortening any wait.  Kept as a parameter.
+constexpr int RT = 1;
+constexpr int TR = TM * RT;              // rows per workgroup
+
+// LayerNorm of the TR x 128 tile in Cs, IN PLACE (one wavefront per TR / 4 rows)
 __device__ __forceinline__ void ln_tile_inplace(float (*Cs)[E128 + 1], const float* gamma, const float* beta, float eps, int lane,
                                                 int wave) {
   const float g0 = gamma[lane], g1 = gamma[lane + 64];
   const float b0 = beta[lane], b1 = beta[lane + 64];
-#pragma unroll
-  for (int i = 0; i < TM / 4; ++i) {
-    const int row = wave * (TM / 4) + i;
+#pragma unroll 4
+  for (int i = 0; i < TR / 4; ++i) {
+    const int row = wave * (TR / 4) + i;
     const float x0 = Cs[row][lane], x1 = Cs[row][lane + 64];
     const float mean = wave_sum(x0 + x1) * (1.0f / E128);
     const float d0 = x0 - mean, d1 = x1 - mean;
@@ -339,47 +346,55 @@ __device__ __forceinline__ void ln_tile_inplace(float (*Cs)[E128 + 1], const flo
   }
 }
 
-// the 32 x 128 fp32 tile in Cs -> three bf16 planes (thread: row tid / 8, two K octets)
+// the TR x 128 fp32 tile in Cs -> three bf16 planes per row tile (thread: row tid / 8 of each tile, two K octets)
 __device__ __forceinline__ void tile_to_planes(__bf16* planes, const float (*Cs)[E128 + 1], int tid) {
-  const int row = tid >> 3;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int o = (tid & 7) + 8 * i;
-    const float* c = &Cs[row][8 * o];
-    bf16x8 h, m, l;
-    split8x3(make_float4(c[0], c[1], c[2], c[3]), make_float4(c[4], c[5], c[6], c[7]), h, m, l);
-    __bf16* d = planes + row * PROW + 8 * o;
-    *reinterpret_cast<bf16x8*>(d) = h;
-    *reinterpret_cast<bf16x8*>(d + PLANE) = m;
-    *reinterpret_cast<bf16x8*>(d + 2 * PLANE) = l;
+  for (int rt = 0; rt < RT; ++rt) {
+    const int row = tid >> 3;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int o = (tid & 7) + 8 * i;
+      const float* c = &Cs[rt * TM + row][8 * o];
+      bf16x8 h, m, l;
+      split8x3(make_float4(c[0], c[1], c[2], c[3]), make_float4(c[4], c[5], c[6], c[7]), h, m, l);
+      __bf16* d = planes + rt * 3 * PLANE + row * PROW + 8 * o;
+      *reinterpret_cast<bf16x8*>(d) = h;
+      *reinterpret_cast<bf16x8*>(d + PLANE) = m;
+      *reinterpret_cast<bf16x8*>(d + 2 * PLANE) = l;
+    }
   }
 }
 
 __global__ __launch_bounds__(256) void layer_tail3_kernel(TailArgs p) {
-  __shared__ __attribute__((aligned(16))) __bf16 xp[3 * PLANE];      // ctx, then x1, then x2 as three-term planes
-  __shared__ __attribute__((aligned(16))) __bf16 hp[3 * PLANE];      // hidden chunk
-  __shared__ float Cs[TM][E128 + 1];                                  // fp32 tile: pre-LN sums, then x1, then x2
+  extern __shared__ __attribute__((aligned(16))) unsigned char tail_lds[];
+  __bf16* xp = reinterpret_cast<__bf16*>(tail_lds);                   // [RT][3 planes]: ctx, then x1, then x2
+  __bf16* hp = xp + RT * 3 * PLANE;                                   // [RT][3 planes]: hidden chunk
+  float (*Cs)[E128 + 1] = reinterpret_cast<float (*)[E128 + 1]>(hp + RT * 3 * PLANE);   // [TR][129] fp32: sums, x1, x2
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
-  const int m0 = blockIdx.x * TM;
+  const int m0 = blockIdx.x * TR;
   const int col = wave * 32 + l31;
   const int ksteps2 = p.FF >> 4, nchunk = p.FF / KC;
 
   // ---- x1 = LN1(x + ctx Wo^T + bo)
   WFrag3 f1, f2;
   load_w3(f1, p.wo_p + ((long)wave * (E128 / 16) * 3) * 512 + lane * 8, E128 / 16);
-  stage_rows3(xp, p.ctx, E128, m0, p.M, 0, E128, tid);
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) stage_rows3(xp + rt * 3 * PLANE, p.ctx, E128, m0 + rt * TM, p.M, 0, E128, tid);
   __syncthreads();
   {
-    f32x16 a = {0};
-    a = chunk_mfma3(a, xp, f1, E128 / 16, l31, hh);
+    f32x16 a[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) a[rt] = chunk_mfma3(f32x16{0}, xp + rt * 3 * PLANE, f1, E128 / 16, l31, hh);
     load_w3(f1, p.w1_p + ((long)wave * (E128 / 16) * 3) * 512 + lane * 8, E128 / 16);      // W1, first chunk: under LN1
     const float bo = p.bo[col];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = acc_row(r, hh), m = m0 + row;
-      Cs[row][col] = a[r] + bo + (m < p.M ? p.x[(long)m * E128 + col] : 0.f);
-    }
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rt * TM + acc_row(r, hh), m = m0 + row;
+        Cs[row][col] = a[rt][r] + bo + (m < p.M ? p.x[(long)m * E128 + col] : 0.f);
+      }
   }
   __syncthreads();
   ln_tile_inplace(Cs, p.g1, p.be1, p.eps, lane, wave);
@@ -388,26 +403,31 @@ __global__ __launch_bounds__(256) void layer_tail3_kernel(TailArgs p) {
   __syncthreads();
 
   // ---- x2 = LN2(x1 + W2 relu(W1 x1 + b1) + b2)
-  f32x16 acc = {0};
+  f32x16 acc[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x16{0};
   for (int c = 0; c < nchunk; ++c) {
     load_w3(f2, p.w2_p + (((long)wave * ksteps2 + c * (KC / 16)) * 3) * 512 + lane * 8, KC / 16);
-    f32x16 h = {0};
-    h = chunk_mfma3(h, xp, f1, E128 / 16, l31, hh);
     const float b1 = p.b1[c * KC + col];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float v = fmaxf(h[r] + b1, 0.f);
-      const __bf16 a = (__bf16)v;
-      const float r1 = v - (float)a;
-      const __bf16 b = (__bf16)r1;
-      __bf16* d = hp + acc_row(r, hh) * PROW + col;
-      d[0] = a;
-      d[PLANE] = b;
-      d[2 * PLANE] = (__bf16)(r1 - (float)b);
+    for (int rt = 0; rt < RT; ++rt) {
+      const f32x16 h = chunk_mfma3(f32x16{0}, xp + rt * 3 * PLANE, f1, E128 / 16, l31, hh);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = fmaxf(h[r] + b1, 0.f);
+        const __bf16 a = (__bf16)v;
+        const float r1 = v - (float)a;
+        const __bf16 b = (__bf16)r1;
+        __bf16* d = hp + rt * 3 * PLANE + acc_row(r, hh) * PROW + col;
+        d[0] = a;
+        d[PLANE] = b;
+        d[2 * PLANE] = (__bf16)(r1 - (float)b);
+      }
     }
     if (c + 1 < nchunk) load_w3(f1, p.w1_p + ((long)((c + 1) * 4 + wave) * (E128 / 16) * 3) * 512 + lane * 8, E128 / 16);
     __syncthreads();
-    acc = chunk_mfma3(acc, hp, f2, KC / 16, l31, hh);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[rt] = chunk_mfma3(acc[rt], hp + rt * 3 * PLANE, f2, KC / 16, l31, hh);
     __syncthreads();
   }
   const bool next = p.wqkv_p != nullptr;
@@ -415,15 +435,17 @@ __global__ __launch_bounds__(256) void layer_tail3_kernel(TailArgs p) {
   {
     const float b2 = p.b2[col];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = acc_row(r, hh);
-      Cs[row][col] = acc[r] + b2 + Cs[row][col];        // residual = x1 (each element read and written by one lane)
-    }
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rt * TM + acc_row(r, hh);
+        Cs[row][col] = acc[rt][r] + b2 + Cs[row][col];   // residual = x1 (each element read and written by one lane)
+      }
   }
   __syncthreads();
   ln_tile_inplace(Cs, p.g2, p.be2, p.eps, lane, wave);
   __syncthreads();
-  for (int i = tid; i < TM * (E128 / 4); i += 256) {     // x2 -> out, 16-byte stores
+  for (int i = tid; i < TR * (E128 / 4); i += 256) {     // x2 -> out, 16-byte stores
     const int row = i / (E128 / 4), c4 = (i % (E128 / 4)) * 4, m = m0 + row;
     if (m < p.M) {
       const bool z = p.zero_mask != nullptr && p.zero_mask[m] != 0;
@@ -441,14 +463,16 @@ __global__ __launch_bounds__(256) void layer_tail3_kernel(TailArgs p) {
     WFrag3& cur = (t & 1) ? f2 : f1;
     WFrag3& nxt = (t & 1) ? f1 : f2;
     if (t + 1 < 3) load_w3(nxt, p.wqkv_p + ((long)(wave * 3 + t + 1) * (E128 / 16) * 3) * 512 + lane * 8, E128 / 16);
-    f32x16 q = {0};
-    q = chunk_mfma3(q, xp, cur, E128 / 16, l31, hh);
     const int n = (wave * 3 + t) * 32 + l31;
     const float bn = p.bqkv[n];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + acc_row(r, hh);
-      if (m < p.M) p.qkv[(long)m * 3 * E128 + n] = q[r] + bn;
+    for (int rt = 0; rt < RT; ++rt) {
+      const f32x16 q = chunk_mfma3(f32x16{0}, xp + rt * 3 * PLANE, cur, E128 / 16, l31, hh);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + rt * TM + acc_row(r, hh);
+        if (m < p.M) p.qkv[(long)m * 3 * E128 + n] = q[r] + bn;
+      }
     }
   }
 }
@@ -551,7 +575,13 @@ extern "C" int ocv_layer_tail_split3_fwd(const float* ctx, const float* x, const
   TailArgs a{ctx, x, (const __bf16*)p->out_proj_p3, (const __bf16*)p->linear1_p3, (const __bf16*)p->linear2_p3,
              (const __bf16*)next_in_proj_p3, p->out_proj_b, p->norm1_w, p->norm1_b, p->linear1_b, p->linear2_b, p->norm2_w,
              p->norm2_b, next_in_proj_b, eps, zero_row_mask, out, qkv_next, M, FF};
-  hipLaunchKernelGGL(layer_tail3_kernel, dim3(ocv_cdiv(M, TM)), dim3(256), 0, (hipStream_t)stream, a);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)layer_tail3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  const size_t lds = (size_t)2 * RT * 3 * PLANE * sizeof(__bf16) + (size_t)TR * (E128 + 1) * sizeof(float);
+  hipLaunchKernelGGL(layer_tail3_kernel, dim3(ocv_cdiv(M, TR)), dim3(256), lds, (hipStream_t)stream, a);
   OCV_CHECK_LAUNCH("ocv_layer_tail_split3_fwd");
   return 0;
 }
