@@ -356,6 +356,21 @@ int ocv_conv3x3_winograd_split_fwd(const void* x_hl, int Cin, const void* u_hi, 
                                    void* y_hl, int B, int H, int W, int Cout, int act, void* workspace,
                                    size_t workspace_bytes, ocv_stream_t stream);
 
+/* Second half of "3 x 3 convolution of an up-sampled tensor, computed at the low resolution" (first convolution of every
+ * UpSampleWithSkip stage: F.interpolate(bilinear, align_corners=True) + torch.cat + Conv2d(k=3) + BatchNorm + LeakyReLU,
+ * modules/DenseFeatureExtractor.py:44-47,37-39).  Bilinear up-sampling is linear and per channel, the convolution mixes
+ * channels per tap, so conv_{Wa}(up(x))[p] = sum_t sum_{4 nb} coef(p + t, nb) (Wa_t x[nb]): the caller forms the nine tap
+ * products once per LOW-resolution pixel -- z [B,h,w,9 Cout] = ocv_conv_nhwc_split_fwd(ksize 1) of x with the weight rows
+ * stacked tap-major, column t Cout + co -- and the skip part s [B,H,W,Cout] = conv3x3 over the skip channels (raw, nullable);
+ * this entry point computes
+ *   y[b][Y][X][co] = act( bias[co] + s[b][Y][X][co] + sum_t [ (Y,X) + t inside H x W ] bilinear(z[..][t Cout + co]; (Y,X) + t) )
+ * with ATen's align_corners=True coefficients, writing fp32 y and / or the hl32 split y_hl.  Exact re-association of the
+ * reference's arithmetic; ~4x fewer matrix-core operations for the up-sampled channels.  ocv_tap_interp_supported tells
+ * whether (h,w) -> (H,W) is an up-sampling the staging buffer covers (ratios of ~2 and more). */
+int ocv_tap_interp_supported(int h, int w, int H, int W, int Cout);
+int ocv_tap_interp_combine_fwd(const float* z, int h, int w, const float* s, const float* bias, float* y, void* y_hl, int B,
+                               int H, int W, int Cout, int act, ocv_stream_t stream);
+
 /* Bilinear resize of x [B,h,w,C1] (NHWC fp32) to H x W with align_corners = True, concatenated along channels with
  * skip [B,H,W,C2] (nullable, then C2 = 0), written in the hl32 split layout for C1+C2 channels (out_hl,
  * ocv_split_act_elems(B,H,W,C1+C2) bf16 elements, 16-byte aligned; pad channels zeroed).  C1, C2 multiples of 4.

@@ -700,6 +700,49 @@ def conv_nhwc_exact(x1: torch.Tensor, x2: Optional[torch.Tensor], w_tap_major: t
     return y
 
 
+def tap_interp_supported(h: int, w: int, H: int, W: int, Cout: int) -> bool:
+    return bool(_lib.load().ocv_tap_interp_supported(int(h), int(w), int(H), int(W), int(Cout)))
+
+
+def tap_interp_combine(z: torch.Tensor, s: Optional[torch.Tensor], bias: Optional[torch.Tensor], size: Tuple[int, int],
+                       act: int = ACT_NONE, out_fp32: bool = True, out_split: bool = False):
+    """act(bias + s + sum over the 9 taps of the bilinear (align_corners) interpolation of z's tap products at the tap
+    position): ocv_tap_interp_combine_fwd.  z [B, 9 Cout, h, w] channels_last (tap-major columns), s [B, Cout, H, W]
+    channels_last or None.  Returns fp32 tensor, SplitAct, or (fp32, SplitAct)."""
+    lib = _lib.load()
+    if not (out_fp32 or out_split):
+        raise ValueError("tap_interp_combine: nothing to output")
+    z = _nhwc(z, "z")
+    B, C9, h, w = z.shape
+    if C9 % 9 != 0:
+        raise ValueError("tap_interp_combine: z must have 9 * Cout channels")
+    Cout = C9 // 9
+    H, W = int(size[0]), int(size[1])
+    if s is not None:
+        s = _nhwc(s, "s")
+        if tuple(s.shape) != (B, Cout, H, W):
+            raise ValueError(f"tap_interp_combine: s must be {(B, Cout, H, W)}, got {tuple(s.shape)}")
+    if bias is not None:
+        _req(bias, "bias")
+        if bias.numel() != Cout:
+            raise ValueError("tap_interp_combine: bias size mismatch")
+    if not tap_interp_supported(h, w, H, W, Cout):
+        raise ValueError(f"tap_interp_combine: unsupported resize {h}x{w} -> {H}x{W} / channel count {Cout}")
+    y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=z.device, memory_format=torch.channels_last) if out_fp32 else None
+    ys = SplitAct.empty(B, Cout, H, W, z.device) if out_split else None
+    with timed(f"tap_interp|{B},{H},{W},{Cout}"):
+        check(lib.ocv_tap_interp_combine_fwd(z.data_ptr(), h, w, _ptr(s), _ptr(bias), _ptr(y), ys.hl.data_ptr() if out_split else None,
+                                             B, H, W, Cout, act, _stream()), "ocv_tap_interp_combine_fwd")
+    if out_fp32 and out_split:
+        return y, ys
+    return y if out_fp32 else ys
+
+
+def split_act(x: torch.Tensor) -> "SplitAct":
+    """fp32 channels_last activation -> hl32 split (the resize kernel at scale 1)."""
+    return upsample_concat_split(x, None, tuple(x.shape[-2:]))
+
+
 _WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
 
 

@@ -50,6 +50,7 @@ class SplitConv3x3:
         self._wino = None
         self._w_folded = None
         self._w_exact = None
+        self._w_up = None
 
     def usable(self, c1: int, c2: int = 0) -> bool:
         k = self.conv.kernel_size
@@ -97,8 +98,27 @@ class SplitConv3x3:
                 self._prep = (hi, lo, None if b is None else b.detach().float().contiguous())
                 self._wino = None                                      # transformed / tap-major weights: built on first use
                 self._w_exact = None
+                self._w_up = None
                 self._w_folded = w.detach()
             self._key = key
+
+    def upconv_weights(self, c1: int):
+        """The weight of a convolution over cat([up(x), skip]) re-arranged for the low-resolution form
+        (csrc/tap_interp.hip): the up-sampled half as ONE 1x1 weight with the nine taps stacked tap-major
+        ([9 Cout, C1]: row t Cout + co, t = 3 ky + kx), the skip half as an ordinary 3x3 weight (None when C2 = 0)."""
+        self._ensure_prepared()
+        if self._w_up is None or self._w_up[0] != c1:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("weight preparation during graph capture: run one eager warm-up call first")
+            w = self._w_folded
+            cout, cin = w.shape[0], w.shape[1]
+            wa = w[:, :c1].permute(2, 3, 0, 1).reshape(9 * cout, c1, 1, 1)
+            a_hi, a_lo = hip_ops.prep_conv_weight(wa)
+            s_hi = s_lo = None
+            if cin > c1:
+                s_hi, s_lo = hip_ops.prep_conv_weight(w[:, c1:].contiguous())
+            self._w_up = (c1, a_hi, a_lo, s_hi, s_lo)
+        return self._w_up[1:] + (self._prep[2],)
 
     def run_split(self, x: "hip_ops.SplitAct", act=hip_ops.ACT_NONE, out_fp32=True, out_split=False):
         """Same convolution on a pre-split activation (no per-tap fp32 -> bf16 work in the kernel)."""
@@ -194,6 +214,13 @@ def _fold_conv_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d):
     return w, (b0 - bn.running_mean) * s + bn.bias
 
 
+class _ShapeOnly:
+    """Stand-in for a tensor where only ``.shape`` is consulted."""
+
+    def __init__(self, *shape):
+        self.shape = torch.Size(shape)
+
+
 class UpSampleWithSkip(nn.Module):
     """bilinear(align_corners=True) resize to the skip's size, concat, then
     2 x [conv3x3, BN, LeakyReLU(0.01)] (reference :30-47)."""
@@ -219,11 +246,38 @@ class UpSampleWithSkip(nn.Module):
         self._folded = None
         return super()._load_from_state_dict(*a, **kw)
 
+    def lowres_ready(self, x, skip_features) -> bool:
+        """Whether the first convolution can run in its low-resolution form (csrc/tap_interp.hip): the up-sampled
+        channels fill whole 32-blocks, the resize is an up-sampling the kernel's staging covers.  OCV_UPCONV=direct in the
+        environment keeps the resize + direct 3x3 convolution (A/B)."""
+        import os
+        if os.environ.get("OCV_UPCONV", "lowres") == "direct":
+            return False
+        c1, cout = x.shape[1], self._net[0].out_channels
+        return (c1 % 32 == 0 and cout % 8 == 0 and x.shape[2] < skip_features.shape[2] and x.shape[3] < skip_features.shape[3]
+                and hip_ops.tap_interp_supported(x.shape[2], x.shape[3], skip_features.shape[2], skip_features.shape[3], cout))
+
     def forward_split(self, x, skip_features, out_fp32=True, out_split=False):
-        """GPU inference plan: resize + concat + fp32->split-bf16 in ONE pass, then both 3x3 convolutions on
-        pre-split activations; the second one hands the next stage fp32 (for its resize) and / or the split pair."""
-        cat = hip_ops.upsample_concat_split(x, skip_features, skip_features.shape[-2:])
-        f = self._split1.run_split(cat, hip_ops.ACT_LEAKY_RELU, out_fp32=False, out_split=True)
+        """GPU inference plan.  ``x``: the stage input, fp32 channels_last or already split (hip_ops.SplitAct).
+        First convolution, low-resolution form (default): conv3x3(cat(up(x), skip)) = sum over the nine taps of the
+        bilinear interpolation of (W_tap x) -- formed once per LOW-resolution pixel by one 1x1 GEMM with 9 Cout columns,
+        ~4x fewer matrix-core operations for the up-sampled channels -- + conv3x3 over the skip channels, combined,
+        biased, activated and split by ocv_tap_interp_combine_fwd.  Otherwise: resize + concat + fp32->split-bf16 in ONE
+        pass, then the direct 3x3 convolution.  The second convolution hands the next stage fp32 and / or the split pair."""
+        H, W = skip_features.shape[-2:]
+        if self.lowres_ready(x, skip_features):
+            xs = x if isinstance(x, hip_ops.SplitAct) else hip_ops.split_act(x)
+            a_hi, a_lo, s_hi, s_lo, b = self._split1.upconv_weights(xs.shape[1])
+            z = hip_ops.conv_nhwc_split(xs, a_hi, a_lo, None, 1, hip_ops.ACT_NONE, out_fp32=True)
+            sk = None
+            if s_hi is not None:
+                sk = hip_ops.conv_nhwc_split(hip_ops.split_act(skip_features), s_hi, s_lo, None, 3, hip_ops.ACT_NONE, out_fp32=True)
+            f = hip_ops.tap_interp_combine(z, sk, b, (H, W), hip_ops.ACT_LEAKY_RELU, out_fp32=False, out_split=True)
+        else:
+            if isinstance(x, hip_ops.SplitAct):
+                x = x.float()
+            cat = hip_ops.upsample_concat_split(x, skip_features, (H, W))
+            f = self._split1.run_split(cat, hip_ops.ACT_LEAKY_RELU, out_fp32=False, out_split=True)
         return self._split2.run_split(f, hip_ops.ACT_LEAKY_RELU, out_fp32=out_fp32, out_split=out_split)
 
     def split_ready(self, x, skip_features) -> bool:
@@ -324,8 +378,11 @@ class Decoder(nn.Module):
                 and self._split3.usable(self.conv3.in_channels) and self.conv3.in_channels % 8 == 0):
             # all-split pipeline: the last stage hands conv3 its input pre-split; conv3 returns the fp32 feature map
             # (patch embedding reads it) AND its split copy, which rides along for the heads' 3x3 convolution
-            for up, skip in stages[:-1]:
-                x = up.forward_split(x, skip)
+            for i, (up, skip) in enumerate(stages[:-1]):
+                # the next stage's low-resolution first convolution reads its input in split form, its resize kernel fp32
+                nxt, nskip = stages[i + 1]
+                want_split = nxt.lowres_ready(_ShapeOnly(x.shape[0], up._net[3].out_channels, skip.shape[2], skip.shape[3]), nskip)
+                x = up.forward_split(x, skip, out_fp32=not want_split, out_split=want_split)
             xs = self.up4.forward_split(x, b0, out_fp32=False, out_split=True)
             out, out_split = self._split3.run_split(xs, hip_ops.ACT_NONE, out_fp32=True, out_split=True)
             out._ocv_split = out_split

@@ -775,6 +775,62 @@ def test_conv_nhwc_exact(ops, B, H, W, C1, C2, Cout, k, act):
     assert got.is_contiguous(memory_format=cl) and rel_dev(got, ref) < 2e-6
 
 
+@pytest.mark.parametrize("B,h,w,H,W,Cout,act", [(2, 15, 20, 30, 40, 64, 2), (1, 17, 22, 30, 40, 72, 0), (1, 5, 7, 11, 13, 8, 3),
+                                                (3, 30, 40, 60, 80, 32, 2), (1, 2, 3, 9, 23, 40, 1)])
+def test_tap_interp_combine(ops, B, h, w, H, W, Cout, act):
+    """ocv_tap_interp_combine_fwd against its definition in fp64: nine bilinear (align_corners) up-samplings of the tap
+    products, each shifted by its tap with zero padding, + skip part + bias, activation; fp32 and split outputs."""
+    z = rnd("z", (B, 9 * Cout, h, w), 1)
+    s, b = rnd("s", (B, Cout, H, W), 2), rnd("b", (Cout,), 3, 0.3)
+    ref = s.double() + b.double().view(1, -1, 1, 1)
+    for t in range(9):
+        up = F.interpolate(z[:, t * Cout:(t + 1) * Cout].double(), size=(H, W), mode="bilinear", align_corners=True)
+        dy, dx = t // 3 - 1, t % 3 - 1
+        ref = ref + F.pad(up, (1, 1, 1, 1))[:, :, 1 + dy:1 + dy + H, 1 + dx:1 + dx + W]
+    ref = [ref, torch.relu(ref), F.leaky_relu(ref, 0.01), F.silu(ref)][act]
+    cl = torch.channels_last
+    assert ops.tap_interp_supported(h, w, H, W, Cout)
+    y, ys = ops.tap_interp_combine(dev(z).contiguous(memory_format=cl), dev(s).contiguous(memory_format=cl), dev(b), (H, W), act,
+                                   out_fp32=True, out_split=True)
+    assert y.is_contiguous(memory_format=cl) and rel_dev(y, ref) < TOL
+    assert rel_dev(ys.float(), y) < 1e-5
+    y2 = ops.tap_interp_combine(dev(z).contiguous(memory_format=cl), None, None, (H, W), 0)
+    ref2 = sum(F.pad(F.interpolate(z[:, t * Cout:(t + 1) * Cout].double(), size=(H, W), mode="bilinear", align_corners=True),
+                     (1, 1, 1, 1))[:, :, t // 3:t // 3 + H, t % 3:t % 3 + W] for t in range(9))
+    assert rel_dev(y2, ref2) < TOL
+    assert not ops.tap_interp_supported(64, 64, 32, 32, Cout)          # a down-scaling: the footprint does not fit
+
+
+@pytest.mark.parametrize("B,h,w,H,W,C1,C2,Cout", [(2, 15, 20, 30, 40, 64, 24, 64), (1, 17, 22, 30, 40, 96, 16, 72),
+                                                  (1, 30, 40, 60, 80, 128, 0, 32), (2, 8, 9, 16, 19, 32, 40, 128)])
+def test_upsampled_conv_at_low_resolution(ops, B, h, w, H, W, C1, C2, Cout):
+    """The whole first convolution of an UpSampleWithSkip stage in its low-resolution form -- 1x1 GEMM with the nine taps
+    stacked, 3x3 convolution over the skip channels, tap interpolation + bias + LeakyReLU -- against the reference's
+    literal form in fp64: conv3x3(cat(interpolate(x), skip)), at the direct split-bf16 kernel's bar."""
+    x = rnd("x", (B, C1, h, w), 1)
+    skip = rnd("k", (B, C2, H, W), 2) if C2 else None
+    wt, b = rnd("w", (Cout, C1 + C2, 3, 3), 3, 1 / math.sqrt((C1 + C2) * 9)), rnd("b", (Cout,), 4, 0.2)
+    up = F.interpolate(x.double(), size=(H, W), mode="bilinear", align_corners=True)
+    cat = up if skip is None else torch.cat([up, skip.double()], 1)
+    ref = F.leaky_relu(F.conv2d(cat, wt.double(), b.double(), padding=1), 0.01)
+    cl = torch.channels_last
+    wa = dev(wt)[:, :C1].permute(2, 3, 0, 1).reshape(9 * Cout, C1, 1, 1)
+    a_hi, a_lo = ops.prep_conv_weight(wa)
+    z = ops.conv_nhwc_split(ops.split_act(dev(x).contiguous(memory_format=cl)), a_hi, a_lo, None, 1, 0)
+    s = None
+    if skip is not None:
+        s_hi, s_lo = ops.prep_conv_weight(dev(wt)[:, C1:].contiguous())
+        s = ops.conv_nhwc_split(ops.split_act(dev(skip).contiguous(memory_format=cl)), s_hi, s_lo, None, 3, 0)
+    y = ops.tap_interp_combine(z, s, dev(b), (H, W), 2)
+    assert rel_dev(y, ref) < SPLIT_TOL
+    # and it agrees with the direct path (resize + concat + split, then the 3x3 kernel) to the same bar
+    hi, lo = ops.prep_conv_weight(dev(wt))
+    direct = ops.conv_nhwc_split(ops.upsample_concat_split(dev(x).contiguous(memory_format=cl),
+                                                           None if skip is None else dev(skip).contiguous(memory_format=cl), (H, W)),
+                                 hi, lo, dev(b), 3, 2)
+    assert rel_dev(y, direct) < SPLIT_TOL
+
+
 @pytest.mark.parametrize("out_fp32,out_split", [(True, False), (False, True), (True, True)])
 def test_conv_nhwc_split_k_halves(ops, out_fp32, out_split):
     """300 tiles on 256 CUs: the launcher halves the channel chunks between two workgroups per tile (fp32 partial
