@@ -202,6 +202,14 @@ def kernel_report(timing, a, B):
                               frac_bf16_mfma_issued=round(issued / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
                               GBps=round(byts / (ms * 1e-3) / 1e9, 1)))
             continue
+        if name.startswith("tap_interp|"):
+            b_, h_, w_, co = (int(v) for v in name.split("|")[1].split(","))
+            m_ = b_ * h_ * w_
+            byts = m_ * co * 4 * (9 / 4 + 1 + 1)        # tap products at ~1/4 of the pixels, skip part, output (hl32 = 4 B too)
+            convs.append(dict(shape=f"B{b_} {h_}x{w_} ->{co}", form="tap interpolation + skip part + bias + LeakyReLU + split "
+                              "(third launch of a low-resolution first convolution)", launches_per_step=cnt / a.steps,
+                              ms=round(ms, 4), alg_MB=round(byts / 1e6, 1), GBps=round(byts / (ms * 1e-3) / 1e9, 1)))
+            continue
         if name not in km:
             continue
         gbs = km[name]["bytes"] / (ms * 1e-3) / 1e9
@@ -216,10 +224,11 @@ def kernel_report(timing, a, B):
     tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     if os.path.exists(tpath):
         traffic_all = json.load(open(tpath))
-    # the roofline launch is a FIXED one -- the eager island of the graph replay, 280 -> 128 at half resolution (the
-    # convolution that moves the most bytes; profiles/roofline_traffic.json holds the PMC traffic of this launch)
-    island_shape = f"B{B} {H // 2}x{W // 2} 280->128 k3"
-    direct = [c for c in convs if c["form"] == "direct"]
+    # the roofline launch is a FIXED one -- the eager islands of the graph replay, the direct 128 -> 128 convolution at
+    # half resolution (three launches per step, the longest single launches of the step since the first convolution of
+    # every decoder stage runs at the low resolution; profiles/roofline_traffic.json holds the PMC traffic of this launch)
+    island_shape = f"B{B} {H // 2}x{W // 2} 128->128 k3"
+    direct = [c for c in convs if c["form"] == "direct" and " k3" in c["shape"]]
     conv_dom = next((c for c in direct if c["shape"] == island_shape), None) or (max(direct, key=lambda c: c["ms"]) if direct else None)
     if conv_dom and (dom is None or max(c["ms"] for c in convs) > kernels[dom]["ms"]):
         # dominant hand-written kernel = the split-bf16 implicit-GEMM convolution (conv_split_dma_kernel): matrix-pipe
@@ -385,17 +394,18 @@ def main():
         if not a.eager:
             from objcavit_amd.graph import GraphedGraphBins
             try:
-                # capture = part of warm-up; each slot clones img as its graph's static input.  The longest launch of the
-                # step (first 3x3 convolution of the last decoder stage) stays outside the graph so that it is timed live.
+                # capture = part of warm-up; each slot clones img as its graph's static input.  The longest launches of the
+                # step (the three direct 128 -> 128 3x3 convolutions at half resolution: second convolution of the last
+                # decoder stage, the decoder's conv3, the head's conv3x3) stay outside the graph so that they are timed live.
                 n = max(1, a.inflight)
-                slots = [GraphedGraphBins(model, img, eager_ops=(f"conv3x3|{B},{H // 2},{W // 2},280,128",)) for _ in range(n)]
+                slots = [GraphedGraphBins(model, img, eager_ops=(f"conv3x3|{B},{H // 2},{W // 2},128,128",)) for _ in range(n)]
                 # a slot is replayed on the stream it was captured on: creating further streams can put two slots on
                 # the same hardware queue (ROCm maps streams round-robin onto GPU_MAX_HW_QUEUES = 4 queues), which
                 # serialises them -- measured: 781 instead of 840 img/s with the same code, depending on creation order
                 streams = [g.stream for g in slots]
                 run = slots[0]
                 launch_mode = (f"hipGraph replay in {len(run.segments) - len(run.islands)} segments + {len(run.islands) + 1} eager, "
-                               "event-timed launches (roofline convolution, bin head) per step"
+                               "event-timed launches (roofline convolutions, bin head) per step"
                                + (f"; {n} batches in flight (one graph instance + stream per slot, steps round-robin; the first "
                                   f"ROOFLINE_STEPS steps of the timed region run alone, which is where the event timings come from)"
                                   if n > 1 else ""))
