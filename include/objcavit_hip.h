@@ -366,10 +366,13 @@ int ocv_conv3x3_winograd_split_fwd(const void* x_hl, int Cin, const void* u_hi, 
  *   y[b][Y][X][co] = act( bias[co] + s[b][Y][X][co] + sum_t [ (Y,X) + t inside H x W ] bilinear(z[..][t Cout + co]; (Y,X) + t) )
  * with ATen's align_corners=True coefficients, writing fp32 y and / or the hl32 split y_hl.  Exact re-association of the
  * reference's arithmetic; ~4x fewer matrix-core operations for the up-sampled channels.  ocv_tap_interp_supported tells
- * whether (h,w) -> (H,W) is an up-sampling the staging buffer covers (ratios of ~2 and more). */
+ * whether (h,w) -> (H,W) is an up-sampling the staging buffer covers (ratios of ~2 and more).
+ * zpad = 1 (Decoder.conv2, the 1 x 1 convolution with padding 1 in front of the first stage, :57,:105): the resize source is
+ * the h x w grid whose one-pixel border ring holds one constant vector per column (zborder [9 Cout]: the tap products of
+ * conv2's bias) and z stores only the (h-2) x (w-2) interior; zpad = 0: zborder NULL, z stores h x w. */
 int ocv_tap_interp_supported(int h, int w, int H, int W, int Cout);
-int ocv_tap_interp_combine_fwd(const float* z, int h, int w, const float* s, const float* bias, float* y, void* y_hl, int B,
-                               int H, int W, int Cout, int act, ocv_stream_t stream);
+int ocv_tap_interp_combine_fwd(const float* z, int h, int w, int zpad, const float* zborder, const float* s, const float* bias,
+                               float* y, void* y_hl, int B, int H, int W, int Cout, int act, ocv_stream_t stream);
 
 /* Bilinear resize of x [B,h,w,C1] (NHWC fp32) to H x W with align_corners = True, concatenated along channels with
  * skip [B,H,W,C2] (nullable, then C2 = 0), written in the hl32 split layout for C1+C2 channels (out_hl,

@@ -26,12 +26,13 @@ constexpr int TY = 8, TX = 16, CB = 32;          // output tile and channel bloc
 constexpr int FQ = 192;                          // low-resolution pixels staged per tap (footprint capacity)
 
 struct TIArgs {
-  const float* z;        // [B][h][w][9 Cout]: column t Cout + co = (Wa_t . x)[co]
+  const float* z;        // [B][h - 2 zpad][w - 2 zpad][9 Cout]: column t Cout + co = (Wa_t . x)[co]
+  const float* zborder;  // [9 Cout]: the value of z on the zpad-wide border ring of the logical h x w grid (zpad = 1)
   const float* s;        // [B][H][W][Cout] skip-part convolution (raw), nullable
   const float* bias;     // nullable
   float* y;              // [B][H][W][Cout] fp32, nullable
   __bf16* yhl;           // hl32 split, nullable
-  int h, w, H, W, Cout, Cpo, act;
+  int h, w, H, W, Cout, Cpo, act, zpad;
   float sh, sw;
   int tiles_x, tiles_y;
 };
@@ -57,14 +58,17 @@ __global__ __launch_bounds__(256) void tap_interp_kernel(TIArgs p) {
   const int qy0 = (int)(p.sh * ya), qx0 = (int)(p.sw * xa);
   const int qy1 = min((int)(p.sh * yb) + 1, p.h - 1), qx1 = min((int)(p.sw * xb) + 1, p.w - 1);
   const int fw = qx1 - qx0 + 1, fq = (qy1 - qy0 + 1) * fw;           // <= FQ (checked on the host)
-  const float* zb = p.z + (long)b * p.h * p.w * 9 * p.Cout + cb0;
+  const int hp = p.h - 2 * p.zpad, wp = p.w - 2 * p.zpad;             // the stored grid
+  const float* zb = p.z + (long)b * hp * wp * 9 * p.Cout + cb0;
 
   auto stage = [&](int t, int buf) {
     for (int i = tid; i < fq * (CB / 4); i += 256) {
       const int q = i >> 3, c4 = (i & 7) * 4;
-      const int qy = qy0 + q / fw, qx = qx0 + q % fw;
-      *reinterpret_cast<float4*>(&zs[buf][q][c4]) =
-          ld4(zb + ((long)qy * p.w + qx) * 9 * p.Cout + (long)t * p.Cout + c4);
+      const int qy = qy0 + q / fw - p.zpad, qx = qx0 + q % fw - p.zpad;
+      const float* src = (unsigned)qy < (unsigned)hp && (unsigned)qx < (unsigned)wp
+                             ? zb + ((long)qy * wp + qx) * 9 * p.Cout + (long)t * p.Cout + c4
+                             : p.zborder + (long)t * p.Cout + cb0 + c4;
+      *reinterpret_cast<float4*>(&zs[buf][q][c4]) = ld4(src);
     }
   };
 
@@ -163,9 +167,12 @@ extern "C" int ocv_tap_interp_supported(int h, int w, int H, int W, int Cout) {
   return ti_footprint(h, w, H, W) <= FQ ? 1 : 0;
 }
 
-extern "C" int ocv_tap_interp_combine_fwd(const float* z, int h, int w, const float* s, const float* bias, float* y, void* y_hl,
-                                          int B, int H, int W, int Cout, int act, ocv_stream_t stream) {
+extern "C" int ocv_tap_interp_combine_fwd(const float* z, int h, int w, int zpad, const float* zborder, const float* s,
+                                          const float* bias, float* y, void* y_hl, int B, int H, int W, int Cout, int act,
+                                          ocv_stream_t stream) {
   OCV_CHECK_ARG(z && (y || y_hl), "ocv_tap_interp_combine_fwd: null pointer");
+  OCV_CHECK_ARG((zpad == 0 && zborder == nullptr) || (zpad == 1 && zborder != nullptr && h >= 3 && w >= 3 && ocv_aligned16(zborder)),
+                "ocv_tap_interp_combine_fwd: zpad must be 0 (no border vector) or 1 (with a 16-byte aligned border vector, h, w >= 3)");
   OCV_CHECK_ARG(B >= 1 && h >= 1 && w >= 1 && H >= 1 && W >= 1 && Cout >= 4 && Cout % 4 == 0,
                 "ocv_tap_interp_combine_fwd: bad sizes (Cout must be a multiple of 4, got %d)", Cout);
   OCV_CHECK_ARG(act >= 0 && act <= 3, "ocv_tap_interp_combine_fwd: unknown activation %d", act);
@@ -173,7 +180,7 @@ extern "C" int ocv_tap_interp_combine_fwd(const float* z, int h, int w, const fl
                 "ocv_tap_interp_combine_fwd: operands must be 16-byte aligned");
   OCV_CHECK_ARG(ocv_tap_interp_supported(h, w, H, W, Cout), "ocv_tap_interp_combine_fwd: the low-resolution footprint of an output tile "
                 "exceeds the staging buffer (h=%d w=%d H=%d W=%d): not an up-sampling by ~2 or more", h, w, H, W);
-  TIArgs a{z, s, bias, y, (__bf16*)y_hl, h, w, H, W, Cout, (Cout + 31) / 32 * 32, act,
+  TIArgs a{z, zborder, s, bias, y, (__bf16*)y_hl, h, w, H, W, Cout, (Cout + 31) / 32 * 32, act, zpad,
            H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f,
            ocv_cdiv(W, TX), ocv_cdiv(H, TY)};
   const long nwg = (long)a.tiles_x * a.tiles_y * B;

@@ -705,10 +705,12 @@ def tap_interp_supported(h: int, w: int, H: int, W: int, Cout: int) -> bool:
 
 
 def tap_interp_combine(z: torch.Tensor, s: Optional[torch.Tensor], bias: Optional[torch.Tensor], size: Tuple[int, int],
-                       act: int = ACT_NONE, out_fp32: bool = True, out_split: bool = False):
+                       act: int = ACT_NONE, out_fp32: bool = True, out_split: bool = False,
+                       border: Optional[torch.Tensor] = None):
     """act(bias + s + sum over the 9 taps of the bilinear (align_corners) interpolation of z's tap products at the tap
     position): ocv_tap_interp_combine_fwd.  z [B, 9 Cout, h, w] channels_last (tap-major columns), s [B, Cout, H, W]
-    channels_last or None.  Returns fp32 tensor, SplitAct, or (fp32, SplitAct)."""
+    channels_last or None.  ``border`` [9 Cout]: z is the interior of an (h+2) x (w+2) grid whose border ring holds this
+    vector (Decoder.conv2's padding).  Returns fp32 tensor, SplitAct, or (fp32, SplitAct)."""
     lib = _lib.load()
     if not (out_fp32 or out_split):
         raise ValueError("tap_interp_combine: nothing to output")
@@ -718,6 +720,12 @@ def tap_interp_combine(z: torch.Tensor, s: Optional[torch.Tensor], bias: Optiona
         raise ValueError("tap_interp_combine: z must have 9 * Cout channels")
     Cout = C9 // 9
     H, W = int(size[0]), int(size[1])
+    zpad = 0
+    if border is not None:
+        _req(border, "border")
+        if border.numel() != C9:
+            raise ValueError("tap_interp_combine: border must hold 9 * Cout values")
+        zpad, h, w = 1, h + 2, w + 2
     if s is not None:
         s = _nhwc(s, "s")
         if tuple(s.shape) != (B, Cout, H, W):
@@ -731,8 +739,9 @@ def tap_interp_combine(z: torch.Tensor, s: Optional[torch.Tensor], bias: Optiona
     y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=z.device, memory_format=torch.channels_last) if out_fp32 else None
     ys = SplitAct.empty(B, Cout, H, W, z.device) if out_split else None
     with timed(f"tap_interp|{B},{H},{W},{Cout}"):
-        check(lib.ocv_tap_interp_combine_fwd(z.data_ptr(), h, w, _ptr(s), _ptr(bias), _ptr(y), ys.hl.data_ptr() if out_split else None,
-                                             B, H, W, Cout, act, _stream()), "ocv_tap_interp_combine_fwd")
+        check(lib.ocv_tap_interp_combine_fwd(z.data_ptr(), h, w, zpad, _ptr(border), _ptr(s), _ptr(bias), _ptr(y),
+                                             ys.hl.data_ptr() if out_split else None, B, H, W, Cout, act, _stream()),
+              "ocv_tap_interp_combine_fwd")
     if out_fp32 and out_split:
         return y, ys
     return y if out_fp32 else ys

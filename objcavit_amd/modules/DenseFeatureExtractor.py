@@ -102,23 +102,34 @@ class SplitConv3x3:
                 self._w_folded = w.detach()
             self._key = key
 
-    def upconv_weights(self, c1: int):
+    def upconv_weights(self, c1: int, compose=None):
         """The weight of a convolution over cat([up(x), skip]) re-arranged for the low-resolution form
         (csrc/tap_interp.hip): the up-sampled half as ONE 1x1 weight with the nine taps stacked tap-major
-        ([9 Cout, C1]: row t Cout + co, t = 3 ky + kx), the skip half as an ordinary 3x3 weight (None when C2 = 0)."""
+        ([9 Cout, C1]: row t Cout + co, t = 3 ky + kx), the skip half as an ordinary 3x3 weight (None when C2 = 0).
+        ``compose`` = (key, fn): x itself is a bias-only-affine image of an earlier tensor, x = P x0 + pb with
+        (P [C1, K], pb [C1] or None) = fn() in float64 -- the tap-stacked weight is then composed with P in float64
+        ([9 Cout, K], applied to x0 directly) and the sixth return value is the tap-stacked image of pb ([9 Cout] fp32,
+        what z holds where x = pb), None without ``compose``."""
         self._ensure_prepared()
-        if self._w_up is None or self._w_up[0] != c1:
+        ckey = None if compose is None else compose[0]
+        if self._w_up is None or self._w_up[0] != (c1, ckey):
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("weight preparation during graph capture: run one eager warm-up call first")
             w = self._w_folded
             cout, cin = w.shape[0], w.shape[1]
-            wa = w[:, :c1].permute(2, 3, 0, 1).reshape(9 * cout, c1, 1, 1)
-            a_hi, a_lo = hip_ops.prep_conv_weight(wa)
+            wa = w[:, :c1].permute(2, 3, 0, 1).reshape(9 * cout, c1)
+            cvec = None
+            if compose is not None:
+                P, pb = compose[1]()
+                wa64 = wa.double()
+                cvec = (wa64 @ pb.double()).float().contiguous() if pb is not None else torch.zeros(9 * cout, device=w.device)
+                wa = (wa64 @ P.double()).float()
+            a_hi, a_lo = hip_ops.prep_conv_weight(wa.reshape(9 * cout, -1, 1, 1))
             s_hi = s_lo = None
             if cin > c1:
                 s_hi, s_lo = hip_ops.prep_conv_weight(w[:, c1:].contiguous())
-            self._w_up = (c1, a_hi, a_lo, s_hi, s_lo)
-        return self._w_up[1:] + (self._prep[2],)
+            self._w_up = ((c1, ckey), a_hi, a_lo, s_hi, s_lo, cvec)
+        return self._w_up[1:5] + (self._prep[2], self._w_up[5])
 
     def run_split(self, x: "hip_ops.SplitAct", act=hip_ops.ACT_NONE, out_fp32=True, out_split=False):
         """Same convolution on a pre-split activation (no per-tap fp32 -> bf16 work in the kernel)."""
@@ -154,7 +165,9 @@ class Encoder(nn.Module):
         self.original_model = backend
         self.keep = keep
 
-    def forward(self, x: torch.Tensor) -> List[Optional[torch.Tensor]]:
+    def forward(self, x: torch.Tensor, _defer_head: bool = False) -> List[Optional[torch.Tensor]]:
+        """``_defer_head`` (DenseFeatureExtractor's GPU inference call only): the bias-free 1x1 ``conv_head``, when nothing
+        but Identity modules follow it, is handed on un-applied (DeferredConv1x1) for the decoder to compose."""
         feats: List[Optional[torch.Tensor]] = [x]
         cur = x
 
@@ -165,12 +178,19 @@ class Encoder(nn.Module):
             feats.append(t if t is not None and (self.keep is None or idx in self.keep) else None)
 
         skip = self._fused_stem(x, push)
-        for name, child in self.original_model._modules.items():
+        names = list(self.original_model._modules)
+        for i, (name, child) in enumerate(self.original_model._modules.items()):
             if name in skip:
                 continue
             if name in ("blocks", "features"):
                 for sub in child._modules.values():
                     push(sub(cur))
+            elif (_defer_head and name == "conv_head" and isinstance(child, nn.Conv2d) and child.bias is None
+                  and child.kernel_size == (1, 1) and child.stride == (1, 1) and child.padding == (0, 0) and child.groups == 1
+                  and isinstance(cur, torch.Tensor) and cur.device.type == "cuda" and not child.training
+                  and not torch.is_grad_enabled()
+                  and all(isinstance(self.original_model._modules[n], nn.Identity) for n in names[i + 1:])):
+                push(DeferredConv1x1(cur, child))
             else:
                 push(child(cur))
         return feats
@@ -215,10 +235,25 @@ def _fold_conv_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d):
 
 
 class _ShapeOnly:
-    """Stand-in for a tensor where only ``.shape`` is consulted."""
+    """Stand-in for a tensor where only ``.shape`` (and ``.device``) is consulted."""
 
-    def __init__(self, *shape):
+    def __init__(self, *shape, device=None):
         self.shape = torch.Size(shape)
+        self.device = device
+
+
+class DeferredConv1x1:
+    """``conv(x)`` for a bias-free 1x1 convolution, not yet applied: what the Encoder hands the Decoder for the backbone's
+    conv_head on the GPU inference path, so the decoder can compose it into its first GEMM (Decoder._up1_affine).
+    ``materialize()`` applies it."""
+
+    def __init__(self, x: torch.Tensor, conv: nn.Conv2d):
+        self.x, self.conv = x, conv
+        self.shape = torch.Size((x.shape[0], conv.out_channels, x.shape[2], x.shape[3]))
+        self.device, self.dtype = x.device, x.dtype
+
+    def materialize(self) -> torch.Tensor:
+        return self.conv(self.x)
 
 
 class UpSampleWithSkip(nn.Module):
@@ -257,22 +292,32 @@ class UpSampleWithSkip(nn.Module):
         return (c1 % 32 == 0 and cout % 8 == 0 and x.shape[2] < skip_features.shape[2] and x.shape[3] < skip_features.shape[3]
                 and hip_ops.tap_interp_supported(x.shape[2], x.shape[3], skip_features.shape[2], skip_features.shape[3], cout))
 
-    def forward_split(self, x, skip_features, out_fp32=True, out_split=False):
+    def forward_split(self, x, skip_features, out_fp32=True, out_split=False, affine_of=None):
         """GPU inference plan.  ``x``: the stage input, fp32 channels_last or already split (hip_ops.SplitAct).
+        ``affine_of`` = (x0, key, fn, (h, w)): the stage input is NOT materialised -- it is the h x w grid whose interior is
+        P x0 + pb (per pixel, (P, pb) = fn() in float64) and whose one-pixel border ring is pb (Decoder.conv2's padded
+        1x1 convolution, optionally behind the backbone's bias-free conv_head): the tap-stacked weight is composed with P
+        once per weight version and the 1x1 GEMM reads x0 (``x`` is then only consulted for its shape).
         First convolution, low-resolution form (default): conv3x3(cat(up(x), skip)) = sum over the nine taps of the
         bilinear interpolation of (W_tap x) -- formed once per LOW-resolution pixel by one 1x1 GEMM with 9 Cout columns,
         ~4x fewer matrix-core operations for the up-sampled channels -- + conv3x3 over the skip channels, combined,
         biased, activated and split by ocv_tap_interp_combine_fwd.  Otherwise: resize + concat + fp32->split-bf16 in ONE
         pass, then the direct 3x3 convolution.  The second convolution hands the next stage fp32 and / or the split pair."""
         H, W = skip_features.shape[-2:]
-        if self.lowres_ready(x, skip_features):
-            xs = x if isinstance(x, hip_ops.SplitAct) else hip_ops.split_act(x)
-            a_hi, a_lo, s_hi, s_lo, b = self._split1.upconv_weights(xs.shape[1])
-            z = hip_ops.conv_nhwc_split(xs, a_hi, a_lo, None, 1, hip_ops.ACT_NONE, out_fp32=True)
+        if affine_of is not None or self.lowres_ready(x, skip_features):
+            if affine_of is not None:
+                x0, key, fn, _ = affine_of
+                xs = x0 if isinstance(x0, hip_ops.SplitAct) else hip_ops.split_act(x0)
+                a_hi, a_lo, s_hi, s_lo, b, border = self._split1.upconv_weights(x.shape[1], compose=(key, fn))
+                z = hip_ops.conv_nhwc_split(xs, a_hi, a_lo, border, 1, hip_ops.ACT_NONE, out_fp32=True)
+            else:
+                xs = x if isinstance(x, hip_ops.SplitAct) else hip_ops.split_act(x)
+                a_hi, a_lo, s_hi, s_lo, b, border = self._split1.upconv_weights(xs.shape[1])
+                z = hip_ops.conv_nhwc_split(xs, a_hi, a_lo, None, 1, hip_ops.ACT_NONE, out_fp32=True)
             sk = None
             if s_hi is not None:
                 sk = hip_ops.conv_nhwc_split(hip_ops.split_act(skip_features), s_hi, s_lo, None, 3, hip_ops.ACT_NONE, out_fp32=True)
-            f = hip_ops.tap_interp_combine(z, sk, b, (H, W), hip_ops.ACT_LEAKY_RELU, out_fp32=False, out_split=True)
+            f = hip_ops.tap_interp_combine(z, sk, b, (H, W), hip_ops.ACT_LEAKY_RELU, out_fp32=False, out_split=True, border=border)
         else:
             if isinstance(x, hip_ops.SplitAct):
                 x = x.float()
@@ -366,13 +411,54 @@ class Decoder(nn.Module):
         out[:, :, 1:-1, 1:-1] = inner
         return out
 
+    def _up1_affine(self, b4, b3):
+        """The first stage's input as an affine image of an EARLIER tensor, when that pays: conv2 (1x1, padding 1, no
+        activation; reference :57,:105) -- and the backbone's bias-free conv_head in front of it, when the encoder deferred
+        it -- are per-pixel linear maps directly in front of up1's low-resolution GEMM (also per-pixel linear), so the three
+        compose into ONE weight [9 Cout, K] applied to the earlier tensor; conv2's border ring (= its bias) becomes a constant
+        vector the interpolation kernel substitutes.  Returns (shape stand-in for conv2's output, affine_of) or None.
+        OCV_UPCONV_FOLD=0 in the environment keeps the separate launches (A/B)."""
+        import os
+        c = self.conv2
+        x0 = b4.x if isinstance(b4, DeferredConv1x1) else b4
+        if os.environ.get("OCV_UPCONV_FOLD", "1") == "0" or not (
+                x0.device.type == "cuda" and not self.training and not torch.is_grad_enabled() and self.final_upscale is None
+                and c.kernel_size == (1, 1) and c.padding == (1, 1) and c.stride == (1, 1) and c.groups == 1
+                and x0.dtype == torch.float32 and x0.shape[1] % 32 == 0):
+            return None
+        B, _, h, w = b4.shape
+        shape = _ShapeOnly(B, c.out_channels, h + 2, w + 2, device=x0.device)
+        if not (self.up1.split_ready(shape, b3) and self.up1.lowres_ready(shape, b3)):
+            return None
+        head = b4.conv if isinstance(b4, DeferredConv1x1) else None
+        ps = [c.weight] + ([c.bias] if c.bias is not None else []) + ([head.weight] if head is not None else [])
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+
+        def fn():
+            P = c.weight.detach().flatten(1).double()
+            if head is not None:
+                P = P @ head.weight.detach().flatten(1).double()
+            return P, None if c.bias is None else c.bias.detach()
+
+        return shape, (x0, key, fn, (h + 2, w + 2))
+
     def forward(self, features):
         b0, b1, b2, b3, b4 = (features[i] for i in self.feature_select)
         if b4.device.type == "cuda" and not self.training and not torch.is_grad_enabled():
             # inference on the GPU: the decoder runs in channels_last (NHWC), the layout of every kernel of the path
             cl = torch.channels_last
-            b0, b1, b2, b3, b4 = (t.contiguous(memory_format=cl) for t in (b0, b1, b2, b3, b4))
-        x = self._conv2_padded_1x1(b4)
+            b0, b1, b2, b3 = (t.contiguous(memory_format=cl) for t in (b0, b1, b2, b3))
+            if isinstance(b4, DeferredConv1x1):
+                b4.x = b4.x.contiguous(memory_format=cl)
+            else:
+                b4 = b4.contiguous(memory_format=cl)
+        affine = self._up1_affine(b4, b3) if self._split3.usable(self.conv3.in_channels) and self.conv3.in_channels % 8 == 0 else None
+        if affine is not None:
+            x = affine[0]
+        else:
+            if isinstance(b4, DeferredConv1x1):
+                b4 = b4.materialize()
+            x = self._conv2_padded_1x1(b4)
         stages = ((self.up1, b3), (self.up2, b2), (self.up3, b1), (self.up4, b0))
         if (self.final_upscale is None and all(up.split_ready(x, skip) for up, skip in stages[:1])
                 and self._split3.usable(self.conv3.in_channels) and self.conv3.in_channels % 8 == 0):
@@ -382,7 +468,8 @@ class Decoder(nn.Module):
                 # the next stage's low-resolution first convolution reads its input in split form, its resize kernel fp32
                 nxt, nskip = stages[i + 1]
                 want_split = nxt.lowres_ready(_ShapeOnly(x.shape[0], up._net[3].out_channels, skip.shape[2], skip.shape[3]), nskip)
-                x = up.forward_split(x, skip, out_fp32=not want_split, out_split=want_split)
+                x = up.forward_split(x, skip, out_fp32=not want_split, out_split=want_split,
+                                     affine_of=affine[1] if i == 0 and affine is not None else None)
             xs = self.up4.forward_split(x, b0, out_fp32=False, out_split=True)
             out, out_split = self._split3.run_split(xs, hip_ops.ACT_NONE, out_fp32=True, out_split=True)
             out._ocv_split = out_split
@@ -432,4 +519,5 @@ class DenseFeatureExtractor(nn.Module):
         self._non_encoder_params_module_list.append(self.decoder)
 
     def forward(self, image):
-        return self.decoder(self.encoder(image))
+        fast = image.device.type == "cuda" and not self.training and not torch.is_grad_enabled()
+        return self.decoder(self.encoder(image, _defer_head=True) if fast else self.encoder(image))

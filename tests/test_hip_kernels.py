@@ -801,6 +801,25 @@ def test_tap_interp_combine(ops, B, h, w, H, W, Cout, act):
     assert not ops.tap_interp_supported(64, 64, 32, 32, Cout)          # a down-scaling: the footprint does not fit
 
 
+@pytest.mark.parametrize("B,h,w,H,W,Cout,act", [(2, 15, 20, 30, 40, 64, 2), (1, 3, 4, 11, 13, 8, 0), (1, 1, 1, 7, 9, 40, 2),
+                                                (2, 6, 9, 17, 23, 96, 1)])
+def test_tap_interp_combine_bordered_grid(ops, B, h, w, H, W, Cout, act):
+    """zpad = 1: z stores the h x w interior of an (h+2) x (w+2) resize source whose border ring holds one constant vector
+    (Decoder.conv2's padding=1 on a 1x1 convolution): equals the plain form on the materialised grid, bit for bit."""
+    cl = torch.channels_last
+    z = dev(rnd("z", (B, 9 * Cout, h, w), 1)).contiguous(memory_format=cl)
+    border = dev(rnd("c", (9 * Cout,), 2))
+    s, b = dev(rnd("s", (B, Cout, H, W), 3)).contiguous(memory_format=cl), dev(rnd("b", (Cout,), 4, 0.3))
+    full = border.view(1, -1, 1, 1).expand(B, 9 * Cout, h + 2, w + 2).contiguous(memory_format=cl).clone()
+    full[:, :, 1:-1, 1:-1] = z
+    want = ops.tap_interp_combine(full.contiguous(memory_format=cl), s, b, (H, W), act)
+    got, gs = ops.tap_interp_combine(z, s, b, (H, W), act, out_fp32=True, out_split=True, border=border)
+    assert torch.equal(got, want)
+    assert rel_dev(gs.float(), got) < 1e-5
+    with pytest.raises(ValueError):
+        ops.tap_interp_combine(z, s, b, (H, W), act, border=border[:-1])
+
+
 @pytest.mark.parametrize("B,h,w,H,W,C1,C2,Cout", [(2, 15, 20, 30, 40, 64, 24, 64), (1, 17, 22, 30, 40, 96, 16, 72),
                                                   (1, 30, 40, 60, 80, 128, 0, 32), (2, 8, 9, 16, 19, 32, 40, 128)])
 def test_upsampled_conv_at_low_resolution(ops, B, h, w, H, W, C1, C2, Cout):

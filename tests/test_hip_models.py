@@ -220,9 +220,11 @@ def test_config2_full_size_properties():
     assert max_rel(d[3:4], ref) < 1e-3 and max_rel(solo, ref) < 1e-3
 
 
-def test_encoder_fast_path_vs_oracle():
+def test_encoder_fast_path_vs_oracle(monkeypatch):
     """EfficientNet-B5 encoder inference plan (folded BN, HIP depthwise kernel) vs the oracle's functional
-    restatement on identical weights: every one of the five skip activations."""
+    restatement on identical weights: every one of the five skip activations; the decoder on them (conv2 composed into
+    the first stage's GEMM), the whole extractor (conv_head composed as well) and the un-composed route
+    (OCV_UPCONV_FOLD=0), all against the oracle's decoder."""
     from oracle import effnet_ref
     from objcavit_amd.modules.DenseFeatureExtractor import DenseFeatureExtractor
     m = DenseFeatureExtractor(make_args()).eval()
@@ -236,6 +238,14 @@ def test_encoder_fast_path_vs_oracle():
     ref_out = restate.decoder_forward(ref, sd, "decoder.")
     assert rel_dev(out, ref_out) < 1e-4
     assert out.is_contiguous(memory_format=torch.channels_last)       # decoder runs NHWC on the GPU
+    from objcavit_amd.modules.DenseFeatureExtractor import DeferredConv1x1
+    deferred = m.encoder(img.cuda(), _defer_head=True)
+    assert isinstance(deferred[11], DeferredConv1x1) and rel_dev(deferred[11].materialize(), ref[11]) < 1e-4
+    whole = m(img.cuda())
+    assert rel_dev(whole, ref_out) < 1e-4
+    monkeypatch.setenv("OCV_UPCONV_FOLD", "0")
+    separate = m(img.cuda())
+    assert rel_dev(separate, ref_out) < 1e-4 and not torch.equal(separate, whole)
 
 
 def test_graph_owns_its_scratch_and_survives_larger_eager_calls():
