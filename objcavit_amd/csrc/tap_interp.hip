@@ -12,9 +12,15 @@
 // activation and writes fp32 and / or the hl32 split layout.  Exact re-association of the reference's arithmetic: the
 // interpolation uses ATen's coefficients (scale = (in - 1) / (out - 1), src = scale * dst, lambda = src - floor(src)).
 //
-// Work item: 4 output channels of one output pixel; a workgroup owns an 8 x 16 pixel tile x 32 channels and walks the nine
-// taps: per tap the 32-channel slab of the low-resolution rows under the tile (<= FQ pixels) is staged in LDS (double
-// buffered, 128 bytes per pixel and tap) and every item reads its 4 neighbours from there.
+// Work item: 4 output channels of 4 output pixels (rows Y, Y+2, Y+4, Y+6 of one column); a workgroup owns an 8 x 16 pixel
+// tile x 32 channels and walks the nine taps.  Per tap the 32-channel slab of the low-resolution pixels under the tile (its
+// footprint, < FQ pixels, 128 bytes each) is staged in LDS, buffer (tap mod 3).  The kernel is bound by the LATENCY of those
+// ~10 KB pieces, not by HBM bandwidth or arithmetic (one piece per tap and workgroup), so the loads run ahead: the piece of
+// tap t+4 is requested (into registers) when tap t's interpolation is done, the piece of tap t+1 -- requested three taps
+// earlier -- is written to its LDS buffer at the same point; three pieces per workgroup are in flight throughout.  The LDS
+// allocation is sized to the real footprint (~37 KB for a 2x up-sampling).  The x interpolation coefficients and LDS offsets
+// depend on (pixel, dx) only and are formed once; the y ones per tap row.  The right-hand x neighbour is always read at
+// +128 bytes: where ATen clamps it (last column) its weight is exactly 0 and the slot read holds staged (finite) data.
 #include "common.hpp"
 #include "../../include/objcavit_hip.h"
 
@@ -24,6 +30,7 @@ typedef __bf16 ti_bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TY = 8, TX = 16, CB = 32;          // output tile and channel block
 constexpr int FQ = 192;                          // low-resolution pixels staged per tap (footprint capacity)
+constexpr int NBUF = 3;                          // LDS buffers: tap t lives in buffer t mod 3 (= dx)
 
 struct TIArgs {
   const float* z;        // [B][h - 2 zpad][w - 2 zpad][9 Cout]: column t Cout + co = (Wa_t . x)[co]
@@ -35,17 +42,25 @@ struct TIArgs {
   int h, w, H, W, Cout, Cpo, act, zpad;
   float sh, sw;
   int tiles_x, tiles_y;
+  int fq_cap;            // pixels per staging buffer (multiple of 32: whole 256-lane rounds)
 };
 
-__device__ __forceinline__ float ti_act(float v, int act) {
-  if (act == OCV_ACT_LEAKY_RELU) return v > 0.f ? v : 0.01f * v;
-  if (act == OCV_ACT_SILU) return fast_silu(v);
-  if (act == OCV_ACT_RELU) return fmaxf(v, 0.f);
+template <int ACT>
+__device__ __forceinline__ float ti_act(float v) {
+  if constexpr (ACT == OCV_ACT_LEAKY_RELU) return v > 0.f ? v : 0.01f * v;
+  if constexpr (ACT == OCV_ACT_SILU) return fast_silu(v);
+  if constexpr (ACT == OCV_ACT_RELU) return fmaxf(v, 0.f);
   return v;
 }
 
-__global__ __launch_bounds__(256) void tap_interp_kernel(TIArgs p) {
-  __shared__ __attribute__((aligned(16))) float zs[2][FQ][CB];
+struct TIArgs;
+template <int ACT>
+__device__ __forceinline__ void ti_store(const TIArgs& p, const float4 (&acc)[4], int b, int Y0, int X, int n);
+
+// NJ = staging rounds of 256 lanes x 16 bytes per tap (ceil(footprint x 8 / 256))
+template <int NJ>
+__global__ __launch_bounds__(256, 2) void tap_interp_kernel(TIArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float zs[];          // [NBUF][fq_cap][CB]
   const int tid = threadIdx.x;
   int wg = blockIdx.x;
   const int tx = wg % p.tiles_x;
@@ -57,71 +72,136 @@ __global__ __launch_bounds__(256) void tap_interp_kernel(TIArgs p) {
   const int ya = max(Y0 - 1, 0), yb = min(Y0 + TY, p.H - 1), xa = max(X0 - 1, 0), xb = min(X0 + TX, p.W - 1);
   const int qy0 = (int)(p.sh * ya), qx0 = (int)(p.sw * xa);
   const int qy1 = min((int)(p.sh * yb) + 1, p.h - 1), qx1 = min((int)(p.sw * xb) + 1, p.w - 1);
-  const int fw = qx1 - qx0 + 1, fq = (qy1 - qy0 + 1) * fw;           // <= FQ (checked on the host)
+  const int fw = qx1 - qx0 + 1, fq = (qy1 - qy0 + 1) * fw;           // <= NJ * 32 <= fq_cap (checked on the host)
   const int hp = p.h - 2 * p.zpad, wp = p.w - 2 * p.zpad;             // the stored grid
   const float* zb = p.z + (long)b * hp * wp * 9 * p.Cout + cb0;
+  const int bufstride = p.fq_cap * CB;
 
-  auto stage = [&](int t, int buf) {
-    for (int i = tid; i < fq * (CB / 4); i += 256) {
-      const int q = i >> 3, c4 = (i & 7) * 4;
-      const int qy = qy0 + q / fw - p.zpad, qx = qx0 + q % fw - p.zpad;
-      const float* src = (unsigned)qy < (unsigned)hp && (unsigned)qx < (unsigned)wp
-                             ? zb + ((long)qy * wp + qx) * 9 * p.Cout + (long)t * p.Cout + c4
-                             : p.zborder + (long)t * p.Cout + cb0 + c4;
-      *reinterpret_cast<float4*>(&zs[buf][q][c4]) = ld4(src);
+  // staging sources of this lane, per round: element offset into the image's z (tap 0), or -1 = border ring
+  int soff[NJ];
+  const int c4 = (tid & 7) * 4;
+  const int c4s = cb0 + c4 < p.Cout ? c4 : 0;                         // channel tail: lanes past Cout re-fetch the block's first group
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    int q = (tid >> 3) + 32 * j;
+    q = q < fq ? q : 0;                                               // lanes past the footprint re-fetch its first pixel
+    const int qy = qy0 + q / fw - p.zpad, qx = qx0 + q % fw - p.zpad;
+    soff[j] = (unsigned)qy < (unsigned)hp && (unsigned)qx < (unsigned)wp ? (qy * wp + qx) * 9 * p.Cout + c4s : -1;
+  }
+  const float* zbr = p.zborder + cb0 + c4s;                           // only dereferenced when some soff is -1
+  // taps past the ninth: every lane re-reads one line (a select, not a branch: the tap loop must stay ONE basic block, or
+  // the compiler sinks every tap's arithmetic below the last barrier and keeps all nine taps' LDS reads live)
+  auto fetch = [&](int t, float4 (&r)[NJ]) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const float* src = soff[j] >= 0 ? zb + soff[j] + t * p.Cout : zbr + t * p.Cout;
+      r[j] = ld4(t < 9 ? src : zb);
     }
   };
+  auto put = [&](int buf, const float4 (&r)[NJ]) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) *reinterpret_cast<float4*>(zs + buf * bufstride + (tid + 256 * j) * 4) = r[j];
+  };
+  float4 r0[NJ], r1[NJ], r2[NJ];                                     // pieces in flight, by tap mod 3
+  fetch(0, r0);
+  fetch(1, r1);
+  fetch(2, r2);
 
-  // items: channel group cg (4 channels), pixels px = (tid >> 3) + 32 i of the 128-pixel tile
-  const int cg = (tid & 7) * 4;
+  // items: channel group cg (4 channels) of pixels (Y0 + (tid >> 7) + 2 i, X0 + ((tid >> 3) & 15)), i = 0..3.
+  // Coefficients are zero where the tap falls outside the image (zero padding of the convolution).
+  const int cg = c4;
+  int xo[3];                                                          // LDS float offset: buffer dx, column x0, channel group
+  float wx0[3], wx1[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int X = X0 + ((tid >> 3) & 15) + d - 1;
+    const bool ok = (unsigned)X < (unsigned)p.W;
+    const float sx = p.sw * (ok ? X : 0);
+    const int x0 = (int)sx;
+    const float w1 = x0 < p.w - 1 ? sx - (float)x0 : 0.f;             // last column: ATen's x1 = x0, i.e. no right-hand share
+    xo[d] = d * bufstride + (ok ? (x0 - qx0) * CB : 0) + cg;
+    wx0[d] = ok ? 1.0f - w1 : 0.f;
+    wx1[d] = ok ? w1 : 0.f;
+  }
+
   float4 acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  stage(0, 0);
+  put(0, r0);
+  fetch(3, r0);
   __syncthreads();
-  for (int t = 0; t < 9; ++t) {
-    if (t + 1 < 9) stage(t + 1, (t + 1) & 1);
-    const int dy = t / 3 - 1, dx = t % 3 - 1;
+#pragma unroll 1
+  for (int dy = 0; dy < 3; ++dy) {
+    int iy0[4], iy1[4];
+    float hy0[4], hy1[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int px = (tid >> 3) + 32 * i;
-      const int Y = Y0 + px / TX + dy, X = X0 + px % TX + dx;
-      if ((unsigned)Y < (unsigned)p.H && (unsigned)X < (unsigned)p.W) {      // zero padding of the convolution
-        const float sy = p.sh * Y, sx = p.sw * X;
-        const int y0 = (int)sy, x0 = (int)sx;
-        const int y1 = y0 + (y0 < p.h - 1 ? 1 : 0), x1 = x0 + (x0 < p.w - 1 ? 1 : 0);
-        const float h1 = sy - (float)y0, h0 = 1.0f - h1, w1 = sx - (float)x0, w0 = 1.0f - w1;
-        const int i0 = (y0 - qy0) * fw - qx0, i1 = (y1 - qy0) * fw - qx0;
-        const float4 v00 = *reinterpret_cast<const float4*>(&zs[t & 1][i0 + x0][cg]);
-        const float4 v01 = *reinterpret_cast<const float4*>(&zs[t & 1][i0 + x1][cg]);
-        const float4 v10 = *reinterpret_cast<const float4*>(&zs[t & 1][i1 + x0][cg]);
-        const float4 v11 = *reinterpret_cast<const float4*>(&zs[t & 1][i1 + x1][cg]);
-        acc[i].x += h0 * (w0 * v00.x + w1 * v01.x) + h1 * (w0 * v10.x + w1 * v11.x);
-        acc[i].y += h0 * (w0 * v00.y + w1 * v01.y) + h1 * (w0 * v10.y + w1 * v11.y);
-        acc[i].z += h0 * (w0 * v00.z + w1 * v01.z) + h1 * (w0 * v10.z + w1 * v11.z);
-        acc[i].w += h0 * (w0 * v00.w + w1 * v01.w) + h1 * (w0 * v10.w + w1 * v11.w);
-      }
+      const int Y = Y0 + (tid >> 7) + 2 * i + dy - 1;
+      const bool ok = (unsigned)Y < (unsigned)p.H;
+      const float sy = p.sh * (ok ? Y : 0);
+      const int y0 = (int)sy, y1 = y0 + (y0 < p.h - 1 ? 1 : 0);
+      const float h1 = sy - (float)y0;
+      iy0[i] = ok ? (y0 - qy0) * fw * CB : 0;
+      iy1[i] = ok ? (y1 - qy0) * fw * CB : 0;
+      hy0[i] = ok ? 1.0f - h1 : 0.f;
+      hy1[i] = ok ? h1 : 0.f;
     }
-    __syncthreads();
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int t = 3 * dy + dx;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float* r0p = zs + iy0[i] + xo[dx];
+        const float* r1p = zs + iy1[i] + xo[dx];
+        const float4 v00 = *reinterpret_cast<const float4*>(r0p);
+        const float4 v01 = *reinterpret_cast<const float4*>(r0p + CB);
+        const float4 v10 = *reinterpret_cast<const float4*>(r1p);
+        const float4 v11 = *reinterpret_cast<const float4*>(r1p + CB);
+        const float a = hy0[i] * wx0[dx], bq = hy0[i] * wx1[dx], c = hy1[i] * wx0[dx], d = hy1[i] * wx1[dx];
+        acc[i].x += a * v00.x + bq * v01.x + c * v10.x + d * v11.x;
+        acc[i].y += a * v00.y + bq * v01.y + c * v10.y + d * v11.y;
+        acc[i].z += a * v00.z + bq * v01.z + c * v10.z + d * v11.z;
+        acc[i].w += a * v00.w + bq * v01.w + c * v10.w + d * v11.w;
+      }
+      __builtin_amdgcn_sched_barrier(0);               // keep each tap's arithmetic with its LDS reads
+      // tap t+1 (requested three taps ago) into buffer (t+1) mod 3 -- last read during tap t-2 -- and tap t+4 requested
+      // into the registers that just drained
+      // (after the ninth tap the put is a dead store into a buffer nobody reads again)
+      if (dx == 0) { put(1, r1); fetch(t + 4, r1); }
+      if (dx == 1) { put(2, r2); fetch(t + 4, r2); }
+      if (dx == 2) { put(0, r0); fetch(t + 4, r0); }
+      __syncthreads();
+    }
   }
 
   const int n = cb0 + cg;
   if (n >= p.Cout) return;
+  const int Yt = Y0 + (tid >> 7), X = X0 + ((tid >> 3) & 15);
+  switch (p.act) {                                                    // uniform
+    case OCV_ACT_LEAKY_RELU: ti_store<OCV_ACT_LEAKY_RELU>(p, acc, b, Yt, X, n); break;
+    case OCV_ACT_SILU: ti_store<OCV_ACT_SILU>(p, acc, b, Yt, X, n); break;
+    case OCV_ACT_RELU: ti_store<OCV_ACT_RELU>(p, acc, b, Yt, X, n); break;
+    default: ti_store<OCV_ACT_NONE>(p, acc, b, Yt, X, n); break;
+  }
+}
+
+// + skip part + bias, activation, fp32 and / or hl32 split store of one item's four pixels (rows Y, Y+2, Y+4, Y+6)
+template <int ACT>
+__device__ __forceinline__ void ti_store(const TIArgs& p, const float4 (&acc)[4], int b, int Y, int X, int n) {
+  if (X >= p.W) return;
   const float4 bv = p.bias != nullptr ? ld4(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int px = (tid >> 3) + 32 * i;
-    const int Y = Y0 + px / TX, X = X0 + px % TX;
-    if (Y >= p.H || X >= p.W) continue;
-    const long pix = ((long)b * p.H + Y) * p.W + X;
+    if (Y + 2 * i >= p.H) break;
+    const long pix = ((long)b * p.H + Y + 2 * i) * p.W + X;
     float4 v = acc[i];
     if (p.s != nullptr) {
       const float4 sv = ld4(p.s + pix * p.Cout + n);
       v.x += sv.x; v.y += sv.y; v.z += sv.z; v.w += sv.w;
     }
-    v.x = ti_act(v.x + bv.x, p.act); v.y = ti_act(v.y + bv.y, p.act);
-    v.z = ti_act(v.z + bv.z, p.act); v.w = ti_act(v.w + bv.w, p.act);
+    v.x = ti_act<ACT>(v.x + bv.x); v.y = ti_act<ACT>(v.y + bv.y);
+    v.z = ti_act<ACT>(v.z + bv.z); v.w = ti_act<ACT>(v.w + bv.w);
     if (p.y != nullptr) *reinterpret_cast<float4*>(p.y + pix * p.Cout + n) = v;
     if (p.yhl != nullptr) {
       const float f[4] = {v.x, v.y, v.z, v.w};
@@ -164,7 +244,7 @@ int ti_footprint(int h, int w, int H, int W) {
 
 extern "C" int ocv_tap_interp_supported(int h, int w, int H, int W, int Cout) {
   if (h < 1 || w < 1 || H < 1 || W < 1 || Cout < 4 || Cout % 4 != 0) return 0;
-  return ti_footprint(h, w, H, W) <= FQ ? 1 : 0;
+  return ti_footprint(h, w, H, W) < FQ ? 1 : 0;                     // + the one spare slot the right-hand neighbour may touch
 }
 
 extern "C" int ocv_tap_interp_combine_fwd(const float* z, int h, int w, int zpad, const float* zborder, const float* s,
@@ -180,16 +260,28 @@ extern "C" int ocv_tap_interp_combine_fwd(const float* z, int h, int w, int zpad
                 "ocv_tap_interp_combine_fwd: operands must be 16-byte aligned");
   OCV_CHECK_ARG(ocv_tap_interp_supported(h, w, H, W, Cout), "ocv_tap_interp_combine_fwd: the low-resolution footprint of an output tile "
                 "exceeds the staging buffer (h=%d w=%d H=%d W=%d): not an up-sampling by ~2 or more", h, w, H, W);
+  const int nj = ocv_cdiv(ti_footprint(h, w, H, W) + 1, 32);       // 1..6 staging rounds per tap (footprint + one spare slot)
   TIArgs a{z, zborder, s, bias, y, (__bf16*)y_hl, h, w, H, W, Cout, (Cout + 31) / 32 * 32, act, zpad,
            H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f,
-           ocv_cdiv(W, TX), ocv_cdiv(H, TY)};
+           ocv_cdiv(W, TX), ocv_cdiv(H, TY), nj * 32};
   const long nwg = (long)a.tiles_x * a.tiles_y * B;
   OCV_CHECK_ARG(nwg < (1L << 31) && ocv_cdiv(Cout, CB) <= 65535, "ocv_tap_interp_combine_fwd: grid too large");
   if (y_hl != nullptr && Cout % 32 != 0) {
     const hipError_t e = hipMemsetAsync(y_hl, 0, ocv_split_act_elems(B, H, W, Cout) * sizeof(__bf16), (hipStream_t)stream);
     OCV_CHECK_ARG(e == hipSuccess, "ocv_tap_interp_combine_fwd: hipMemsetAsync failed: %s", hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(tap_interp_kernel, dim3((unsigned)nwg, ocv_cdiv(Cout, CB)), dim3(256), 0, (hipStream_t)stream, a);
+  const dim3 grid((unsigned)nwg, ocv_cdiv(Cout, CB));
+  const size_t lds = (size_t)NBUF * a.fq_cap * CB * sizeof(float);
+  if (nj == 6) {                                                    // 72 KB of dynamic LDS: above the 64 KB default limit
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&tap_interp_kernel<6>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, NBUF * FQ * CB * (int)sizeof(float));
+    OCV_CHECK_ARG(attr == hipSuccess, "ocv_tap_interp_combine_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(attr));
+  }
+  switch (nj) {
+#define OCV_TI_CASE(NJ) case NJ: hipLaunchKernelGGL(tap_interp_kernel<NJ>, grid, dim3(256), lds, (hipStream_t)stream, a); break;
+    OCV_TI_CASE(1) OCV_TI_CASE(2) OCV_TI_CASE(3) OCV_TI_CASE(4) OCV_TI_CASE(5) OCV_TI_CASE(6)
+#undef OCV_TI_CASE
+  }
   OCV_CHECK_LAUNCH("ocv_tap_interp_combine_fwd");
   return 0;
 }

@@ -289,6 +289,8 @@ class UpSampleWithSkip(nn.Module):
         if os.environ.get("OCV_UPCONV", "lowres") == "direct":
             return False
         c1, cout = x.shape[1], self._net[0].out_channels
+        if cout < int(os.environ.get("OCV_UPCONV_MIN_COUT", "0")):
+            return False
         return (c1 % 32 == 0 and cout % 8 == 0 and x.shape[2] < skip_features.shape[2] and x.shape[3] < skip_features.shape[3]
                 and hip_ops.tap_interp_supported(x.shape[2], x.shape[3], skip_features.shape[2], skip_features.shape[3], cout))
 
