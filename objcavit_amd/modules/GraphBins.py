@@ -127,7 +127,7 @@ class GraphBins(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 pre = self.objcavit.object_prepass(object_features, object_xywh_list, image.device)
-            encoded = self.dense_feature_extractor.encoder(image)
+            encoded = self.dense_feature_extractor.encoder(image, _defer_head=not torch.is_grad_enabled() and not self.training)
             main.wait_stream(side)
             dense_features = self.dense_feature_extractor.decoder(encoded)
         else:
