@@ -14,13 +14,15 @@
 //
 // Work item: 4 output channels of 4 output pixels (rows Y, Y+2, Y+4, Y+6 of one column); a workgroup owns an 8 x 16 pixel
 // tile x 32 channels and walks the nine taps.  Per tap the 32-channel slab of the low-resolution pixels under the tile (its
-// footprint, < FQ pixels, 128 bytes each) is staged in LDS, buffer (tap mod 3).  The kernel is bound by the LATENCY of those
-// ~10 KB pieces, not by HBM bandwidth or arithmetic (one piece per tap and workgroup), so the loads run ahead: the piece of
-// tap t+4 is requested (into registers) when tap t's interpolation is done, the piece of tap t+1 -- requested three taps
-// earlier -- is written to its LDS buffer at the same point; three pieces per workgroup are in flight throughout.  The LDS
-// allocation is sized to the real footprint (~37 KB for a 2x up-sampling).  The x interpolation coefficients and LDS offsets
-// depend on (pixel, dx) only and are formed once; the y ones per tap row.  The right-hand x neighbour is always read at
-// +128 bytes: where ATen clamps it (last column) its weight is exactly 0 and the slot read holds staged (finite) data.
+// footprint, < FQ pixels, 128 bytes each) is staged in LDS buffer (tap mod 3) by a FIFTH, producer wavefront with LDS-DMA
+// (global_load_lds_dwordx4: no registers, no ds_write), two taps ahead of the four consumer wavefronts.  The kernel is bound
+// by the latency of those ~10 KB pieces and by how much of it other workgroups on the CU can cover, not by HBM bandwidth
+// (ablations, tools/diag/tap_interp_diag.patch: interpolation alone 0.43 ms, staging + epilogue alone 0.55 ms, together
+// 0.80 ms when every wavefront did both through registers at two workgroups per CU): the producer / consumer split keeps the
+// consumers at <= 128 registers, i.e. four workgroups per CU (LDS: ~37 KB each for a 2x up-sampling).  The x interpolation
+// coefficients and LDS offsets depend on (pixel, dx) only and are formed once; the y ones per tap row.  The right-hand x
+// neighbour is always read at +128 bytes: where ATen clamps it (last column) its weight is exactly 0 and the slot read holds
+// staged (finite) data.
 #include "common.hpp"
 #include "../../include/objcavit_hip.h"
 
@@ -55,14 +57,30 @@ __device__ __forceinline__ float ti_act(float v) {
 
 struct TIArgs;
 template <int ACT>
-__device__ __forceinline__ void ti_store(const TIArgs& p, const float4 (&acc)[4], int b, int Y0, int X, int n);
+__device__ __forceinline__ void ti_store(const TIArgs& p, const float4 (&acc)[4], const float4 (&sv)[4], int b, int Y0, int X, int n);
 
-// NJ = staging rounds of 256 lanes x 16 bytes per tap (ceil(footprint x 8 / 256))
+typedef __attribute__((address_space(1))) const void* ti_gptr;
+typedef __attribute__((address_space(3))) void* ti_lptr;
+
+// s_waitcnt vmcnt(N) alone (gfx9 encoding: vmcnt in bits 3:0 and 15:14; expcnt / lgkmcnt fields at "no wait"), and a
+// compiler-level memory barrier with it
+template <int N>
+__device__ __forceinline__ void ti_wait_vm() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+  __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
+  asm volatile("" ::: "memory");
+}
+
+// NJ = 256-chunk rounds (16 bytes per chunk) per tap: ceil((footprint + 1) x 8 / 256)
 template <int NJ>
-__global__ __launch_bounds__(256, 2) void tap_interp_kernel(TIArgs p) {
+__global__ __launch_bounds__(320, 4) void tap_interp_kernel(TIArgs p) {
   extern __shared__ __attribute__((aligned(16))) float zs[];          // [NBUF][fq_cap][CB]
   const int tid = threadIdx.x;
   int wg = blockIdx.x;
+  {                                                    // XCD-aware: the eight L2s each take a contiguous run of tiles (shared halos)
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
   const int tx = wg % p.tiles_x;
   wg /= p.tiles_x;
   const int ty = wg % p.tiles_y, b = wg / p.tiles_y;
@@ -72,44 +90,57 @@ __global__ __launch_bounds__(256, 2) void tap_interp_kernel(TIArgs p) {
   const int ya = max(Y0 - 1, 0), yb = min(Y0 + TY, p.H - 1), xa = max(X0 - 1, 0), xb = min(X0 + TX, p.W - 1);
   const int qy0 = (int)(p.sh * ya), qx0 = (int)(p.sw * xa);
   const int qy1 = min((int)(p.sh * yb) + 1, p.h - 1), qx1 = min((int)(p.sw * xb) + 1, p.w - 1);
-  const int fw = qx1 - qx0 + 1, fq = (qy1 - qy0 + 1) * fw;           // <= NJ * 32 <= fq_cap (checked on the host)
-  const int hp = p.h - 2 * p.zpad, wp = p.w - 2 * p.zpad;             // the stored grid
-  const float* zb = p.z + (long)b * hp * wp * 9 * p.Cout + cb0;
+  const int fw = qx1 - qx0 + 1, fq = (qy1 - qy0 + 1) * fw;           // < NJ * 32 = fq_cap (checked on the host)
   const int bufstride = p.fq_cap * CB;
 
-  // staging sources of this lane, per round: element offset into the image's z (tap 0), or -1 = border ring
-  int soff[NJ];
-  const int c4 = (tid & 7) * 4;
-  const int c4s = cb0 + c4 < p.Cout ? c4 : 0;                         // channel tail: lanes past Cout re-fetch the block's first group
+  if (tid >= 256) {
+    // =========================== PRODUCER wavefront: LDS-DMA issuer ===========================
+    // One instruction moves 64 chunks = 8 footprint pixels x 128 bytes to wave-uniform base + 16 lane; 4 NJ instructions
+    // per tap.  Three buffers, two taps ahead: in interval t (consumers on buffer t mod 3) tap t+2 is issued into the
+    // buffer read in interval t-1 and only tap t+1 -- issued a whole interval earlier -- is waited for (counted vmcnt).
+    const int lane = tid & 63;
+    const int hp = p.h - 2 * p.zpad, wp = p.w - 2 * p.zpad;           // the stored grid
+    const int c4 = (lane & 7) * 4;
+    const int c4s = cb0 + c4 < p.Cout ? c4 : 0;                       // channel tail: lanes past Cout re-fetch the block's first group
+    const float* zb = p.z + (long)b * hp * wp * 9 * p.Cout + cb0 + c4s;
+    const float* zbr = p.zborder + cb0 + c4s;                         // only dereferenced for border-ring pixels
+    int soff[4 * NJ];                                                 // element offset into the image's z (tap 0), -1 = border ring
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    int q = (tid >> 3) + 32 * j;
-    q = q < fq ? q : 0;                                               // lanes past the footprint re-fetch its first pixel
-    const int qy = qy0 + q / fw - p.zpad, qx = qx0 + q % fw - p.zpad;
-    soff[j] = (unsigned)qy < (unsigned)hp && (unsigned)qx < (unsigned)wp ? (qy * wp + qx) * 9 * p.Cout + c4s : -1;
-  }
-  const float* zbr = p.zborder + cb0 + c4s;                           // only dereferenced when some soff is -1
-  // taps past the ninth: every lane re-reads one line (a select, not a branch: the tap loop must stay ONE basic block, or
-  // the compiler sinks every tap's arithmetic below the last barrier and keeps all nine taps' LDS reads live)
-  auto fetch = [&](int t, float4 (&r)[NJ]) {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const float* src = soff[j] >= 0 ? zb + soff[j] + t * p.Cout : zbr + t * p.Cout;
-      r[j] = ld4(t < 9 ? src : zb);
+    for (int j = 0; j < 4 * NJ; ++j) {
+      int q = (lane >> 3) + 8 * j;
+      q = q < fq ? q : 0;                                             // slots past the footprint hold its first pixel (finite data)
+      const int qy = qy0 + q / fw - p.zpad, qx = qx0 + q % fw - p.zpad;
+      soff[j] = (unsigned)qy < (unsigned)hp && (unsigned)qx < (unsigned)wp ? (qy * wp + qx) * 9 * p.Cout : -1;
     }
-  };
-  auto put = [&](int buf, const float4 (&r)[NJ]) {
+    auto issue = [&](int t) {
+      __attribute__((address_space(3))) float* dst = (__attribute__((address_space(3))) float*)zs + (t % NBUF) * bufstride;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) *reinterpret_cast<float4*>(zs + buf * bufstride + (tid + 256 * j) * 4) = r[j];
-  };
-  float4 r0[NJ], r1[NJ], r2[NJ];                                     // pieces in flight, by tap mod 3
-  fetch(0, r0);
-  fetch(1, r1);
-  fetch(2, r2);
+      for (int j = 0; j < 4 * NJ; ++j) {
+        const float* src = soff[j] >= 0 ? zb + soff[j] + t * p.Cout : zbr + t * p.Cout;
+        __builtin_amdgcn_global_load_lds((ti_gptr)src, (ti_lptr)(dst + j * 256), 16, 0, 0);
+      }
+    };
+    issue(0);
+    issue(1);
+    ti_wait_vm<4 * NJ>();
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      if (t + 2 < 9) {
+        issue(t + 2);
+        ti_wait_vm<4 * NJ>();                           // tap t+1 has landed, tap t+2 may stay in flight
+      } else {
+        ti_wait_vm<0>();
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
 
+  // =========================== CONSUMERS ===========================
   // items: channel group cg (4 channels) of pixels (Y0 + (tid >> 7) + 2 i, X0 + ((tid >> 3) & 15)), i = 0..3.
   // Coefficients are zero where the tap falls outside the image (zero padding of the convolution).
-  const int cg = c4;
+  const int cg = (tid & 7) * 4;
   int xo[3];                                                          // LDS float offset: buffer dx, column x0, channel group
   float wx0[3], wx1[3];
 #pragma unroll
@@ -124,13 +155,17 @@ __global__ __launch_bounds__(256, 2) void tap_interp_kernel(TIArgs p) {
     wx1[d] = ok ? w1 : 0.f;
   }
 
-  float4 acc[4];
+  float4 acc[4], sv[4];                                // sv: the skip part of this item's pixels, requested before the taps
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = 0; i < 4; ++i) {
+    acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int Y = Y0 + (tid >> 7) + 2 * i, X = X0 + ((tid >> 3) & 15);
+    const bool ok = p.s != nullptr && Y < p.H && X < p.W && cb0 + cg < p.Cout;
+    sv[i] = ok ? ld4(p.s + (((long)b * p.H + Y) * p.W + X) * p.Cout + cb0 + cg) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 
-  put(0, r0);
-  fetch(3, r0);
-  __syncthreads();
+  __builtin_amdgcn_s_barrier();                        // tap 0 is in LDS
+  asm volatile("" ::: "memory");
 #pragma unroll 1
   for (int dy = 0; dy < 3; ++dy) {
     int iy0[4], iy1[4];
@@ -148,8 +183,7 @@ __global__ __launch_bounds__(256, 2) void tap_interp_kernel(TIArgs p) {
       hy1[i] = ok ? h1 : 0.f;
     }
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      const int t = 3 * dy + dx;
+    for (int dx = 0; dx < 3; ++dx) {                   // tap 3 dy + dx lives in buffer dx
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float* r0p = zs + iy0[i] + xo[dx];
@@ -165,13 +199,9 @@ __global__ __launch_bounds__(256, 2) void tap_interp_kernel(TIArgs p) {
         acc[i].w += a * v00.w + bq * v01.w + c * v10.w + d * v11.w;
       }
       __builtin_amdgcn_sched_barrier(0);               // keep each tap's arithmetic with its LDS reads
-      // tap t+1 (requested three taps ago) into buffer (t+1) mod 3 -- last read during tap t-2 -- and tap t+4 requested
-      // into the registers that just drained
-      // (after the ninth tap the put is a dead store into a buffer nobody reads again)
-      if (dx == 0) { put(1, r1); fetch(t + 4, r1); }
-      if (dx == 1) { put(2, r2); fetch(t + 4, r2); }
-      if (dx == 2) { put(0, r0); fetch(t + 4, r0); }
-      __syncthreads();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this tap's LDS reads are done before the buffer is handed back
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
     }
   }
 
@@ -179,16 +209,16 @@ __global__ __launch_bounds__(256, 2) void tap_interp_kernel(TIArgs p) {
   if (n >= p.Cout) return;
   const int Yt = Y0 + (tid >> 7), X = X0 + ((tid >> 3) & 15);
   switch (p.act) {                                                    // uniform
-    case OCV_ACT_LEAKY_RELU: ti_store<OCV_ACT_LEAKY_RELU>(p, acc, b, Yt, X, n); break;
-    case OCV_ACT_SILU: ti_store<OCV_ACT_SILU>(p, acc, b, Yt, X, n); break;
-    case OCV_ACT_RELU: ti_store<OCV_ACT_RELU>(p, acc, b, Yt, X, n); break;
-    default: ti_store<OCV_ACT_NONE>(p, acc, b, Yt, X, n); break;
+    case OCV_ACT_LEAKY_RELU: ti_store<OCV_ACT_LEAKY_RELU>(p, acc, sv, b, Yt, X, n); break;
+    case OCV_ACT_SILU: ti_store<OCV_ACT_SILU>(p, acc, sv, b, Yt, X, n); break;
+    case OCV_ACT_RELU: ti_store<OCV_ACT_RELU>(p, acc, sv, b, Yt, X, n); break;
+    default: ti_store<OCV_ACT_NONE>(p, acc, sv, b, Yt, X, n); break;
   }
 }
 
 // + skip part + bias, activation, fp32 and / or hl32 split store of one item's four pixels (rows Y, Y+2, Y+4, Y+6)
 template <int ACT>
-__device__ __forceinline__ void ti_store(const TIArgs& p, const float4 (&acc)[4], int b, int Y, int X, int n) {
+__device__ __forceinline__ void ti_store(const TIArgs& p, const float4 (&acc)[4], const float4 (&sv)[4], int b, int Y, int X, int n) {
   if (X >= p.W) return;
   const float4 bv = p.bias != nullptr ? ld4(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -196,10 +226,7 @@ __device__ __forceinline__ void ti_store(const TIArgs& p, const float4 (&acc)[4]
     if (Y + 2 * i >= p.H) break;
     const long pix = ((long)b * p.H + Y + 2 * i) * p.W + X;
     float4 v = acc[i];
-    if (p.s != nullptr) {
-      const float4 sv = ld4(p.s + pix * p.Cout + n);
-      v.x += sv.x; v.y += sv.y; v.z += sv.z; v.w += sv.w;
-    }
+    v.x += sv[i].x; v.y += sv[i].y; v.z += sv[i].z; v.w += sv[i].w;
     v.x = ti_act<ACT>(v.x + bv.x); v.y = ti_act<ACT>(v.y + bv.y);
     v.z = ti_act<ACT>(v.z + bv.z); v.w = ti_act<ACT>(v.w + bv.w);
     if (p.y != nullptr) *reinterpret_cast<float4*>(p.y + pix * p.Cout + n) = v;
@@ -278,7 +305,7 @@ extern "C" int ocv_tap_interp_combine_fwd(const float* z, int h, int w, int zpad
     OCV_CHECK_ARG(attr == hipSuccess, "ocv_tap_interp_combine_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(attr));
   }
   switch (nj) {
-#define OCV_TI_CASE(NJ) case NJ: hipLaunchKernelGGL(tap_interp_kernel<NJ>, grid, dim3(256), lds, (hipStream_t)stream, a); break;
+#define OCV_TI_CASE(NJ) case NJ: hipLaunchKernelGGL(tap_interp_kernel<NJ>, grid, dim3(320), lds, (hipStream_t)stream, a); break;
     OCV_TI_CASE(1) OCV_TI_CASE(2) OCV_TI_CASE(3) OCV_TI_CASE(4) OCV_TI_CASE(5) OCV_TI_CASE(6)
 #undef OCV_TI_CASE
   }

@@ -1,5 +1,6 @@
 #!/bin/bash
-# tools/build_variant.sh NAME "-DFLAG ..." : diagnostic build of the library into objcavit_amd/lib/variants/NAME.so
+# tools/build_variant.sh NAME "-DFLAG ..." [PATCH ...] : diagnostic build of the library into objcavit_amd/lib/variants/NAME.so
+# (patches default to every tools/diag/*.patch)
 #
 # The product sources under objcavit_amd/csrc carry no diagnostic code.  The ablation switches (-DOCV_ABL_NOLOAD,
 # -DOCV_ABL_KXSHARE, -DOCV_ABL_KXRAND, -DOCV_ABL_SMALLFOOT, -DOCV_ABL_NOWRITE, -DPW_ABL_NOW / NOA / NOGATE / NOMFMA /
@@ -12,10 +13,12 @@ scratch=$(mktemp -d /tmp/ocv_csrc.XXXXXX)
 mkdir -p "$scratch/objcavit_amd/csrc" "$scratch/include"
 cp objcavit_amd/csrc/* "$scratch/objcavit_amd/csrc/"
 cp include/objcavit_hip.h "$scratch/include/"
-for p in tools/diag/*.patch; do patch -s -d "$scratch/objcavit_amd/csrc" -p1 < "$p"; done
+name=$1; flags=$2; shift 2 || true
+if [ $# -eq 0 ]; then set -- tools/diag/*.patch; fi
+for p in "$@"; do patch -s -d "$scratch/objcavit_amd/csrc" -p1 < "$p"; done
 cp objcavit_amd/lib/libobjcavit_hip.so /tmp/ocv_keep.so 2>/dev/null || true
-OCV_CSRC_DIR="$scratch/objcavit_amd/csrc" OCV_EXTRA_HIPCC_FLAGS="$2" python -m objcavit_amd.build --force > /dev/null
-mv objcavit_amd/lib/libobjcavit_hip.so objcavit_amd/lib/variants/$1.so
+OCV_CSRC_DIR="$scratch/objcavit_amd/csrc" OCV_EXTRA_HIPCC_FLAGS="$flags" python -m objcavit_amd.build --force > /dev/null
+mv objcavit_amd/lib/libobjcavit_hip.so objcavit_amd/lib/variants/$name.so
 [ -f /tmp/ocv_keep.so ] && mv /tmp/ocv_keep.so objcavit_amd/lib/libobjcavit_hip.so
 rm -rf "$scratch"
-echo built objcavit_amd/lib/variants/$1.so
+echo built objcavit_amd/lib/variants/$name.so
