@@ -520,10 +520,12 @@ def main():
             "metrics_gathered": dp.summarise(table),
         }
         if not a.stub_cpu:
-            res["dtype_note"] = ("fp32 results; contractions of the 3x3 / 1x1 convolutions run as split-bf16 (hi*hi + hi*lo + lo*hi on "
-                                 "v_mfma_*_bf16, fp32 accumulate: product error <= 2^-17; the two 30x40 decoder convolutions in Winograd "
-                                 "F(2x2,3x3) form with fp32 transforms, same parity bar); patch embedding, transformer stacks, bin head "
-                                 "and depthwise on exact fp32 (MFMA f32 / FMA)")
+            res["dtype_note"] = ("fp32 results; contractions of the 3x3 / 1x1 / 16x16-patch convolutions run as split-bf16 (hi*hi + hi*lo + "
+                                 "lo*hi on v_mfma_*_bf16, fp32 accumulate: product error <= 2^-17; the first convolution of every decoder "
+                                 "stage at the low resolution = an exact re-association; the 30x40 second convolution in Winograd "
+                                 "F(2x2,3x3) form with fp32 transforms, same parity bar); transformer projections / feed-forward and the bin "
+                                 "head as a three-term bf16 split (six products, dropped terms <= 2^-24: fp32-faithful); attention, "
+                                 "depthwise and squeeze-excite on exact fp32 (MFMA f32 / FMA)")
             res.update(kernel_report(timing, a, B))
             if world == 1 and not a.no_cpu_baseline:
                 feats, boxes, _ = model.object_provider(img)

@@ -173,6 +173,19 @@ int ocv_patch_embed_fwd(const float* fmap, int channels_last, const float* W, co
                         long pos_bs, float* out, int B, int C, int h, int w, int E, void* workspace,
                         size_t workspace_bytes, ocv_stream_t stream);
 
+/* The same patch embedding on a feature map that is already stored in the "hl32" split-bf16 layout (below: what the
+ * decoder's last convolution leaves beside its fp32 result), as 16 split-bf16 GEMMs -- one per patch row ky -- in ONE launch
+ * of the LDS-DMA convolution kernel, summed in a fixed order with bias and positional embedding.  In that layout the 16 x C
+ * values of one patch row are contiguous and the patches of an image row follow each other, so the map is read in place.
+ * Products hi*hi + hi*lo + lo*hi (error <= 2^-17 per product, as in every convolution of the path), fp32 accumulation.
+ *   x_hl  [B][h][w][2 C] bf16 (C a multiple of 32);   w_hi / w_lo [16 (ky)][E][16 C] bf16, column kx*C + c =
+ *   bf16 split of W[e][c][ky][kx];   pos / pos_bs / out as above;   E a multiple of 8;   h a multiple of 16 when B > 1.
+ *   workspace: ocv_patch_embed_split_workspace_bytes (the 16 raw results). */
+size_t ocv_patch_embed_split_workspace_bytes(int B, int C, int h, int w, int E);
+int ocv_patch_embed_split_fwd(const void* x_hl, int C, const void* w_hi, const void* w_lo, const float* bias,
+                              const float* pos, long pos_bs, float* out, int B, int h, int w, int E, void* workspace,
+                              size_t workspace_bytes, ocv_stream_t stream);
+
 /* PixelWiseDotProduct (modules/layers.py:31-36): ram[b][q][p] = sum_c feat[b][c][p] * queries[b][q][c].
  * feat [B,C,P] (NCHW with P = h*w), queries addressed as ptr + b*q_bs + q*q_ld + c, ram [B,Q,P].  C == Q == 128. */
 int ocv_pixel_dot_fwd(const float* feat, int channels_last, const float* queries, long q_bs, int q_ld, float* ram,

@@ -57,6 +57,9 @@ PROTOTYPES = {
     "ocv_encoder_layer_fwd": (C.c_int, [_f32p, C.POINTER(EncoderLayerParams), _u8p, C.c_int, _f32p, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_size_t, _stream]),
     "ocv_patch_embed_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ocv_patch_embed_split_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ocv_patch_embed_split_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _f32p, _f32p, C.c_long, _f32p, C.c_int,
+                                            C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, _stream]),
     "ocv_patch_embed_fwd": (C.c_int, [_f32p, C.c_int, _f32p, _f32p, _f32p, C.c_long, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_void_p, C.c_size_t, _stream]),
     "ocv_pixel_dot_fwd": (C.c_int, [_f32p, C.c_int, _f32p, C.c_long, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),

@@ -67,6 +67,9 @@ struct ConvArgs {
   int zbatch;                           // conv_split_dma_kernel: > 1 = that many independent GEMMs in one launch (the 16
   long xz_bytes, wz_bytes;              // Winograd positions): operand z at xhl + z xz_bytes / whi, wlo + z wz_bytes, raw fp32
                                         // result at y + (z ksplit + khalf) * M * Cout
+  unsigned rowpitch;                    // conv_split_dma_kernel: bytes between consecutive rows of the (B H) x W pixel grid of the
+                                        // split input when they are not dense (0 = dense, W * 4 Cp); the patch embedding reads
+                                        // every 16th image row of the feature map as one GEMM row grid this way
 };
 
 // 16-byte global load (compiler-visible: hipcc tracks it and inserts the s_waitcnt before the first use).
@@ -545,7 +548,8 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
     for (int i = 0; i < 4; ++i) {
       const unsigned am = (unsigned)m0 + 64 * pw + 16 * i + lrow;           // M < 2^30 (4 GiB operand limit)
       const bool valid = am < (unsigned)p.M;
-      const unsigned rem = valid ? am % hw : 0u;
+      const unsigned img = valid ? am / hw : 0u;
+      const unsigned rem = valid ? am - img * hw : 0u;
       const int y = (int)(rem / (unsigned)p.W), x = (int)(rem - (unsigned)y * (unsigned)p.W);
       unsigned mask = 0;
       int t = 0;
@@ -553,7 +557,9 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
         for (int dx = -pad; dx <= pad; ++dx, ++t)
           if (valid && (unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W) mask |= 1u << t;
       tapmask[i] = mask;
-      rbA[i] = (valid ? am : 0u) * (unsigned)(4 * p.Cp) + (unsigned)(lchunk * 16);
+      rbA[i] = (p.rowpitch == 0 ? (valid ? am : 0u) * (unsigned)(4 * p.Cp)
+                                : (img * (unsigned)p.H + (unsigned)y) * p.rowpitch + (unsigned)x * (unsigned)(4 * p.Cp)) +
+               (unsigned)(lchunk * 16);
     }
   }
   unsigned rbB[2];
@@ -982,5 +988,74 @@ extern "C" int ocv_conv3x3_winograd_split_fwd(const void* x_hl, int Cin, const v
   WinoOutArgs wo{m, bias, y, (__bf16*)y_hl, B, H, W, Cout, a.Cpo, th, tw, act, T, T * (Cout / 4)};
   hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)((wo.items + 255) / 256)), dim3(256), 0, st, wo);
   OCV_CHECK_LAUNCH("ocv_conv3x3_winograd_split_fwd(output transform)");
+  return 0;
+}
+
+
+// =====================================================================================================================
+// Patch embedding (Conv2d(C -> E, kernel = stride = 16) + flatten + bias + positional embedding; modules/ObjCAViT.py:287-288,
+// 333,362-364, modules/layers.py:11-12,17-22) on a PRE-SPLIT feature map, as 16 split-bf16 GEMMs in ONE launch of the DMA
+// kernel.  In the hl32 layout the 16 pixels x C channels of one patch row are 16 C consecutive "channels" (C a multiple of
+// 32: whole hi|lo blocks), and the patches of one image row follow each other without a gap: for a fixed ky the feature map
+// IS the row-major operand of a 1 x 1 GEMM over a (B gh) x gw pixel grid with 16 C channels whose grid rows lie 16 image rows
+// apart (ConvArgs::rowpitch) and whose first row is image row ky (the batch offset xz_bytes).  The 16 raw results
+// [ky][B S][E] are summed in a fixed order with bias and positional embedding by patch_sum_kernel.
+// Products as everywhere in the convolutions: hi*hi + hi*lo + lo*hi, error <= 2^-17 per product, fp32 accumulation.
+// =====================================================================================================================
+namespace {
+__global__ __launch_bounds__(256) void patch_sum_kernel(const float* __restrict__ part, long M, int E, int S,
+                                                        const float* __restrict__ bias, const float* __restrict__ pos,
+                                                        long pos_bs, float* __restrict__ out) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;     // float4 index
+  const int e4 = E / 4;
+  if (idx >= M * e4) return;
+  const long m = idx / e4;
+  const int e = (int)(idx - m * e4) * 4;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  for (int ky = 0; ky < 16; ++ky) a += *reinterpret_cast<const f32x4*>(part + ((long)ky * M + m) * E + e);
+  if (bias != nullptr) a += *reinterpret_cast<const f32x4*>(bias + e);
+  if (pos != nullptr) {
+    const long b = m / S, s = m - b * S;
+    a += *reinterpret_cast<const f32x4*>(pos + b * pos_bs + s * E + e);
+  }
+  *reinterpret_cast<f32x4*>(out + m * E + e) = a;
+}
+}  // namespace
+
+extern "C" size_t ocv_patch_embed_split_workspace_bytes(int B, int C, int h, int w, int E) {
+  if (B < 1 || C < 32 || C % 32 != 0 || h < 16 || w < 16 || E < 8 || E % 8 != 0) return 0;
+  return (size_t)16 * B * (h / 16) * (w / 16) * E * sizeof(float);
+}
+
+extern "C" int ocv_patch_embed_split_fwd(const void* x_hl, int C, const void* w_hi, const void* w_lo, const float* bias,
+                                         const float* pos, long pos_bs, float* out, int B, int h, int w, int E,
+                                         void* workspace, size_t workspace_bytes, ocv_stream_t stream) {
+  OCV_CHECK_ARG(x_hl && w_hi && w_lo && out && workspace, "ocv_patch_embed_split_fwd: null pointer");
+  const size_t need = ocv_patch_embed_split_workspace_bytes(B, C, h, w, E);
+  OCV_CHECK_ARG(need != 0, "ocv_patch_embed_split_fwd: needs C a multiple of 32 (got %d), E a multiple of 8 (got %d), a map of at "
+                "least one 16 x 16 patch (got %d x %d)", C, E, h, w);
+  OCV_CHECK_ARG(workspace_bytes >= need, "ocv_patch_embed_split_fwd: workspace too small");
+  OCV_CHECK_ARG((reinterpret_cast<uintptr_t>(x_hl) & 127) == 0 && ocv_aligned16(w_hi) && ocv_aligned16(w_lo) && ocv_aligned16(bias) &&
+                    ocv_aligned16(pos) && ocv_aligned16(out) && ocv_aligned16(workspace) && (pos == nullptr || pos_bs % 4 == 0),
+                "ocv_patch_embed_split_fwd: x_hl must be 128-byte aligned, the rest 16-byte aligned");
+  OCV_CHECK_ARG((long)B * h * w * C * 4 < (1L << 32) && (long)E * 16 * C * 2 < (1L << 32),
+                "ocv_patch_embed_split_fwd: each operand must be smaller than 4 GiB");
+  const int gh = h / 16, gw = w / 16;
+  ConvArgs a{};
+  a.xhl = (const __bf16*)x_hl; a.whi = (const __bf16*)w_hi; a.wlo = (const __bf16*)w_lo; a.y = (float*)workspace;
+  a.C1 = 16 * C; a.Cin = 16 * C; a.Cout = E; a.H = B * gh; a.W = gw; a.ks = 1; a.act = OCV_ACT_NONE; a.ksplit = 1;
+  a.Cpo = (E + 31) / 32 * 32;
+  a.zbatch = 16;
+  a.xz_bytes = (long)w * 2 * C * (long)sizeof(__bf16);                        // one image row down
+  a.wz_bytes = (long)E * 16 * C * (long)sizeof(__bf16);
+  a.rowpitch = (unsigned)(16L * w * 2 * C * (long)sizeof(__bf16));           // grid rows: 16 image rows apart
+  // image b's rows start at image row b h, not b gh 16, when h is not a multiple of 16: only then is the grid not uniform
+  OCV_CHECK_ARG(h % 16 == 0 || B == 1, "ocv_patch_embed_split_fwd: the map height must be a multiple of 16 for B > 1 (got %d)", h);
+  const int rc = launch_conv(a, 1, true, (hipStream_t)stream);
+  if (rc != 0) return rc;
+  const long M = (long)B * gh * gw;
+  hipLaunchKernelGGL(patch_sum_kernel, dim3((unsigned)((M * (E / 4) + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)workspace, M, E, gh * gw, bias, pos, pos_bs, out);
+  OCV_CHECK_LAUNCH("ocv_patch_embed_split_fwd(sum)");
   return 0;
 }

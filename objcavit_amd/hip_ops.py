@@ -532,6 +532,96 @@ def patch_embed(fmap: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.T
     return out
 
 
+class PatchEmbedSplitWeight:
+    """Per-owner cache of a 16x16 patch-embedding weight in the operand order of ocv_patch_embed_split_fwd (bf16 hi / lo,
+    [16, E, 16 C]), keyed on (data_ptr, version) like every other weight cache here."""
+
+    def __init__(self):
+        self._key = None
+        self._val = None
+
+    def get(self, w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        key = (w.data_ptr(), w._version, tuple(w.shape))
+        if key != self._key:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("weight preparation during graph capture: run one eager warm-up call first")
+            self._val = prep_patch_embed_weight(w)
+            self._key = key
+        return self._val
+
+
+def patch_embed_auto(fmap: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], pos: Optional[torch.Tensor],
+                     cl_cache: Optional[ChannelsLastWeight], split_cache: Optional[PatchEmbedSplitWeight]) -> torch.Tensor:
+    """The patch embedding of a feature map: when the map carries its split copy (``fmap._ocv_split``, left there by the
+    decoder's last convolution) the split-bf16 form reads that (0.39 -> 0.2 ms at bs = 16); else, or with
+    OCV_PATCH_EMBED=exact in the environment, the exact-fp32 kernel reads the fp32 map."""
+    pre = getattr(fmap, "_ocv_split", None)
+    mode = os.environ.get("OCV_PATCH_EMBED", "split")
+    if mode not in ("split", "exact"):
+        raise ValueError(f"OCV_PATCH_EMBED={mode!r}: expected 'split' (default) or 'exact'")
+    if (pre is not None and mode == "split" and split_cache is not None and tuple(pre.shape) == tuple(fmap.shape)
+            and patch_embed_split_supported(fmap.shape[0], fmap.shape[1], fmap.shape[2], fmap.shape[3], weight.shape[0])):
+        hi, lo = split_cache.get(weight)
+        return patch_embed_split(pre, hi, lo, bias, pos)
+    return patch_embed(fmap, weight, bias, pos, cl_cache=cl_cache)
+
+
+def prep_patch_embed_weight(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[E, C, 16, 16] fp32 -> (w_hi, w_lo) bf16 [16 (ky), E, 16 C] with column kx * C + c, w_hi = bf16(W), w_lo = bf16(W - w_hi):
+    the operand order of ocv_patch_embed_split_fwd.  Done once per weight version by the callers (cached there)."""
+    E, Cc, kh, kw = weight.shape
+    if (kh, kw) != (16, 16) or Cc % 32 != 0:
+        raise ValueError("prep_patch_embed_weight: needs a 16x16 kernel and a multiple of 32 input channels")
+    w = weight.detach().float().permute(2, 0, 3, 1).reshape(16, E, 16 * Cc)
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    return hi.contiguous(), lo.contiguous()
+
+
+def patch_embed_split_supported(B: int, Cc: int, h: int, w: int, E: int) -> bool:
+    return (h % 16 == 0 or B == 1) and int(_lib.load().ocv_patch_embed_split_workspace_bytes(B, Cc, h, w, E)) > 0
+
+
+def patch_embed_split(fmap: "SplitAct", w_hi: torch.Tensor, w_lo: torch.Tensor, bias: Optional[torch.Tensor],
+                      pos: Optional[torch.Tensor]) -> torch.Tensor:
+    """tokens [B, S, E] = conv16x16/16(fmap) flattened + bias + pos on a feature map held in the hl32 split layout
+    (ocv_patch_embed_split_fwd: 16 split-bf16 GEMMs in one launch of the convolution kernel + a fixed-order sum).
+    w_hi / w_lo from ``prep_patch_embed_weight``; pos is [S, E] or [B, S, E]."""
+    lib = _lib.load()
+    _req(fmap.hl, "fmap.hl", torch.bfloat16)
+    B, Cc, h, w = fmap.shape
+    for n, t in (("w_hi", w_hi), ("w_lo", w_lo)):
+        _req(t, n, torch.bfloat16)
+    if w_hi.dim() != 3 or w_hi.shape[0] != 16 or w_hi.shape[2] != 16 * Cc or w_lo.shape != w_hi.shape:
+        raise ValueError(f"patch_embed_split: weights {tuple(w_hi.shape)} do not match {Cc} channels / 16x16 patches")
+    E = w_hi.shape[1]
+    gh, gw = h // 16, w // 16
+    S = gh * gw
+    nb = int(lib.ocv_patch_embed_split_workspace_bytes(B, Cc, h, w, E))
+    if nb == 0 or not (h % 16 == 0 or B == 1):
+        raise ValueError(f"patch_embed_split: unsupported configuration B={B} C={Cc} h={h} w={w} E={E}")
+    pos_bs = 0
+    if pos is not None:
+        _req(pos, "pos")
+        if pos.shape == (S, E):
+            pos_bs = 0
+        elif pos.shape == (B, S, E):
+            pos_bs = S * E
+        else:
+            raise ValueError(f"patch_embed_split: pos must be {(S, E)} or {(B, S, E)}, got {tuple(pos.shape)}")
+    if bias is not None:
+        _req(bias, "bias")
+        if bias.numel() != E:
+            raise ValueError("patch_embed_split: bias size mismatch")
+    ws = workspace(nb, fmap.hl.device, "patch_embed_split")
+    out = torch.empty(B, S, E, dtype=torch.float32, device=fmap.hl.device)
+    with timed("patch_embed"):
+        check(lib.ocv_patch_embed_split_fwd(fmap.hl.data_ptr(), Cc, w_hi.data_ptr(), w_lo.data_ptr(), _ptr(bias), _ptr(pos), pos_bs,
+                                            out.data_ptr(), B, h, w, E, ws.data_ptr(), ws.numel(), _stream()),
+              "ocv_patch_embed_split_fwd")
+    return out
+
+
 def _check_queries(queries: torch.Tensor, B: int, Cc: int) -> None:
     _req(queries, "queries", contiguous=False)
     if queries.dim() != 3 or queries.shape[0] != B or queries.shape[2] != Cc or queries.stride(2) != 1:

@@ -228,6 +228,7 @@ class ObjCAViT(nn.Module):
                                        nn.Linear(256, dim_out))
         self._img_pos_cache = {}
         self._w_cl = hip_ops.ChannelsLastWeight()
+        self._w_pe = hip_ops.PatchEmbedSplitWeight()
 
     # -- positional embeddings ------------------------------------------------
     def _patch_coords(self, B: int, gh: int, gw: int, device) -> torch.Tensor:
@@ -320,9 +321,9 @@ class ObjCAViT(nn.Module):
         gh, gw = image_features.shape[2] // 16, image_features.shape[3] // 16
         if gh * gw < self.n_query_channels + 1:
             raise ValueError(f"need at least {self.n_query_channels + 1} patches, got {gh * gw}")
-        tok = hip_ops.patch_embed(image_features, self.image_embedding_convPxP.weight.detach(),
-                                  self.image_embedding_convPxP.bias.detach(), self._image_pos(image_features, gh, gw),
-                                  cl_cache=self._w_cl)
+        tok = hip_ops.patch_embed_auto(image_features, self.image_embedding_convPxP.weight.detach(),
+                                       self.image_embedding_convPxP.bias.detach(), self._image_pos(image_features, gh, gw),
+                                       self._w_cl, self._w_pe)
 
         # 3. self-attention / cross-attention stacks (reference :366-368)
         tok, obj = self.saca_1(tok, objs, want_object_output=self.use_2_saca, pre_obj=pre_obj)

@@ -69,6 +69,7 @@ class PatchTransformerEncoder(nn.Module):
         self.positional_encodings = nn.Parameter(torch.rand(max_seq_len, embedding_dim), requires_grad=True)
         self._stack = HipEncoderStack(self.transformer_encoder)
         self._w_cl = hip_ops.ChannelsLastWeight()
+        self._w_pe = hip_ops.PatchEmbedSplitWeight()
 
     def forward_batch_first(self, x: torch.Tensor) -> torch.Tensor:
         """B x S x E tokens (the layout the kernels work in)."""
@@ -77,8 +78,8 @@ class PatchTransformerEncoder(nn.Module):
         S = (x.shape[2] // 16) * (x.shape[3] // 16)
         if S > self.positional_encodings.shape[0]:
             raise ValueError(f"sequence length {S} exceeds max_seq_len {self.positional_encodings.shape[0]}")
-        tok = hip_ops.patch_embed(x, self.embedding_convPxP.weight.detach(), self.embedding_convPxP.bias.detach(),
-                                  self.positional_encodings.detach()[:S], cl_cache=self._w_cl)
+        tok = hip_ops.patch_embed_auto(x, self.embedding_convPxP.weight.detach(), self.embedding_convPxP.bias.detach(),
+                                       self.positional_encodings.detach()[:S], self._w_cl, self._w_pe)
         return self._stack(tok)
 
     def forward(self, x):

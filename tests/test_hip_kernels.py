@@ -281,6 +281,40 @@ def test_patch_embed(ops, B, h, w, pos_mode):
     assert rel_dev(got, ref) < TOL
 
 
+@pytest.mark.parametrize("B,C,h,w,E,pos_mode", [(2, 128, 64, 96, 128, "shared"), (16, 128, 240, 320, 128, "shared"),
+                                                (1, 64, 37, 53, 40, "none"), (3, 32, 48, 50, 128, "batched"),
+                                                (2, 128, 176, 608, 128, "shared")])
+def test_patch_embed_split(ops, B, C, h, w, E, pos_mode):
+    """ocv_patch_embed_split_fwd (16 split-bf16 GEMMs over the hl32 map in one launch + fixed-order sum) against the
+    convolution in fp64, at the split-bf16 convolutions' bar; ragged widths / heights (B = 1), KITTI's half-resolution map;
+    and bitwise repeatable."""
+    x = rnd("x", (B, C, h, w), 1)
+    wt, b = rnd("w", (E, C, 16, 16), 2, 1 / math.sqrt(C * 256)), rnd("b", (E,), 3, 0.1)
+    S = (h // 16) * (w // 16)
+    pos = {"none": None, "shared": rnd("p", (S, E), 4), "batched": rnd("p", (B, S, E), 4)}[pos_mode]
+    ref = F.conv2d(x.double(), wt.double(), b.double(), stride=16).flatten(2).permute(0, 2, 1)
+    if pos is not None:
+        ref = ref + pos.double()
+    xs = ops.split_act(dev(x).contiguous(memory_format=torch.channels_last))
+    hi, lo = ops.prep_patch_embed_weight(dev(wt))
+    assert ops.patch_embed_split_supported(B, C, h, w, E)
+    got = ops.patch_embed_split(xs, hi, lo, dev(b), None if pos is None else dev(pos))
+    assert got.shape == (B, S, E) and rel_dev(got, ref) < SPLIT_TOL
+    assert torch.equal(got, ops.patch_embed_split(xs, hi, lo, dev(b), None if pos is None else dev(pos)))
+    if (C, E) == (128, 128):                                  # the exact-fp32 kernel is built for the model's 128 -> 128
+        exact = ops.patch_embed(dev(x), dev(wt), dev(b), None if pos is None else dev(pos))
+        assert rel_dev(got, exact) < SPLIT_TOL
+
+
+def test_patch_embed_split_rejects_what_it_cannot_address(ops):
+    assert not ops.patch_embed_split_supported(2, 128, 40, 64, 128)       # two images, height not a multiple of 16
+    assert not ops.patch_embed_split_supported(1, 24, 64, 64, 128)        # channels not whole hi|lo blocks
+    xs = ops.split_act(dev(rnd("x", (2, 128, 40, 64), 1)).contiguous(memory_format=torch.channels_last))
+    hi, lo = ops.prep_patch_embed_weight(dev(rnd("w", (128, 128, 16, 16), 2, 0.01)))
+    with pytest.raises(ValueError):
+        ops.patch_embed_split(xs, hi, lo, None, None)
+
+
 def test_patch_embed_is_deterministic(ops):
     x, wt, b = dev(rnd("x", (4, 128, 96, 128), 1)), dev(rnd("w", (128, 128, 16, 16), 2, 0.01)), dev(rnd("b", (128,), 3))
     a = ops.patch_embed(x, wt, b, None).clone()
