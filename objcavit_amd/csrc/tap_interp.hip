@@ -283,6 +283,8 @@ extern "C" int ocv_tap_interp_combine_fwd(const float* z, int h, int w, int zpad
   OCV_CHECK_ARG(B >= 1 && h >= 1 && w >= 1 && H >= 1 && W >= 1 && Cout >= 4 && Cout % 4 == 0,
                 "ocv_tap_interp_combine_fwd: bad sizes (Cout must be a multiple of 4, got %d)", Cout);
   OCV_CHECK_ARG(act >= 0 && act <= 3, "ocv_tap_interp_combine_fwd: unknown activation %d", act);
+  OCV_CHECK_ARG((long)h * w * 9 * Cout < (1L << 31), "ocv_tap_interp_combine_fwd: one image's tap products must stay below 2^31 elements "
+                "(32-bit offsets inside the kernel)");
   OCV_CHECK_ARG(ocv_aligned16(z) && ocv_aligned16(s) && ocv_aligned16(bias) && ocv_aligned16(y) && ocv_aligned16(y_hl),
                 "ocv_tap_interp_combine_fwd: operands must be 16-byte aligned");
   OCV_CHECK_ARG(ocv_tap_interp_supported(h, w, H, W, Cout), "ocv_tap_interp_combine_fwd: the low-resolution footprint of an output tile "
