@@ -248,6 +248,25 @@ def test_encoder_fast_path_vs_oracle(monkeypatch):
     assert rel_dev(separate, ref_out) < 1e-4 and not torch.equal(separate, whole)
 
 
+def test_final_upscale_variant_vs_oracle():
+    """do_final_upscale=True (reference DenseFeatureExtractor.py:60,116-117): a fifth UpSampleWithSkip stage against the
+    IMAGE (3 skip channels: the exact-fp32 convolution kernel takes what the split kernels do not), output at full
+    resolution; the all-split pipeline and the composed conv_head / conv2 weight do not apply, so conv_head is applied
+    where the encoder deferred it.  Encoder + decoder against the oracle."""
+    from oracle import effnet_ref
+    from objcavit_amd.modules.DenseFeatureExtractor import DenseFeatureExtractor
+    args = make_args()
+    args[args.model.name]["do_final_upscale"] = True
+    m = DenseFeatureExtractor(args).eval()
+    sd = gen.load_into(m, 21)
+    img = gen.randn("img", (1, 3, 160, 192), 21)
+    ref = restate.decoder_forward(effnet_ref.encoder_features(img, sd, "encoder.original_model."), sd, "decoder.",
+                                  do_final_upscale=True)
+    out = m.cuda()(img.cuda())
+    assert out.shape == ref.shape == (1, 128, 160, 192)
+    assert rel_dev(out, ref) < 1e-4
+
+
 def test_graph_owns_its_scratch_and_survives_larger_eager_calls():
     """A captured graph bakes workspace addresses into its nodes: it keeps its own WorkspaceStore, so an eager forward
     at a LARGER batch afterwards (which re-allocates the module-level buffers) cannot free memory the graph still
