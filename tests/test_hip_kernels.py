@@ -810,7 +810,9 @@ def test_conv_nhwc_exact(ops, B, H, W, C1, C2, Cout, k, act):
 
 
 @pytest.mark.parametrize("B,h,w,H,W,Cout,act", [(2, 15, 20, 30, 40, 64, 2), (1, 17, 22, 30, 40, 72, 0), (1, 5, 7, 11, 13, 8, 3),
-                                                (3, 30, 40, 60, 80, 32, 2), (1, 2, 3, 9, 23, 40, 1)])
+                                                (3, 30, 40, 60, 80, 32, 2), (1, 2, 3, 9, 23, 40, 1),
+                                                (1, 13, 40, 22, 76, 64, 2), (2, 11, 38, 22, 76, 32, 2),      # KITTI's first stages
+                                                (1, 4, 5, 13, 17, 36, 0), (1, 1, 1, 8, 16, 32, 2)])           # > 3x, a single source pixel
 def test_tap_interp_combine(ops, B, h, w, H, W, Cout, act):
     """ocv_tap_interp_combine_fwd against its definition in fp64: nine bilinear (align_corners) up-samplings of the tap
     products, each shifted by its tap with zero padding, + skip part + bias, activation; fp32 and split outputs."""
