@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* ocv_stream_t;
 
-#define OCV_ABI_VERSION 1
+#define OCV_ABI_VERSION 2 /* 2: ocv_encoder_layer_params starts with struct_size (round 3) */
 int ocv_abi_version(void);
 const char* ocv_last_error(void);
 
@@ -108,6 +108,11 @@ int ocv_mha_fwd(const float* q_src, const float* k_src, const float* v_src, cons
  * zero_padded_rows != 0: rows flagged in key_padding_mask are written as 0.0 in `out` (last layer of a masked
  * encoder). */
 typedef struct {
+  /* = sizeof(ocv_encoder_layer_params) AS THE CALLER WAS COMPILED.  The library reads only the first struct_size bytes
+   * and treats every field beyond them as NULL, so the struct can grow at its end without breaking callers built
+   * against an earlier header (ABI 1 had no such field and grew by the four *_p3 pointers: a silent break).  In an
+   * array of layers (ocv_encoder_stack_fwd) consecutive elements lie struct_size bytes apart. */
+  size_t struct_size;
   const float *in_proj_w, *in_proj_b, *out_proj_w, *out_proj_b;
   const float *norm1_w, *norm1_b, *linear1_w, *linear1_b, *linear2_w, *linear2_b, *norm2_w, *norm2_b;
   /* optional: the four weight matrices packed by ocv_pack_split3_fwd (all four or none).  With them the projections and

@@ -15,14 +15,19 @@ LIB_PATH = os.environ.get("OCV_LIB_PATH") or os.path.join(_HERE, "lib", "libobjc
 _f32p = C.c_void_p      # device pointers travel as integers
 _u8p = C.c_void_p
 _stream = C.c_void_p
+ABI_VERSION = 2          # include/objcavit_hip.h: OCV_ABI_VERSION
 
 
 class EncoderLayerParams(C.Structure):
     """ocv_encoder_layer_params"""
-    _fields_ = [(n, C.c_void_p) for n in (
+    _fields_ = [("struct_size", C.c_size_t)] + [(n, C.c_void_p) for n in (
         "in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "norm1_w", "norm1_b",
         "linear1_w", "linear1_b", "linear2_w", "linear2_b", "norm2_w", "norm2_b",
         "in_proj_p3", "out_proj_p3", "linear1_p3", "linear2_p3")]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size = C.sizeof(EncoderLayerParams)      # the library reads this many bytes, later fields = NULL
 
 
 # name -> (restype, argtypes); every symbol declared in include/objcavit_hip.h
@@ -147,8 +152,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
             raise HipLibraryError(f"{p} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.ocv_abi_version() != 1:
-        raise HipLibraryError(f"ABI version mismatch: library {lib.ocv_abi_version()}, binding 1")
+    if lib.ocv_abi_version() != ABI_VERSION:
+        raise HipLibraryError(f"ABI version mismatch: library {lib.ocv_abi_version()}, binding {ABI_VERSION}")
     if path is None:
         _lib = lib
     return lib

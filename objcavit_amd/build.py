@@ -35,16 +35,26 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, out: str = None) -> str:
+    """``out``: write the library THERE (diagnostic variants, tools/build_variant.sh / OCV_LIB_OUT in the environment) --
+    objects go to a directory of their own next to it and the product library is not touched."""
+    out = out or os.environ.get("OCV_LIB_OUT")
+    if out:
+        return _build_to(os.path.abspath(out), os.path.abspath(out) + ".objs", verbose)
     if not force and not _stale():
         return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
-    if os.path.exists(LIB_PATH):
-        os.remove(LIB_PATH)            # a failed rebuild must not leave a stale library behind
+    return _build_to(LIB_PATH, LIB_DIR, verbose)
+
+
+def _build_to(lib_path: str, obj_dir: str, verbose: bool) -> str:
+    os.makedirs(os.path.dirname(lib_path), exist_ok=True)
+    os.makedirs(obj_dir, exist_ok=True)
+    if os.path.exists(lib_path):
+        os.remove(lib_path)            # a failed rebuild must not leave a stale library behind
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+        obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
         cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-c",
                os.path.join(CSRC, src), "-o", obj] + os.environ.get("OCV_EXTRA_HIPCC_FLAGS", "").split()
         if verbose:
@@ -57,13 +67,15 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose:
             print(out)
-    link = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    link = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib_path] + objs
     r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
     for o in objs:
         os.remove(o)
-    return LIB_PATH
+    if obj_dir != LIB_DIR:
+        os.rmdir(obj_dir)
+    return lib_path
 
 
 if __name__ == "__main__":

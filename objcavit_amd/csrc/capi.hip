@@ -7,6 +7,8 @@
 #include <math.h>
 
 #include <stdlib.h>
+#include <string.h>
+#include <stddef.h>
 
 #include "common.hpp"
 #include "../../include/objcavit_hip.h"
@@ -21,6 +23,17 @@ void ocv_set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+bool ocv_layer_params_view(const void* caller_params, int index, void* lib_params) {
+  ocv_encoder_layer_params* out = (ocv_encoder_layer_params*)lib_params;
+  memset(out, 0, sizeof(*out));
+  const size_t sz = ((const ocv_encoder_layer_params*)caller_params)->struct_size;
+  if (sz < offsetof(ocv_encoder_layer_params, in_proj_p3) || sz > 4096 || (sz & (sizeof(void*) - 1)) != 0) return false;
+  const char* src = (const char*)caller_params + (size_t)index * sz;
+  memcpy(out, src, sz < sizeof(*out) ? sz : sizeof(*out));
+  out->struct_size = sizeof(*out);
+  return true;
 }
 
 extern "C" int ocv_abi_version(void) { return OCV_ABI_VERSION; }
@@ -82,11 +95,14 @@ extern "C" size_t ocv_encoder_layer_workspace_bytes(int B, int S, int E, int FF)
   return align_up(M * 3 * E * sizeof(float)) + 2 * align_up(M * E * sizeof(float)) + align_up(M * FF * sizeof(float));
 }
 
-extern "C" int ocv_encoder_layer_fwd(const float* x, const ocv_encoder_layer_params* p,
+extern "C" int ocv_encoder_layer_fwd(const float* x, const ocv_encoder_layer_params* p_caller,
                                      const uint8_t* key_padding_mask, int zero_padded_rows, float* out, int B, int S,
                                      int E, int H, int FF, float eps, void* workspace, size_t workspace_bytes,
                                      ocv_stream_t stream) {
-  OCV_CHECK_ARG(x && p && out && workspace, "ocv_encoder_layer_fwd: null pointer");
+  OCV_CHECK_ARG(x && p_caller && out && workspace, "ocv_encoder_layer_fwd: null pointer");
+  ocv_encoder_layer_params pv;
+  OCV_CHECK_ARG(ocv_layer_params_view(p_caller, 0, &pv), "ocv_encoder_layer_fwd: params->struct_size (%zu) is not a valid ocv_encoder_layer_params size", p_caller->struct_size);
+  const ocv_encoder_layer_params* p = &pv;
   OCV_CHECK_ARG(E == 128 && H == 4, "ocv_encoder_layer_fwd: built for E = 128, H = 4 (got %d, %d)", E, H);
   OCV_CHECK_ARG(workspace_bytes >= ocv_encoder_layer_workspace_bytes(B, S, E, FF), "ocv_encoder_layer_fwd: workspace too small");
   const int M = B * S;
@@ -148,10 +164,13 @@ extern "C" size_t ocv_encoder_stack_workspace_bytes(int B, int S, int E) {
   return align_up(M * 3 * E * sizeof(float)) + 3 * align_up(M * E * sizeof(float));
 }
 
-extern "C" int ocv_encoder_stack_fwd(const float* x, const ocv_encoder_layer_params* layers, int n_layers,
+extern "C" int ocv_encoder_stack_fwd(const float* x, const ocv_encoder_layer_params* layers_caller, int n_layers,
                                      const uint8_t* key_padding_mask, int zero_padded_rows, float* out, int B, int S, int E,
                                      int H, int FF, float eps, void* workspace, size_t workspace_bytes, ocv_stream_t stream) {
-  OCV_CHECK_ARG(x && layers && out && workspace && n_layers >= 1, "ocv_encoder_stack_fwd: null pointer / no layers");
+  OCV_CHECK_ARG(x && layers_caller && out && workspace && n_layers >= 1 && n_layers <= 64, "ocv_encoder_stack_fwd: null pointer / layer count not in 1..64");
+  ocv_encoder_layer_params layers[64];
+  for (int l = 0; l < n_layers; ++l)
+    OCV_CHECK_ARG(ocv_layer_params_view(layers_caller, l, &layers[l]), "ocv_encoder_stack_fwd: layers[0].struct_size (%zu) is not a valid ocv_encoder_layer_params size", layers_caller->struct_size);
   OCV_CHECK_ARG(E == 128 && H == 4 && FF >= 128 && FF % 128 == 0, "ocv_encoder_stack_fwd: built for E = 128, H = 4, FF a multiple of 128 (got %d, %d, %d)", E, H, FF);
   OCV_CHECK_ARG(workspace_bytes >= ocv_encoder_stack_workspace_bytes(B, S, E), "ocv_encoder_stack_fwd: workspace too small");
   for (int l = 0; l < n_layers; ++l)

@@ -80,5 +80,10 @@ int ocv_ffn_split_launch(const float* x, const float* w1, const float* b1, const
                          const float* gamma, const float* beta, float eps, const uint8_t* zero_row_mask, float* out, int M,
                          int FF, float* part, int nsplit, hipStream_t st);
 
+// A caller's ocv_encoder_layer_params (element ``index`` of an array whose stride is the caller's struct_size) copied into
+// the library's own struct: fields beyond the caller's struct_size read as NULL.  false = struct_size too small to hold
+// the twelve fp32 parameter pointers.
+bool ocv_layer_params_view(const void* caller_params, int index, void* lib_params);
+
 static inline bool ocv_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline int ocv_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

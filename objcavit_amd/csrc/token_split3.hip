@@ -560,11 +560,14 @@ extern "C" int ocv_linear_residual_layernorm_split3_fwd(const float* A, int lda,
   return 0;
 }
 
-extern "C" int ocv_layer_tail_split3_fwd(const float* ctx, const float* x, const ocv_encoder_layer_params* p,
+extern "C" int ocv_layer_tail_split3_fwd(const float* ctx, const float* x, const ocv_encoder_layer_params* p_caller,
                                          const void* next_in_proj_p3, const float* next_in_proj_b, float eps,
                                          const uint8_t* zero_row_mask, float* out, float* qkv_next, int M, int E, int FF,
                                          ocv_stream_t stream) {
-  OCV_CHECK_ARG(ctx && x && p && out, "ocv_layer_tail_split3_fwd: null pointer");
+  OCV_CHECK_ARG(ctx && x && p_caller && out, "ocv_layer_tail_split3_fwd: null pointer");
+  ocv_encoder_layer_params pv;
+  OCV_CHECK_ARG(ocv_layer_params_view(p_caller, 0, &pv), "ocv_layer_tail_split3_fwd: params->struct_size (%zu) is not a valid ocv_encoder_layer_params size", p_caller->struct_size);
+  const ocv_encoder_layer_params* p = &pv;
   OCV_CHECK_ARG(p->out_proj_p3 && p->linear1_p3 && p->linear2_p3, "ocv_layer_tail_split3_fwd: needs the packed split3 weights");
   OCV_CHECK_ARG(E == E128 && FF >= KC && FF % KC == 0, "ocv_layer_tail_split3_fwd: needs E = %d and FF a multiple of %d (got %d, %d)", E128, KC, E, FF);
   OCV_CHECK_ARG((next_in_proj_p3 == nullptr) == (qkv_next == nullptr) && (next_in_proj_p3 == nullptr || next_in_proj_b != nullptr),

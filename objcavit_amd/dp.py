@@ -9,7 +9,7 @@ dist_reduce_fx=...)``; formulas metrics/AbsRel.py:23 etc.).
 from __future__ import annotations
 
 import os
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -81,6 +81,42 @@ def gather_records(local: torch.Tensor, world: int, n_total: Optional[int] = Non
     out = torch.empty(world * local.shape[0], local.shape[1], dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous())
     return drop_padding(out) if n_total is not None else out
+
+
+def agree_object_nmax(local_counts: Sequence[int], world: int, device=None, global_counts: Optional[Sequence[int]] = None) -> int:
+    """The longest object list of the GLOBAL batch, identical on every rank.
+
+    SURVEY.md Q3: with ``use_2_saca`` the reference pads every object list to the batch's longest one (modules/
+    ObjCAViT.py:180-183) and the second SA/CA stack sees the padding rows, so an image's result depends on the Nmax of
+    the batch it sits in.  A shard that pads only to ITS longest list therefore differs from the single-process run in
+    the fifth digit whenever the ranks' maxima differ.  ``global_counts`` (every image's count, known on the host --
+    e.g. the benchmark's fixed counts or a detection cache): plain arithmetic, no collective.  Otherwise one MAX
+    all-reduce of a single integer before the forward."""
+    if global_counts is not None:
+        nmax = max(int(c) for c in global_counts)
+        if local_counts and max(int(c) for c in local_counts) > nmax:
+            raise ValueError("agree_object_nmax: a local count exceeds the largest of global_counts")
+        return nmax
+    local = max((int(c) for c in local_counts), default=0)
+    if world == 1:
+        return local
+    t = torch.tensor([local], dtype=torch.int64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
+
+
+def sharded_forward(model, image: torch.Tensor, object_features: List[torch.Tensor], object_xywh_list: List[Optional[torch.Tensor]],
+                    world: int, global_counts: Optional[Sequence[int]] = None):
+    """One rank's forward over its shard of a global batch, reproducing the single-process result image for image: when
+    the model's second SA/CA stack is on (``use_2_saca``) the object lists are padded to the global Nmax
+    (``agree_object_nmax``); otherwise an image's result does not depend on its batch and nothing is exchanged."""
+    objcavit = getattr(model, "objcavit", None)
+    if objcavit is None or not getattr(objcavit, "use_2_saca", False):
+        return model(image, object_features, object_xywh_list)
+    counts = [int(f.shape[0]) for f in object_features]
+    dev = image.device if image.device.type == "cuda" else None
+    nmax = agree_object_nmax(counts, world, dev, global_counts)
+    return model(image, object_features, object_xywh_list, pad_objects_to=nmax)
 
 
 def summarise(records: torch.Tensor) -> Dict[str, float]:

@@ -16,6 +16,7 @@ read back on ROCm 7.2).
 """
 from __future__ import annotations
 
+import warnings
 from typing import Callable, List, Sequence, Tuple, Union
 
 import torch
@@ -52,8 +53,19 @@ class GraphedGraphBins:
             state["g"] = g
 
         def end():
-            state["g"].capture_end()
-            self.segments.append(state["g"])
+            # a segment without a single node (two adjacent islands, or nothing behind the last one) is DROPPED: torch
+            # reports it with a warning at capture_end, and replaying an empty hipGraph on every step is pure overhead
+            with warnings.catch_warnings(record=True) as seen:
+                warnings.simplefilter("always")
+                state["g"].capture_end()
+            empty = any("empty" in str(w.message).lower() for w in seen)
+            for w in seen:
+                if "empty" not in str(w.message).lower():
+                    warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
+            if empty:
+                self.empty_segments_dropped += 1
+            else:
+                self.segments.append(state["g"])
             state["g"] = None
 
         def on_break(name, call):
@@ -63,14 +75,13 @@ class GraphedGraphBins:
             self.segments.append((name, call))
             begin()
 
-        hip_ops._Islands.names, hip_ops._Islands.on_break = tuple(eager_ops), on_break
-        try:
-            with hip_ops.workspace_scope(self.scratch), torch.cuda.stream(self.stream), torch.no_grad():
-                begin()
-                parts = model.forward_until_head(self.static_image)
-                end()
-        finally:
-            hip_ops._Islands.names, hip_ops._Islands.on_break = (), None
+        self.empty_segments_dropped = 0
+        # the hook is an object handed to hip_ops for the duration of THIS capture on THIS thread (thread-local scope)
+        with hip_ops.island_scope(hip_ops.IslandHook(eager_ops, on_break)), hip_ops.workspace_scope(self.scratch), \
+                torch.cuda.stream(self.stream), torch.no_grad():
+            begin()
+            parts = model.forward_until_head(self.static_image)
+            end()
         torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
         self.scratch.freeze()

@@ -11,6 +11,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import threading
 from typing import Dict, Optional, Sequence, Tuple
 
 import torch
@@ -67,19 +68,47 @@ def timing_results() -> Dict[str, Tuple[int, float]]:
     return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in _Timing.events.items() if v}
 
 
-class _Islands:
-    """Set by objcavit_amd.graph while it captures: launches whose timing name is in ``names`` are kept OUT of the
-    hipGraph (capture is ended in front of them and re-opened behind them) so that they run eagerly between two
-    graph segments on every step and can be bracketed by HIP events."""
-    names: tuple = ()
-    on_break = None            # callable(name, closure) installed by the capturer
+class IslandHook:
+    """Installed by objcavit_amd.graph around ONE capture (``with island_scope(hook)``): launches whose timing name is in
+    ``names`` are kept OUT of the hipGraph (capture is ended in front of them and re-opened behind them) so that they
+    run eagerly between two graph segments on every step and can be bracketed by HIP events.  The hook lives in
+    thread-local state: two captures on two threads do not see each other's islands."""
+
+    def __init__(self, names, on_break):
+        self.names = tuple(names)
+        self.on_break = on_break             # callable(name, closure)
+
+
+class _Tls(threading.local):
+    def __init__(self):
+        self.island_hook = None
+        self.ws_stack = None                 # workspace stores of this thread (bottom = the module-level store)
+
+
+_TLS = _Tls()
+
+
+class island_scope:
+    def __init__(self, hook: IslandHook):
+        self.hook = hook
+
+    def __enter__(self):
+        if _TLS.island_hook is not None:
+            raise RuntimeError("island_scope: a capture with eager islands is already open on this thread")
+        _TLS.island_hook = self.hook
+        return self.hook
+
+    def __exit__(self, *exc):
+        _TLS.island_hook = None
+        return False
 
 
 def launch(name: str, call) -> None:
     """Issue one C-ABI launch (``call`` enqueues it on the current stream) under the timing hook -- or hand it to the
-    graph capturer as an eager island."""
-    if _Islands.on_break is not None and name in _Islands.names:
-        _Islands.on_break(name, call)
+    graph capturer of this thread as an eager island."""
+    hook = _TLS.island_hook
+    if hook is not None and name in hook.names:
+        hook.on_break(name, call)
         return
     with timed(name):
         call()
@@ -125,24 +154,31 @@ class WorkspaceStore(dict):
 
 
 _WS = WorkspaceStore()
-_WS_STACK = [_WS]
+
+
+def _ws_stack() -> list:
+    if _TLS.ws_stack is None:
+        _TLS.ws_stack = [_WS]
+    return _TLS.ws_stack
 
 
 class workspace_scope:
+    """``with workspace_scope(store)``: workspace requests of THIS thread come from ``store`` (a graph's own scratch)."""
+
     def __init__(self, store: WorkspaceStore):
         self.store = store
 
     def __enter__(self):
-        _WS_STACK.append(self.store)
+        _ws_stack().append(self.store)
         return self.store
 
     def __exit__(self, *exc):
-        _WS_STACK.pop()
+        _ws_stack().pop()
         return False
 
 
 def workspace(nbytes: int, device: torch.device, tag: str = "default") -> torch.Tensor:
-    store = _WS_STACK[-1]
+    store = _ws_stack()[-1]
     idx = device.index if device.index is not None else torch.cuda.current_device()
     key = (idx, torch.cuda.current_stream(idx).cuda_stream, tag)
     buf = store.get(key)

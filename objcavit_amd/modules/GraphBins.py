@@ -104,7 +104,7 @@ class GraphBins(nn.Module):
             yield from m.parameters()
 
     def forward_until_head(self, image, object_features: Optional[List[torch.Tensor]] = None,
-                           object_xywh_list: Optional[List[Optional[torch.Tensor]]] = None):
+                           object_xywh_list: Optional[List[Optional[torch.Tensor]]] = None, pad_objects_to: Optional[int] = None):
         """Everything up to the inputs of the fused bin head: (feat, queries, centers, bin_edges, detections).
         Split out so that a hipGraph can capture it while the head kernel stays individually timeable."""
         detections = None
@@ -126,13 +126,14 @@ class GraphBins(nn.Module):
                 side = self.__dict__["_side_stream"] = torch.cuda.Stream(device=image.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                pre = self.objcavit.object_prepass(object_features, object_xywh_list, image.device)
+                pre = self.objcavit.object_prepass(object_features, object_xywh_list, image.device, pad_objects_to)
             encoded = self.dense_feature_extractor.encoder(image, _defer_head=not torch.is_grad_enabled() and not self.training)
             main.wait_stream(side)
             dense_features = self.dense_feature_extractor.decoder(encoded)
         else:
             dense_features = self.dense_feature_extractor(image)
-        bin_widths_normed, feat, queries = self.objcavit.forward_parts(dense_features, object_features, object_xywh_list, pre=pre)
+        bin_widths_normed, feat, queries = self.objcavit.forward_parts(dense_features, object_features, object_xywh_list, pre=pre,
+                                                                     pad_objects_to=pad_objects_to)
         ds = self.args[self.args.basic.dataset]
         bin_edges, centers = bin_edges_and_centers(bin_widths_normed, ds.min_depth, ds.max_depth)
         return feat, queries, centers, bin_edges, detections
@@ -142,7 +143,9 @@ class GraphBins(nn.Module):
         return hip_ops.bin_head(feat, queries, conv.weight.detach(), conv.bias.detach(), centers)
 
     def forward(self, image, object_features: Optional[List[torch.Tensor]] = None,
-                object_xywh_list: Optional[List[Optional[torch.Tensor]]] = None):
-        feat, queries, centers, bin_edges, detections = self.forward_until_head(image, object_features, object_xywh_list)
+                object_xywh_list: Optional[List[Optional[torch.Tensor]]] = None, pad_objects_to: Optional[int] = None):
+        """``pad_objects_to``: the longest object list of the GLOBAL batch when ``image`` is one rank's shard of it
+        (objcavit_amd/dp.py ``sharded_forward``); None = this batch's own maximum, as the reference pads."""
+        feat, queries, centers, bin_edges, detections = self.forward_until_head(image, object_features, object_xywh_list, pad_objects_to)
         depth_pred = self.head(feat, queries, centers)
         return self.ReturnType(depth_pred=depth_pred, bin_edges=bin_edges, detections=detections)

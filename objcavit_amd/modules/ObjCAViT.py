@@ -27,6 +27,7 @@ from __future__ import annotations
 
 import math
 import sys
+from collections import OrderedDict
 from typing import List, Optional, Sequence, Tuple, Union
 
 import torch
@@ -42,10 +43,12 @@ PAD_VALUE = 0.0001          # reference :183,194
 
 class _PerDevice:
     """Small constant device tensors built on first use (outside graph capture) and reused: building them inside a
-    forward would be a host -> device copy, which a hipGraph capture cannot contain."""
+    forward would be a host -> device copy, which a hipGraph capture cannot contain.  The cache is a small LRU
+    (``capacity`` entries): with a real detector almost every batch has a new tuple of object counts, and an unbounded
+    dict would grow by one device tensor per batch for the life of the process."""
 
-    def __init__(self, make):
-        self._make, self._vals = make, {}
+    def __init__(self, make, capacity: int = 16):
+        self._make, self._vals, self._cap, self._pinned = make, OrderedDict(), capacity, {}
 
     def get(self, dev, *key):
         k = (str(dev),) + key
@@ -54,11 +57,20 @@ class _PerDevice:
             if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("constant not cached yet: run one eager warm-up call before graph capture")
             v = self._vals[k] = self._make(dev, *key)
+            while len(self._vals) > self._cap:
+                self._vals.popitem(last=False)          # (tensors a captured graph reads are held in _pinned)
+        else:
+            self._vals.move_to_end(k)
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            self._pinned[k] = v                         # a hipGraph now reads this address on every replay: never freed
         return v
+
+    def __len__(self):
+        return len(self._vals)
 
 
 _NO_BOX = _PerDevice(lambda dev: torch.full((1, 4), -1.0, device=dev))                      # reference :313
-_RAGGED_MASK = _PerDevice(lambda dev, counts: (torch.arange(max(counts))[None, :] >= torch.tensor(counts)[:, None]).to(dev))
+_RAGGED_MASK = _PerDevice(lambda dev, counts, nmax: (torch.arange(nmax)[None, :] >= torch.tensor(counts)[:, None]).to(dev))
 
 
 # ---------------------------------------------------------------------------
@@ -137,32 +149,45 @@ class SelfAttnCrossAttn(nn.Module):
         self.cross_attn_im_obj = nn.MultiheadAttention(embed_dim=embedding_dim, num_heads=4, batch_first=True)
 
     @staticmethod
-    def _pad_objects(object_features, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    def _pad_objects(object_features, device, pad_to: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """list of N_i x E (or a B x S x E tensor, iterated over its batch dim) ->
-        (B x Nmax x E padded with 1e-4, B x Nmax bool mask, True = padding)  (reference :180-183)."""
+        (B x Nmax x E padded with 1e-4, B x Nmax bool mask, True = padding)  (reference :180-183).
+        ``pad_to``: pad to that many rows instead of the largest count of THIS batch -- what the reference computes for
+        these images inside a larger batch whose longest object list has ``pad_to`` entries (with
+        ``use_2_saca`` an image's result depends on the batch's Nmax; a data-parallel shard passes the global Nmax so
+        that it reproduces the single-process batch, objcavit_amd/dp.py)."""
         if isinstance(object_features, torch.Tensor):
             B, N = object_features.shape[:2]
+            if pad_to is not None and int(pad_to) != N:
+                raise ValueError("pad_to applies to object LISTS; a B x S x E tensor (saca_2's input) is never padded")
             return object_features.contiguous(), torch.zeros(B, N, dtype=torch.bool, device=device)
         counts = [int(o.shape[0]) for o in object_features]
         nmax = max(counts)
+        if pad_to is not None:
+            if int(pad_to) < nmax:
+                raise ValueError(f"pad_to = {pad_to} is smaller than the longest object list of the batch ({nmax})")
+            nmax = int(pad_to)
         if all(c == nmax for c in counts):
             return torch.stack(list(object_features), dim=0), torch.zeros(len(counts), nmax, dtype=torch.bool, device=device)
         feats = nn.utils.rnn.pad_sequence(list(object_features), batch_first=True, padding_value=PAD_VALUE)
-        return feats, _RAGGED_MASK.get(device, tuple(counts))     # True = padding (:180-181)
+        if feats.shape[1] < nmax:
+            feats = F.pad(feats, (0, 0, 0, nmax - feats.shape[1]), value=PAD_VALUE)
+        return feats, _RAGGED_MASK.get(device, tuple(counts), nmax)     # True = padding (:180-181)
 
-    def object_self_attention(self, object_features, device):
+    def object_self_attention(self, object_features, device, pad_to: Optional[int] = None):
         """The object half of ``forward`` -- pad + mask, self-attention stack -- which does not depend on the image
         tokens: (att_obj [B, Nmax, E], mask [B, Nmax]).  May be issued ahead of time on another stream."""
-        feats, mask = self._pad_objects(object_features, device)
+        feats, mask = self._pad_objects(object_features, device, pad_to)
         if self._obj_stack is None:
             return feats, mask                                                            # :186
         return self._obj_stack(feats, mask), mask                                         # :188 (padded rows -> 0)
 
-    def forward(self, image_patch_embeddings, object_features, want_object_output: bool = True, pre_obj=None):
+    def forward(self, image_patch_embeddings, object_features, want_object_output: bool = True, pre_obj=None,
+                pad_objects_to: Optional[int] = None):
         x = image_patch_embeddings.contiguous()
         B, S, E = x.shape
         att_img = self._img_stack(x)                                                      # reference :169
-        att_obj, mask = pre_obj if pre_obj is not None else self.object_self_attention(object_features, x.device)
+        att_obj, mask = pre_obj if pre_obj is not None else self.object_self_attention(object_features, x.device, pad_objects_to)
         amt = S - att_obj.shape[1]                                                        # :192
         if amt < 0:
             raise ValueError(f"more objects per image ({att_obj.shape[1]}) than image tokens ({S})")
@@ -292,16 +317,17 @@ class ObjCAViT(nn.Module):
         true for the MLP positional strategies -- so that it can run beside the encoder on a second stream."""
         return self.strategy in _MLP_IN and not self.training
 
-    def object_prepass(self, object_features, object_xywh_list, dev):
+    def object_prepass(self, object_features, object_xywh_list, dev, pad_objects_to: Optional[int] = None):
         """Steps of ``forward_parts`` that do not need the dense features: (embedded objects, (att_obj, mask))."""
         if len(object_features) != len(object_xywh_list):
             raise ValueError("object_features / object_xywh_list must have one entry per image")
         objs = self._embed_objects(object_features, object_xywh_list, dev, None)
-        return objs, self.saca_1.object_self_attention(objs, dev)
+        return objs, self.saca_1.object_self_attention(objs, dev, pad_objects_to)
 
-    def forward_parts(self, image_features, object_features, object_xywh_list, pre=None):
+    def forward_parts(self, image_features, object_features, object_xywh_list, pre=None, pad_objects_to: Optional[int] = None):
         """-> (bin_widths_normed, conv3x3 features, queries view B x n_query x E).  ``pre``: result of
-        ``object_prepass`` when the caller has already issued the object branch."""
+        ``object_prepass`` when the caller has already issued the object branch.  ``pad_objects_to``: see
+        ``SelfAttnCrossAttn._pad_objects`` (the batch's Nmax when this batch is a shard of a larger one)."""
         if self.training:
             raise RuntimeError("the HIP path implements inference (eval mode) only")
         dev = image_features.device
@@ -326,7 +352,7 @@ class ObjCAViT(nn.Module):
                                        self._w_cl, self._w_pe)
 
         # 3. self-attention / cross-attention stacks (reference :366-368)
-        tok, obj = self.saca_1(tok, objs, want_object_output=self.use_2_saca, pre_obj=pre_obj)
+        tok, obj = self.saca_1(tok, objs, want_object_output=self.use_2_saca, pre_obj=pre_obj, pad_objects_to=pad_objects_to)
         if self.use_2_saca:
             tok, obj = self.saca_2(tok, obj, want_object_output=False)
 
@@ -347,6 +373,6 @@ class ObjCAViT(nn.Module):
             return plan(x)                                            # split-bf16 implicit GEMM, NHWC in / out
         return plan.exact(x)                                          # OCV_CONV=exact, or channels not a multiple of 4
 
-    def forward(self, image_features, object_features, object_xywh_list):
-        y, feat, queries = self.forward_parts(image_features, object_features, object_xywh_list)
+    def forward(self, image_features, object_features, object_xywh_list, pad_objects_to: Optional[int] = None):
+        y, feat, queries = self.forward_parts(image_features, object_features, object_xywh_list, pad_objects_to=pad_objects_to)
         return y, self.dot_product_layer(feat, queries)

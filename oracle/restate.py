@@ -319,8 +319,8 @@ def grid_random_pos_emb(table: torch.Tensor, coords: torch.Tensor, feat_hw: Tupl
 # ----------------------------------------------------------------------------
 # a6: SelfAttnCrossAttn.forward (modules/ObjCAViT.py:167-213)
 # ----------------------------------------------------------------------------
-def _pad_sequence(seqs: Sequence[torch.Tensor], value) -> torch.Tensor:
-    n = max(s.shape[0] for s in seqs)
+def _pad_sequence(seqs: Sequence[torch.Tensor], value, n: Optional[int] = None) -> torch.Tensor:
+    n = max(s.shape[0] for s in seqs) if n is None else n
     out = seqs[0].new_full((len(seqs), n) + tuple(seqs[0].shape[1:]), value)
     for i, s in enumerate(seqs):
         out[i, : s.shape[0]] = s
@@ -328,16 +328,18 @@ def _pad_sequence(seqs: Sequence[torch.Tensor], value) -> torch.Tensor:
 
 
 def saca_forward(img_tok: torch.Tensor, objs: Union[List[torch.Tensor], torch.Tensor], sd: SD, pfx: str,
-                 no_obj_sa: bool = False, want_obj_out: bool = True
+                 no_obj_sa: bool = False, want_obj_out: bool = True, batch_nmax: Optional[int] = None
                  ) -> Tuple[torch.Tensor, Optional[torch.Tensor], dict]:
     """Returns (final_image_features B x S x E, final_object_features B x S x E,
     intermediates).  ``objs`` is a list of N_i x E tensors, or (saca_2, SURVEY
-    Q3) a B x S x E tensor that is iterated over its batch dim."""
+    Q3) a B x S x E tensor that is iterated over its batch dim.
+    ``batch_nmax``: the images are a SLICE of a larger batch whose longest object
+    list has that many entries -- pad_sequence (:180-183) would have padded to it."""
     B, S, E = img_tok.shape
     att_img = transformer_encoder(img_tok, sd, pfx + "image_transformer_encoder.")          # :169
     seqs = [o for o in objs]
-    masks = _pad_sequence([torch.zeros(o.shape[0], dtype=torch.bool) for o in seqs], True)  # :180-181
-    feats = _pad_sequence(seqs, PAD_VALUE)                                                  # :183
+    masks = _pad_sequence([torch.zeros(o.shape[0], dtype=torch.bool) for o in seqs], True, batch_nmax)  # :180-181
+    feats = _pad_sequence(seqs, PAD_VALUE, batch_nmax)                                      # :183
     if no_obj_sa:
         att_obj = feats                                                                     # :186
     else:
@@ -380,8 +382,9 @@ def objcavit_forward(image_features: torch.Tensor, object_features: List[torch.T
                      object_xywh_list: List[Optional[torch.Tensor]], sd: SD, pfx: str = "", *,
                      strategy: str = "learned", no_obj_sa: bool = False, use_2_saca: bool = False,
                      n_query: int = 128, patch: int = 16, norm: str = "linear",
-                     return_intermediates: bool = False):
-    """-> (bin_widths_normed B x 256, range_attention_maps B x 128 x h x w)."""
+                     return_intermediates: bool = False, batch_nmax: Optional[int] = None):
+    """-> (bin_widths_normed B x 256, range_attention_maps B x 128 x h x w).
+    ``batch_nmax``: see saca_forward (these images as a slice of a larger batch)."""
     B, C, fh, fw = image_features.shape
     pe = pfx + "positional_encoder."
     objs = []
@@ -416,7 +419,7 @@ def objcavit_forward(image_features: torch.Tensor, object_features: List[torch.T
     tok = (emb.flatten(2) + ipos.permute(0, 2, 1)).permute(0, 2, 1)                        # :362-364
 
     inter = {"tokens_in": tok, "objs_in": objs}
-    img, obj, i1 = saca_forward(tok, objs, sd, pfx + "saca_1.", no_obj_sa, want_obj_out=use_2_saca)   # :366
+    img, obj, i1 = saca_forward(tok, objs, sd, pfx + "saca_1.", no_obj_sa, want_obj_out=use_2_saca, batch_nmax=batch_nmax)   # :366
     inter["saca1_img"] = img
     inter["saca1_att_img"] = i1["att_img"]
     inter["saca1_att_obj"] = i1["att_obj"]
@@ -488,28 +491,29 @@ def decoder_forward(features: Sequence[torch.Tensor], sd: SD, pfx: str = "",
 # ----------------------------------------------------------------------------
 # Boundary A: full models
 # ----------------------------------------------------------------------------
-def dense_features(image: torch.Tensor, sd: SD, pfx: str = "dense_feature_extractor.") -> torch.Tensor:
+def dense_features(image: torch.Tensor, sd: SD, pfx: str = "dense_feature_extractor.", do_final_upscale: bool = False) -> torch.Tensor:
     """DenseFeatureExtractor.forward (:195-198) with the EfficientNet-B5 encoder
     restated in effnet_ref.py (encoder arithmetic: parity unpinned)."""
     from .effnet_ref import encoder_features
     feats = encoder_features(image, sd, pfx + "encoder.original_model.")
-    return decoder_forward(feats, sd, pfx + "decoder.")
+    return decoder_forward(feats, sd, pfx + "decoder.", do_final_upscale=do_final_upscale)   # :99-101,116-117
 
 
-def adabins_forward(image: torch.Tensor, sd: SD, min_depth: float, max_depth: float):
-    """AdaBins.forward (modules/AdaBins.py:73-89) -> (depth_pred, bin_edges)."""
-    unet = dense_features(image, sd)
+def adabins_forward(image: torch.Tensor, sd: SD, min_depth: float, max_depth: float, do_final_upscale: bool = False):
+    """AdaBins.forward (modules/AdaBins.py:73-89) -> (depth_pred, bin_edges).  ``do_final_upscale``
+    (modules/AdaBins.py:43, DenseFeatureExtractor.py:99-101,116-117): the decoder's fifth stage, features at full resolution."""
+    unet = dense_features(image, sd, do_final_upscale=do_final_upscale)
     y, ram = mvit_forward(unet, sd, "adaptive_bins_layer.")
     return bin_head(y, ram, sd["conv_out.0.weight"], sd["conv_out.0.bias"], min_depth, max_depth)
 
 
 def graphbins_forward(image: torch.Tensor, object_features: List[torch.Tensor],
                       object_xywh_list: List[Optional[torch.Tensor]], sd: SD,
-                      min_depth: float, max_depth: float, **objcavit_kw):
+                      min_depth: float, max_depth: float, do_final_upscale: bool = False, **objcavit_kw):
     """GraphBins.forward (modules/GraphBins.py:81-121) with the frozen detector /
     language producers replaced by their outputs (object_features list of
     N_i x 512, object_xywh_list) -> (depth_pred, bin_edges)."""
-    feats = dense_features(image, sd)
+    feats = dense_features(image, sd, do_final_upscale=do_final_upscale)
     y, ram = objcavit_forward(feats, [f.float() for f in object_features], object_xywh_list, sd,
                               "objcavit.", **objcavit_kw)
     return bin_head(y, ram, sd["conv_out.0.weight"], sd["conv_out.0.bias"], min_depth, max_depth)

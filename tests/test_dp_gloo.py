@@ -87,3 +87,67 @@ def test_two_rank_gather_equals_single_process(tmp_path, n):
     assert table[:, 9].tolist() == list(range(n))           # rank-ordered, contiguous image ids
     s = dp.summarise(table)
     assert s["images"] == n and 0 < s["abs_rel"] < 0.2
+
+
+# ---------------------------------------------------------------------------
+# SURVEY.md Q3 under sharding: with use_2_saca an image's result depends on the batch's longest object list.
+# ---------------------------------------------------------------------------
+NMAX_COUNTS = [70, 12, 5, 9]          # rank 0 holds [70, 12], rank 1 holds [5, 9]: the ranks' own maxima differ (70 vs 9)
+
+
+def _nmax_case():
+    """ObjCAViT (learned_bbox_wh, use_2_saca) weights and a 4-image batch on the mini 176 x 192 feature map (S = 132)."""
+    import gen
+    from util import gains_of, load_golden, state_dict_from
+    meta, _ = load_golden("g3_objcavit_bbox_wh_2saca_many")
+    sd = state_dict_from(meta["shapes"], meta["seed"], gains_of(meta))
+    fh, fw, seed = meta["fh"], meta["fw"], 77
+    x = gen.randn("x", (len(NMAX_COUNTS), 128, fh, fw), seed)
+    feats = [gen.randn(f"f{i}", (n, 512), seed, 10.0 / np.sqrt(512)) for i, n in enumerate(NMAX_COUNTS)]
+    xywh = [gen.boxes(f"b{i}", n, seed, 2 * fh, 2 * fw) for i, n in enumerate(NMAX_COUNTS)]
+    return sd, meta["kw"], x, feats, xywh
+
+
+def _nmax_worker(rank, world, port, out_path, agree):
+    from oracle import restate
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dp.init_from_env("cpu")
+    torch.set_grad_enabled(False)
+    sd, kw, x, feats, xywh = _nmax_case()
+    lo, hi = dp.shard_range(len(NMAX_COUNTS), rank, world)
+    counts = NMAX_COUNTS[lo:hi]
+    nmax = dp.agree_object_nmax(counts, world) if agree else None       # ONE integer MAX all-reduce, before the forward
+    if agree:
+        assert nmax == max(NMAX_COUNTS)
+        assert dp.agree_object_nmax(counts, world, global_counts=NMAX_COUNTS) == nmax      # host-side counts: no collective
+    y, _, inter = restate.objcavit_forward(x[lo:hi], feats[lo:hi], xywh[lo:hi], sd, "", batch_nmax=nmax, return_intermediates=True, **kw)
+    rec = torch.cat([y, inter["saca2_img"][:, :4].flatten(1), torch.arange(lo, hi, dtype=torch.float32)[:, None]], 1).contiguous()
+    # = bin widths, the first four tokens leaving the second SA/CA stack, image id
+    out = torch.empty(world * rec.shape[0], rec.shape[1])
+    dist.all_gather_into_tensor(out, rec)
+    if rank == 0:
+        torch.save(out, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_with_different_nmax_reproduce_the_single_process_batch(tmp_path):
+    """Rank 0 and rank 1 hold shards whose longest object lists differ.  Padding every shard to the agreed GLOBAL Nmax
+    reproduces the single-process batch; padding to the shard's own maximum (what a naive shard does) does not."""
+    from oracle import restate
+    torch.set_grad_enabled(False)
+    sd, kw, x, feats, xywh = _nmax_case()
+    y, _, inter = restate.objcavit_forward(x, feats, xywh, sd, "", return_intermediates=True, **kw)
+    single = torch.cat([y, inter["saca2_img"][:, :4].flatten(1)], 1)
+    tables = {}
+    for agree in (True, False):
+        out = str(tmp_path / f"t{int(agree)}.pt")
+        mp.spawn(_nmax_worker, args=(2, _free_port(), out, agree), nprocs=2, join=True)
+        tables[agree] = torch.load(out)
+    assert tables[True][:, -1].tolist() == [0.0, 1.0, 2.0, 3.0]
+    dev_agree = float((tables[True][:, :-1] - single).abs().max() / single.abs().max())
+    dev_naive = float((tables[False][2:, :-1] - single[2:]).abs().max() / single.abs().max())
+    assert dev_agree <= 1e-7, dev_agree                # same arithmetic on the same padded rows (0.0 here)
+    assert dev_naive > 5e-7 and dev_naive > 5 * dev_agree, (dev_naive, dev_agree)      # Q3: the coupling is real and is what the agreement removes
+    assert float((tables[False][:2, :-1] - single[:2]).abs().max() / single.abs().max()) < 2e-6    # rank 0 held the global maximum anyway

@@ -265,6 +265,27 @@ def test_transformer_encoder_stack(ops, B, S, counts):
     assert rel_dev(got[ok], exact[ok]) < 2e-5
 
 
+def test_encoder_layer_params_truncated_struct_reads_missing_fields_as_null(ops):
+    """ABI 2: a caller built against a header without the packed-weight fields passes struct_size = size field + 12
+    pointers; whatever lies behind that in memory is NOT read (here: poison pointers), the layer runs on the exact-fp32
+    route and equals the full struct with the *_p3 fields NULL, bit for bit."""
+    import ctypes as C
+    from objcavit_amd import _lib
+    enc, sd = _encoder_sd(13)
+    layer = enc.cuda().layers[0]
+    x = dev(rnd("x", (2, 40, 128), 14))
+    full, keep = ops.layer_params(layer, None)
+    ref = ops.encoder_layer(x, full)
+    trunc, keep2 = ops.layer_params(layer, None)
+    trunc.struct_size = 8 * 13
+    for f in ("in_proj_p3", "out_proj_p3", "linear1_p3", "linear2_p3"):
+        setattr(trunc, f, 0xdead0000)
+    got = ops.encoder_layer(x, trunc)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+    assert rel_dev(got, restate.encoder_layer(x.cpu(), sd, "layers.0.")) < 5e-5
+
+
 # ------------------------------------------------------------------ patch embedding
 @pytest.mark.parametrize("B,h,w,pos_mode", [(1, 16, 16, "none"), (2, 176, 192, "shared"), (1, 240, 320, "batched"),
                                             (3, 48, 80, "shared"), (1, 176, 608, "shared"), (2, 50, 70, "batched")])

@@ -180,7 +180,9 @@ def test_graph_replay_with_eager_island_equals_eager_dispatch():
     ref = m(img).depth_pred.clone()
     island = f"conv3x3|2,{H // 2},{W // 2},128,128"          # three launches per forward: decoder up4 / conv3, head conv3x3
     g = GraphedGraphBins(m, img, eager_ops=(island,))
-    assert g.islands == [island] * 3 and len(g.segments) == 7
+    # three islands + three graph segments: the EMPTY segment between up4's second convolution and conv3 (two adjacent
+    # islands) is dropped at capture instead of being replayed on every step
+    assert g.islands == [island] * 3 and len(g.segments) == 6 and g.empty_segments_dropped == 1
     assert torch.equal(g(img).depth_pred, ref)
     img2 = gen.randn("img2", (2, 3, H, W), 56).cuda()
     ref2 = m(img2).depth_pred.clone()
@@ -191,6 +193,66 @@ def test_graph_replay_with_eager_island_equals_eager_dispatch():
     assert torch.equal(out2.depth_pred, ref2) and not torch.equal(ref2, ref)
     assert island in t and "bin_head" in t and t[island][0] == 3          # the islands are event-timed on every replay
     assert torch.equal(g(img).depth_pred, ref)
+
+
+def test_two_captures_on_two_threads_do_not_share_island_state():
+    """The island hook and the workspace stack are thread-local objects handed to hip_ops for one capture: a capture with
+    islands on one thread and a capture without on another, started together, each see only their own."""
+    import threading
+    from objcavit_amd.graph import GraphedGraphBins
+    from objcavit_amd.modules.GraphBins import GraphBins, SyntheticObjectProvider
+    H, W = 352, 384
+    args = make_args(dimensions_train=[H, W], dimensions_test=[H, W], language="clip")
+    models, imgs, refs = [], [], []
+    for i in range(2):
+        m = GraphBins(args, object_provider=SyntheticObjectProvider(8, "clip", seed=3 + i)).eval()
+        gen.load_into(m, 60 + i, gen.PEAKY)
+        m = m.cuda()
+        img = gen.randn(f"img{i}", (1, 3, H, W), 60 + i).cuda()
+        models.append(m); imgs.append(img); refs.append(m(img).depth_pred.clone())
+    torch.cuda.synchronize()
+    island = f"conv3x3|1,{H // 2},{W // 2},128,128"
+    out, err = [None, None], []
+    gate = threading.Barrier(2)
+
+    def work(i):
+        try:
+            torch.cuda.set_device(0)
+            gate.wait(timeout=60)
+            out[i] = GraphedGraphBins(models[i], imgs[i], eager_ops=(island,) if i == 0 else ())
+        except Exception as e:          # noqa: BLE001
+            err.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not err, err
+    assert out[0].islands == [island] * 3 and out[1].islands == []
+    for i in range(2):
+        assert torch.equal(out[i](imgs[i]).depth_pred, refs[i])
+
+
+def test_shard_padded_to_the_global_nmax_reproduces_the_full_batch():
+    """SURVEY.md Q3 under data-parallel sharding: with use_2_saca an image's result depends on the batch's longest object
+    list.  A shard that passes the global Nmax (dp.sharded_forward / pad_objects_to) gives the full batch's result; padded to
+    its own maximum it computes something else; and the padded shard equals the oracle's statement of the same thing."""
+    from objcavit_amd import dp
+    kw = dict(strategy="learned_bbox_wh", use_2_saca=True)
+    H, W, counts = 352, 384, [70, 12, 5, 9]
+    m, sd, img, _, _, _ = _graphbins_pair(kw, 4, H, W, 1, 91)
+    feats = [gen.randn(f"f{i}", (n, 512), 91, 10.0 / np.sqrt(512)) for i, n in enumerate(counts)]
+    xywh = [gen.boxes(f"b{i}", n, 91, H, W) for i, n in enumerate(counts)]
+    cu = lambda ts: [t.cuda() for t in ts]          # noqa: E731
+    full = m(img.cuda(), cu(feats), cu(xywh))
+    naive = m(img[2:].cuda(), cu(feats[2:]), cu(xywh[2:]))
+    shard = dp.sharded_forward(m, img[2:].cuda(), cu(feats[2:]), cu(xywh[2:]), world=2, global_counts=counts)
+    # (kernel dispatch depends on the batch size -- split-K, FFN sharing -- so batches of 4 and 2 agree to rounding, not bits)
+    assert rel_dev(shard.bin_edges, full.bin_edges[2:]) < 1e-5 and max_rel(shard.depth_pred, full.depth_pred[2:]) < 1e-3
+    assert not torch.equal(naive.bin_edges, shard.bin_edges)      # same batch size, same kernels: only the padding rows differ
+    ref_depth, ref_edges = restate.graphbins_forward(img[2:], feats[2:], xywh[2:], sd, 0.001, 10, batch_nmax=70, **kw)
+    assert rel_dev(shard.bin_edges, ref_edges) < 1e-4 and max_rel(shard.depth_pred, ref_depth) < 1e-3
+    with pytest.raises(ValueError):
+        m(img[:2].cuda(), cu(feats[:2]), cu(xywh[:2]), pad_objects_to=12)      # smaller than the shard's own longest list
 
 
 def test_config2_full_size_properties():

@@ -28,7 +28,7 @@ def test_library_loads_and_exports_every_symbol():
     lib = _lib.load()
     for name in _lib.PROTOTYPES:
         assert hasattr(lib, name), name
-    assert lib.ocv_abi_version() == 1
+    assert lib.ocv_abi_version() == _lib.ABI_VERSION == 2
     # argument validation runs on the host before any launch
     assert lib.ocv_patch_embed_workspace_bytes(16, 128, 240, 320, 128) == 16 * 4800 * 128 * 4      # 16 K slices x [M, E] fp32
     assert lib.ocv_patch_embed_workspace_bytes(1, 128, 240, 320, 64) == 0
@@ -230,3 +230,40 @@ def test_relative_size_index_vs_reference_golden():
         for c, r in zip(clauses, got):
             assert f" appears {objects.REL_SIZE_SCALE[r]} the " in c          # the phrase the reference handed to CLIP
     assert seen == set(range(7))                                              # every entry of the scale is exercised
+
+
+def test_encoder_layer_params_carry_their_size():
+    """ABI 2: ocv_encoder_layer_params starts with struct_size; the library reads only that many bytes (later fields =
+    NULL) and rejects a size that cannot hold the twelve fp32 parameter pointers -- checked on the host, before any launch."""
+    import ctypes as C
+    lib = _lib.load()
+    p = _lib.EncoderLayerParams()
+    assert p.struct_size == C.sizeof(_lib.EncoderLayerParams) == 8 * 17
+    one = C.c_void_p(256)                                   # non-null, never dereferenced: validation fails first
+    for bad in (0, 8 * 12, 8 * 13 + 4, 1 << 20):
+        p.struct_size = bad
+        rc = lib.ocv_encoder_layer_fwd(one, C.byref(p), None, 0, one, 1, 8, 128, 4, 1024, 1e-5, one, 1 << 30, None)
+        assert rc == -1 and b"struct_size" in lib.ocv_last_error(), bad
+        rc = lib.ocv_encoder_stack_fwd(one, C.byref(p), 1, None, 0, one, 1, 8, 128, 4, 1024, 1e-5, one, 1 << 30, None)
+        assert rc == -1 and b"struct_size" in lib.ocv_last_error(), bad
+    # a caller built against a header WITHOUT the packed-weight fields (size + 12 pointers): accepted, *_p3 read as NULL,
+    # which ocv_encoder_stack_fwd then reports as "lacks its packed split3 weights" instead of reading garbage
+    p.struct_size = 8 * 13
+    p.in_proj_p3 = 0xdead0                                   # beyond struct_size: must be ignored
+    rc = lib.ocv_encoder_stack_fwd(one, C.byref(p), 1, None, 0, one, 1, 8, 128, 4, 1024, 1e-5, one, 1 << 30, None)
+    assert rc == -1 and b"lacks its packed split3 weights" in lib.ocv_last_error()
+
+
+def test_pad_objects_to_a_larger_batch_nmax():
+    """SelfAttnCrossAttn._pad_objects(pad_to=...): rows beyond a list's count are 1e-4 and masked, up to the agreed Nmax."""
+    from objcavit_amd.modules.ObjCAViT import PAD_VALUE, SelfAttnCrossAttn
+    objs = [torch.ones(3, 4), torch.ones(2, 4) * 2]
+    f, m = SelfAttnCrossAttn._pad_objects(objs, torch.device("cpu"))
+    assert f.shape == (2, 3, 4) and m.tolist() == [[False, False, False], [False, False, True]]
+    f, m = SelfAttnCrossAttn._pad_objects(objs, torch.device("cpu"), pad_to=5)
+    assert f.shape == (2, 5, 4) and m.tolist() == [[False] * 3 + [True] * 2, [False] * 2 + [True] * 3]
+    assert float(f[0, 3:].max()) == float(f[1, 2:].min()) == float(torch.tensor(PAD_VALUE)) and float(f[1, 1, 0]) == 2.0
+    f, m = SelfAttnCrossAttn._pad_objects([torch.ones(2, 4), torch.ones(2, 4)], torch.device("cpu"), pad_to=4)   # equal counts, still padded
+    assert f.shape == (2, 4, 4) and m.sum().item() == 4
+    with pytest.raises(ValueError):
+        SelfAttnCrossAttn._pad_objects(objs, torch.device("cpu"), pad_to=2)

@@ -10,15 +10,14 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p objcavit_amd/lib/variants
 scratch=$(mktemp -d /tmp/ocv_csrc.XXXXXX)
+trap 'rm -rf "$scratch"' EXIT
 mkdir -p "$scratch/objcavit_amd/csrc" "$scratch/include"
 cp objcavit_amd/csrc/* "$scratch/objcavit_amd/csrc/"
 cp include/objcavit_hip.h "$scratch/include/"
 name=$1; flags=$2; shift 2 || true
 if [ $# -eq 0 ]; then set -- tools/diag/*.patch; fi
 for p in "$@"; do patch -s -d "$scratch/objcavit_amd/csrc" -p1 < "$p"; done
-cp objcavit_amd/lib/libobjcavit_hip.so /tmp/ocv_keep.so 2>/dev/null || true
-OCV_CSRC_DIR="$scratch/objcavit_amd/csrc" OCV_EXTRA_HIPCC_FLAGS="$flags" python -m objcavit_amd.build --force > /dev/null
-mv objcavit_amd/lib/libobjcavit_hip.so objcavit_amd/lib/variants/$name.so
-[ -f /tmp/ocv_keep.so ] && mv /tmp/ocv_keep.so objcavit_amd/lib/libobjcavit_hip.so
-rm -rf "$scratch"
+# OCV_LIB_OUT: build.py writes the variant (and its objects) there; the product library is never moved or deleted
+OCV_LIB_OUT="$PWD/objcavit_amd/lib/variants/$name.so" OCV_CSRC_DIR="$scratch/objcavit_amd/csrc" OCV_EXTRA_HIPCC_FLAGS="$flags" \
+  python -m objcavit_amd.build --force > /dev/null
 echo built objcavit_amd/lib/variants/$name.so
