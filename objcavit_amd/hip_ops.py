@@ -340,7 +340,8 @@ def mha(q_src: torch.Tensor, k_src: torch.Tensor, v_src: torch.Tensor, in_proj_w
     nb = lib.ocv_mha_workspace_bytes(B, Sq, Sk, E)
     ws = workspace(nb, q_src.device)
     out = torch.empty(B, Sq, E, dtype=torch.float32, device=q_src.device)
-    with timed("mha_cross" if q_src.data_ptr() != k_src.data_ptr() else "mha_self"):
+    name = "mha_self" if q_src.data_ptr() == k_src.data_ptr() else ("mha_cross" if kv_limit else "mha_cross_full")
+    with timed(name):
       check(lib.ocv_mha_fwd(q_src.data_ptr(), k_src.data_ptr(), v_src.data_ptr(), _ptr(m), in_proj_w.data_ptr(),
                             in_proj_b.data_ptr(), out_w.data_ptr(), out_b.data_ptr(), out.data_ptr(), B, Sq, Sk, int(kv_limit), E, n_heads,
                             ws.data_ptr(), ws.numel(), _stream()), "ocv_mha_fwd")
@@ -685,6 +686,10 @@ def bin_head(feat: torch.Tensor, queries: torch.Tensor, w_out: torch.Tensor, b_o
     terms <= 2^-24 of a product; 2.7x the matrix rate), or the exact fp32 MFMA kernel with ``exact=True``; ``split=True``
     computes them in the TWO-term split -- faster still, ~3x the depth error under near-one-hot softmaxes (opt-in)."""
     lib = _lib.load()
+    mode = os.environ.get("OCV_BINHEAD", "split3")          # read per call (the library's own getenv is latched once)
+    if mode not in ("split3", "exact", "split"):
+        raise ValueError(f"OCV_BINHEAD={mode!r}: expected 'split3' (default), 'exact' or 'split'")
+    exact, split = exact or mode == "exact", split or mode == "split"
     feat, cl = _map4(feat, "feat")
     _req(b_out, "b_out"); _req(centers, "centers")
     B, Cc, h, w = feat.shape

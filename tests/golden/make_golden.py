@@ -189,6 +189,33 @@ def g5_adabins():
               depth_stats=np.array([float(depth.min()), float(depth.max()), float(depth.mean())], dtype=np.float32))
 
 
+def g5_adabins_final_upscale():
+    """The reference's AdaBins with ``do_final_upscale`` (modules/AdaBins.py:43 -> max_seq_len 1200; the decoder's fifth
+    UpSampleWithSkip stage against the input image, modules/DenseFeatureExtractor.py:99-101,116-117): features, patch grid
+    and depth at FULL resolution.  51 of the reference's 108 params/*.yaml files set it."""
+    from objcavit_amd.modules.efficientnet import tf_efficientnet_b5_ap
+    tag, (H, W), seed = "mini_upscale", (192, 208), 53            # 12 x 13 = 156 patches of the 192 x 208 feature map
+    args = make_args(model="adabins", do_final_upscale=True, dimensions_train=[H, W], dimensions_test=[H, W])
+    m = ref_import.build_reference_adabins(args, tf_efficientnet_b5_ap()).eval()
+    assert m.adaptive_bins_layer.patch_transformer.positional_encodings.shape[0] == 1200
+    assert m.dense_feature_extractor.decoder.final_upscale is not None
+    sd = gen.load_into(m, seed, gen.PEAKY)
+    img = gen.randn("img", (1, 3, H, W), seed)
+    out = m(img)
+    depth, edges = out.depth_pred, out.bin_edges
+    assert tuple(depth.shape) == (1, 1, H, W)
+    do, eo = restate.adabins_forward(img, sd, args.nyu.min_depth, args.nyu.max_depth, do_final_upscale=True)
+    d = max(_dev(do, depth), _dev(eo, edges))
+    rel = float(((do - depth).abs() / depth).max())
+    print(f"G5 AdaBins[{tag}] rel dev {d:.2e}; depth max-rel {rel:.2e}; depth range {float(depth.min()):.3f}..{float(depth.max()):.3f}")
+    assert d < TOL
+    pix = gen.sample_pixels(H * W, 256, seed)
+    _save(f"g5_adabins_{tag}", dict(seed=seed, H=H, W=W, shapes=_shapes_json(m), dev=d, gains=gen.PEAKY, fields=list(out._fields),
+                                    do_final_upscale=True),
+          depth_px=_np(depth.flatten()[pix]), pix=pix, bin_edges=_np(edges),
+          depth_stats=np.array([float(depth.min()), float(depth.max()), float(depth.mean())], dtype=np.float32))
+
+
 # ------------------------------------------------------------------ G6 validation-step arithmetic (row N2)
 def _reference_metrics():
     """The reference's metrics/*.py classes.  They derive from torchmetrics.Metric, which is absent here; the only
@@ -313,6 +340,6 @@ def g7_relsize():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g5u", "g6", "g7"]
     for w in which:
-        {"g1": g1_mvit, "g2": g2_saca, "g3": g3_objcavit, "g4": g4_decoder, "g5": g5_adabins, "g6": g6_validation, "g7": g7_relsize}[w]()
+        {"g1": g1_mvit, "g2": g2_saca, "g3": g3_objcavit, "g4": g4_decoder, "g5": g5_adabins, "g5u": g5_adabins_final_upscale, "g6": g6_validation, "g7": g7_relsize}[w]()

@@ -97,6 +97,48 @@ def test_g5_adabins_depth_vs_reference_golden(tag):
     assert rel_dev(out.bin_edges, z["bin_edges"]) < 1e-4
 
 
+def test_g5_adabins_final_upscale_vs_reference_golden():
+    """do_final_upscale end to end on the GPU path vs the reference's own AdaBins(do_final_upscale=True) CPU forward:
+    fifth decoder stage against the image, feature map / patch embedding / bin head at full resolution, 1200-row table."""
+    from objcavit_amd.modules.AdaBins import AdaBins
+    meta, z = load_golden("g5_adabins_mini_upscale")
+    H, W = meta["H"], meta["W"]
+    m = _load(AdaBins(make_args(model="adabins", do_final_upscale=True, dimensions_train=[H, W], dimensions_test=[H, W])), meta)
+    out = m(gen.randn("img", (1, 3, H, W), meta["seed"]).cuda())
+    assert tuple(out.depth_pred.shape) == (1, 1, H, W)
+    got = out.depth_pred.flatten()[torch.from_numpy(z["pix"]).cuda()]
+    assert max_rel(got, z["depth_px"]) < 1e-3
+    assert rel_dev(out.bin_edges, z["bin_edges"]) < 1e-4
+
+
+@pytest.mark.parametrize("model,H,W,B", [("adabins", 480, 640, 1), ("graphbins", 192, 208, 2), ("graphbins", 480, 640, 1)])
+def test_final_upscale_models_end_to_end_vs_oracle(model, H, W, B):
+    """GraphBins / AdaBins with do_final_upscale=True against the oracle (restate.*_forward(do_final_upscale=True), pinned
+    by g5_adabins_mini_upscale).  480 x 640: S = 1200 tokens -- the longest sequence the reference allows
+    (modules/AdaBins.py:43, GraphBins.py:45) -- through the patch embedding, both attention kernels and the bin head on a
+    307 200-pixel map."""
+    from objcavit_amd.modules.AdaBins import AdaBins
+    from objcavit_amd.modules.GraphBins import GraphBins
+    seed = 64
+    args = make_args(model=model, do_final_upscale=True, language="clip", dimensions_train=[H, W], dimensions_test=[H, W])
+    m = (AdaBins(args) if model == "adabins" else GraphBins(args)).eval()
+    sd = gen.load_into(m, seed, gen.PEAKY)
+    m = m.cuda()
+    img = gen.randn("img", (B, 3, H, W), seed)
+    if model == "adabins":
+        out = m(img.cuda())
+        ref_depth, ref_edges = restate.adabins_forward(img, sd, 0.001, 10, do_final_upscale=True)
+    else:
+        feats = [gen.randn(f"f{i}", (9 + i, 512), seed, 10.0 / np.sqrt(512)) for i in range(B)]
+        xywh = [gen.boxes(f"b{i}", 9 + i, seed, H, W) for i in range(B)]
+        out = m(img.cuda(), [f.cuda() for f in feats], [b.cuda() for b in xywh])
+        ref_depth, ref_edges = restate.graphbins_forward(img, feats, xywh, sd, 0.001, 10, do_final_upscale=True, strategy="learned")
+    assert tuple(out.depth_pred.shape) == tuple(ref_depth.shape) == (B, 1, H, W)
+    assert rel_dev(out.bin_edges, ref_edges) < 1e-4
+    assert max_rel(out.depth_pred, ref_depth) < 1e-3
+    assert float(ref_depth.max() - ref_depth.min()) > 0.1
+
+
 def _graphbins_pair(args_kw, B, H, W, n_obj, seed, lang="clip"):
     from objcavit_amd.modules.GraphBins import GraphBins
     args = make_args(dimensions_train=[H, W], dimensions_test=[H, W], language=lang, **args_kw)
@@ -280,6 +322,11 @@ def test_config2_full_size_properties():
     sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
     ref, _ = restate.graphbins_forward(img[3:4].cpu(), [feats[3].cpu()], [boxes[3].cpu()], sd, 0.001, 10, strategy="learned")
     assert max_rel(d[3:4], ref) < 1e-3 and max_rel(solo, ref) < 1e-3
+    # MARGIN PIN: the default route -- split-bf16 convolutions, Winograd at 30 x 40, low-resolution first
+    # convolutions, three-term-split token path and bin head -- measured 4.1e-4 .. 4.7e-4 on this stress case (exact-fp32
+    # convolutions: 1.0e-4).  Half of the 1e-3 bar must stay free: a new re-association or a wider Winograd dispatch that
+    # eats it fails HERE, not silently.
+    assert max_rel(d[3:4], ref) < 6e-4, max_rel(d[3:4], ref)
 
 
 def test_encoder_fast_path_vs_oracle(monkeypatch):

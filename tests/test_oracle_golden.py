@@ -109,6 +109,22 @@ def test_g5_adabins_config1(tag):
     assert abs(float(depth.min()) - float(z["depth_stats"][0])) < 1e-3
 
 
+def test_g5_adabins_final_upscale():
+    """do_final_upscale (51 of the reference's 108 params files): the reference's own AdaBins with the decoder's fifth
+    stage -- features, 12 x 13 patch grid and depth at FULL resolution, positional table of 1200 rows."""
+    meta, z = load_golden("g5_adabins_mini_upscale")
+    assert meta["do_final_upscale"] and meta["shapes"]["adaptive_bins_layer.patch_transformer.positional_encodings"] == [1200, 128]
+    assert "dense_feature_extractor.decoder.final_upscale._net.0.weight" in meta["shapes"]
+    sd = state_dict_from(meta["shapes"], meta["seed"], gains_of(meta))
+    img = gen.randn("img", (1, 3, meta["H"], meta["W"]), meta["seed"])
+    depth, edges = restate.adabins_forward(img, sd, 0.001, 10, do_final_upscale=True)
+    assert depth.shape == (1, 1, meta["H"], meta["W"]) and edges.shape == (1, 257)
+    ref = torch.from_numpy(z["depth_px"])
+    got = depth.flatten()[torch.from_numpy(z["pix"])]
+    assert float(((got - ref).abs() / ref).max()) < 1e-4
+    assert rel_dev(edges, z["bin_edges"]) < TOL
+
+
 def test_ps_roi_align_restatement_vs_hand_computed_boxes():
     """ps_roi_align is third-party and absent (parity unpinned): the restatement is checked against hand-computed
     boxes (tests/roi_cases.py) and against an independent separable float64 formulation on random boxes."""
