@@ -261,6 +261,26 @@ int ocv_pointwise_split_set_dispatch(int family, int a, int b);
 int ocv_pointwise_conv_nhwc_split_fwd(const float* x, const float* gate, int rows_per_image, const void* w_packed,
                                       const float* bias, const float* residual, float* y, long M, int Cin, int Cout,
                                       int act, ocv_stream_t stream);
+/* ... that also leaves y_hl (nullable): the output in the hl32 split layout ([M][2 ceil32(Cout)] bf16, pad channels zero),
+ * for a consumer that reads its rows by LDS-DMA (ocv_pointwise_hl_fwd).  Cout % 8 == 0 when y_hl is given. */
+int ocv_pointwise_conv_nhwc_split_hl_fwd(const float* x, const float* gate, int rows_per_image, const void* w_packed,
+                                         const float* bias, const float* residual, float* y, void* y_hl, long M, int Cin,
+                                         int Cout, int act, ocv_stream_t stream);
+/* The same contraction on a row operand that is ALREADY split, in the "hl32" layout (below: per pixel and 32-channel block,
+ * 32 hi then 32 lo bf16 values, pad channels zero) -- what the depthwise / project epilogues of the late encoder stages
+ * write -- read by LDS-DMA with no conversion work, and with the squeeze-excite gate folded into PER-IMAGE weights
+ * (ocv_se_gate_weights_fwd) instead of multiplied into the rows:
+ *   y[m][co] = act( bias[co] + sum_ci x[m][ci] * Wimg[co][ci] ) + residual[m][co],  img = m / rows_per_image
+ *   x_hl [M][2 ceil32(Cin)] bf16;  w_packed as above; w_image_elems = 0: one matrix for all rows, else the packed matrix
+ *   of image i starts at w_packed + i * w_image_elems (>= ocv_pointwise_packed_weight_elems) and no tile spans two images
+ *   (M a multiple of rows_per_image);  y (fp32 [M][Cout]) and / or y_hl (hl32 [M][2 ceil32(Cout)], pad channels written as
+ *   zero) -- at least one;  Cin % 8 == 0, Cout % 4 == 0 (% 8 for y_hl).  Same reference lines as above.
+ * ocv_pointwise_hl_set_dispatch(rt, tn): pin the wavefront tile (rt x tn blocks of 32 x 32; rt in {1,2,4}, tn in {1,2});
+ * (0, 0) = automatic.  Diagnostics / tests only. */
+int ocv_pointwise_hl_set_dispatch(int rt, int tn);
+int ocv_pointwise_hl_fwd(const void* x_hl, int Cin, const void* w_packed, long w_image_elems, int rows_per_image,
+                         const float* bias, const float* residual, float* y, void* y_hl, long M, int Cout, int act,
+                         ocv_stream_t stream);
 /* Stem convolution: dense 3x3 (Cin * 9 <= 32, Cout <= 64), any stride, explicit top/left zero padding (bottom/right
  * implied by Ho/Wo: TensorFlow "SAME"), + bias (folded BatchNorm) + activation; reads the NCHW image x [B,Cin,H,W] and
  * writes the NHWC activation y [B,Ho,Wo,Cout]; w [Cout][Cin*3*3] (PyTorch's weight, flattened).  Exact fp32.  Replaces
@@ -287,6 +307,18 @@ int ocv_depthwise_conv_nhwc_sum_fwd(const float* in, const float* w, const float
 int ocv_se_gate_partials_fwd(const float* part, int tiles, long pixels_per_image, const float* w1, const float* b1,
                              const float* w2t, const float* b2, float* gate, float* hidden_ws, int B, int C, int R,
                              ocv_stream_t stream);
+/* ocv_depthwise_conv_nhwc_sum_fwd that writes its output (also, or only: out nullable) in the hl32 split layout: out_hl
+ * [B][Ho][Wo][2 C] bf16, C a multiple of 32.  The values are split where they are produced; ocv_pointwise_hl_fwd reads them. */
+int ocv_depthwise_conv_nhwc_sum_hl_fwd(const float* in, const float* w, const float* bias, float* out, void* out_hl, float* part,
+                                       int B, int C, int H, int W, int k, int stride, int pad_t, int pad_l, int Ho, int Wo,
+                                       ocv_stream_t stream);
+/* ocv_se_gate_partials_fwd that FOLDS THE GATE INTO THE PROJECT WEIGHTS: for every image b
+ *   w_packed + b * w_image_elems  <-  pack(split(W[n][k] * gate[b][k]))      (packed order of ocv_pointwise_conv_nhwc_split_fwd)
+ * W fp32 [N][C] (the BN-folded conv_pwl weight), w_image_elems >= ocv_pointwise_packed_weight_elems(C, N) and a multiple of 8;
+ * gate (nullable) also receives the [B][C] gate itself.  C a multiple of 8.  Two launches (hidden layer; gate + weights). */
+int ocv_se_gate_weights_fwd(const float* part, int tiles, long pixels_per_image, const float* w1, const float* b1,
+                            const float* w2t, const float* b2, const float* W, void* w_packed, long w_image_elems, float* gate,
+                            float* hidden_ws, int B, int C, int R, int N, ocv_stream_t stream);
 
 /* squeeze: out[b][c] = mean over the P = H*W pixels of x [B,P,C]; two-stage, fixed summation order. */
 size_t ocv_channel_mean_workspace_bytes(int B, int C, long P);

@@ -61,6 +61,14 @@ PROTOTYPES = {
     "ocv_encoder_layer_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "ocv_encoder_layer_fwd": (C.c_int, [_f32p, C.POINTER(EncoderLayerParams), _u8p, C.c_int, _f32p, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_size_t, _stream]),
+    "ocv_pointwise_conv_nhwc_split_hl_fwd": (C.c_int, [_f32p, _f32p, C.c_int, C.c_void_p, _f32p, _f32p, _f32p, C.c_void_p, C.c_long, C.c_int,
+                                                       C.c_int, C.c_int, _stream]),
+    "ocv_pointwise_hl_set_dispatch": (C.c_int, [C.c_int, C.c_int]),
+    "ocv_pointwise_hl_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_int, _f32p, _f32p, _f32p, C.c_void_p, C.c_long,
+                                       C.c_int, C.c_int, _stream]),
+    "ocv_depthwise_conv_nhwc_sum_hl_fwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_void_p, _f32p] + [C.c_int] * 10 + [_stream]),
+    "ocv_se_gate_weights_fwd": (C.c_int, [_f32p, C.c_int, C.c_long, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_void_p, C.c_long, _f32p,
+                                          _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
     "ocv_patch_embed_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ocv_patch_embed_split_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ocv_patch_embed_split_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _f32p, _f32p, C.c_long, _f32p, C.c_int,

@@ -16,9 +16,13 @@
 
 namespace {
 
+typedef __bf16 dw_bf16x4 __attribute__((ext_vector_type(4)));
+
 struct DWSArgs {
   const float *in, *w, *bias;
-  float *out, *part;
+  float *out, *part;               // out nullable when out_hl is given
+  __bf16* out_hl;                  // nullable: the output in the "hl32" split layout (C a multiple of 32), what the project
+                                   // 1x1 convolution reads by LDS-DMA (csrc/pointwise_hl.hip): split ONCE, where it is produced
   int C, H, W, Ho, Wo, pad_t, pad_l;
   int QL, PL, RY;                  // quads per chunk, pixel lanes, output rows per work item
   int wox, nwork, tiles, chunks;   // x-blocks per output row, work items per image, workgroups per (image, chunk), chunks
@@ -78,7 +82,9 @@ __global__ __launch_bounds__(256, 2) void dw_slide_kernel(DWSArgs p) {
     const int iyb = y0 * S - p.pad_t;                           // input row of window-relative row 0
     const bool allc = ix0 >= 0 && ix0 + NIN <= p.W;
     const float* ib = p.in + b * (long)p.H * p.W * p.C + c;
-    float* ob = p.out + ((b * p.Ho + y0) * (long)p.Wo + ox) * p.C + c;
+    const long opix = (b * p.Ho + y0) * (long)p.Wo + ox;
+    float* ob = p.out + opix * p.C + c;
+    __bf16* ohb = p.out_hl + opix * 2 * p.C + (c >> 5) * 64 + (c & 31);       // hl32: hi quad here, lo quad 32 elements on
     float4 win[K][NIN];
     auto load_row = [&](int rel, float4 (&dst)[NIN]) {
       const int iy = iyb + rel;
@@ -134,13 +140,26 @@ __global__ __launch_bounds__(256, 2) void dw_slide_kernel(DWSArgs p) {
 #pragma unroll
             for (int sidx = 0; sidx < S; ++sidx) load_row((y + u + 1 - y0) * S + K - S + sidx, win[(S * (u + 1) + K - S + sidx) % K]);
           }
-          float* orow = ob + (long)(y + u - y0) * p.Wo * p.C;
+          const long roff = (long)(y + u - y0) * p.Wo;
 #pragma unroll
           for (int o = 0; o < PX; ++o) {
             if (ox + o < p.Wo) {
               float4 r4 = acc[o];
               r4.x = fast_silu(r4.x); r4.y = fast_silu(r4.y); r4.z = fast_silu(r4.z); r4.w = fast_silu(r4.w);
-              *reinterpret_cast<float4*>(orow + (long)o * p.C) = r4;
+              if (p.out != nullptr) *reinterpret_cast<float4*>(ob + (roff + o) * p.C) = r4;
+              if (p.out_hl != nullptr) {
+                const float f[4] = {r4.x, r4.y, r4.z, r4.w};
+                dw_bf16x4 h, l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const __bf16 hb = (__bf16)f[e];
+                  h[e] = hb;
+                  l[e] = (__bf16)(f[e] - (float)hb);
+                }
+                __bf16* d = ohb + (roff + o) * 2 * p.C;
+                *reinterpret_cast<dw_bf16x4*>(d) = h;
+                *reinterpret_cast<dw_bf16x4*>(d + 32) = l;
+              }
               sum.x += r4.x; sum.y += r4.y; sum.z += r4.z; sum.w += r4.w;
             }
           }
@@ -253,6 +272,77 @@ __global__ __launch_bounds__(256) void se_gate_hid_kernel(const float* __restric
   gate[b * C + c] = fast_sigmoid((s0 + s1) + (s2 + s3));
 }
 
+// The gate FOLDED INTO THE PROJECT WEIGHTS, per image: Wg[b][n][k] = W[n][k] * gate[b][k], split (hi = bf16, lo = bf16 of the
+// rest) and packed in the B-operand order of the pointwise kernels ([jt][s][part][lane][8], hip_ops.SplitWeight) -- so that
+// the project convolution's row operand is the depthwise output AS STORED (hl32, LDS-DMA) instead of rows re-gated and
+// re-split by every workgroup that touches them.  Grid (ceil(K / 64), B): a workgroup forms the gate of its 64 input
+// channels (same summation order as se_gate_hid_kernel) and scales / splits / packs their column block of W for all N
+// rows; thread = (octet of 8 inputs, one of 32 consecutive output rows): a wavefront half writes 512 contiguous bytes.
+__global__ __launch_bounds__(256) void se_gate_weights_kernel(const float* __restrict__ hid, const float* __restrict__ w2t,
+                                                              const float* __restrict__ b2, const float* __restrict__ W,
+                                                              __bf16* __restrict__ wpk, long img_elems, float* __restrict__ gate,
+                                                              int C, int R, int N) {
+  __shared__ float hs[256];
+  __shared__ float gs[64];
+  const long b = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int k0 = blockIdx.x * 64;
+  if (tid < R) hs[tid] = hid[b * R + tid];
+  __syncthreads();
+  if (tid < 64) {
+    const int c = k0 + tid;
+    float g = 0.f;                                   // inputs past C (K padded to 16): weight columns of zeros
+    if (c < C) {
+      const float* w = w2t + c;
+      float s0 = b2[c], s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int r = 0;
+      for (; r + 3 < R; r += 4) {
+        s0 = fmaf(w[(long)r * C], hs[r], s0);
+        s1 = fmaf(w[(long)(r + 1) * C], hs[r + 1], s1);
+        s2 = fmaf(w[(long)(r + 2) * C], hs[r + 2], s2);
+        s3 = fmaf(w[(long)(r + 3) * C], hs[r + 3], s3);
+      }
+      for (; r < R; ++r) s0 = fmaf(w[(long)r * C], hs[r], s0);
+      g = fast_sigmoid((s0 + s1) + (s2 + s3));
+      if (gate != nullptr) gate[b * C + c] = g;
+    }
+    gs[tid] = g;
+  }
+  __syncthreads();
+  const int o = tid >> 5, nl = tid & 31;             // octet of the 64-channel block, row inside a 32-row channel tile
+  const int k = k0 + 8 * o;
+  const int Kp = (C + 15) & ~15;
+  if (k >= Kp) return;
+  const int nsteps = Kp >> 4, s = k >> 4, hh = (k >> 3) & 1;
+  float g8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) g8[e] = gs[8 * o + e];
+  __bf16* ob = wpk + b * img_elems;
+  const int ntl = (N + 31) >> 5;
+  for (int jt = 0; jt < ntl; ++jt) {
+    const int n = jt * 32 + nl;
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = 0.f;
+    if (n < N && k < C) {                            // C is a multiple of 8: an octet is inside or outside as a whole
+      const float4 u = ld4(W + (long)n * C + k), v = ld4(W + (long)n * C + k + 4);
+      f[0] = u.x * g8[0]; f[1] = u.y * g8[1]; f[2] = u.z * g8[2]; f[3] = u.w * g8[3];
+      f[4] = v.x * g8[4]; f[5] = v.y * g8[5]; f[6] = v.z * g8[6]; f[7] = v.w * g8[7];
+    }
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    bf16x8_t h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const __bf16 hb = (__bf16)f[e];
+      h[e] = hb;
+      l[e] = (__bf16)(f[e] - (float)hb);
+    }
+    __bf16* d = ob + (((long)jt * nsteps + s) * 2) * 512 + (hh * 32 + nl) * 8;
+    *reinterpret_cast<bf16x8_t*>(d) = h;
+    *reinterpret_cast<bf16x8_t*>(d + 512) = l;
+  }
+}
+
 template <int K, int S, int PX>
 int launch_dws(const DWSArgs& a, const DWSGeom& g, int B, hipStream_t st) {
   hipLaunchKernelGGL((dw_slide_kernel<K, S, PX>), dim3((unsigned)((long)g.tiles * g.chunks * B)), dim3(256), 0, st, a);
@@ -270,7 +360,14 @@ extern "C" int ocv_depthwise_sum_tiles(int B, int C, int Ho, int Wo, int k, int 
 extern "C" int ocv_depthwise_conv_nhwc_sum_fwd(const float* in, const float* w, const float* bias, float* out, float* part,
                                                int B, int C, int H, int W, int k, int stride, int pad_t, int pad_l,
                                                int Ho, int Wo, ocv_stream_t stream) {
-  OCV_CHECK_ARG(in && w && out && part, "ocv_depthwise_conv_nhwc_sum_fwd: null pointer");
+  return ocv_depthwise_conv_nhwc_sum_hl_fwd(in, w, bias, out, nullptr, part, B, C, H, W, k, stride, pad_t, pad_l, Ho, Wo, stream);
+}
+
+extern "C" int ocv_depthwise_conv_nhwc_sum_hl_fwd(const float* in, const float* w, const float* bias, float* out, void* out_hl,
+                                                  float* part, int B, int C, int H, int W, int k, int stride, int pad_t,
+                                                  int pad_l, int Ho, int Wo, ocv_stream_t stream) {
+  OCV_CHECK_ARG(in && w && (out || out_hl) && part, "ocv_depthwise_conv_nhwc_sum_fwd: null pointer");
+  OCV_CHECK_ARG(out_hl == nullptr || (C % 32 == 0 && ocv_aligned16(out_hl)), "ocv_depthwise_conv_nhwc_sum_hl_fwd: the split output needs C to be a multiple of 32 (got %d) and 16-byte alignment", C);
   OCV_CHECK_ARG(B >= 1 && C >= 4 && C % 4 == 0 && H >= 1 && W >= 1 && Ho >= 1 && Wo >= 1, "ocv_depthwise_conv_nhwc_sum_fwd: bad sizes (C must be a multiple of 4)");
   OCV_CHECK_ARG((k == 3 || k == 5) && (stride == 1 || stride == 2), "ocv_depthwise_conv_nhwc_sum_fwd: k must be 3 or 5 and stride 1 or 2");
   OCV_CHECK_ARG(pad_t >= 0 && pad_l >= 0 && pad_t < k && pad_l < k, "ocv_depthwise_conv_nhwc_sum_fwd: bad padding");
@@ -278,7 +375,7 @@ extern "C" int ocv_depthwise_conv_nhwc_sum_fwd(const float* in, const float* w, 
   OCV_CHECK_ARG(ocv_aligned16(in) && ocv_aligned16(w) && ocv_aligned16(out) && ocv_aligned16(bias) && ocv_aligned16(part), "ocv_depthwise_conv_nhwc_sum_fwd: operands must be 16-byte aligned");
   const DWSGeom g = dws_geom(B, C, Ho, Wo, k, stride);
   OCV_CHECK_ARG((long)g.tiles * g.chunks * B < (1L << 31), "ocv_depthwise_conv_nhwc_sum_fwd: too many workgroups");
-  DWSArgs a{in, w, bias, out, part, C, H, W, Ho, Wo, pad_t, pad_l, g.QL, g.PL, g.RY, g.wox, g.nwork, g.tiles, g.chunks};
+  DWSArgs a{in, w, bias, out, part, (__bf16*)out_hl, C, H, W, Ho, Wo, pad_t, pad_l, g.QL, g.PL, g.RY, g.wox, g.nwork, g.tiles, g.chunks};
   hipStream_t st = (hipStream_t)stream;
   if (k == 3 && stride == 1) return launch_dws<3, 1, 4>(a, g, B, st);
   if (k == 3 && stride == 2) return launch_dws<3, 2, 2>(a, g, B, st);
@@ -299,5 +396,26 @@ extern "C" int ocv_se_gate_partials_fwd(const float* part, int tiles, long pixel
   OCV_CHECK_LAUNCH("ocv_se_gate_partials_fwd(hidden)");
   hipLaunchKernelGGL(se_gate_hid_kernel, dim3((C + 255) / 256, B), dim3(256), 0, st, (const float*)hidden_ws, w2t, b2, gate, C, R);
   OCV_CHECK_LAUNCH("ocv_se_gate_partials_fwd(gate)");
+  return 0;
+}
+
+extern "C" int ocv_se_gate_weights_fwd(const float* part, int tiles, long pixels_per_image, const float* w1, const float* b1,
+                                       const float* w2t, const float* b2, const float* W, void* w_packed, long w_image_elems,
+                                       float* gate, float* hidden_ws, int B, int C, int R, int N, ocv_stream_t stream) {
+  OCV_CHECK_ARG(part && w1 && b1 && w2t && b2 && W && w_packed && hidden_ws, "ocv_se_gate_weights_fwd: null pointer");
+  OCV_CHECK_ARG(B >= 1 && B <= 65535 && C >= 8 && C % 8 == 0 && R >= 1 && R <= 256 && N >= 1 && tiles >= 1 && pixels_per_image >= 1,
+                "ocv_se_gate_weights_fwd: bad sizes (C a multiple of 8, R <= 256)");
+  OCV_CHECK_ARG(C <= 8192, "ocv_se_gate_weights_fwd: C too large (%d)", C);
+  OCV_CHECK_ARG(w_image_elems >= (long)ocv_pointwise_packed_weight_elems(C, N) && (w_image_elems & 7) == 0 && ocv_aligned16(w_packed) && ocv_aligned16(W),
+                "ocv_se_gate_weights_fwd: w_image_elems must hold one packed matrix (ocv_pointwise_packed_weight_elems) and keep 16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)(C + (C >= 1024 ? C : (1024 / C) * C)) * sizeof(float);
+  hipLaunchKernelGGL(se_hidden_partials_kernel, dim3((R + 15) / 16, B), dim3(1024), lds, st, part, tiles,
+                     1.0f / (float)pixels_per_image, w1, b1, hidden_ws, C, R);
+  OCV_CHECK_LAUNCH("ocv_se_gate_weights_fwd(hidden)");
+  const int Kp = (C + 15) / 16 * 16;
+  hipLaunchKernelGGL(se_gate_weights_kernel, dim3((Kp + 63) / 64, B), dim3(256), 0, st, (const float*)hidden_ws, w2t, b2, W,
+                     (__bf16*)w_packed, w_image_elems, gate, C, R, N);
+  OCV_CHECK_LAUNCH("ocv_se_gate_weights_fwd(gate + weights)");
   return 0;
 }

@@ -41,6 +41,8 @@ struct PSArgs {
   float* y;
   long M;
   int K, Kp, N, rows_per_image, act;
+  __bf16* yhl;                      // nullable: hl32 split copy of the output (pad channels written as zero), for a consumer that
+  int Cpo;                          // reads its rows by LDS-DMA (csrc/pointwise_hl.hip); Cpo = ceil32(N)
   int nbx, nby, col_major;          // tile kernel: row blocks, channel blocks, traversal order
 };
 
@@ -151,6 +153,22 @@ __device__ __forceinline__ void store_tile_lds(const PSArgs& p, const f32x16& ac
         v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
       }
       *reinterpret_cast<float4*>(p.y + m * p.N + ncol) = v;
+    } else {
+      v = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (p.yhl != nullptr && ncol < p.Cpo && m < p.M) {
+      typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+      const float f[4] = {v.x, v.y, v.z, v.w};
+      bf16x4_t h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const __bf16 hb = (__bf16)f[e];
+        h[e] = hb;
+        l[e] = (__bf16)(f[e] - (float)hb);
+      }
+      __bf16* d = p.yhl + m * 2 * p.Cpo + (ncol >> 5) * 64 + (ncol & 31);
+      *reinterpret_cast<bf16x4_t*>(d) = h;
+      *reinterpret_cast<bf16x4_t*>(d + 32) = l;
     }
   }
 }
@@ -502,7 +520,14 @@ extern "C" size_t ocv_pointwise_packed_weight_elems(int Cin, int Cout) {
 extern "C" int ocv_pointwise_conv_nhwc_split_fwd(const float* x, const float* gate, int rows_per_image,
                                                  const void* w_packed, const float* bias, const float* residual,
                                                  float* y, long M, int Cin, int Cout, int act, ocv_stream_t stream) {
+  return ocv_pointwise_conv_nhwc_split_hl_fwd(x, gate, rows_per_image, w_packed, bias, residual, y, nullptr, M, Cin, Cout, act, stream);
+}
+
+extern "C" int ocv_pointwise_conv_nhwc_split_hl_fwd(const float* x, const float* gate, int rows_per_image,
+                                                    const void* w_packed, const float* bias, const float* residual,
+                                                    float* y, void* y_hl, long M, int Cin, int Cout, int act, ocv_stream_t stream) {
   const int Kp = (Cin + 15) / 16 * 16;
+  OCV_CHECK_ARG(y_hl == nullptr || (Cout % 8 == 0 && ocv_aligned16(y_hl)), "ocv_pointwise_conv_nhwc_split_hl_fwd: the split output needs Cout to be a multiple of 8 (got %d) and 16-byte alignment", Cout);
   OCV_CHECK_ARG(x && w_packed && y, "ocv_pointwise_conv_nhwc_split_fwd: null pointer");
   OCV_CHECK_ARG(M >= 0 && Cin >= 8 && Cin % 8 == 0 && Cout >= 1, "ocv_pointwise_conv_nhwc_split_fwd: Cin must be a positive multiple of 8 (got M=%ld Cin=%d Cout=%d)", M, Cin, Cout);
   OCV_CHECK_ARG(gate == nullptr || rows_per_image >= 1, "ocv_pointwise_conv_nhwc_split_fwd: gate needs rows_per_image");
@@ -511,7 +536,7 @@ extern "C" int ocv_pointwise_conv_nhwc_split_fwd(const float* x, const float* ga
                 "ocv_pointwise_conv_nhwc_split_fwd: x / w_packed / gate / y / residual must be 16-byte aligned");
   if (M == 0) return 0;
   PSArgs a{x, gate, bias, residual, (const __bf16*)w_packed, y, M, Cin, Kp, Cout,
-           rows_per_image > 0 ? rows_per_image : 1, act};
+           rows_per_image > 0 ? rows_per_image : 1, act, (__bf16*)y_hl, (Cout + 31) / 32 * 32};
   hipStream_t st = (hipStream_t)stream;
   // Dispatch (measured on MI355X, bs = 16 encoder shapes, tools/run_pw.py):
   //   rows   : Cin <= 128 and >= 2 10^5 rows (the stage 1-2 expand layers: one pass over the rows, channels walked)

@@ -16,12 +16,18 @@ read back on ROCm 7.2).
 """
 from __future__ import annotations
 
+import threading
 import warnings
 from typing import Callable, List, Sequence, Tuple, Union
 
 import torch
 
 from . import hip_ops
+
+# Stream capture is a process-wide affair on ROCm 7.2: two threads capturing at the same time abort inside capture_end
+# (measured: tests, round 3), whatever capture_error_mode says.  Captures are therefore serialised; everything a capture
+# hands to hip_ops (island hook, scratch store) is thread-local state, so a thread that merely LAUNCHES meanwhile is safe.
+_CAPTURE_LOCK = threading.Lock()
 
 
 class GraphedGraphBins:
@@ -77,7 +83,7 @@ class GraphedGraphBins:
 
         self.empty_segments_dropped = 0
         # the hook is an object handed to hip_ops for the duration of THIS capture on THIS thread (thread-local scope)
-        with hip_ops.island_scope(hip_ops.IslandHook(eager_ops, on_break)), hip_ops.workspace_scope(self.scratch), \
+        with _CAPTURE_LOCK, hip_ops.island_scope(hip_ops.IslandHook(eager_ops, on_break)), hip_ops.workspace_scope(self.scratch), \
                 torch.cuda.stream(self.stream), torch.no_grad():
             begin()
             parts = model.forward_until_head(self.static_image)

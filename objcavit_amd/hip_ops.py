@@ -1028,10 +1028,10 @@ def pointwise_weight(weight: torch.Tensor):
 
 
 def pointwise_nhwc(x: torch.Tensor, weight, bias: Optional[torch.Tensor], act: int = ACT_NONE,
-                   gate: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   gate: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, out_split: bool = False):
     """1x1 convolution on a channels_last [B, C, H, W] tensor (or a plain [M, C] matrix): act(x*gate @ W^T + b) + res.
     weight: fp32 [Cout, Cin] (or [Cout, Cin, 1, 1]) -> exact fp32 kernel; a SplitWeight -> split-bf16 kernel.
-    gate [B, Cin]."""
+    gate [B, Cin].  ``out_split`` (SplitWeight, 4-D x, Cout % 8 == 0): also return the hl32 split copy -> (y, SplitAct)."""
     lib = _lib.load()
     four = x.dim() == 4
     if four:
@@ -1067,16 +1067,82 @@ def pointwise_nhwc(x: torch.Tensor, weight, bias: Optional[torch.Tensor], act: i
         residual = _nhwc(residual, "residual") if four else _req(residual, "residual")
         if residual.shape != y.shape:
             raise ValueError("pointwise_nhwc: residual shape mismatch")
+    ys = None
+    if out_split:
+        if not (split and four and Cout % 8 == 0):
+            raise ValueError("pointwise_nhwc: out_split needs a SplitWeight, a 4-D input and Cout % 8 == 0")
+        ys = SplitAct.empty(B, Cout, H, Wd, x.device)
     with timed(f"pointwise|{M},{Cin},{Cout}"):
         if split:
-            check(lib.ocv_pointwise_conv_nhwc_split_fwd(x.data_ptr(), _ptr(gate), rpi, weight.packed.data_ptr(),
-                                                        _ptr(bias), _ptr(residual), y.data_ptr(), M, Cin, Cout, act,
-                                                        _stream()),
-                  "ocv_pointwise_conv_nhwc_split_fwd")
+            check(lib.ocv_pointwise_conv_nhwc_split_hl_fwd(x.data_ptr(), _ptr(gate), rpi, weight.packed.data_ptr(),
+                                                           _ptr(bias), _ptr(residual), y.data_ptr(),
+                                                           ys.hl.data_ptr() if ys is not None else None, M, Cin, Cout, act, _stream()),
+                  "ocv_pointwise_conv_nhwc_split_hl_fwd")
         else:
             check(lib.ocv_pointwise_conv_nhwc_fwd(x.data_ptr(), _ptr(gate), rpi, w2.data_ptr(), _ptr(bias), _ptr(residual),
                                                   y.data_ptr(), M, Cin, Cout, act, _stream()), "ocv_pointwise_conv_nhwc_fwd")
-    return y
+    return (y, ys) if out_split else y
+
+
+class PerImageSplitWeight:
+    """B packed split-bf16 matrices [Cout, Cin] (hip_ops.SplitWeight order), one per image, ``img_elems`` bf16 elements
+    apart: the project weight with the image's squeeze-excite gate folded in (depthwise_se_gate_weights)."""
+    __slots__ = ("packed", "cout", "cin", "img_elems", "images")
+
+    def __init__(self, packed: torch.Tensor, cout: int, cin: int, img_elems: int, images: int):
+        self.packed, self.cout, self.cin, self.img_elems, self.images = packed, int(cout), int(cin), int(img_elems), int(images)
+
+
+def pointwise_hl_mode() -> str:
+    """OCV_PW_HL: '1' (default) = the late encoder stages read pre-split rows by LDS-DMA where that pays
+    (modules/efficientnet.py decides per block), '0' = never (the fp32-row kernels of round 2: the A/B route)."""
+    mode = os.environ.get("OCV_PW_HL", "1")
+    if mode not in ("0", "1"):
+        raise ValueError(f"OCV_PW_HL={mode!r}: expected '1' (default) or '0'")
+    return mode
+
+
+def pointwise_hl(x: "SplitAct", weight, bias: Optional[torch.Tensor], act: int = ACT_NONE,
+                 residual: Optional[torch.Tensor] = None, out_fp32: bool = True, out_split: bool = False):
+    """1x1 convolution of a PRE-SPLIT activation (hl32, read by LDS-DMA; csrc/pointwise_hl.hip): act(x @ W^T + b) + res.
+    weight: a SplitWeight (one matrix) or a PerImageSplitWeight (gate folded in per image; no tile spans two images).
+    Returns the fp32 channels_last tensor, the SplitAct, or (fp32, SplitAct)."""
+    lib = _lib.load()
+    if not (out_fp32 or out_split):
+        raise ValueError("pointwise_hl: nothing to output")
+    _req(x.hl, "x.hl", torch.bfloat16)
+    B, Cin, H, Wd = x.shape
+    if x.hl.dim() != 4 or x.hl.shape[3] != 2 * ((Cin + 31) // 32 * 32):
+        raise ValueError("pointwise_hl: x.hl must be [B, H, W, 2 * ceil32(C)] bf16")
+    per_image = isinstance(weight, PerImageSplitWeight)
+    if not per_image and not isinstance(weight, SplitWeight):
+        raise TypeError("pointwise_hl: weight must be a SplitWeight or a PerImageSplitWeight")
+    _req(weight.packed, "weight.packed", torch.bfloat16)
+    if weight.cin != Cin:
+        raise ValueError(f"pointwise_hl: weight with {weight.cin} input channels does not match {Cin} input channels")
+    Cout = weight.cout
+    if per_image and (weight.images != B or weight.packed.numel() < B * weight.img_elems):
+        raise ValueError("pointwise_hl: per-image weights do not match the batch")
+    if Cout % 4 != 0 or (out_split and Cout % 8 != 0):
+        raise ValueError(f"pointwise_hl: unsupported channel count {Cout}")
+    if bias is not None:
+        _req(bias, "bias")
+        if bias.numel() != Cout:
+            raise ValueError("pointwise_hl: bias size mismatch")
+    M = B * H * Wd
+    y = torch.empty(B, Cout, H, Wd, dtype=torch.float32, device=x.hl.device, memory_format=torch.channels_last) if out_fp32 else None
+    ys = SplitAct.empty(B, Cout, H, Wd, x.hl.device) if out_split else None
+    if residual is not None:
+        residual = _nhwc(residual, "residual")
+        if tuple(residual.shape) != (B, Cout, H, Wd):
+            raise ValueError("pointwise_hl: residual shape mismatch")
+    with timed(f"pointwise_hl|{M},{Cin},{Cout}"):
+        check(lib.ocv_pointwise_hl_fwd(x.hl.data_ptr(), Cin, weight.packed.data_ptr(), weight.img_elems if per_image else 0,
+                                       H * Wd, _ptr(bias), _ptr(residual), _ptr(y), ys.hl.data_ptr() if ys is not None else None,
+                                       M, Cout, act, _stream()), "ocv_pointwise_hl_fwd")
+    if out_fp32 and out_split:
+        return y, ys
+    return y if out_fp32 else ys
 
 
 def depth_metrics(pred: torch.Tensor, gt: torch.Tensor, min_depth: float, max_depth: float,
@@ -1188,6 +1254,49 @@ def depthwise_se_gate(x: torch.Tensor, weight_kkc: torch.Tensor, bias: Optional[
                                            b2.data_ptr(), gate.data_ptr(), hid.data_ptr(), B, Cc, R, _stream()),
               "ocv_se_gate_partials_fwd")
     return out, gate
+
+
+def depthwise_se_gate_weights(x: torch.Tensor, weight_kkc: torch.Tensor, bias: Optional[torch.Tensor], k: int, stride: int,
+                              w1: torch.Tensor, b1: torch.Tensor, w2t: torch.Tensor, b2: torch.Tensor, w_proj: torch.Tensor,
+                              want_gate: bool = False):
+    """silu(depthwise k x k (TF 'SAME') + bias) of a channels_last tensor written ONCE, in the hl32 split layout, and the
+    squeeze-excite gate of that output FOLDED INTO the project weight per image: returns (y SplitAct [B, C, Ho, Wo],
+    PerImageSplitWeight of w_proj [N, C] * diag(gate[b])) (+ the gate [B, C] with ``want_gate``).  Three launches."""
+    lib = _lib.load()
+    x = _nhwc(x, "x")
+    _req(weight_kkc, "weight")
+    B, Cc, H, W = x.shape
+    if weight_kkc.shape != (k * k, Cc) or Cc % 32 != 0:
+        raise ValueError(f"depthwise_se_gate_weights: weight {tuple(weight_kkc.shape)} does not match k={k}, C={Cc} (C % 32 == 0)")
+    for n, t in (("bias", bias), ("w1", w1), ("b1", b1), ("w2t", w2t), ("b2", b2), ("w_proj", w_proj)):
+        if t is not None:
+            _req(t, n)
+    R = w1.shape[0]
+    N = w_proj.shape[0]
+    if w1.shape != (R, Cc) or w2t.shape != (R, Cc) or b1.numel() != R or b2.numel() != Cc or tuple(w_proj.shape) != (N, Cc):
+        raise ValueError("depthwise_se_gate_weights: parameter shape mismatch")
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    ph = max((Ho - 1) * stride + k - H, 0)
+    pw = max((Wo - 1) * stride + k - W, 0)
+    tiles = lib.ocv_depthwise_sum_tiles(B, Cc, Ho, Wo, k, stride)
+    if tiles <= 0:
+        raise ValueError("depthwise_se_gate_weights: unsupported shape")
+    ys = SplitAct.empty(B, Cc, Ho, Wo, x.device)
+    part = workspace(B * tiles * Cc * 4, x.device, "dw_part")
+    hid = workspace(B * R * 4, x.device, "se_hidden")
+    img_elems = int(lib.ocv_pointwise_packed_weight_elems(Cc, N))
+    wpk = torch.empty(B * img_elems, dtype=torch.bfloat16, device=x.device)
+    gate = torch.empty(B, Cc, dtype=torch.float32, device=x.device) if want_gate else None
+    with timed(f"depthwise|{B},{H},{W},{Cc},k{k}s{stride}"):
+        check(lib.ocv_depthwise_conv_nhwc_sum_hl_fwd(x.data_ptr(), weight_kkc.data_ptr(), _ptr(bias), None, ys.hl.data_ptr(),
+                                                     part.data_ptr(), B, Cc, H, W, k, stride, ph // 2, pw // 2, Ho, Wo,
+                                                     _stream()), "ocv_depthwise_conv_nhwc_sum_hl_fwd")
+    with timed("se_gate_weights"):
+        check(lib.ocv_se_gate_weights_fwd(part.data_ptr(), tiles, Ho * Wo, w1.data_ptr(), b1.data_ptr(), w2t.data_ptr(),
+                                          b2.data_ptr(), w_proj.data_ptr(), wpk.data_ptr(), img_elems, _ptr(gate), hid.data_ptr(),
+                                          B, Cc, R, N, _stream()), "ocv_se_gate_weights_fwd")
+    wg = PerImageSplitWeight(wpk, N, Cc, img_elems, B)
+    return (ys, wg, gate) if want_gate else (ys, wg)
 
 
 def expand_depthwise_fusable(cin: int, weight, k: int = 3) -> bool:

@@ -237,43 +237,6 @@ def test_graph_replay_with_eager_island_equals_eager_dispatch():
     assert torch.equal(g(img).depth_pred, ref)
 
 
-def test_two_captures_on_two_threads_do_not_share_island_state():
-    """The island hook and the workspace stack are thread-local objects handed to hip_ops for one capture: a capture with
-    islands on one thread and a capture without on another, started together, each see only their own."""
-    import threading
-    from objcavit_amd.graph import GraphedGraphBins
-    from objcavit_amd.modules.GraphBins import GraphBins, SyntheticObjectProvider
-    H, W = 352, 384
-    args = make_args(dimensions_train=[H, W], dimensions_test=[H, W], language="clip")
-    models, imgs, refs = [], [], []
-    for i in range(2):
-        m = GraphBins(args, object_provider=SyntheticObjectProvider(8, "clip", seed=3 + i)).eval()
-        gen.load_into(m, 60 + i, gen.PEAKY)
-        m = m.cuda()
-        img = gen.randn(f"img{i}", (1, 3, H, W), 60 + i).cuda()
-        models.append(m); imgs.append(img); refs.append(m(img).depth_pred.clone())
-    torch.cuda.synchronize()
-    island = f"conv3x3|1,{H // 2},{W // 2},128,128"
-    out, err = [None, None], []
-    gate = threading.Barrier(2)
-
-    def work(i):
-        try:
-            torch.cuda.set_device(0)
-            gate.wait(timeout=60)
-            out[i] = GraphedGraphBins(models[i], imgs[i], eager_ops=(island,) if i == 0 else ())
-        except Exception as e:          # noqa: BLE001
-            err.append(e)
-
-    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
-    [t.start() for t in ts]
-    [t.join() for t in ts]
-    assert not err, err
-    assert out[0].islands == [island] * 3 and out[1].islands == []
-    for i in range(2):
-        assert torch.equal(out[i](imgs[i]).depth_pred, refs[i])
-
-
 def test_shard_padded_to_the_global_nmax_reproduces_the_full_batch():
     """SURVEY.md Q3 under data-parallel sharding: with use_2_saca an image's result depends on the batch's longest object
     list.  A shard that passes the global Nmax (dp.sharded_forward / pad_objects_to) gives the full batch's result; padded to

@@ -267,3 +267,41 @@ def test_pad_objects_to_a_larger_batch_nmax():
     assert f.shape == (2, 4, 4) and m.sum().item() == 4
     with pytest.raises(ValueError):
         SelfAttnCrossAttn._pad_objects(objs, torch.device("cpu"), pad_to=2)
+
+
+def test_island_hook_and_workspace_scope_are_thread_local():
+    """The capturer's island hook and the workspace stack are per-thread context objects (not module globals): while one
+    thread holds an island scope open, a launch of the SAME name on another thread is not diverted into it, and a
+    workspace scope entered on one thread is invisible to the other.  (No GPU call: the launches are plain closures.)"""
+    import threading
+    from objcavit_amd import hip_ops
+    seen = {"diverted": [], "ran": []}
+    hook = hip_ops.IslandHook(("conv3x3|x",), lambda name, call: seen["diverted"].append(name))
+    store = hip_ops.WorkspaceStore()
+    entered, release = threading.Event(), threading.Event()
+    err = []
+
+    def holder():
+        try:
+            with hip_ops.island_scope(hook), hip_ops.workspace_scope(store):
+                hip_ops.launch("conv3x3|x", lambda: seen["ran"].append("holder"))          # -> the hook
+                hip_ops.launch("other", lambda: seen["ran"].append("holder-other"))        # -> runs
+                assert hip_ops._ws_stack()[-1] is store
+                entered.set()
+                release.wait(timeout=30)
+        except Exception as e:          # noqa: BLE001
+            err.append(e)
+            entered.set()
+
+    t = threading.Thread(target=holder)
+    t.start()
+    assert entered.wait(timeout=30)
+    hip_ops.launch("conv3x3|x", lambda: seen["ran"].append("main"))                         # other thread: NOT diverted
+    assert hip_ops._ws_stack()[-1] is not store
+    with pytest.raises(RuntimeError):
+        with hip_ops.island_scope(hook), hip_ops.island_scope(hook):                         # one capture per thread at a time
+            pass
+    release.set()
+    t.join()
+    assert not err, err
+    assert seen["diverted"] == ["conv3x3|x"] and seen["ran"] == ["holder-other", "main"]
