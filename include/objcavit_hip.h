@@ -102,6 +102,16 @@ int ocv_mha_fwd(const float* q_src, const float* k_src, const float* v_src, cons
                 int B, int Sq, int Sk, int kv_limit, int E, int H, void* workspace, size_t workspace_bytes,
                 ocv_stream_t stream);
 
+/* ocv_mha_fwd with the four projections as three-term bf16 splits (fp32-faithful; weights packed once by
+ * ocv_pack_split3_fwd: in_proj_p3 = packed in_proj_weight [3E, E], out_proj_p3 = packed out_proj.weight [E, E]); QK^T and
+ * PV stay on exact fp32 MFMA.  With at most 32 live keys (the image <- object cross-attention, modules/ObjCAViT.py:192-201)
+ * K and V are projected ONCE per image (a [B][2][32][E] record in the workspace) and every 32-query tile is one fused launch
+ * reading it; otherwise split3 linears around ocv_attention_fwd.  Same workspace size as ocv_mha_fwd. */
+int ocv_mha_split3_fwd(const float* q_src, const float* k_src, const float* v_src, const uint8_t* key_padding_mask,
+                       const void* in_proj_p3, const float* in_proj_b, const void* out_proj_p3, const float* out_b, float* out,
+                       int B, int Sq, int Sk, int kv_limit, int E, int H, void* workspace, size_t workspace_bytes,
+                       ocv_stream_t stream);
+
 /* One post-norm nn.TransformerEncoderLayer(E=128, H=4, FF, relu, eps) in eval mode on x [B,S,E] (dense):
  *   x1 = LN1(x + MHA(x, x, x, mask));  out = LN2(x1 + W2 relu(W1 x1 + b1) + b2)
  * (modules/ObjCAViT.py:155-161,169,188; modules/layers.py:8-9,23).  `out` may alias `x`.

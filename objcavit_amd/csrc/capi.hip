@@ -46,7 +46,8 @@ extern "C" const char* ocv_last_error(void) { return g_err; }
 extern "C" size_t ocv_mha_workspace_bytes(int B, int Sq, int Sk, int E) {
   if (B < 1 || Sq < 1 || Sk < 1 || E < 1) return 0;
   const size_t q = align_up((size_t)B * Sq * E * sizeof(float)), k = align_up((size_t)B * Sk * E * sizeof(float));
-  return 2 * q + 2 * k;
+  const size_t kv = align_up((size_t)B * 2 * 32 * E * sizeof(float));      // ocv_mha_split3_fwd: the per-image K / V record
+  return 2 * q + (2 * k > kv ? 2 * k : kv);
 }
 
 extern "C" int ocv_mha_fwd(const float* q_src, const float* k_src, const float* v_src, const uint8_t* key_padding_mask,
@@ -83,6 +84,47 @@ extern "C" int ocv_mha_fwd(const float* q_src, const float* k_src, const float* 
   if ((rc = ocv_attention_launch(qp, (long)Sq * E, E, kp, (long)Se * E, E, vp, (long)Se * E, E, key_padding_mask, Sk, ctx,
                                  (long)Sq * E, E, B, H, Sq, Se, 1.0f / sqrtf(32.0f), (hipStream_t)stream))) return rc;
   return ocv_linear_fwd(ctx, E, 0, out_w, E, 0, 0, out_b, out, E, 0, 1, B * Sq, E, E, OCV_ACT_NONE, stream);
+}
+
+// nn.MultiheadAttention forward on packed three-term-split projection weights (ocv_pack_split3_fwd of in_proj_weight
+// [3E, E] and out_proj.weight [E, E]); QK^T / PV stay on exact fp32 MFMA.  <= 32 live keys: K / V projected once per image
+// + one fused launch per 32-query tile; otherwise the split3 linears around the attention kernel.
+extern "C" int ocv_mha_split3_fwd(const float* q_src, const float* k_src, const float* v_src, const uint8_t* key_padding_mask,
+                                  const void* in_proj_p3, const float* in_proj_b, const void* out_proj_p3, const float* out_b,
+                                  float* out, int B, int Sq, int Sk, int kv_limit, int E, int H, void* workspace,
+                                  size_t workspace_bytes, ocv_stream_t stream) {
+  OCV_CHECK_ARG(q_src && k_src && v_src && in_proj_p3 && in_proj_b && out_proj_p3 && out_b && out && workspace,
+                "ocv_mha_split3_fwd: null pointer");
+  OCV_CHECK_ARG(H == 4 && E == 128, "ocv_mha_split3_fwd: built for E = 128, H = 4 (got %d, %d)", E, H);
+  OCV_CHECK_ARG(B >= 1 && Sq >= 1 && Sk >= 1, "ocv_mha_split3_fwd: bad sizes");
+  OCV_CHECK_ARG(workspace_bytes >= ocv_mha_workspace_bytes(B, Sq, Sk, E), "ocv_mha_split3_fwd: workspace too small");
+  OCV_CHECK_ARG(kv_limit >= 0, "ocv_mha_split3_fwd: negative kv_limit");
+  OCV_CHECK_ARG(kv_limit == 0 || key_padding_mask != nullptr, "ocv_mha_split3_fwd: kv_limit needs a key_padding_mask");
+  const int Se = (kv_limit > 0 && kv_limit < Sk) ? kv_limit : Sk;
+  const size_t qb = align_up((size_t)B * Sq * E * sizeof(float)), kb = align_up((size_t)B * Sk * E * sizeof(float));
+  char* ws = (char*)workspace;
+  int rc;
+  {
+    static const bool unfused = getenv("OCV_MHA_UNFUSED") != nullptr;
+    if (!unfused) {
+      rc = ocv_cross_attn_split3_launch(q_src, k_src, v_src, key_padding_mask, Sk, in_proj_p3, in_proj_b, out_proj_p3, out_b, out,
+                                        (float*)(ws + 2 * qb), B, Sq, Sk, Se, E, H, (hipStream_t)stream);
+      if (rc != 1) return rc;
+    }
+  }
+  float* qp = (float*)ws;
+  float* ctx = (float*)(ws + qb);
+  float* kp = (float*)(ws + 2 * qb);
+  float* vp = (float*)(ws + 2 * qb + kb);
+  const size_t tile = (size_t)4 * (E / 16) * 3 * 512;                       // packed elements of 128 weight rows
+  const __bf16* wp = (const __bf16*)in_proj_p3;
+  // all Sk key rows are projected (contiguous rows; keys >= Se are simply not scored)
+  if ((rc = ocv_linear_split3_fwd(q_src, E, wp, in_proj_b, qp, E, B * Sq, E, E, OCV_ACT_NONE, stream))) return rc;
+  if ((rc = ocv_linear_split3_fwd(k_src, E, wp + tile, in_proj_b + E, kp, E, B * Sk, E, E, OCV_ACT_NONE, stream))) return rc;
+  if ((rc = ocv_linear_split3_fwd(v_src, E, wp + 2 * tile, in_proj_b + 2 * E, vp, E, B * Sk, E, E, OCV_ACT_NONE, stream))) return rc;
+  if ((rc = ocv_attention_launch(qp, (long)Sq * E, E, kp, (long)Sk * E, E, vp, (long)Sk * E, E, key_padding_mask, Sk, ctx,
+                                 (long)Sq * E, E, B, H, Sq, Se, 1.0f / sqrtf(32.0f), (hipStream_t)stream))) return rc;
+  return ocv_linear_split3_fwd(ctx, E, out_proj_p3, out_b, out, E, B * Sq, E, E, OCV_ACT_NONE, stream);
 }
 
 // ---------------------------------------------------------------------------

@@ -74,6 +74,11 @@ int ocv_cross_attn_fused_launch(const float* q_src, const float* k_src, const fl
                                 const float* in_w, const float* in_b, const float* out_w, const float* out_b, float* out, int B,
                                 int Sq, int Sk, int Se, int E, int H, hipStream_t st);
 
+// the same on packed three-term-split weights, K / V projected once per image into kv_ws [B][2][32][128] (csrc/token_split3.hip)
+int ocv_cross_attn_split3_launch(const float* q_src, const float* k_src, const float* v_src, const uint8_t* mask, int mask_ld,
+                                 const void* in_p3, const float* in_b, const void* out_p3, const float* out_b, float* out,
+                                 float* kv_ws, int B, int Sq, int Sk, int Se, int E, int H, hipStream_t st);
+
 // FFN with a row tile's hidden units shared out over several workgroups + finish pass (csrc/linear.hip)
 int ocv_ffn_split_count(int M, int FF);
 int ocv_ffn_split_launch(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,

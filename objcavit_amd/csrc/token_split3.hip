@@ -19,6 +19,8 @@
 //   ffn3_kernel            out = LayerNorm(x + W2 relu(W1 x + b1) + b2), hidden units 128 at a time through LDS
 // Replace nn.Linear / nn.MultiheadAttention projections / linear1 + linear2 of nn.TransformerEncoderLayer at
 // modules/ObjCAViT.py:155-161,169,188 and modules/layers.py:8-9,23 (same lines as the fp32 kernels of csrc/linear.hip).
+#include <math.h>
+
 #include "common.hpp"
 #include "../../include/objcavit_hip.h"
 
@@ -510,7 +512,190 @@ int launch_lin3(const L3Args& a, int act, hipStream_t st) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Few-key multi-head attention, the image <- object cross-attention (modules/ObjCAViT.py:192-201): at most 32 live keys
+// per image, E = 128, 4 heads of 32.  Round 2's single launch (csrc/linear.hip, cross_attn_fused_kernel) spent 128 of its
+// 288 exact-fp32 MFMAs per wavefront RE-PROJECTING K and V for every 32-query tile and was bound by that dependent
+// matrix chain (4 % of the HBM roofline at bs = 16, 7.6 % at bs >= 512: profiles/r02_cross_attention_roofline.txt).  Here
+//   xattn_kv3_kernel    K = Xk Wk^T + bk, V = Xv Wv^T + bv ONCE per image (32 rows, a 32 KB record the query tiles of the
+//                       image then read from L2), and
+//   xattn_main3_kernel  per 32-query tile: wavefront h projects head h of Q TRANSPOSED (weights as the MFMA A operand,
+//                       query rows as B), so its accumulator IS the B operand of the score MFMAs -- Q never touches LDS
+//                       --, scores / softmax / context exactly as before on exact fp32 MFMA (both operands are
+//                       activations), then 32 columns of the output projection.
+// The four projections are three-term-split contractions (six bf16 MFMAs per product block, dropped terms <= 2^-24) on
+// weights packed once by ocv_pack_split3_fwd: 48 + 48 bf16 MFMAs (32 cycles) + 32 fp32 MFMAs (64 cycles) per wavefront =
+// 5.1 K matrix-pipe cycles against 18.4 K.
+// ---------------------------------------------------------------------------
+struct XKV3Args {
+  const float *k_src, *v_src;          // [B][Sk][128]
+  const __bf16* in_p3;                 // packed in_proj_weight [384][128]
+  const float* in_b;                   // [384]
+  float* kv;                           // [B][2][32][128]
+  int Sk, Se;
+};
+
+__global__ __launch_bounds__(256) void xattn_kv3_kernel(XKV3Args p) {
+  __shared__ __attribute__((aligned(16))) __bf16 planes[3 * PLANE];
+  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const long b = blockIdx.x;
+  const int col = h * 32 + l31;
+  constexpr int NS = E128 / 16;
+  WFrag3 fk, fv;
+  load_w3(fk, p.in_p3 + ((long)(4 + h) * NS * 3) * 512 + lane * 8, NS);          // Wk rows of head h
+  stage_rows3(planes, p.k_src + b * p.Sk * E128, E128, 0, p.Se, 0, E128, tid);
+  load_w3(fv, p.in_p3 + ((long)(8 + h) * NS * 3) * 512 + lane * 8, NS);          // Wv, in flight during the K projection
+  __syncthreads();
+  f32x16 ak = {0};
+  ak = chunk_mfma3(ak, planes, fk, NS, l31, hh);
+  const float bk = p.in_b[E128 + col];
+  float* kd = p.kv + (b * 2 * 32) * E128 + col;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) kd[(long)acc_row(r, hh) * E128] = ak[r] + bk;
+  __syncthreads();                                                               // every wavefront is done with the key rows
+  stage_rows3(planes, p.v_src + b * p.Sk * E128, E128, 0, p.Se, 0, E128, tid);
+  __syncthreads();
+  f32x16 av = {0};
+  av = chunk_mfma3(av, planes, fv, NS, l31, hh);
+  const float bv = p.in_b[2 * E128 + col];
+  float* vd = kd + 32 * E128;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) vd[(long)acc_row(r, hh) * E128] = av[r] + bv;
+}
+
+struct XA3Args {
+  const float* q_src;                  // [B][Sq][128]
+  const uint8_t* mask;                 // [B][mask_ld] (nullable)
+  const float* kv;                     // [B][2][32][128] from xattn_kv3_kernel
+  const __bf16 *in_p3, *out_p3;
+  const float *in_b, *out_b;
+  float* out;                          // [B][Sq][128]
+  int Sq, Se, mask_ld;
+  float scale;
+};
+
+constexpr int XLD = E128 + 1;          // floats per K / V row in LDS: column reads of 32 rows hit 32 banks
+
+__global__ __launch_bounds__(256) void xattn_main3_kernel(XA3Args p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char xa3_lds[];
+  __bf16* planes = reinterpret_cast<__bf16*>(xa3_lds);                            // query rows, later the context rows (3 planes)
+  float (*Ks)[XLD] = reinterpret_cast<float (*)[XLD]>(xa3_lds + 3 * PLANE * sizeof(__bf16));
+  float (*Vs)[XLD] = Ks + 32;
+  float* Ms = reinterpret_cast<float*>(Vs + 32);
+  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const long b = blockIdx.y;
+  const int q0 = blockIdx.x * TM;
+  constexpr float NEG_INF = -__builtin_inff();
+  constexpr int NS = E128 / 16;
+
+  // the image's K / V record: 2 x 32 x 128 floats, 8 float4 per thread, requested first (L2), parked in LDS below
+  const float* kvb = p.kv + b * 2 * 32 * E128;
+  float4 kvr[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) kvr[i] = ld4(kvb + (long)(tid + 256 * i) * 4);
+  WFrag3 fq;
+  load_w3(fq, p.in_p3 + ((long)h * NS * 3) * 512 + lane * 8, NS);                // Wq rows of head h
+  stage_rows3(planes, p.q_src + b * p.Sq * E128, E128, q0, p.Sq, 0, E128, tid);
+  if (tid < 32) Ms[tid] = (tid >= p.Se || (p.mask != nullptr && p.mask[b * p.mask_ld + tid] != 0)) ? NEG_INF : 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int e = (tid + 256 * i) * 4;                                            // element of the [2][32][128] record
+    float* d = &Ks[0][0] + (e >> 7) * XLD + (e & 127);                            // Ks and Vs are contiguous: row e / 128 of 64
+    d[0] = kvr[i].x; d[1] = kvr[i].y; d[2] = kvr[i].z; d[3] = kvr[i].w;
+  }
+  __syncthreads();
+
+  // Q^T of head h: D[d][query] = sum_k Wq[32 h + d][k] X[query][k]  (weight fragment = A operand, row fragment = B operand)
+  f32x16 q = {0};
+  {
+    const __bf16* pa = planes + l31 * PROW + 8 * hh;
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      const bf16x8 xh = *reinterpret_cast<const bf16x8*>(pa + 16 * st);
+      const bf16x8 xm = *reinterpret_cast<const bf16x8*>(pa + 16 * st + PLANE);
+      const bf16x8 xl = *reinterpret_cast<const bf16x8*>(pa + 16 * st + 2 * PLANE);
+      q = mfma6(fq.w[st][0], fq.w[st][1], fq.w[st][2], xh, xm, xl, q);
+    }
+  }
+  WFrag3 fo;
+  load_w3(fo, p.out_p3 + ((long)h * NS * 3) * 512 + lane * 8, NS);               // Wo rows 32 h ..: in flight from here on
+#pragma unroll
+  for (int r = 0; r < 16; ++r) q[r] = (q[r] + p.in_b[h * 32 + acc_row(r, hh)]) * p.scale;
+  __syncthreads();                                   // every wavefront has read the query planes: they may take the context
+
+  // scores^T (rows = keys, columns = queries): step st contracts d = acc_row(st, 0 | 1) -- register st of q IS the B operand
+  f32x16 s = {0};
+#pragma unroll
+  for (int st = 0; st < 16; ++st) s = mfma_32x32x2(Ks[l31][h * 32 + acc_row(st, hh)], q[st], s);
+  float tmax = NEG_INF;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    s[r] += Ms[acc_row(r, hh)];
+    tmax = fmaxf(tmax, s[r]);
+  }
+  tmax = xor32_max(tmax);
+  const bool none = tmax == NEG_INF;                 // every key masked for this image: 0 / 0 = NaN, as torch
+  float psum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float pr = none ? 0.f : fast_exp(s[r] - tmax);
+    s[r] = pr;
+    psum += pr;
+  }
+  const float inv = 1.0f / xor32_sum(psum);
+  f32x16 o = {0};
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o = mfma_32x32x2(Vs[acc_row(r, hh)][h * 32 + l31], s[r], o);
+  // o: register r = context[query l31][d = acc_row(r, hh)] of head h -> three-term planes, row = query, column 32 h + d
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float v = o[r] * inv;
+    const __bf16 a = (__bf16)v;
+    const float r1 = v - (float)a;
+    const __bf16 m = (__bf16)r1;
+    __bf16* d = planes + l31 * PROW + h * 32 + acc_row(r, hh);
+    d[0] = a;
+    d[PLANE] = m;
+    d[2 * PLANE] = (__bf16)(r1 - (float)m);
+  }
+  __syncthreads();
+
+  // output projection, 32 columns per wavefront
+  f32x16 acc = {0};
+  acc = chunk_mfma3(acc, planes, fo, NS, l31, hh);
+  const int col = h * 32 + l31;
+  const float bo = p.out_b[col];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int qi = q0 + acc_row(r, hh);
+    if (qi < p.Sq) p.out[(b * p.Sq + qi) * E128 + col] = acc[r] + bo;
+  }
+}
+
 }  // namespace
+
+// fused few-key attention on packed three-term-split weights; returns 1 when the shape is not covered
+int ocv_cross_attn_split3_launch(const float* q_src, const float* k_src, const float* v_src, const uint8_t* mask, int mask_ld,
+                                 const void* in_p3, const float* in_b, const void* out_p3, const float* out_b, float* out,
+                                 float* kv_ws, int B, int Sq, int Sk, int Se, int E, int H, hipStream_t st) {
+  if (E != E128 || H != 4 || Se < 1 || Se > 32 || B > 65535) return 1;
+  if (!(ocv_aligned16(q_src) && ocv_aligned16(k_src) && ocv_aligned16(v_src) && ocv_aligned16(in_p3) && ocv_aligned16(out_p3) && ocv_aligned16(kv_ws))) return 1;
+  XKV3Args ka{k_src, v_src, (const __bf16*)in_p3, in_b, kv_ws, Sk, Se};
+  hipLaunchKernelGGL(xattn_kv3_kernel, dim3(B), dim3(256), 0, st, ka);
+  OCV_CHECK_LAUNCH("ocv_mha_split3_fwd(K / V projection)");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)xattn_main3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  XA3Args a{q_src, mask, kv_ws, (const __bf16*)in_p3, (const __bf16*)out_p3, in_b, out_b, out, Sq, Se, mask_ld, 1.0f / sqrtf(32.0f)};
+  const size_t lds = (size_t)3 * PLANE * sizeof(__bf16) + (size_t)(64 * XLD + 32) * sizeof(float);
+  hipLaunchKernelGGL(xattn_main3_kernel, dim3(ocv_cdiv(Sq, TM), B), dim3(256), lds, st, a);
+  OCV_CHECK_LAUNCH("ocv_mha_split3_fwd(fused)");
+  return 0;
+}
 
 extern "C" size_t ocv_split3_packed_elems(int N, int K) {
   if (N < 1 || K < 1) return 0;

@@ -323,9 +323,12 @@ def attention_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, key_paddin
 
 def mha(q_src: torch.Tensor, k_src: torch.Tensor, v_src: torch.Tensor, in_proj_w: torch.Tensor, in_proj_b: torch.Tensor,
         out_w: torch.Tensor, out_b: torch.Tensor, key_padding_mask: Optional[torch.Tensor] = None,
-        n_heads: int = 4, kv_limit: int = 0) -> torch.Tensor:
+        n_heads: int = 4, kv_limit: int = 0, packed: Optional[dict] = None) -> torch.Tensor:
     """nn.MultiheadAttention(batch_first=True, need_weights=False) forward.
-    kv_limit > 0: the caller guarantees every key j >= kv_limit is masked in every row, so those keys are skipped."""
+    kv_limit > 0: the caller guarantees every key j >= kv_limit is masked in every row, so those keys are skipped.
+    ``packed``: the caller's cache of SplitWeight3 objects for this module (filled / refreshed here, keyed on the weights'
+    identity and version) -> the projections run as three-term bf16 splits and, with at most 32 live keys, K / V are
+    projected once per image (ocv_mha_split3_fwd); None, or OCV_TOKENS=fp32 -> the exact-fp32 kernels (ocv_mha_fwd)."""
     lib = _lib.load()
     for n, t in (("q_src", q_src), ("k_src", k_src), ("v_src", v_src), ("in_proj_weight", in_proj_w),
                  ("in_proj_bias", in_proj_b), ("out_proj.weight", out_w), ("out_proj.bias", out_b)):
@@ -341,10 +344,23 @@ def mha(q_src: torch.Tensor, k_src: torch.Tensor, v_src: torch.Tensor, in_proj_w
     ws = workspace(nb, q_src.device)
     out = torch.empty(B, Sq, E, dtype=torch.float32, device=q_src.device)
     name = "mha_self" if q_src.data_ptr() == k_src.data_ptr() else ("mha_cross" if kv_limit else "mha_cross_full")
+    if packed is not None and token_split3_enabled() and E == 128 and n_heads == 4:
+        p3 = []
+        for field, w in (("in_proj_p3", in_proj_w), ("out_proj_p3", out_w)):
+            ver = (w.data_ptr(), w._version)
+            hit = packed.get(field)
+            if hit is None or hit[0] != ver:
+                hit = packed[field] = (ver, SplitWeight3(w))
+            p3.append(hit[1].packed)
+        with timed(name):
+            check(lib.ocv_mha_split3_fwd(q_src.data_ptr(), k_src.data_ptr(), v_src.data_ptr(), _ptr(m), p3[0].data_ptr(),
+                                         in_proj_b.data_ptr(), p3[1].data_ptr(), out_b.data_ptr(), out.data_ptr(), B, Sq, Sk,
+                                         int(kv_limit), E, n_heads, ws.data_ptr(), ws.numel(), _stream()), "ocv_mha_split3_fwd")
+        return out
     with timed(name):
-      check(lib.ocv_mha_fwd(q_src.data_ptr(), k_src.data_ptr(), v_src.data_ptr(), _ptr(m), in_proj_w.data_ptr(),
-                            in_proj_b.data_ptr(), out_w.data_ptr(), out_b.data_ptr(), out.data_ptr(), B, Sq, Sk, int(kv_limit), E, n_heads,
-                            ws.data_ptr(), ws.numel(), _stream()), "ocv_mha_fwd")
+        check(lib.ocv_mha_fwd(q_src.data_ptr(), k_src.data_ptr(), v_src.data_ptr(), _ptr(m), in_proj_w.data_ptr(),
+                              in_proj_b.data_ptr(), out_w.data_ptr(), out_b.data_ptr(), out.data_ptr(), B, Sq, Sk, int(kv_limit), E, n_heads,
+                              ws.data_ptr(), ws.numel(), _stream()), "ocv_mha_fwd")
     return out
 
 
@@ -1100,6 +1116,29 @@ def pointwise_hl_mode() -> str:
     if mode not in ("0", "1"):
         raise ValueError(f"OCV_PW_HL={mode!r}: expected '1' (default) or '0'")
     return mode
+
+
+def pointwise_hl_expand_pays(M: int, cin: int, cout: int) -> bool:
+    """Whether a 1x1 convolution with M rows should read a pre-split (hl32) copy of its input by LDS-DMA
+    (ocv_pointwise_hl_fwd) instead of fp32 rows (measured at bs = 16, tools/run_pw_hl.py, profiles/r03_pointwise_hl_sweep.txt):
+    the late stages -- few rows, wide layers -- where the 32-row tile kernel re-converted every row N / 128 times."""
+    if pointwise_hl_mode() == "0" or cin % 8 != 0 or cout % 4 != 0:
+        return False
+    return M <= int(os.environ.get("OCV_PW_HL_MAX_ROWS", "32768")) and cin >= int(os.environ.get("OCV_PW_HL_MIN_CIN", "96"))
+
+
+def pointwise_hl_project_pays(B: int, rows_per_image: int, cin: int, cout: int) -> bool:
+    """Whether an MBConv project convolution should take the pre-split route with the squeeze-excite gate folded into
+    PER-IMAGE weights.  Measured at bs = 16 (profiles/r03_pointwise_hl_sweep.txt): the project GEMM itself gains on every
+    late layer with K >= 1056 (1056 -> 176: 57 -> 46 us, 1824 -> 304: 42 -> 30, 3072 -> 512: 86 -> 71), but writing and
+    re-reading B x Cout x Cin x 4 bytes of gated weights costs 6 us at 1200 rows per image (stage 5: 12 MB against 81 MB of
+    rows) and 10 - 18 us at 300 rows (stages 6, 7: as many bytes as the rows themselves), which eats the gain there; at
+    K = 768 (stage 4) the GEMM does not gain.  So: long K and weights well under the rows' own traffic."""
+    if pointwise_hl_mode() == "0" or cin % 32 != 0 or cout % 4 != 0:
+        return False
+    M = B * rows_per_image
+    return (M <= int(os.environ.get("OCV_PW_HL_MAX_ROWS", "32768")) and cin >= int(os.environ.get("OCV_PW_HL_PROJECT_MIN_CIN", "1024"))
+            and cout * int(os.environ.get("OCV_PW_HL_WEIGHT_RATIO", "4")) <= rows_per_image)
 
 
 def pointwise_hl(x: "SplitAct", weight, bias: Optional[torch.Tensor], act: int = ACT_NONE,

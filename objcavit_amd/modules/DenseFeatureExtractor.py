@@ -309,7 +309,7 @@ class UpSampleWithSkip(nn.Module):
         if affine_of is not None or self.lowres_ready(x, skip_features):
             if affine_of is not None:
                 x0, key, fn, _ = affine_of
-                xs = x0 if isinstance(x0, hip_ops.SplitAct) else hip_ops.split_act(x0)
+                xs = x0 if isinstance(x0, hip_ops.SplitAct) else (getattr(x0, "_ocv_hl", None) or hip_ops.split_act(x0))
                 a_hi, a_lo, s_hi, s_lo, b, border = self._split1.upconv_weights(x.shape[1], compose=(key, fn))
                 z = hip_ops.conv_nhwc_split(xs, a_hi, a_lo, border, 1, hip_ops.ACT_NONE, out_fp32=True)
             else:
@@ -318,7 +318,9 @@ class UpSampleWithSkip(nn.Module):
                 z = hip_ops.conv_nhwc_split(xs, a_hi, a_lo, None, 1, hip_ops.ACT_NONE, out_fp32=True)
             sk = None
             if s_hi is not None:
-                sk = hip_ops.conv_nhwc_split(hip_ops.split_act(skip_features), s_hi, s_lo, None, 3, hip_ops.ACT_NONE, out_fp32=True)
+                # (an encoder block of the late stages leaves the split copy of its output beside it: read in place)
+                sks = getattr(skip_features, "_ocv_hl", None) or hip_ops.split_act(skip_features)
+                sk = hip_ops.conv_nhwc_split(sks, s_hi, s_lo, None, 3, hip_ops.ACT_NONE, out_fp32=True)
             f = hip_ops.tap_interp_combine(z, sk, b, (H, W), hip_ops.ACT_LEAKY_RELU, out_fp32=False, out_split=True, border=border)
         else:
             if isinstance(x, hip_ops.SplitAct):

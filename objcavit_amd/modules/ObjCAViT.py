@@ -147,6 +147,7 @@ class SelfAttnCrossAttn(nn.Module):
             self._obj_stack = HipEncoderStack(self.obj_transformer_encoder)
         self.cross_attn_obj_im = nn.MultiheadAttention(embed_dim=embedding_dim, num_heads=4, batch_first=True)
         self.cross_attn_im_obj = nn.MultiheadAttention(embed_dim=embedding_dim, num_heads=4, batch_first=True)
+        self._ca1_p3, self._ca2_p3 = {}, {}          # packed three-term-split projection weights, keyed on the weights' versions
 
     @staticmethod
     def _pad_objects(object_features, device, pad_to: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -198,12 +199,13 @@ class SelfAttnCrossAttn(nn.Module):
         # True at the back): the kernel only projects / scores the first Nmax keys -- same result, ~10x less work
         final_img = hip_ops.mha(att_img, att_obj_p, att_img, ca1.in_proj_weight.detach(), ca1.in_proj_bias.detach(),
                                 ca1.out_proj.weight.detach(), ca1.out_proj.bias.detach(), kpm, ca1.num_heads,
-                                kv_limit=int(mask.shape[1]))                                                  # :195-201
+                                kv_limit=int(mask.shape[1]), packed=self._ca1_p3)                             # :195-201
         final_obj = None
         if want_object_output:
             ca2 = self.cross_attn_im_obj
             final_obj = hip_ops.mha(att_obj_p, att_img, att_obj_p, ca2.in_proj_weight.detach(), ca2.in_proj_bias.detach(),
-                                    ca2.out_proj.weight.detach(), ca2.out_proj.bias.detach(), None, ca2.num_heads)  # :202-207
+                                    ca2.out_proj.weight.detach(), ca2.out_proj.bias.detach(), None, ca2.num_heads,
+                                    packed=self._ca2_p3)                                                      # :202-207
         return final_img, final_obj
 
 

@@ -197,21 +197,47 @@ class InvertedResidual(_FoldedMixin, nn.Module):
         we, be = fold_bn(self.conv_pw, self.bn1)
         wd, bd = fold_bn(self.conv_dw, self.bn2)
         wl, bl = fold_bn(self.conv_pwl, self.bn3)
-        return (hip_ops.pointwise_weight(we), be, _dw_tap_major(wd), bd, hip_ops.pointwise_weight(wl), bl) + _se_params(self.se)
+        # wl also as the plain fp32 matrix: the pre-split route folds the squeeze-excite gate into it per image
+        return (hip_ops.pointwise_weight(we), be, _dw_tap_major(wd), bd, hip_ops.pointwise_weight(wl), bl) + _se_params(self.se) + \
+            (wl.flatten(1).contiguous(),)
 
     def forward(self, x):
         if self._fast(x):
             # NHWC plan, 4 launches: expand 1x1 (+BN+SiLU) -> depthwise (+BN+SiLU, + pooling partials) -> gate ->
             # project 1x1 (+BN) with the gate applied to its input rows and the skip connection added in the epilogue
-            we, be, wd, bd, wl, bl, s1, sb1, s2, sb2 = self._folded(x)
-            k = self.conv_dw.kernel_size[0]
-            if hip_ops.expand_depthwise_fusable(x.shape[1], we, k):
+            we, be, wd, bd, wl, bl, s1, sb1, s2, sb2, wl_f32 = self._folded(x)
+            k, stride = self.conv_dw.kernel_size[0], self.conv_dw.stride[0]
+            B, cin, H, W = x.shape
+            mid, cout = self.conv_pw.out_channels, self.conv_pwl.out_channels
+            Ho, Wo = -(-H // stride), -(-W // stride)
+            split_w = isinstance(we, hip_ops.SplitWeight)
+            res = x if self.has_residual else None
+            # LATE STAGES (few rows, wide layers): the row operand of both 1x1 convolutions arrives PRE-SPLIT from its
+            # producer (hl32: the project epilogue of the block in front, the depthwise epilogue) and is read by LDS-DMA,
+            # the gate is folded into per-image project weights (csrc/pointwise_hl.hip); hip_ops decides per layer
+            emit_hl = split_w and hip_ops.pointwise_hl_expand_pays(B * Ho * Wo, cout, 6 * cout)      # for the block behind this one
+            if hip_ops.expand_depthwise_fusable(cin, we, k):
                 # 3 launches: the expanded tensor stays in LDS (csrc/mbconv_fused.hip)
-                y, g = hip_ops.expand_depthwise_se_gate(x, we, be, wd, bd, k, self.conv_dw.stride[0], s1, sb1, s2, sb2)
+                y, g = hip_ops.expand_depthwise_se_gate(x, we, be, wd, bd, k, stride, s1, sb1, s2, sb2)
+                out = hip_ops.pointwise_nhwc(y, wl, bl, hip_ops.ACT_NONE, gate=g, residual=res, out_split=emit_hl)
             else:
-                y = hip_ops.pointwise_nhwc(x, we, be, hip_ops.ACT_SILU)
-                y, g = hip_ops.depthwise_se_gate(y, wd, bd, k, self.conv_dw.stride[0], s1, sb1, s2, sb2)
-            return hip_ops.pointwise_nhwc(y, wl, bl, hip_ops.ACT_NONE, gate=g, residual=x if self.has_residual else None)
+                if split_w and hip_ops.pointwise_hl_expand_pays(B * H * W, cin, mid):
+                    x_hl = getattr(x, "_ocv_hl", None)
+                    if x_hl is None:
+                        x_hl = hip_ops.split_act(x)                     # first block of the region only
+                    y = hip_ops.pointwise_hl(x_hl, we, be, hip_ops.ACT_SILU)
+                else:
+                    y = hip_ops.pointwise_nhwc(x, we, be, hip_ops.ACT_SILU)
+                if split_w and hip_ops.pointwise_hl_project_pays(B, Ho * Wo, mid, cout):
+                    y_hl, wg = hip_ops.depthwise_se_gate_weights(y, wd, bd, k, stride, s1, sb1, s2, sb2, wl_f32)
+                    out = hip_ops.pointwise_hl(y_hl, wg, bl, hip_ops.ACT_NONE, residual=res, out_fp32=True, out_split=emit_hl)
+                else:
+                    y, g = hip_ops.depthwise_se_gate(y, wd, bd, k, stride, s1, sb1, s2, sb2)
+                    out = hip_ops.pointwise_nhwc(y, wl, bl, hip_ops.ACT_NONE, gate=g, residual=res, out_split=emit_hl)
+            if emit_hl:
+                out, out_hl = out
+                out._ocv_hl = out_hl              # rides along: the next block's expand / the decoder read it in place
+            return out
         y = self.act1(self.bn1(self.conv_pw(x)))
         y = self.act2(self.bn2(self.conv_dw(y)))
         y = self.bn3(self.conv_pwl(self.se(y)))

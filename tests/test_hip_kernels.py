@@ -235,6 +235,32 @@ def test_mha_fused_few_keys(ops, Sq, counts):
     assert rel_dev(torch.where(nan_ref, torch.zeros_like(got), got), torch.where(nan_ref, torch.zeros_like(full), full)) < TOL
 
 
+@pytest.mark.parametrize("Sq,Sk,counts,kv", [(300, 300, [32, 7, 1], 32), (45, 300, [5, 0], 5), (32, 40, [32], 32), (1, 132, [3, 3], 3),
+                                            (418, 418, [24] * 8, 24), (132, 132, [100, 3], 100), (77, 50, None, 0), (300, 1200, [1200, 640], 0)])
+def test_mha_split3(ops, Sq, Sk, counts, kv):
+    """ocv_mha_split3_fwd: packed three-term-split projections.  <= 32 live keys: K / V projected once per image + the fused
+    per-tile launch (ragged tiles, an image without a live key -> NaN rows as torch, V from another tensor than K, KITTI's
+    S = 418); more keys / no mask: split3 linears around the attention kernel (multi-chunk Sk).  Against the oracle at the
+    kernels' tolerance and against the exact-fp32 route."""
+    B, E = (len(counts) if counts else 2), 128
+    qs, ks, vs = rnd("qs", (B, Sq, E), 1), rnd("ks", (B, Sk, E), 2), rnd("vs", (B, Sk, E), 3)
+    iw, ib = rnd("iw", (3 * E, E), 4, 2 / math.sqrt(E)), rnd("ib", (3 * E,), 5, 0.1)
+    ow, ob = rnd("ow", (E, E), 6, 1 / math.sqrt(E)), rnd("ob", (E,), 7, 0.1)
+    mask = None if counts is None else torch.arange(Sk)[None, :] >= torch.tensor(counts)[:, None]
+    ref = restate.multi_head_attention(qs, ks, vs, iw, ib, ow, ob, mask)
+    args = (dev(qs), dev(ks), dev(vs), dev(iw), dev(ib), dev(ow), dev(ob), None if mask is None else dev(mask))
+    cache = {}
+    got = ops.mha(*args, kv_limit=kv, packed=cache).cpu()
+    assert set(cache) == {"in_proj_p3", "out_proj_p3"}
+    again = ops.mha(*args, kv_limit=kv, packed=cache).cpu()
+    exact = ops.mha(*args, kv_limit=kv).cpu()
+    nan_ref = torch.isnan(ref)
+    assert torch.equal(torch.isnan(got), nan_ref) and bool(nan_ref.any()) == bool(counts and 0 in counts)
+    z = lambda t: torch.where(nan_ref, torch.zeros_like(t), t)          # noqa: E731
+    assert rel_dev(z(got), z(ref)) < TOL and rel_dev(z(got), z(exact)) < TOL
+    assert torch.equal(z(got), z(again))
+
+
 def _encoder_sd(seed, prefix="layers."):
     import torch.nn as nn
     enc = nn.TransformerEncoder(nn.TransformerEncoderLayer(128, 4, 1024, batch_first=True), 4, enable_nested_tensor=False).eval()
@@ -604,6 +630,150 @@ def test_pointwise_nhwc_split_keeps_fp32_range(ops):
     ref = F.conv2d(x.double(), w.double()).float()
     got = ops.pointwise_nhwc(dev(x).contiguous(memory_format=torch.channels_last), ops.SplitWeight(dev(w)), None, 0)
     assert rel_dev(got, ref) < SPLIT_TOL
+
+
+def _to_split_act(ops, x):
+    """fp32 [B, C, H, W] -> SplitAct on the GPU (the resize kernel at scale 1), plus the value it holds (hi + lo)."""
+    s = ops.split_act(dev(x).contiguous(memory_format=torch.channels_last))
+    return s, s.float().cpu()
+
+
+@pytest.mark.parametrize("cfg", [(0, 0), (1, 1), (1, 2), (2, 1), (2, 2), (4, 1), (4, 2)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,act,use_res,outs", [
+    (2, 30, 40, 176, 1056, 3, False, "f"),      # stage-5 expand: K = 11 steps (3 slabs, last one short), 33 channel blocks
+    (2, 15, 20, 304, 1824, 3, False, "f"),      # stage-6 expand: Cp = 320 (5 hl32 blocks: half a slab at the end)
+    (1, 15, 20, 512, 3072, 3, False, "fs"),     # stage-7 expand, both outputs
+    (2, 30, 40, 1056, 176, 0, True, "fs"),      # project: ragged channel block (176 = 5.5 x 32), pad channels of the split copy
+    (3, 7, 9, 128, 304, 0, True, "s"),          # 63 rows per image, split output only (Cpo = 320)
+    (2, 9, 11, 136, 200, 4, True, "f"),         # Kp = 144 (Cin % 16 == 8), ragged everything, sigmoid
+    (1, 4, 5, 64, 36, 1, False, "f"),           # one slab, N = 36 (not a multiple of 8), ReLU
+])
+def test_pointwise_hl(ops, cfg, B, H, W, Cin, Cout, act, use_res, outs):
+    """ocv_pointwise_hl_fwd (pre-split rows by LDS-DMA) on every wavefront tile shape, pinned through
+    ocv_pointwise_hl_set_dispatch, against float64 of the same contraction; ragged M / N / K; fp32 and / or split output."""
+    x, w, b = rnd("x", (B, Cin, H, W), 1), rnd("w", (Cout, Cin, 1, 1), 2, 1 / math.sqrt(Cin)), rnd("b", (Cout,), 3, 0.2)
+    res = rnd("r", (B, Cout, H, W), 5) if use_res else None
+    xs, _ = _to_split_act(ops, x)
+    ref = F.conv2d(x.double(), w.double(), b.double())
+    ref = [ref, torch.relu(ref), F.leaky_relu(ref, 0.01), F.silu(ref), torch.sigmoid(ref)][act]
+    if res is not None:
+        ref = ref + res
+    cl = torch.channels_last
+    sw = ops.SplitWeight(dev(w))
+    kw = dict(residual=None if res is None else dev(res).contiguous(memory_format=cl), out_fp32="f" in outs, out_split="s" in outs)
+    lib = ops._lib.load()
+    try:
+        assert lib.ocv_pointwise_hl_set_dispatch(*cfg) == 0
+        got = ops.pointwise_hl(xs, sw, dev(b), act, **kw)
+        again = ops.pointwise_hl(xs, sw, dev(b), act, **kw)
+    finally:
+        lib.ocv_pointwise_hl_set_dispatch(0, 0)
+    y, ys = (got if outs == "fs" else (got, None)) if "f" in outs else (None, got)
+    y2, ys2 = (again if outs == "fs" else (again, None)) if "f" in outs else (None, again)
+    if y is not None:
+        assert y.shape == ref.shape and y.is_contiguous(memory_format=cl)
+        assert rel_dev(y, ref) < SPLIT_TOL and torch.equal(y, y2)
+    if ys is not None:
+        assert tuple(ys.shape) == tuple(ref.shape) and ys.hl.shape[-1] == 2 * ((Cout + 31) // 32 * 32)
+        assert rel_dev(ys.float(), ref) < SPLIT_TOL and torch.equal(ys.hl, ys2.hl)
+        if y is not None:                                              # the split copy is the split of the fp32 result
+            hi = y.to(torch.bfloat16)
+            assert torch.equal(ys.hi.contiguous(), hi) and torch.equal(ys.lo.contiguous(), (y - hi.float()).to(torch.bfloat16))
+        pad = ys.hl.view(B, H, W, -1, 2, 32)[..., Cout // 32:, :, :].reshape(B, H, W, -1) if Cout % 32 else None
+        if pad is not None:                                            # pad channels of the last block are written as zero
+            blk = ys.hl.view(B, H, W, -1, 2, 32)[:, :, :, Cout // 32]
+            assert float(blk[..., Cout % 32:].float().abs().max()) == 0.0
+    assert lib.ocv_pointwise_hl_set_dispatch(3, 1) == -1
+
+
+@pytest.mark.parametrize("panel", ["1,1,1", "1,2,3", "2,1,2", "2,2,1", "1,1,7"])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,act,use_res", [
+    (2, 30, 40, 176, 1056, 3, False),       # stage-5 expand: 3 slabs, 33 channel blocks (ragged over 4 wavefronts / the N split)
+    (1, 15, 20, 512, 3072, 3, False),       # K = 512: the largest panel (8 slabs)
+    (3, 7, 9, 136, 200, 4, True),           # 63 rows per launch... ragged rows, Kp = 144, 6.25 channel blocks, residual
+    (1, 3, 3, 64, 36, 0, False),            # 9 rows, one slab, two channel blocks for four wavefronts (idle wavefronts)
+])
+def test_pointwise_hl_row_panel(ops, monkeypatch, panel, B, H, W, Cin, Cout, act, use_res):
+    """The row-panel form of ocv_pointwise_hl_fwd (short K: a workgroup loads its rows once and walks the channel blocks),
+    every wavefront tile / N split pinned through OCV_PWHL_PANEL = "rt,tn,nsplit", against float64 and against the tile form."""
+    x, w, b = rnd("x", (B, Cin, H, W), 1), rnd("w", (Cout, Cin, 1, 1), 2, 1 / math.sqrt(Cin)), rnd("b", (Cout,), 3, 0.2)
+    res = rnd("r", (B, Cout, H, W), 5) if use_res else None
+    xs, _ = _to_split_act(ops, x)
+    ref = F.conv2d(x.double(), w.double(), b.double())
+    ref = [ref, torch.relu(ref), F.leaky_relu(ref, 0.01), F.silu(ref), torch.sigmoid(ref)][act]
+    if res is not None:
+        ref = ref + res
+    sw = ops.SplitWeight(dev(w))
+    kw = dict(residual=None if res is None else dev(res).contiguous(memory_format=torch.channels_last))
+    monkeypatch.setenv("OCV_PWHL_PANEL", panel)
+    got = ops.pointwise_hl(xs, sw, dev(b), act, **kw)
+    again = ops.pointwise_hl(xs, sw, dev(b), act, **kw)
+    monkeypatch.setenv("OCV_PWHL_PANEL", "0")
+    tile = ops.pointwise_hl(xs, sw, dev(b), act, **kw)
+    assert rel_dev(got, ref) < SPLIT_TOL and torch.equal(got, again)
+    assert torch.equal(got, tile)               # same K order, same products: the two forms agree bit for bit
+
+
+@pytest.mark.parametrize("cfg", [(0, 0), (1, 1), (2, 2), (4, 1)])
+@pytest.mark.parametrize("k,s,B,C,H,W,R,N", [(5, 1, 2, 1056, 30, 40, 44, 176), (3, 1, 3, 768, 9, 11, 32, 128),
+                                             (5, 2, 2, 96, 13, 17, 4, 24), (3, 2, 16, 384, 15, 20, 16, 128)])
+def test_depthwise_hl_gate_weights_project(ops, cfg, k, s, B, C, H, W, R, N):
+    """The late-stage MBConv tail on the pre-split route: depthwise + SiLU written ONCE in the hl32 layout, the
+    squeeze-excite gate folded into per-image packed project weights (ocv_se_gate_weights_fwd), the project 1x1 on the
+    LDS-DMA kernel with tiles that never span images -- against the definition (gate applied to the rows) in float64, and
+    piece by piece against the fp32-row kernels."""
+    x, w, b = rnd("x", (B, C, H, W), 1), rnd("w", (C, 1, k, k), 2, 0.3), rnd("b", (C,), 3, 0.2)
+    w1, b1 = rnd("w1", (R, C), 4, 1 / math.sqrt(C)), rnd("b1", (R,), 5, 0.3)
+    w2, b2 = rnd("w2", (C, R), 6, 1 / math.sqrt(R)), rnd("b2", (C,), 7, 0.3)
+    wp, bp = rnd("wp", (N, C), 8, 1 / math.sqrt(C)), rnd("bp", (N,), 9, 0.2)
+    d = F.silu(F.conv2d(_same_pad(x, k, s), w, b, stride=s, groups=C)).double()
+    gref = torch.sigmoid(F.silu(d.mean((2, 3)) @ w1.double().T + b1.double()) @ w2.double().T + b2.double())
+    res = rnd("r", (B, N, d.shape[2], d.shape[3]), 10)
+    ref = F.conv2d(d * gref[:, :, None, None], wp.double()[:, :, None, None], bp.double()) + res
+    args = (dev(x).contiguous(memory_format=torch.channels_last), dev(w).flatten(1).t().contiguous(), dev(b), k, s,
+            dev(w1), dev(b1), dev(w2).t().contiguous(), dev(b2))
+    y_fp32, g_fp32 = ops.depthwise_se_gate(*args)
+    ys, wg, gate = ops.depthwise_se_gate_weights(*args, dev(wp), want_gate=True)
+    # the split output is the split of the fp32 kernel's output, bit for bit; the gate equals the two-launch gate
+    hi = y_fp32.to(torch.bfloat16)
+    assert torch.equal(ys.hi.contiguous(), hi) and torch.equal(ys.lo.contiguous(), (y_fp32 - hi.float()).to(torch.bfloat16))
+    assert torch.equal(gate, g_fp32) and rel_dev(gate, gref) < TOL
+    # per-image packed weights = SplitWeight of W * diag(gate[b]), bit for bit
+    for i in (0, B - 1):
+        one = ops.SplitWeight(dev(wp) * gate[i][None, :])
+        assert torch.equal(wg.packed[i * wg.img_elems: i * wg.img_elems + one.packed.numel()], one.packed)
+    lib = ops._lib.load()
+    try:
+        assert lib.ocv_pointwise_hl_set_dispatch(*cfg) == 0
+        out, outs = ops.pointwise_hl(ys, wg, dev(bp), 0, residual=dev(res).contiguous(memory_format=torch.channels_last),
+                                     out_fp32=True, out_split=N % 8 == 0) if N % 8 == 0 else \
+            (ops.pointwise_hl(ys, wg, dev(bp), 0, residual=dev(res).contiguous(memory_format=torch.channels_last)), None)
+    finally:
+        lib.ocv_pointwise_hl_set_dispatch(0, 0)
+    assert rel_dev(out, ref) < SPLIT_TOL
+    if outs is not None:
+        assert rel_dev(outs.float(), ref) < SPLIT_TOL
+    # and the round-2 route (gate multiplied into fp32 rows by the consumer) agrees to the split tolerance
+    old = ops.pointwise_nhwc(y_fp32, ops.SplitWeight(dev(wp)), dev(bp), 0, gate=g_fp32,
+                             residual=dev(res).contiguous(memory_format=torch.channels_last))
+    assert rel_dev(out, old) < SPLIT_TOL
+
+
+def test_pointwise_nhwc_split_also_writes_the_split_copy(ops):
+    """ocv_pointwise_conv_nhwc_split_hl_fwd: the fp32-row kernel leaves the hl32 copy of its result for an LDS-DMA consumer."""
+    B, H, W, Cin, Cout = 2, 15, 20, 1824, 304
+    x, w, b = rnd("x", (B, Cin, H, W), 1), rnd("w", (Cout, Cin, 1, 1), 2, 1 / math.sqrt(Cin)), rnd("b", (Cout,), 3, 0.2)
+    g = torch.sigmoid(rnd("g", (B, Cin), 4))
+    res = dev(rnd("r", (B, Cout, H, W), 5)).contiguous(memory_format=torch.channels_last)
+    xg = dev(x).contiguous(memory_format=torch.channels_last)
+    sw = ops.SplitWeight(dev(w))
+    y0 = ops.pointwise_nhwc(xg, sw, dev(b), 0, gate=dev(g), residual=res)
+    y, ys = ops.pointwise_nhwc(xg, sw, dev(b), 0, gate=dev(g), residual=res, out_split=True)
+    assert torch.equal(y, y0)
+    hi = y.to(torch.bfloat16)
+    assert torch.equal(ys.hi.contiguous(), hi) and torch.equal(ys.lo.contiguous(), (y - hi.float()).to(torch.bfloat16))
+    blk = ys.hl.view(B, H, W, -1, 2, 32)[:, :, :, Cout // 32]
+    assert float(blk[..., Cout % 32:].float().abs().max()) == 0.0          # 304 = 9.5 blocks: the pad half-block is zero
 
 
 @pytest.mark.parametrize("B,Cin,H,W,Cout,stride,act", [
