@@ -12,4 +12,13 @@ dp.py       data-parallel sharding + the single metric all-gather
 Importing this package does not load the HIP library; the first kernel call
 does, and raises if the library or a GPU is missing (there is no CPU fallback).
 """
-__version__ = "0.1.0"
+import os as _os
+
+# ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4: the first two streams a process creates get
+# queues of their own, later ones share the last) and streams that share a queue run one after the other.  Several
+# GraphedGraphBins instances in flight (one stream each, bench.py --inflight) need queues of their own: measured 781 instead
+# of 840 img/s on shared queues.  Only a default, only effective when this package is imported before the HIP runtime
+# initialises (first GPU call); INTEGRATION.md says so too.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+__version__ = "0.3.0"

@@ -19,7 +19,9 @@
 // by the latency of those ~10 KB pieces and by how much of it other workgroups on the CU can cover, not by HBM bandwidth
 // (ablations, tools/diag/tap_interp_diag.patch: interpolation alone 0.43 ms, staging + epilogue alone 0.55 ms, together
 // 0.80 ms when every wavefront did both through registers at two workgroups per CU): the producer / consumer split keeps the
-// consumers at <= 128 registers, i.e. four workgroups per CU (LDS: ~37 KB each for a 2x up-sampling).  The x interpolation
+// consumers at 128 registers = 4 wavefronts per SIMD = THREE five-wavefront workgroups per CU (LDS: ~37 KB each for a 2x up-sampling; at
+// __launch_bounds__(320, 5) -- four workgroups -- the compiler spills 27 - 37 registers and the launch takes 1.9x as long, and removing the
+// kernel's LDS bank conflicts made it 9 % slower: profiles/r03_tap_interp_swizzle.txt).  The x interpolation
 // coefficients and LDS offsets depend on (pixel, dx) only and are formed once; the y ones per tap row.  The right-hand x
 // neighbour is always read at +128 bytes: where ATen clamps it (last column) its weight is exactly 0 and the slot read holds
 // staged (finite) data.

@@ -1110,8 +1110,8 @@ class PerImageSplitWeight:
 
 
 def pointwise_hl_mode() -> str:
-    """OCV_PW_HL: '1' (default) = the late encoder stages read pre-split rows by LDS-DMA where that pays
-    (modules/efficientnet.py decides per block), '0' = never (the fp32-row kernels of round 2: the A/B route)."""
+    """OCV_PW_HL: '1' (default) = the late encoder stages take the pre-split 1x1 route where it pays END TO END
+    (pointwise_hl_project_pays / pointwise_hl_expand_pays), '0' = never (the fp32-row kernels of round 2: the A/B route)."""
     mode = os.environ.get("OCV_PW_HL", "1")
     if mode not in ("0", "1"):
         raise ValueError(f"OCV_PW_HL={mode!r}: expected '1' (default) or '0'")
@@ -1119,10 +1119,14 @@ def pointwise_hl_mode() -> str:
 
 
 def pointwise_hl_expand_pays(M: int, cin: int, cout: int) -> bool:
-    """Whether a 1x1 convolution with M rows should read a pre-split (hl32) copy of its input by LDS-DMA
-    (ocv_pointwise_hl_fwd) instead of fp32 rows (measured at bs = 16, tools/run_pw_hl.py, profiles/r03_pointwise_hl_sweep.txt):
-    the late stages -- few rows, wide layers -- where the 32-row tile kernel re-converted every row N / 128 times."""
-    if pointwise_hl_mode() == "0" or cin % 8 != 0 or cout % 4 != 0:
+    """Whether an expand 1x1 convolution (and the project in front of it, which then also writes the hl32 copy) should take
+    the pre-split route.  OPT-IN (OCV_PW_HL_EXPAND=1): layer by layer, launched back to back, the LDS-DMA kernel is 2 - 11 us
+    faster on every late expand layer (profiles/r03_pointwise_hl_sweep.txt), but in the real forward the route LOSES:
+    bench.py --inflight 1, same box, two rounds: 915.7 / 914.2 img/s without it, 896.5 / 894.9 with every late expand layer on
+    it, 907.8 / 907.2 with stages 6 - 7 only, 914.8 / 915.1 with 512 -> 3072 only.  The fp32 rows the round-2 kernel reads
+    were written by the launch in front of it and are still in L2 / Infinity Cache, while the hl32 copy is a second output
+    stream for every project layer; the isolated timing sees neither."""
+    if pointwise_hl_mode() == "0" or os.environ.get("OCV_PW_HL_EXPAND", "0") != "1" or cin % 8 != 0 or cout % 4 != 0:
         return False
     return M <= int(os.environ.get("OCV_PW_HL_MAX_ROWS", "32768")) and cin >= int(os.environ.get("OCV_PW_HL_MIN_CIN", "96"))
 
@@ -1133,7 +1137,9 @@ def pointwise_hl_project_pays(B: int, rows_per_image: int, cin: int, cout: int) 
     late layer with K >= 1056 (1056 -> 176: 57 -> 46 us, 1824 -> 304: 42 -> 30, 3072 -> 512: 86 -> 71), but writing and
     re-reading B x Cout x Cin x 4 bytes of gated weights costs 6 us at 1200 rows per image (stage 5: 12 MB against 81 MB of
     rows) and 10 - 18 us at 300 rows (stages 6, 7: as many bytes as the rows themselves), which eats the gain there; at
-    K = 768 (stage 4) the GEMM does not gain.  So: long K and weights well under the rows' own traffic."""
+    K = 768 (stage 4) the GEMM does not gain.  So: long K and weights well under the rows' own traffic -- stage 5's six
+    1056 -> 176 blocks.  End to end (bench.py --inflight 1, same box, two rounds): 919.7 / 918.0 img/s with this route
+    against 915.7 / 914.2 without; with the stage 6 - 7 layers as well 889.5 / 888.5."""
     if pointwise_hl_mode() == "0" or cin % 32 != 0 or cout % 4 != 0:
         return False
     M = B * rows_per_image

@@ -319,7 +319,12 @@ class UpSampleWithSkip(nn.Module):
             sk = None
             if s_hi is not None:
                 # (an encoder block of the late stages leaves the split copy of its output beside it: read in place)
-                sks = getattr(skip_features, "_ocv_hl", None) or hip_ops.split_act(skip_features)
+                sks = getattr(skip_features, "_ocv_hl", None)
+                if sks is None:
+                    c2 = skip_features.shape[1]
+                    if c2 % 4:                       # 3-channel image: one zero channel more (the weight's pad columns are zero too)
+                        skip_features = F.pad(skip_features, (0, 0, 0, 0, 0, 4 - c2 % 4))
+                    sks = hip_ops.split_act(skip_features)
                 sk = hip_ops.conv_nhwc_split(sks, s_hi, s_lo, None, 3, hip_ops.ACT_NONE, out_fp32=True)
             f = hip_ops.tap_interp_combine(z, sk, b, (H, W), hip_ops.ACT_LEAKY_RELU, out_fp32=False, out_split=True, border=border)
         else:
@@ -331,8 +336,14 @@ class UpSampleWithSkip(nn.Module):
 
     def split_ready(self, x, skip_features) -> bool:
         c1, c2 = x.shape[1], skip_features.shape[1]
-        return (not self.training and not torch.is_grad_enabled() and x.device.type == "cuda" and split_bf16_convs_enabled()
-                and self._split1.usable(c1, c2) and (c1 + c2) % 8 == 0 and self._net[0].out_channels % 8 == 0)
+        if not (not self.training and not torch.is_grad_enabled() and x.device.type == "cuda" and split_bf16_convs_enabled()
+                and self._net[0].out_channels % 8 == 0):
+            return False
+        if self._split1.usable(c1, c2) and (c1 + c2) % 8 == 0:
+            return True
+        # skip channels the concatenating kernels do not take (the final_upscale stage's skip is the 3-channel IMAGE): in the
+        # low-resolution form the skip part is a convolution of its own, over the skip tensor zero-padded to 4 channels
+        return self._split1.usable(c1, 0) and self.lowres_ready(x, skip_features)
 
     def forward(self, x, skip_features):
         if self.split_ready(x, skip_features):
@@ -426,7 +437,7 @@ class Decoder(nn.Module):
         c = self.conv2
         x0 = b4.x if isinstance(b4, DeferredConv1x1) else b4
         if os.environ.get("OCV_UPCONV_FOLD", "1") == "0" or not (
-                x0.device.type == "cuda" and not self.training and not torch.is_grad_enabled() and self.final_upscale is None
+                x0.device.type == "cuda" and not self.training and not torch.is_grad_enabled()
                 and c.kernel_size == (1, 1) and c.padding == (1, 1) and c.stride == (1, 1) and c.groups == 1
                 and x0.dtype == torch.float32 and x0.shape[1] % 32 == 0):
             return None
@@ -464,8 +475,10 @@ class Decoder(nn.Module):
                 b4 = b4.materialize()
             x = self._conv2_padded_1x1(b4)
         stages = ((self.up1, b3), (self.up2, b2), (self.up3, b1), (self.up4, b0))
-        if (self.final_upscale is None and all(up.split_ready(x, skip) for up, skip in stages[:1])
-                and self._split3.usable(self.conv3.in_channels) and self.conv3.in_channels % 8 == 0):
+        fin = self.final_upscale
+        if (all(up.split_ready(x, skip) for up, skip in stages[:1])
+                and self._split3.usable(self.conv3.in_channels) and self.conv3.in_channels % 8 == 0
+                and (fin is None or fin.split_ready(_ShapeOnly(b0.shape[0], self.up4._net[3].out_channels, b0.shape[2], b0.shape[3], device=b0.device), features[0]))):
             # all-split pipeline: the last stage hands conv3 its input pre-split; conv3 returns the fp32 feature map
             # (patch embedding reads it) AND its split copy, which rides along for the heads' 3x3 convolution
             for i, (up, skip) in enumerate(stages[:-1]):
@@ -475,6 +488,10 @@ class Decoder(nn.Module):
                 x = up.forward_split(x, skip, out_fp32=not want_split, out_split=want_split,
                                      affine_of=affine[1] if i == 0 and affine is not None else None)
             xs = self.up4.forward_split(x, b0, out_fp32=False, out_split=True)
+            if fin is not None:
+                # do_final_upscale (reference :99-101,116-117): a fifth stage against the IMAGE, in the same low-resolution form
+                # (tap GEMM at half resolution, a 3 x 3 convolution over the image's three channels, tap interpolation)
+                xs = fin.forward_split(xs, features[0], out_fp32=False, out_split=True)
             out, out_split = self._split3.run_split(xs, hip_ops.ACT_NONE, out_fp32=True, out_split=True)
             out._ocv_split = out_split
             return out

@@ -320,6 +320,27 @@ def test_encoder_fast_path_vs_oracle(monkeypatch):
     assert rel_dev(separate, ref_out) < 1e-4 and not torch.equal(separate, whole)
 
 
+@pytest.mark.parametrize("env", [{"OCV_PW_HL": "0"}, {"OCV_PW_HL_EXPAND": "1"},
+                                 {"OCV_PW_HL_EXPAND": "1", "OCV_PW_HL_PROJECT_MIN_CIN": "256", "OCV_PW_HL_WEIGHT_RATIO": "0"}])
+def test_encoder_pre_split_pointwise_routes_vs_oracle(monkeypatch, env):
+    """The late MBConv stages on each 1x1 route: round 2's fp32-row kernels (OCV_PW_HL=0), the opt-in pre-split expand layers
+    (hl32 copies riding along between blocks, split_act of the region's first input), and every project layer with the
+    gate folded into per-image weights -- the five skip activations and the extractor's output against the oracle, at a
+    batch whose late stages have ragged row counts (7 x 9 and 4 x 5 pixels per image)."""
+    from oracle import effnet_ref
+    from objcavit_amd.modules.DenseFeatureExtractor import DenseFeatureExtractor
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    m = DenseFeatureExtractor(make_args()).eval()
+    sd = gen.load_into(m, 9)
+    img = gen.randn("img", (3, 3, 224, 288), 9)
+    ref = effnet_ref.encoder_features(img, sd, "encoder.original_model.")
+    feats = m.cuda().encoder(img.cuda())
+    for i in (4, 5, 6, 8, 11):
+        assert rel_dev(feats[i], ref[i]) < 1e-4, i
+    assert rel_dev(m(img.cuda()), restate.decoder_forward(ref, sd, "decoder.")) < 1e-4
+
+
 def test_final_upscale_variant_vs_oracle():
     """do_final_upscale=True (reference DenseFeatureExtractor.py:60,116-117): a fifth UpSampleWithSkip stage against the
     IMAGE (3 skip channels: the exact-fp32 convolution kernel takes what the split kernels do not), output at full
