@@ -283,134 +283,6 @@ __global__ __launch_bounds__(320) void pw_hl_kernel(PHArgs p) {
         ph_store_tile(p, acc[rt][j], scratch, m0 + rt * 32, rows_left - rt * 32, jt[j] * 32, lane);
 }
 
-// SHORT K (the expand layers: K = 128 ... 512, N = 6 K): the ROW PANEL form.  One pass load -> multiply -> store per
-// workgroup is a latency chain (prologue, first DMA round trip, epilogue) of ~10 us for ~0.3 us of MFMAs at K = 176, and
-// only the number of workgroups in flight hides it (profiles/r03_pointwise_hl_sweep.txt: 43 us for 95 MB, whatever the
-// tile).  Here a workgroup loads its 32 RT rows ONCE, all of K (<= 8 slabs, <= 64 KB for 32 rows), and its four
-// wavefronts then walk the channel blocks of the workgroup's share of N (blockIdx.y splits N when there are few row
-// panels) with NO further barrier: the weight ring keeps running across block boundaries, the epilogue of one block
-// (per-wavefront scratch, fire-and-forget stores) overlaps the next block's weight loads, and the chain is paid once
-// per panel instead of once per (panel, 128 channels).
-template <int RT, int TN>
-__global__ __launch_bounds__(320) void pw_panel_kernel(PHArgs p) {
-  constexpr int ROWS = 32 * RT;
-  constexpr int BUFB = ROWS * PH_SLABB;
-  constexpr int PIECES = ROWS / 4;
-  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bx = blockIdx.x, by = blockIdx.y;
-  const int img = bx / p.tiles_per_image, tl = bx - img * p.tiles_per_image;
-  const int r0 = tl * ROWS;
-  const int rows_left = min(ROWS, p.rows_per_image - r0);
-  const long m0 = (long)img * p.rows_per_image + r0;
-  const int nslab = (p.Cp + 63) >> 6;
-
-  if (wave == 4) {
-    const int lrow = lane >> 4, cst = lane & 15;
-    const unsigned rowb = (unsigned)p.Cp * 4u;
-    const char* xb = (const char*)p.xhl + m0 * (long)rowb;
-    for (int it = 0; it < nslab; ++it) {
-      unsigned char* base = lds + it * BUFB;
-      const unsigned kb = (unsigned)it * PH_SLABB;
-#pragma unroll
-      for (int i = 0; i < PIECES; ++i) {
-        const int row = 4 * i + lrow;
-        const unsigned cb = kb + (unsigned)((cst ^ (row & 15)) * 16);
-        const bool ok = row < rows_left && cb < rowb;
-        const void* src = ok ? (const void*)(xb + (long)row * rowb + cb) : (const void*)ocv_pwhl_zero_page;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + i * 1024), 16, 0, 0);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    return;
-  }
-
-  const int l31 = lane & 31, hh = lane >> 5;
-  const int nsteps = p.Kp >> 4, nst4 = 4 * nslab;
-  const int ntl_all = (p.N + 31) >> 5;
-  const int ngroups = (ntl_all + TN - 1) / TN;                        // groups of TN channel blocks
-  const int glo = (int)((long)ngroups * by / gridDim.y), ghi = (int)((long)ngroups * (by + 1) / gridDim.y);
-  const int cnt = (ghi - glo - wave + 3) >> 2;                         // groups glo + wave, glo + wave + 4, ... of this wavefront
-  const __bf16* wimg = p.wp + (long)img * p.w_img_elems + lane * 8;
-
-  bf16x8 bh[4][TN], bl[4][TN];
-  int pi = 0, ps = 0;                                                  // (group, step) the next weight load belongs to
-  auto load_next = [&](bf16x8 (&h)[TN], bf16x8 (&l)[TN]) {
-    const int g = glo + wave + 4 * min(pi, max(cnt - 1, 0));
-    const long so = (long)min(ps, nsteps - 1) * 1024;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const __bf16* f = wimg + ((long)min(g * TN + j, ntl_all - 1) * nsteps * 2) * 512 + so;
-      h[j] = ph_ldb8(f);
-      l[j] = ph_ldb8(f + 512);
-    }
-    if (++ps == nst4) { ps = 0; ++pi; }
-  };
-  load_next(bh[0], bl[0]);
-  load_next(bh[1], bl[1]);
-  load_next(bh[2], bl[2]);
-
-  const int key = l31 & 15;
-  const unsigned char* arow = lds + l31 * PH_SLABB;
-  int coff[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) coff[s] = ((((s >> 1) * 8 + (s & 1) * 2 + hh) ^ key) * 16);
-  float* scratch = reinterpret_cast<float*>(lds + (size_t)nslab * BUFB) + wave * PH_TSCRATCH;
-
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_barrier();                                       // the panel has landed
-  asm volatile("" ::: "memory");
-  for (int i = 0; i < cnt; ++i) {
-    const int g = glo + wave + 4 * i;
-    f32x16 acc[RT][TN];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[rt][j] = f32x16{0};
-    for (int it = 0; it < nslab; ++it) {
-      const unsigned char* base = arow + it * BUFB;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        load_next(bh[(s + 3) & 3], bl[(s + 3) & 3]);
-        bf16x8 ah[RT], al[RT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          ah[rt] = *reinterpret_cast<const bf16x8*>(base + rt * 32 * PH_SLABB + coff[s]);
-          al[rt] = *reinterpret_cast<const bf16x8*>(base + rt * 32 * PH_SLABB + (coff[s] ^ 64));
-        }
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[rt][j] = ph_mfma3(ah[rt], al[rt], bh[s][j], bl[s][j], acc[rt][j]);
-      }
-    }
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        if (g * TN + j < ntl_all && rt * 32 < rows_left)
-          ph_store_tile(p, acc[rt][j], scratch, m0 + rt * 32, rows_left - rt * 32, (g * TN + j) * 32, lane);
-  }
-}
-
-template <int RT, int TN>
-int launch_panel(PHArgs a, int nsplit, hipStream_t st) {
-  constexpr int ROWS = 32 * RT;
-  const int nslab = (a.Cp + 63) >> 6;
-  const size_t LDS = (size_t)nslab * ROWS * PH_SLABB + 4 * PH_TSCRATCH * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)pw_panel_kernel<RT, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
-  a.tiles_per_image = ocv_cdiv(a.rows_per_image, ROWS);
-  a.nbx = (int)(a.M / a.rows_per_image) * a.tiles_per_image;
-  hipLaunchKernelGGL((pw_panel_kernel<RT, TN>), dim3((unsigned)a.nbx, (unsigned)nsplit), dim3(320), LDS, st, a);
-  OCV_CHECK_LAUNCH("ocv_pointwise_hl_fwd(panel)");
-  return 0;
-}
-
 template <int RT, int TN, int NBUF>
 int launch_ph(PHArgs a, hipStream_t st) {
   constexpr int ROWS = 32 * RT;
@@ -479,29 +351,6 @@ extern "C" int ocv_pointwise_hl_fwd(const void* x_hl, int Cin, const void* w_pac
   // launches are bound by the latency of a workgroup's single pass load -> multiply -> store, and the most workgroups in
   // flight win, as they did for the fp32-row kernel.
   int rt = ph_cfg().rt, tn = ph_cfg().tn;
-  {
-    // row-panel form for short K (OCV_PWHL_PANEL = "0": never; "rt,tn,nsplit": that shape; default: automatic)
-    const char* e = getenv("OCV_PWHL_PANEL");
-    int prt = 0, ptn = 0, pns = 0;
-    const bool off = e != nullptr && strcmp(e, "0") == 0;
-    if (e != nullptr && !off && sscanf(e, "%d,%d,%d", &prt, &ptn, &pns) != 3) prt = ptn = pns = 0;
-    const int nslab = (Cp + 63) / 64;
-    if (!off && rt == 0 && nslab <= 8 && (prt != 0 || Cout >= 4 * Cin)) {
-      if (prt == 0) { prt = 1; ptn = 1; }
-      if (!((prt == 1 || prt == 2) && (ptn == 1 || ptn == 2)) || (size_t)nslab * 32 * prt * PH_SLABB + 4 * PH_TSCRATCH * 4 > 160 * 1024) { prt = 1; ptn = 1; }
-      const long panels = (a.M / a.rows_per_image) * ((a.rows_per_image + 32 * prt - 1) / (32 * prt));
-      const int groups = ((Cout + 31) / 32 + ptn - 1) / ptn;
-      if (pns <= 0) {                                       // split N until ~1000 workgroups, at least 2 groups per wavefront
-        pns = 1;
-        while (panels * pns < 1000 && groups / (pns * 2) >= 8) pns *= 2;
-      }
-      if (pns > groups) pns = groups;
-      if (prt == 1 && ptn == 1) return launch_panel<1, 1>(a, pns, st);
-      if (prt == 1 && ptn == 2) return launch_panel<1, 2>(a, pns, st);
-      if (prt == 2 && ptn == 1) return launch_panel<2, 1>(a, pns, st);
-      return launch_panel<2, 2>(a, pns, st);
-    }
-  }
   if (rt == 0) {
     if (Cin >= 512) { rt = 2; tn = Cout >= 512 ? 2 : 1; }
     else { rt = 1; tn = 1; }

@@ -686,34 +686,6 @@ def test_pointwise_hl(ops, cfg, B, H, W, Cin, Cout, act, use_res, outs):
     assert lib.ocv_pointwise_hl_set_dispatch(3, 1) == -1
 
 
-@pytest.mark.parametrize("panel", ["1,1,1", "1,2,3", "2,1,2", "2,2,1", "1,1,7"])
-@pytest.mark.parametrize("B,H,W,Cin,Cout,act,use_res", [
-    (2, 30, 40, 176, 1056, 3, False),       # stage-5 expand: 3 slabs, 33 channel blocks (ragged over 4 wavefronts / the N split)
-    (1, 15, 20, 512, 3072, 3, False),       # K = 512: the largest panel (8 slabs)
-    (3, 7, 9, 136, 200, 4, True),           # 63 rows per launch... ragged rows, Kp = 144, 6.25 channel blocks, residual
-    (1, 3, 3, 64, 36, 0, False),            # 9 rows, one slab, two channel blocks for four wavefronts (idle wavefronts)
-])
-def test_pointwise_hl_row_panel(ops, monkeypatch, panel, B, H, W, Cin, Cout, act, use_res):
-    """The row-panel form of ocv_pointwise_hl_fwd (short K: a workgroup loads its rows once and walks the channel blocks),
-    every wavefront tile / N split pinned through OCV_PWHL_PANEL = "rt,tn,nsplit", against float64 and against the tile form."""
-    x, w, b = rnd("x", (B, Cin, H, W), 1), rnd("w", (Cout, Cin, 1, 1), 2, 1 / math.sqrt(Cin)), rnd("b", (Cout,), 3, 0.2)
-    res = rnd("r", (B, Cout, H, W), 5) if use_res else None
-    xs, _ = _to_split_act(ops, x)
-    ref = F.conv2d(x.double(), w.double(), b.double())
-    ref = [ref, torch.relu(ref), F.leaky_relu(ref, 0.01), F.silu(ref), torch.sigmoid(ref)][act]
-    if res is not None:
-        ref = ref + res
-    sw = ops.SplitWeight(dev(w))
-    kw = dict(residual=None if res is None else dev(res).contiguous(memory_format=torch.channels_last))
-    monkeypatch.setenv("OCV_PWHL_PANEL", panel)
-    got = ops.pointwise_hl(xs, sw, dev(b), act, **kw)
-    again = ops.pointwise_hl(xs, sw, dev(b), act, **kw)
-    monkeypatch.setenv("OCV_PWHL_PANEL", "0")
-    tile = ops.pointwise_hl(xs, sw, dev(b), act, **kw)
-    assert rel_dev(got, ref) < SPLIT_TOL and torch.equal(got, again)
-    assert torch.equal(got, tile)               # same K order, same products: the two forms agree bit for bit
-
-
 @pytest.mark.parametrize("cfg", [(0, 0), (1, 1), (2, 2), (4, 1)])
 @pytest.mark.parametrize("k,s,B,C,H,W,R,N", [(5, 1, 2, 1056, 30, 40, 44, 176), (3, 1, 3, 768, 9, 11, 32, 128),
                                              (5, 2, 2, 96, 13, 17, 4, 24), (3, 2, 16, 384, 15, 20, 16, 128)])

@@ -54,14 +54,14 @@ for (M, Ci, Co, act, gate, res, n) in LAYERS:
     else:
         wq = sw
     row = []
-    os.environ["OCV_PWHL_PANEL"] = "0"                   # the tile form in this table; the panel form below
+
     for cfg in CFGS:
         lib.ocv_pointwise_hl_set_dispatch(*cfg)
         us = timeit(lambda: hip_ops.pointwise_hl(xs, wq, b, act, residual=r4, out_fp32=True, out_split=(Co % 8 == 0 and not act)))
         row.append(us)
         tot_new[cfg] += us * n
     lib.ocv_pointwise_hl_set_dispatch(0, 0)
-    if Co >= 4 * Ci:                                   # expand layers: the row-panel form, "rt,tn,nsplit" (0 = automatic split)
+    if Co >= 4 * Ci and os.environ.get("OCV_RUN_PANEL"):   # expand layers: the row-panel form (tools/diag/pointwise_row_panel.patch.txt applied), "rt,tn,nsplit"
         prow = []
         for pc in PANELS:
             os.environ["OCV_PWHL_PANEL"] = pc
