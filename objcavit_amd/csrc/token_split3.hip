@@ -20,6 +20,7 @@
 // Replace nn.Linear / nn.MultiheadAttention projections / linear1 + linear2 of nn.TransformerEncoderLayer at
 // modules/ObjCAViT.py:155-161,169,188 and modules/layers.py:8-9,23 (same lines as the fp32 kernels of csrc/linear.hip).
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.hpp"
 #include "../../include/objcavit_hip.h"
@@ -691,8 +692,9 @@ int ocv_cross_attn_split3_launch(const float* q_src, const float* k_src, const f
     attr = true;
   }
   XA3Args a{q_src, mask, kv_ws, (const __bf16*)in_p3, (const __bf16*)out_p3, in_b, out_b, out, Sq, Se, mask_ld, 1.0f / sqrtf(32.0f)};
+  const int tpi = ocv_cdiv(Sq, TM);
   const size_t lds = (size_t)3 * PLANE * sizeof(__bf16) + (size_t)(64 * XLD + 32) * sizeof(float);
-  hipLaunchKernelGGL(xattn_main3_kernel, dim3(ocv_cdiv(Sq, TM), B), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(xattn_main3_kernel, dim3(tpi, B), dim3(256), lds, st, a);
   OCV_CHECK_LAUNCH("ocv_mha_split3_fwd(fused)");
   return 0;
 }

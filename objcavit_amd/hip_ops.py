@@ -344,7 +344,11 @@ def mha(q_src: torch.Tensor, k_src: torch.Tensor, v_src: torch.Tensor, in_proj_w
     ws = workspace(nb, q_src.device)
     out = torch.empty(B, Sq, E, dtype=torch.float32, device=q_src.device)
     name = "mha_self" if q_src.data_ptr() == k_src.data_ptr() else ("mha_cross" if kv_limit else "mha_cross_full")
-    if packed is not None and token_split3_enabled() and E == 128 and n_heads == 4:
+    # few live keys AND few query tiles (the benchmark's bs = 16: 160 tiles): round 2's single exact-fp32 launch is as fast as the
+    # two split3 launches (22.5 vs 24.4 us -- both are one tile's latency chain, profiles/r03_cross_attention_roofline.txt);
+    # from a few hundred tiles on the split3 form wins (bs 64: 36 vs 62 us)
+    small = 0 < kv_limit <= 32 and B * ((Sq + 31) // 32) < int(os.environ.get("OCV_XATTN_SPLIT3_MIN_TILES", "384"))
+    if packed is not None and token_split3_enabled() and E == 128 and n_heads == 4 and not small:
         p3 = []
         for field, w in (("in_proj_p3", in_proj_w), ("out_proj_p3", out_w)):
             ver = (w.data_ptr(), w._version)

@@ -236,8 +236,9 @@ def test_mha_fused_few_keys(ops, Sq, counts):
 
 
 @pytest.mark.parametrize("Sq,Sk,counts,kv", [(300, 300, [32, 7, 1], 32), (45, 300, [5, 0], 5), (32, 40, [32], 32), (1, 132, [3, 3], 3),
-                                            (418, 418, [24] * 8, 24), (132, 132, [100, 3], 100), (77, 50, None, 0), (300, 1200, [1200, 640], 0)])
-def test_mha_split3(ops, Sq, Sk, counts, kv):
+                                            (418, 418, [24] * 8, 24), (132, 132, [100, 3], 100), (77, 50, None, 0), (300, 1200, [1200, 640], 0),
+                                            (300, 300, [(7 * i) % 33 for i in range(40)], 32)])
+def test_mha_split3(ops, monkeypatch, Sq, Sk, counts, kv):
     """ocv_mha_split3_fwd: packed three-term-split projections.  <= 32 live keys: K / V projected once per image + the fused
     per-tile launch (ragged tiles, an image without a live key -> NaN rows as torch, V from another tensor than K, KITTI's
     S = 418); more keys / no mask: split3 linears around the attention kernel (multi-chunk Sk).  Against the oracle at the
@@ -250,6 +251,7 @@ def test_mha_split3(ops, Sq, Sk, counts, kv):
     ref = restate.multi_head_attention(qs, ks, vs, iw, ib, ow, ob, mask)
     args = (dev(qs), dev(ks), dev(vs), dev(iw), dev(ib), dev(ow), dev(ob), None if mask is None else dev(mask))
     cache = {}
+    monkeypatch.setenv("OCV_XATTN_SPLIT3_MIN_TILES", "0")            # small launches default to the single exact-fp32 launch
     got = ops.mha(*args, kv_limit=kv, packed=cache).cpu()
     assert set(cache) == {"in_proj_p3", "out_proj_p3"}
     again = ops.mha(*args, kv_limit=kv, packed=cache).cpu()

@@ -6,8 +6,8 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/prof && mkdir -p gpurun_out/prof
 # per-kernel passes run with one batch in flight (kernels of different steps must not overlap in a per-step breakdown);
 # the first pass is the DEFAULT command (three batches in flight) and keeps rocprof's own per-kernel statistics of it
-B="bench.py --no-cpu-baseline --inflight 1"
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/kt_default -- python3 bench.py --no-cpu-baseline --steps 6 --warmup 2 > gpurun_out/prof/kt_default.log 2>&1 || exit 1
+B="bench.py --no-cpu-baseline --no-extras --inflight 1"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/kt_default -- python3 bench.py --no-cpu-baseline --no-extras --steps 6 --warmup 2 > gpurun_out/prof/kt_default.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/kt -- python3 $B --steps 3 --warmup 2 > gpurun_out/prof/kt.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof/pmc_fetch -- python3 $B --steps 2 --warmup 1 > gpurun_out/prof/pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof/pmc_write -- python3 $B --steps 2 --warmup 1 > gpurun_out/prof/pmc_write.log 2>&1 || exit 1

@@ -5,6 +5,7 @@ the HBM roofline for this kernel: the table says at which batch, if any, a launc
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+os.environ["OCV_XATTN_SPLIT3_MIN_TILES"] = "0"      # measure the split3 form at every batch
 from objcavit_amd import hip_ops
 E, H, N = 128, 4, 32
 torch.manual_seed(0)
