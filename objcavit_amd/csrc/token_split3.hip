@@ -532,43 +532,62 @@ struct XKV3Args {
   const float *k_src, *v_src;          // [B][Sk][128]
   const __bf16* in_p3;                 // packed in_proj_weight [384][128]
   const float* in_b;                   // [384]
-  float* kv;                           // [B][2][32][128]
+  float* kv;                           // [B][2][4 heads][64 lanes][16]: the fragments xattn_main3_kernel's lanes consume
   int Sk, Se;
 };
 
+// The record is written in the ORDER THE QUERY TILES' LANES READ IT (round 3b): K projected transposed (weights as the A
+// operand, like Q below), so lane (key l31, half hh) of wavefront h holds K[key][32 h + acc_row(r, hh)], r = 0..15 -- the 16
+// A-operand values of its 16 score MFMAs; V projected straight, so lane (d l31, half hh) holds V[acc_row(r, hh)][32 h + d] --
+// the A operands of its 16 context MFMAs.  Each lane stores 64 contiguous bytes, the query tiles load them back with four
+// 16-byte loads per operand and K / V never pass through LDS (the tiled form parked the record at a 129-float row pitch:
+// 33 KB of LDS and 32 four-way-conflicting scalar stores per thread and tile, which held the kernel at two workgroups per CU).
 __global__ __launch_bounds__(256) void xattn_kv3_kernel(XKV3Args p) {
   __shared__ __attribute__((aligned(16))) __bf16 planes[3 * PLANE];
   const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
   const long b = blockIdx.x;
-  const int col = h * 32 + l31;
+  const bool is_v = blockIdx.y != 0;                  // one workgroup per image and operand: two short chains instead of one long
   constexpr int NS = E128 / 16;
-  WFrag3 fk, fv;
-  load_w3(fk, p.in_p3 + ((long)(4 + h) * NS * 3) * 512 + lane * 8, NS);          // Wk rows of head h
-  stage_rows3(planes, p.k_src + b * p.Sk * E128, E128, 0, p.Se, 0, E128, tid);
-  load_w3(fv, p.in_p3 + ((long)(8 + h) * NS * 3) * 512 + lane * 8, NS);          // Wv, in flight during the K projection
+  WFrag3 f;
+  load_w3(f, p.in_p3 + ((long)((is_v ? 8 : 4) + h) * NS * 3) * 512 + lane * 8, NS);   // Wk / Wv rows of head h
+  stage_rows3(planes, (is_v ? p.v_src : p.k_src) + b * p.Sk * E128, E128, 0, p.Se, 0, E128, tid);
   __syncthreads();
-  f32x16 ak = {0};
-  ak = chunk_mfma3(ak, planes, fk, NS, l31, hh);
-  const float bk = p.in_b[E128 + col];
-  float* kd = p.kv + (b * 2 * 32) * E128 + col;
+  float* d = p.kv + (((b * 2 + (is_v ? 1 : 0)) * 4 + h) * 64 + lane) * 16;
+  f32x16 a = {0};
+  if (!is_v) {
+    // K^T of head h: D[d][key] = sum_k Wk[32 h + d][k] X[key][k]
+    const __bf16* pa = planes + l31 * PROW + 8 * hh;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) kd[(long)acc_row(r, hh) * E128] = ak[r] + bk;
-  __syncthreads();                                                               // every wavefront is done with the key rows
-  stage_rows3(planes, p.v_src + b * p.Sk * E128, E128, 0, p.Se, 0, E128, tid);
-  __syncthreads();
-  f32x16 av = {0};
-  av = chunk_mfma3(av, planes, fv, NS, l31, hh);
-  const float bv = p.in_b[2 * E128 + col];
-  float* vd = kd + 32 * E128;
+    for (int st = 0; st < NS; ++st) {
+      const bf16x8 xh = *reinterpret_cast<const bf16x8*>(pa + 16 * st);
+      const bf16x8 xm = *reinterpret_cast<const bf16x8*>(pa + 16 * st + PLANE);
+      const bf16x8 xl = *reinterpret_cast<const bf16x8*>(pa + 16 * st + 2 * PLANE);
+      a = mfma6(f.w[st][0], f.w[st][1], f.w[st][2], xh, xm, xl, a);
+    }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) vd[(long)acc_row(r, hh) * E128] = av[r] + bv;
+    for (int r = 0; r < 16; ++r) a[r] += p.in_b[E128 + h * 32 + acc_row(r, hh)];
+  } else {
+    const __bf16* pa = planes + l31 * PROW + 8 * hh;
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      const bf16x8 ah = *reinterpret_cast<const bf16x8*>(pa + 16 * st);
+      const bf16x8 am = *reinterpret_cast<const bf16x8*>(pa + 16 * st + PLANE);
+      const bf16x8 al = *reinterpret_cast<const bf16x8*>(pa + 16 * st + 2 * PLANE);
+      a = mfma6(ah, am, al, f.w[st][0], f.w[st][1], f.w[st][2], a);
+    }
+    const float bv = p.in_b[2 * E128 + h * 32 + l31];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] += bv;
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(d + 4 * g) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
 }
 
 struct XA3Args {
   const float* q_src;                  // [B][Sq][128]
   const uint8_t* mask;                 // [B][mask_ld] (nullable)
-  const float* kv;                     // [B][2][32][128] from xattn_kv3_kernel
+  const float* kv;                     // [B][2][4][64][16] from xattn_kv3_kernel
   const __bf16 *in_p3, *out_p3;
   const float *in_b, *out_b;
   float* out;                          // [B][Sq][128]
@@ -576,102 +595,139 @@ struct XA3Args {
   float scale;
 };
 
-constexpr int XLD = E128 + 1;          // floats per K / V row in LDS: column reads of 32 rows hit 32 banks
-
-__global__ __launch_bounds__(256) void xattn_main3_kernel(XA3Args p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char xa3_lds[];
-  __bf16* planes = reinterpret_cast<__bf16*>(xa3_lds);                            // query rows, later the context rows (3 planes)
-  float (*Ks)[XLD] = reinterpret_cast<float (*)[XLD]>(xa3_lds + 3 * PLANE * sizeof(__bf16));
-  float (*Vs)[XLD] = Ks + 32;
-  float* Ms = reinterpret_cast<float*>(Vs + 32);
+// One workgroup = NSUB sub-tiles of 32 queries on ONE load of the weight fragments.  What a tile costs (ablation builds at bs
+// 512, profiles/r03_cross_attention_roofline.txt): the two 24 KB fragment sets per wavefront are 192 KB per workgroup through
+// the CU's 64 B/clk vector-memory path = 3.1 K cycles, beside 5.1 K of matrix-pipe time -- NSUB = 2 halves the former per query.
+// Both projections run TRANSPOSED (weights = A operand): Q^T's accumulator is the score MFMAs' B operand, and the output's
+// accumulator holds four consecutive columns of one query row per register quad -> 16-byte stores (sixteen 4-byte stores per
+// lane cost 1.9 K cycles of store issue per tile).
+template <int NSUB>
+__global__ __launch_bounds__(256, 3) void xattn_main3_kernel(XA3Args p) {
+  __shared__ __attribute__((aligned(16))) __bf16 planes[NSUB * 3 * PLANE];       // query rows, later the context rows (3 planes each)
+  __shared__ float Ms[32];
   const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
   const long b = blockIdx.y;
-  const int q0 = blockIdx.x * TM;
+  const int q0 = blockIdx.x * TM * NSUB;
   constexpr float NEG_INF = -__builtin_inff();
   constexpr int NS = E128 / 16;
 
-  // the image's K / V record: 2 x 32 x 128 floats, 8 float4 per thread, requested first (L2), parked in LDS below
-  const float* kvb = p.kv + b * 2 * 32 * E128;
-  float4 kvr[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) kvr[i] = ld4(kvb + (long)(tid + 256 * i) * 4);
   WFrag3 fq;
   load_w3(fq, p.in_p3 + ((long)h * NS * 3) * 512 + lane * 8, NS);                // Wq rows of head h
-  stage_rows3(planes, p.q_src + b * p.Sq * E128, E128, q0, p.Sq, 0, E128, tid);
-  if (tid < 32) Ms[tid] = (tid >= p.Se || (p.mask != nullptr && p.mask[b * p.mask_ld + tid] != 0)) ? NEG_INF : 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int e = (tid + 256 * i) * 4;                                            // element of the [2][32][128] record
-    float* d = &Ks[0][0] + (e >> 7) * XLD + (e & 127);                            // Ks and Vs are contiguous: row e / 128 of 64
-    d[0] = kvr[i].x; d[1] = kvr[i].y; d[2] = kvr[i].z; d[3] = kvr[i].w;
+  for (int u = 0; u < NSUB; ++u) stage_rows3(planes + u * 3 * PLANE, p.q_src + b * p.Sq * E128, E128, q0 + u * TM, p.Sq, 0, E128, tid);
+  if (tid < 32) Ms[tid] = (tid >= p.Se || (p.mask != nullptr && p.mask[b * p.mask_ld + tid] != 0)) ? NEG_INF : 0.f;
+  const float* kf = p.kv + ((b * 2 * 4 + h) * 64 + lane) * 16;                  // this lane's 16 K and 16 V operands (L2)
+  float4 kr[4], vr[4];
+  if (NSUB == 1) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) kr[g] = ld4(kf + 4 * g);                         // in flight under the Q projection
   }
   __syncthreads();
 
   // Q^T of head h: D[d][query] = sum_k Wq[32 h + d][k] X[query][k]  (weight fragment = A operand, row fragment = B operand)
-  f32x16 q = {0};
-  {
-    const __bf16* pa = planes + l31 * PROW + 8 * hh;
+  f32x16 q[NSUB];
+#pragma unroll
+  for (int u = 0; u < NSUB; ++u) {
+    q[u] = f32x16{0};
+    const __bf16* pa = planes + u * 3 * PLANE + l31 * PROW + 8 * hh;
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
       const bf16x8 xh = *reinterpret_cast<const bf16x8*>(pa + 16 * st);
       const bf16x8 xm = *reinterpret_cast<const bf16x8*>(pa + 16 * st + PLANE);
       const bf16x8 xl = *reinterpret_cast<const bf16x8*>(pa + 16 * st + 2 * PLANE);
-      q = mfma6(fq.w[st][0], fq.w[st][1], fq.w[st][2], xh, xm, xl, q);
+      q[u] = mfma6(fq.w[st][0], fq.w[st][1], fq.w[st][2], xh, xm, xl, q[u]);
+    }
+  }
+  if (NSUB > 1) {                                                                 // two query accumulators live: K after them
+#pragma unroll
+    for (int g = 0; g < 4; ++g) kr[g] = ld4(kf + 4 * g);
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) vr[g] = ld4(kf + 4 * 64 * 16 + 4 * g);            // V operands: under the score MFMAs
+  float4 bq[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bq[g] = ld4(p.in_b + h * 32 + 8 * g + 4 * hh);    // bias of rows acc_row(4 g .. 4 g + 3, hh)
+  __syncthreads();                                   // every wavefront has read the query planes: they may take the context
+#pragma unroll
+  for (int u = 0; u < NSUB; ++u) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      q[u][4 * g] = (q[u][4 * g] + bq[g].x) * p.scale;
+      q[u][4 * g + 1] = (q[u][4 * g + 1] + bq[g].y) * p.scale;
+      q[u][4 * g + 2] = (q[u][4 * g + 2] + bq[g].z) * p.scale;
+      q[u][4 * g + 3] = (q[u][4 * g + 3] + bq[g].w) * p.scale;
     }
   }
   WFrag3 fo;
-  load_w3(fo, p.out_p3 + ((long)h * NS * 3) * 512 + lane * 8, NS);               // Wo rows 32 h ..: in flight from here on
+  const float kop[16] = {kr[0].x, kr[0].y, kr[0].z, kr[0].w, kr[1].x, kr[1].y, kr[1].z, kr[1].w,
+                         kr[2].x, kr[2].y, kr[2].z, kr[2].w, kr[3].x, kr[3].y, kr[3].z, kr[3].w};
+  const float vop[16] = {vr[0].x, vr[0].y, vr[0].z, vr[0].w, vr[1].x, vr[1].y, vr[1].z, vr[1].w,
+                         vr[2].x, vr[2].y, vr[2].z, vr[2].w, vr[3].x, vr[3].y, vr[3].z, vr[3].w};
 #pragma unroll
-  for (int r = 0; r < 16; ++r) q[r] = (q[r] + p.in_b[h * 32 + acc_row(r, hh)]) * p.scale;
-  __syncthreads();                                   // every wavefront has read the query planes: they may take the context
-
-  // scores^T (rows = keys, columns = queries): step st contracts d = acc_row(st, 0 | 1) -- register st of q IS the B operand
-  f32x16 s = {0};
+  for (int u = 0; u < NSUB; ++u) {
+    // scores^T (rows = keys, columns = queries): step st contracts d = acc_row(st, 0 | 1) -- register st of q IS the B operand
+    f32x16 s = {0};
 #pragma unroll
-  for (int st = 0; st < 16; ++st) s = mfma_32x32x2(Ks[l31][h * 32 + acc_row(st, hh)], q[st], s);
-  float tmax = NEG_INF;
+    for (int st = 0; st < 16; ++st) s = mfma_32x32x2(kop[st], q[u][st], s);
+    // Wo rows 32 h ..: requested once no query accumulator is live any more, in flight under the last softmax / context
+    if (u == NSUB - 1) load_w3(fo, p.out_p3 + ((long)h * NS * 3) * 512 + lane * 8, NS);
+    float tmax = NEG_INF;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    s[r] += Ms[acc_row(r, hh)];
-    tmax = fmaxf(tmax, s[r]);
+    for (int r = 0; r < 16; ++r) {
+      s[r] += Ms[acc_row(r, hh)];
+      tmax = fmaxf(tmax, s[r]);
+    }
+    tmax = xor32_max(tmax);
+    const bool none = tmax == NEG_INF;               // every key masked for this image: 0 / 0 = NaN, as torch
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pr = none ? 0.f : fast_exp(s[r] - tmax);
+      s[r] = pr;
+      psum += pr;
+    }
+    const float inv = 1.0f / xor32_sum(psum);
+    f32x16 o = {0};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o = mfma_32x32x2(vop[r], s[r], o);
+    // o: register r = context[query l31][d = acc_row(r, hh)] of head h -> three-term planes, row = query, column 32 h + d
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = o[r] * inv;
+      const __bf16 a = (__bf16)v;
+      const float r1 = v - (float)a;
+      const __bf16 m = (__bf16)r1;
+      __bf16* d = planes + u * 3 * PLANE + l31 * PROW + h * 32 + acc_row(r, hh);
+      d[0] = a;
+      d[PLANE] = m;
+      d[2 * PLANE] = (__bf16)(r1 - (float)m);
+    }
   }
-  tmax = xor32_max(tmax);
-  const bool none = tmax == NEG_INF;                 // every key masked for this image: 0 / 0 = NaN, as torch
-  float psum = 0.f;
+  float4 bo[4];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const float pr = none ? 0.f : fast_exp(s[r] - tmax);
-    s[r] = pr;
-    psum += pr;
-  }
-  const float inv = 1.0f / xor32_sum(psum);
-  f32x16 o = {0};
-#pragma unroll
-  for (int r = 0; r < 16; ++r) o = mfma_32x32x2(Vs[acc_row(r, hh)][h * 32 + l31], s[r], o);
-  // o: register r = context[query l31][d = acc_row(r, hh)] of head h -> three-term planes, row = query, column 32 h + d
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const float v = o[r] * inv;
-    const __bf16 a = (__bf16)v;
-    const float r1 = v - (float)a;
-    const __bf16 m = (__bf16)r1;
-    __bf16* d = planes + l31 * PROW + h * 32 + acc_row(r, hh);
-    d[0] = a;
-    d[PLANE] = m;
-    d[2 * PLANE] = (__bf16)(r1 - (float)m);
-  }
+  for (int g = 0; g < 4; ++g) bo[g] = ld4(p.out_b + h * 32 + 8 * g + 4 * hh);
   __syncthreads();
 
-  // output projection, 32 columns per wavefront
-  f32x16 acc = {0};
-  acc = chunk_mfma3(acc, planes, fo, NS, l31, hh);
-  const int col = h * 32 + l31;
-  const float bo = p.out_b[col];
+  // output projection TRANSPOSED, 32 columns per wavefront: register 4 g + j = out[query l31][32 h + 8 g + 4 hh + j]
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int qi = q0 + acc_row(r, hh);
-    if (qi < p.Sq) p.out[(b * p.Sq + qi) * E128 + col] = acc[r] + bo;
+  for (int u = 0; u < NSUB; ++u) {
+    f32x16 acc = {0};
+    const __bf16* pa = planes + u * 3 * PLANE + l31 * PROW + 8 * hh;
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      const bf16x8 ch = *reinterpret_cast<const bf16x8*>(pa + 16 * st);
+      const bf16x8 cm = *reinterpret_cast<const bf16x8*>(pa + 16 * st + PLANE);
+      const bf16x8 cl = *reinterpret_cast<const bf16x8*>(pa + 16 * st + 2 * PLANE);
+      acc = mfma6(fo.w[st][0], fo.w[st][1], fo.w[st][2], ch, cm, cl, acc);
+    }
+    const int qi = q0 + u * TM + l31;
+    if (qi < p.Sq) {
+      float* od = p.out + (b * p.Sq + qi) * E128 + h * 32 + 4 * hh;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(od + 8 * g) = make_float4(acc[4 * g] + bo[g].x, acc[4 * g + 1] + bo[g].y, acc[4 * g + 2] + bo[g].z, acc[4 * g + 3] + bo[g].w);
+    }
   }
 }
 
@@ -682,19 +738,21 @@ int ocv_cross_attn_split3_launch(const float* q_src, const float* k_src, const f
                                  const void* in_p3, const float* in_b, const void* out_p3, const float* out_b, float* out,
                                  float* kv_ws, int B, int Sq, int Sk, int Se, int E, int H, hipStream_t st) {
   if (E != E128 || H != 4 || Se < 1 || Se > 32 || B > 65535) return 1;
-  if (!(ocv_aligned16(q_src) && ocv_aligned16(k_src) && ocv_aligned16(v_src) && ocv_aligned16(in_p3) && ocv_aligned16(out_p3) && ocv_aligned16(kv_ws))) return 1;
+  if (!(ocv_aligned16(q_src) && ocv_aligned16(k_src) && ocv_aligned16(v_src) && ocv_aligned16(in_p3) && ocv_aligned16(out_p3) && ocv_aligned16(kv_ws) &&
+        ocv_aligned16(in_b) && ocv_aligned16(out_b) && ocv_aligned16(out))) return 1;
   XKV3Args ka{k_src, v_src, (const __bf16*)in_p3, in_b, kv_ws, Sk, Se};
-  hipLaunchKernelGGL(xattn_kv3_kernel, dim3(B), dim3(256), 0, st, ka);
+  hipLaunchKernelGGL(xattn_kv3_kernel, dim3(B, 2), dim3(256), 0, st, ka);
   OCV_CHECK_LAUNCH("ocv_mha_split3_fwd(K / V projection)");
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)xattn_main3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
   XA3Args a{q_src, mask, kv_ws, (const __bf16*)in_p3, (const __bf16*)out_p3, in_b, out_b, out, Sq, Se, mask_ld, 1.0f / sqrtf(32.0f)};
-  const int tpi = ocv_cdiv(Sq, TM);
-  const size_t lds = (size_t)3 * PLANE * sizeof(__bf16) + (size_t)(64 * XLD + 32) * sizeof(float);
-  hipLaunchKernelGGL(xattn_main3_kernel, dim3(tpi, B), dim3(256), lds, st, a);
+  // two sub-tiles per workgroup once the 64-query workgroups alone fill the chip several times over (256 CUs x 3 resident):
+  // 110 against 117 us at bs 512, S = 300; slower below (bs 128: 44.9 against 41.8 us)
+  static const int forced = getenv("OCV_XATTN_NSUB") ? atoi(getenv("OCV_XATTN_NSUB")) : 0;
+  const long wg64 = (long)ocv_cdiv(Sq, 2 * TM) * B;
+  const int nsub = forced == 1 || forced == 2 ? forced : (wg64 >= 2048 ? 2 : 1);
+  if (nsub == 2)
+    hipLaunchKernelGGL(xattn_main3_kernel<2>, dim3(ocv_cdiv(Sq, 2 * TM), B), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(xattn_main3_kernel<1>, dim3(ocv_cdiv(Sq, TM), B), dim3(256), 0, st, a);
   OCV_CHECK_LAUNCH("ocv_mha_split3_fwd(fused)");
   return 0;
 }

@@ -344,10 +344,11 @@ def mha(q_src: torch.Tensor, k_src: torch.Tensor, v_src: torch.Tensor, in_proj_w
     ws = workspace(nb, q_src.device)
     out = torch.empty(B, Sq, E, dtype=torch.float32, device=q_src.device)
     name = "mha_self" if q_src.data_ptr() == k_src.data_ptr() else ("mha_cross" if kv_limit else "mha_cross_full")
-    # few live keys AND few query tiles (the benchmark's bs = 16: 160 tiles): round 2's single exact-fp32 launch is as fast as the
-    # two split3 launches (22.5 vs 24.4 us -- both are one tile's latency chain, profiles/r03_cross_attention_roofline.txt);
-    # from a few hundred tiles on the split3 form wins (bs 64: 36 vs 62 us)
-    small = 0 < kv_limit <= 32 and B * ((Sq + 31) // 32) < int(os.environ.get("OCV_XATTN_SPLIT3_MIN_TILES", "384"))
+    # few live keys AND few query tiles: round 3's first split3 form tied with round 2's single exact-fp32 launch at the benchmark's
+    # bs = 16 (160 tiles: both one tile's latency chain) and kept it below 384 tiles; with the K / V record in operand order and the
+    # transposed output projection the split3 launches win at every size (bs 16: 19.9 vs 22.6 us, bs 64: 31 vs 63 us --
+    # profiles/r03_cross_attention_roofline.txt), so the threshold defaults to 0 and stays as the A/B switch
+    small = 0 < kv_limit <= 32 and B * ((Sq + 31) // 32) < int(os.environ.get("OCV_XATTN_SPLIT3_MIN_TILES", "0"))
     if packed is not None and token_split3_enabled() and E == 128 and n_heads == 4 and not small:
         p3 = []
         for field, w in (("in_proj_p3", in_proj_w), ("out_proj_p3", out_w)):
