@@ -637,7 +637,7 @@ def main():
             "value": value, "unit": "images/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "stub" if a.stub_cpu else "f32 (bf16x3 split contractions)",
+            "dtype": "stub" if a.stub_cpu else "f32 (bf16 / fp16 split contractions)",
             "data": "stub" if a.stub_cpu else "synthetic",
             # like-for-like with round 1 and with a caller that submits one batch at a time: value_sequential;
             # `value` is the timed region as the driver clocks it (= value_pipelined when inflight > 1)

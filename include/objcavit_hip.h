@@ -105,12 +105,30 @@ int ocv_mha_fwd(const float* q_src, const float* k_src, const float* v_src, cons
 /* ocv_mha_fwd with the four projections as three-term bf16 splits (fp32-faithful; weights packed once by
  * ocv_pack_split3_fwd: in_proj_p3 = packed in_proj_weight [3E, E], out_proj_p3 = packed out_proj.weight [E, E]); QK^T and
  * PV stay on exact fp32 MFMA.  With at most 32 live keys (the image <- object cross-attention, modules/ObjCAViT.py:192-201)
- * K and V are projected ONCE per image (a [B][2][32][E] record in the workspace) and every 32-query tile is one fused launch
+ * K and V are projected ONCE per image (a 32 KB record per image in the workspace, in the order the query tiles' lanes read it) and every 32-query tile is one fused launch
  * reading it; otherwise split3 linears around ocv_attention_fwd.  Same workspace size as ocv_mha_fwd. */
 int ocv_mha_split3_fwd(const float* q_src, const float* k_src, const float* v_src, const uint8_t* key_padding_mask,
                        const void* in_proj_p3, const float* in_proj_b, const void* out_proj_p3, const float* out_b, float* out,
                        int B, int Sq, int Sk, int kv_limit, int E, int H, void* workspace, size_t workspace_bytes,
                        ocv_stream_t stream);
+
+/* nn.MultiheadAttention forward with AT MOST 32 LIVE KEYS per image (kv_limit, or Sk itself, <= 32; E = 128, H = 4: the image <-
+ * object cross-attention, modules/ObjCAViT.py:192-201) with EVERY contraction -- the four projections, Q K^T and P V -- as a
+ * two-term fp16 split: x = hi + 2^-11 lo', hi = fp16(x), lo' = fp16((x - hi) 2^11), three v_mfma_f32_32x32x16_f16 per product
+ * block (hi hi into one accumulator, hi lo' + lo' hi into a second that is added scaled by 2^-11); products carry 22 bits,
+ * measured error = that of an fp32 FMA chain.  fp16's range applies: an activation beyond +-65504 turns its output rows inf / NaN
+ * (packed weights saturate there); ocv_mha_split3_fwd has fp32's range.
+ *   ocv_pack_split_h2_fwd: W [N][K] fp32 -> ocv_split_h2_packed_elems(N, K) fp16, 16-byte aligned, laid out
+ *     packed[((jt * nsteps + s) * 2 + part) * 512 + lane * 8 + e] = part(W[32 jt + (lane & 31)][16 s + 8 (lane >> 5) + e]).
+ *   in_proj_h2 / out_proj_h2 = packed in_proj_weight [3E, E] / out_proj.weight [E, E]; workspace: the K / V record,
+ *   ocv_mha_few_keys_h2_workspace_bytes(B); every pointer 16-byte aligned; two launches. */
+size_t ocv_split_h2_packed_elems(int N, int K);
+int ocv_pack_split_h2_fwd(const float* W, int ldw, int N, int K, void* packed, ocv_stream_t stream);
+size_t ocv_mha_few_keys_h2_workspace_bytes(int B);
+int ocv_mha_few_keys_h2_fwd(const float* q_src, const float* k_src, const float* v_src, const uint8_t* key_padding_mask,
+                            const void* in_proj_h2, const float* in_proj_b, const void* out_proj_h2, const float* out_b,
+                            float* out, int B, int Sq, int Sk, int kv_limit, int E, int H, void* workspace,
+                            size_t workspace_bytes, ocv_stream_t stream);
 
 /* One post-norm nn.TransformerEncoderLayer(E=128, H=4, FF, relu, eps) in eval mode on x [B,S,E] (dense):
  *   x1 = LN1(x + MHA(x, x, x, mask));  out = LN2(x1 + W2 relu(W1 x1 + b1) + b2)

@@ -327,8 +327,9 @@ def mha(q_src: torch.Tensor, k_src: torch.Tensor, v_src: torch.Tensor, in_proj_w
     """nn.MultiheadAttention(batch_first=True, need_weights=False) forward.
     kv_limit > 0: the caller guarantees every key j >= kv_limit is masked in every row, so those keys are skipped.
     ``packed``: the caller's cache of SplitWeight3 objects for this module (filled / refreshed here, keyed on the weights'
-    identity and version) -> the projections run as three-term bf16 splits and, with at most 32 live keys, K / V are
-    projected once per image (ocv_mha_split3_fwd); None, or OCV_TOKENS=fp32 -> the exact-fp32 kernels (ocv_mha_fwd)."""
+    identity and version) -> with at most 32 live keys every contraction runs as a two-term fp16 split with K / V projected once
+    per image (ocv_mha_few_keys_h2_fwd; OCV_XATTN_FORM selects the older forms), otherwise the projections run as three-term bf16
+    splits (ocv_mha_split3_fwd); None, or OCV_TOKENS=fp32 -> the exact-fp32 kernels (ocv_mha_fwd)."""
     lib = _lib.load()
     for n, t in (("q_src", q_src), ("k_src", k_src), ("v_src", v_src), ("in_proj_weight", in_proj_w),
                  ("in_proj_bias", in_proj_b), ("out_proj.weight", out_w), ("out_proj.bias", out_b)):
@@ -344,11 +345,27 @@ def mha(q_src: torch.Tensor, k_src: torch.Tensor, v_src: torch.Tensor, in_proj_w
     ws = workspace(nb, q_src.device)
     out = torch.empty(B, Sq, E, dtype=torch.float32, device=q_src.device)
     name = "mha_self" if q_src.data_ptr() == k_src.data_ptr() else ("mha_cross" if kv_limit else "mha_cross_full")
-    # few live keys AND few query tiles: round 3's first split3 form tied with round 2's single exact-fp32 launch at the benchmark's
-    # bs = 16 (160 tiles: both one tile's latency chain) and kept it below 384 tiles; with the K / V record in operand order and the
-    # transposed output projection the split3 launches win at every size (bs 16: 19.9 vs 22.6 us, bs 64: 31 vs 63 us --
-    # profiles/r03_cross_attention_roofline.txt), so the threshold defaults to 0 and stays as the A/B switch
-    small = 0 < kv_limit <= 32 and B * ((Sq + 31) // 32) < int(os.environ.get("OCV_XATTN_SPLIT3_MIN_TILES", "0"))
+    # few live keys (the image <- object cross-attention): OCV_XATTN_FORM = h2 (default: every contraction a two-term fp16 split,
+    # csrc/xattn_h2.hip) | split3 (three-term bf16 projections + exact-fp32 scores, fp32's range) | fp32 (round 2's single
+    # exact-fp32 launch); profiles/r03_cross_attention_roofline.txt has the three side by side at bs 16 ... 2048
+    form = os.environ.get("OCV_XATTN_FORM", "h2")
+    if form not in ("h2", "split3", "fp32"):
+        raise ValueError(f"OCV_XATTN_FORM={form!r}: expected h2, split3 or fp32")
+    few = 0 < (kv_limit if 0 < kv_limit < Sk else Sk) <= 32 and (kv_limit == 0 or m is not None)
+    small = few and form == "fp32"
+    if packed is not None and token_split3_enabled() and E == 128 and n_heads == 4 and few and form == "h2" and B <= 65535:
+        h2 = []
+        for field, w in (("in_proj_h2", in_proj_w), ("out_proj_h2", out_w)):
+            ver = (w.data_ptr(), w._version)
+            hit = packed.get(field)
+            if hit is None or hit[0] != ver:
+                hit = packed[field] = (ver, SplitWeightH2(w))
+            h2.append(hit[1].packed)
+        with timed(name):                              # the K / V record (32 KB per image) fits the MHA workspace sized above
+            check(lib.ocv_mha_few_keys_h2_fwd(q_src.data_ptr(), k_src.data_ptr(), v_src.data_ptr(), _ptr(m), h2[0].data_ptr(),
+                                              in_proj_b.data_ptr(), h2[1].data_ptr(), out_b.data_ptr(), out.data_ptr(), B, Sq, Sk,
+                                              int(kv_limit), E, n_heads, ws.data_ptr(), ws.numel(), _stream()), "ocv_mha_few_keys_h2_fwd")
+        return out
     if packed is not None and token_split3_enabled() and E == 128 and n_heads == 4 and not small:
         p3 = []
         for field, w in (("in_proj_p3", in_proj_w), ("out_proj_p3", out_w)):
@@ -375,6 +392,20 @@ _LAYER_FIELDS = (("in_proj_w", "self_attn.in_proj_weight"), ("in_proj_b", "self_
                  ("linear1_w", "linear1.weight"), ("linear1_b", "linear1.bias"),
                  ("linear2_w", "linear2.weight"), ("linear2_b", "linear2.bias"),
                  ("norm2_w", "norm2.weight"), ("norm2_b", "norm2.bias"))
+
+
+class SplitWeightH2:
+    """A static [N, K] matrix as two fp16 terms, w = hi + 2^-11 lo' (22 significant bits), packed in matrix-core operand order
+    by the device (ocv_pack_split_h2_fwd; layout in include/objcavit_hip.h).  Built once per weight version by the callers."""
+
+    def __init__(self, weight: torch.Tensor):
+        lib = _lib.load()
+        w = _req(weight.detach().reshape(weight.shape[0], -1).contiguous(), "weight")
+        self.n, self.k = int(w.shape[0]), int(w.shape[1])
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("weight packing during graph capture: run one eager warm-up call first")
+        self.packed = torch.empty(int(lib.ocv_split_h2_packed_elems(self.n, self.k)), dtype=torch.float16, device=w.device)
+        check(lib.ocv_pack_split_h2_fwd(w.data_ptr(), self.k, self.n, self.k, self.packed.data_ptr(), _stream()), "ocv_pack_split_h2_fwd")
 
 
 class SplitWeight3:

@@ -235,14 +235,17 @@ def test_mha_fused_few_keys(ops, Sq, counts):
     assert rel_dev(torch.where(nan_ref, torch.zeros_like(got), got), torch.where(nan_ref, torch.zeros_like(full), full)) < TOL
 
 
+@pytest.mark.parametrize("form", ["h2", "split3"])
 @pytest.mark.parametrize("Sq,Sk,counts,kv", [(300, 300, [32, 7, 1], 32), (45, 300, [5, 0], 5), (32, 40, [32], 32), (1, 132, [3, 3], 3),
                                             (418, 418, [24] * 8, 24), (132, 132, [100, 3], 100), (77, 50, None, 0), (300, 1200, [1200, 640], 0),
-                                            (300, 300, [(7 * i) % 33 for i in range(40)], 32)])
-def test_mha_split3(ops, monkeypatch, Sq, Sk, counts, kv):
-    """ocv_mha_split3_fwd: packed three-term-split projections.  <= 32 live keys: K / V projected once per image + the fused
-    per-tile launch (ragged tiles, an image without a live key -> NaN rows as torch, V from another tensor than K, KITTI's
-    S = 418); more keys / no mask: split3 linears around the attention kernel (multi-chunk Sk).  Against the oracle at the
-    kernels' tolerance and against the exact-fp32 route."""
+                                            (300, 300, [(7 * i) % 33 for i in range(40)], 32), (64, 20, None, 0), (70, 32, [32, 31], 0)])
+def test_mha_split3(ops, monkeypatch, Sq, Sk, counts, kv, form):
+    """hip_ops.mha on packed split weights.  <= 32 live keys: K / V projected once per image + the fused per-tile launch, as
+    two-term fp16 splits throughout (form h2, ocv_mha_few_keys_h2_fwd) or three-term bf16 projections + exact-fp32 scores (form
+    split3, ocv_mha_split3_fwd): ragged tiles, an image without a live key -> NaN rows as torch, V from another tensor than K,
+    KITTI's S = 418, 40 images with 0..32 objects, Sk <= 32 without a mask or a kv_limit; more keys / no mask: split3 linears
+    around the attention kernel (multi-chunk Sk) under either form.  Against the oracle at the kernels' tolerance and against
+    the exact-fp32 route."""
     B, E = (len(counts) if counts else 2), 128
     qs, ks, vs = rnd("qs", (B, Sq, E), 1), rnd("ks", (B, Sk, E), 2), rnd("vs", (B, Sk, E), 3)
     iw, ib = rnd("iw", (3 * E, E), 4, 2 / math.sqrt(E)), rnd("ib", (3 * E,), 5, 0.1)
@@ -251,9 +254,10 @@ def test_mha_split3(ops, monkeypatch, Sq, Sk, counts, kv):
     ref = restate.multi_head_attention(qs, ks, vs, iw, ib, ow, ob, mask)
     args = (dev(qs), dev(ks), dev(vs), dev(iw), dev(ib), dev(ow), dev(ob), None if mask is None else dev(mask))
     cache = {}
-    monkeypatch.setenv("OCV_XATTN_SPLIT3_MIN_TILES", "0")            # small launches default to the single exact-fp32 launch
+    monkeypatch.setenv("OCV_XATTN_FORM", form)
     got = ops.mha(*args, kv_limit=kv, packed=cache).cpu()
-    assert set(cache) == {"in_proj_p3", "out_proj_p3"}
+    few = (kv if 0 < kv < Sk else Sk) <= 32
+    assert set(cache) == ({"in_proj_h2", "out_proj_h2"} if few and form == "h2" else {"in_proj_p3", "out_proj_p3"})
     again = ops.mha(*args, kv_limit=kv, packed=cache).cpu()
     exact = ops.mha(*args, kv_limit=kv).cpu()
     nan_ref = torch.isnan(ref)
@@ -261,6 +265,82 @@ def test_mha_split3(ops, monkeypatch, Sq, Sk, counts, kv):
     z = lambda t: torch.where(nan_ref, torch.zeros_like(t), t)          # noqa: E731
     assert rel_dev(z(got), z(ref)) < TOL and rel_dev(z(got), z(exact)) < TOL
     assert torch.equal(z(got), z(again))
+    # (sub-tile count of the fused kernels: automatic here = one; two from 2048 64-query workgroups on: test_mha_few_keys_large_launch)
+
+
+@pytest.mark.parametrize("form", ["h2", "split3"])
+def test_mha_few_keys_large_launch(ops, monkeypatch, form):
+    """Enough 64-query workgroups (>= 2048) for the two-sub-tile form of the fused few-key kernels: 420 images x 300 queries
+    (a ragged last sub-tile: 300 = 4 x 64 + 44), 0..32 objects per image, every image checked against the exact-fp32 route and
+    a sample of them against the oracle."""
+    B, Sq, Sk, E = 420, 300, 40, 128
+    counts = [(11 * i) % 33 for i in range(B)]
+    qs, ks, vs = rnd("qs", (B, Sq, E), 21), rnd("ks", (B, Sk, E), 22), rnd("vs", (B, Sk, E), 23)
+    iw, ib = rnd("iw", (3 * E, E), 4, 2 / math.sqrt(E)), rnd("ib", (3 * E,), 5, 0.1)
+    ow, ob = rnd("ow", (E, E), 6, 1 / math.sqrt(E)), rnd("ob", (E,), 7, 0.1)
+    mask = torch.arange(Sk)[None, :] >= torch.tensor(counts)[:, None]
+    args = (dev(qs), dev(ks), dev(vs), dev(iw), dev(ib), dev(ow), dev(ob), dev(mask))
+    monkeypatch.setenv("OCV_XATTN_FORM", form)
+    got = ops.mha(*args, kv_limit=32, packed={}).cpu()
+    exact = ops.mha(*args, kv_limit=32).cpu()
+    nan = torch.isnan(exact)
+    assert torch.equal(torch.isnan(got), nan) and bool(nan[0].all()) and not bool(nan[1].any())
+    z = lambda t: torch.where(nan, torch.zeros_like(t), t)              # noqa: E731
+    assert rel_dev(z(got), z(exact)) < TOL
+    pick = [1, 2, 4, 32, 34, 419]                                       # images with at least one live key (11 i mod 33 != 0)
+    ref = restate.multi_head_attention(qs[pick], ks[pick], vs[pick], iw, ib, ow, ob, mask[pick])
+    assert rel_dev(got[pick], ref) < TOL
+
+
+def test_split_h2_pack_layout_saturation_and_product_precision(ops):
+    """ocv_pack_split_h2_fwd: the documented operand-order layout on a ragged [70, 40] matrix (zero padding to 32 rows / 16
+    columns), saturation at fp16's range instead of inf, and what the two-term split is for: hi hi + 2^-11 (hi lo' + lo' hi)
+    reproduces an fp64 product to ~3e-7 of its largest element where a two-term bf16 split gives ~5e-6."""
+    N, K = 70, 40
+    w = rnd("w", (N, K), 31, 0.3)
+    w[3, 5], w[4, 6], w[5, 7] = 1.0e6, -3.0e5, 65504.0
+    sw = ops.SplitWeightH2(dev(w))
+    nsteps, ntiles = (K + 15) // 16, (N + 31) // 32
+    pk = sw.packed.cpu().view(ntiles, nsteps, 2, 64, 8)
+    wp = torch.zeros(ntiles * 32, nsteps * 16)
+    wp[:N, :K] = w.clamp(-65504.0, 65504.0)
+    hi = wp.half()
+    lo = ((wp - hi.float()) * 2048.0).half()
+    for part, t in ((0, hi), (1, lo)):
+        exp = t.view(ntiles, 32, nsteps, 2, 8).permute(0, 2, 3, 1, 4).reshape(ntiles, nsteps, 64, 8)      # lane = 32 * half + row
+        assert torch.equal(pk[:, :, part], exp)
+    assert bool(torch.isfinite(pk.float()).all())
+    x, v = rnd("x", (64, 128), 32).double(), rnd("v", (128, 128), 33, 0.1).double()
+    ref = x @ v.T
+
+    def h2(a):
+        a = a.float()
+        h = a.half()
+        return h.double(), ((a - h.float()) * 2048.0).half().double()
+
+    def bf2(a):
+        a = a.float()
+        h = a.bfloat16()
+        return h.double(), (a - h.float()).bfloat16().double()
+    (xh, xl), (vh, vl) = h2(x), h2(v)
+    got = xh @ vh.T + (xh @ vl.T + xl @ vh.T) / 2048.0
+    (bh, bl), (ch, cl) = bf2(x), bf2(v)
+    two = bh @ ch.T + bh @ cl.T + bl @ ch.T
+    e_h2, e_b2 = float((got - ref).abs().max() / ref.abs().max()), float((two - ref).abs().max() / ref.abs().max())
+    assert e_h2 < 6e-7 and e_b2 > 4 * e_h2, (e_h2, e_b2)
+
+
+def test_mha_few_keys_h2_on_large_tokens(ops):
+    """Tokens of magnitude ~100 (far above this model's, far below fp16's 65504): the scaled low term keeps the two-term fp16
+    split at fp32's relative error whatever the magnitude."""
+    B, Sq, Sk, E = 3, 100, 32, 128
+    qs, ks, vs = rnd("qs", (B, Sq, E), 41) * 100.0, rnd("ks", (B, Sk, E), 42) * 100.0, rnd("vs", (B, Sk, E), 43) * 100.0
+    iw, ib = rnd("iw", (3 * E, E), 4, 0.02 / math.sqrt(E)), rnd("ib", (3 * E,), 5, 0.1)       # logits stay O(1 .. 10)
+    ow, ob = rnd("ow", (E, E), 6, 1 / math.sqrt(E)), rnd("ob", (E,), 7, 0.1)
+    mask = torch.arange(Sk)[None, :] >= torch.tensor([32, 9, 1])[:, None]
+    ref = restate.multi_head_attention(qs, ks, vs, iw, ib, ow, ob, mask)
+    got = ops.mha(dev(qs), dev(ks), dev(vs), dev(iw), dev(ib), dev(ow), dev(ob), dev(mask), kv_limit=32, packed={}).cpu()
+    assert rel_dev(got, ref) < TOL
 
 
 def _encoder_sd(seed, prefix="layers."):

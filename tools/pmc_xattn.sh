@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of the split3 cross-attention kernels at a large batch (tools/xattn_one.py B S)
+# SQ counters of the few-key cross-attention kernels at a large batch (tools/xattn_one.py B S; OCV_XATTN_FORM = h2 | split3)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 d=gpurun_out/pmc_xattn; rm -rf $d; mkdir -p $d
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_WAVES --output-format csv -d $d/a -- python3 tools/xattn_one.py "$@" > $d/a.log 2>&1 || { tail -3 $d/a.log; exit 1; }
@@ -8,7 +8,7 @@ rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_V
 python3 - $d <<'PY'
 import collections, csv, glob, sys
 d = sys.argv[1]
-for kern in ("xattn_main3_kernel", "xattn_kv3_kernel"):
+for kern in ("xattn_main_h2_kernel", "xattn_kv_h2_kernel", "xattn_main3_kernel", "xattn_kv3_kernel"):
     m = collections.defaultdict(list); ns = []
     for sub in "abc":
         fs = glob.glob(f"{d}/{sub}/*/*_counter_collection.csv")

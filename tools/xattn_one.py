@@ -1,6 +1,5 @@
 """The split3 cross-attention launches at one batch size, back to back (for tools/pmc_xattn.sh).  Usage: xattn_one.py B S"""
 import os, sys
-os.environ["OCV_XATTN_SPLIT3_MIN_TILES"] = "0"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from objcavit_amd import hip_ops

@@ -1,7 +1,6 @@
 """HIP-event time of the split3 cross-attention call (both launches) at one batch: xattn_time.py B S [reps].  With OCV_LIB_PATH
 pointing at an ablation build (tools/diag/xattn_ablation.patch.txt) the differences localise the cost inside the tile."""
 import os, sys
-os.environ["OCV_XATTN_SPLIT3_MIN_TILES"] = "0"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from objcavit_amd import hip_ops
