@@ -235,7 +235,11 @@ size_t ocv_bin_head_workspace_bytes(int B, int n_bins, int C);
  *   ocv_bin_head_fold_fwd   Wf[b] = Wout (n_bins x Q) . queries[b] (Q x C)            -> Wf [B, n_bins, C]
  *   ocv_bin_head_folded_fwd depth[b][p] = sum_k softmax_k(bout + Wf[b] . feat[b][:, p]) * centers[b][k]  * channels_last: 0 = feat is NCHW, 1 = NHWC (both exact fp32 MFMA); 2 = NHWC with the logits on the bf16 matrix cores
  * in split form (hi*hi + hi*lo + lo*hi, fp32 accumulate: product error <= 2^-17; twice as fast, opt-in because a
- * near-one-hot softmax passes logit errors straight into depth). */
+ * near-one-hot softmax passes logit errors straight into depth); 3 = NHWC with the logits as a TWO-term fp16 split with a
+ * scaled low term (v = hi + 2^-11 lo', hi = fp16(v), lo' = fp16((v - hi) 2^11): three v_mfma_f32_32x32x16_f16 per product
+ * block, 22-bit products = the error of an fp32 FMA chain; both parts of Wf[b] fit the LDS, so one workgroup walks all
+ * 256 bins and the map is read once -- the fastest faithful form; fp16's range: a map value or folded weight beyond
+ * +-65504 turns the pixel's depth inf / NaN). */
 int ocv_bin_head_fold_fwd(const float* queries, long q_bs, int q_ld, const float* Wout, float* Wf, int B, int C, int Q,
                           int n_bins, ocv_stream_t stream);
 int ocv_bin_head_folded_fwd(const float* feat, int channels_last, const float* Wf, const float* bout,

@@ -734,14 +734,17 @@ def pixel_dot(feat: torch.Tensor, queries: torch.Tensor) -> torch.Tensor:
 def bin_head(feat: torch.Tensor, queries: torch.Tensor, w_out: torch.Tensor, b_out: torch.Tensor,
              centers: torch.Tensor, split: bool = False, exact: bool = False) -> torch.Tensor:
     """depth [B,1,h,w] = sum_k softmax_k(conv1x1(pixel_dot(feat, queries)))_k * centers_k, fused.
-    feat NCHW-contiguous: exact fp32 MFMA.  feat channels_last: logits as a THREE-term bf16 split (fp32-faithful: dropped
-    terms <= 2^-24 of a product; 2.7x the matrix rate), or the exact fp32 MFMA kernel with ``exact=True``; ``split=True``
-    computes them in the TWO-term split -- faster still, ~3x the depth error under near-one-hot softmaxes (opt-in)."""
+    feat NCHW-contiguous: exact fp32 MFMA.  feat channels_last: logits as a TWO-term fp16 split with a scaled low term (22-bit
+    products at the error of an fp32 FMA chain, three MFMAs per block, all 256 bins per workgroup: OCV_BINHEAD=h2, the default),
+    as a THREE-term bf16 split (OCV_BINHEAD=split3: six MFMAs, two bin halves + a merge launch; fp32's range), or on the exact
+    fp32 MFMA kernel with ``exact=True`` / OCV_BINHEAD=exact; ``split=True`` / OCV_BINHEAD=split computes them in the two-term
+    BF16 split -- ~3x the depth error under near-one-hot softmaxes (opt-in)."""
     lib = _lib.load()
-    mode = os.environ.get("OCV_BINHEAD", "split3")          # read per call (the library's own getenv is latched once)
-    if mode not in ("split3", "exact", "split"):
-        raise ValueError(f"OCV_BINHEAD={mode!r}: expected 'split3' (default), 'exact' or 'split'")
+    mode = os.environ.get("OCV_BINHEAD", "h2")              # read per call (the library's own getenv is latched once)
+    if mode not in ("h2", "split3", "exact", "split"):
+        raise ValueError(f"OCV_BINHEAD={mode!r}: expected 'h2' (default), 'split3', 'exact' or 'split'")
     exact, split = exact or mode == "exact", split or mode == "split"
+    h2 = mode == "h2" and not exact and not split
     feat, cl = _map4(feat, "feat")
     _req(b_out, "b_out"); _req(centers, "centers")
     B, Cc, h, w = feat.shape
@@ -759,10 +762,10 @@ def bin_head(feat: torch.Tensor, queries: torch.Tensor, w_out: torch.Tensor, b_o
     wf = ws.view(torch.float32)
     check(lib.ocv_bin_head_fold_fwd(queries.data_ptr(), queries.stride(0), queries.stride(1), w2.data_ptr(), wf.data_ptr(), B,
                                     Cc, Q, nbins, _stream()), "ocv_bin_head_fold_fwd")
-    npart = int(lib.ocv_bin_head_partials_bytes(B, h * w)) if (cl and not exact and not split) else 0
+    npart = int(lib.ocv_bin_head_partials_bytes(B, h * w)) if (cl and not exact and not split and not h2) else 0
     part = workspace(npart, feat.device, "bin_head_partials") if npart else None
     with timed("bin_head"):          # the logit / softmax / depth launch(es): split-3 halves + merge, or the exact kernel
-        check(lib.ocv_bin_head_folded_ws_fwd(feat.data_ptr(), 2 if (cl and split) else cl, wf.data_ptr(), b_out.data_ptr(),
+        check(lib.ocv_bin_head_folded_ws_fwd(feat.data_ptr(), (3 if h2 else 2 if split else 1) if cl else 0, wf.data_ptr(), b_out.data_ptr(),
                                              centers.data_ptr(), depth.data_ptr(), B, Cc, nbins, h * w, _ptr(part), npart,
                                              _stream()), "ocv_bin_head_folded_ws_fwd")
     return depth

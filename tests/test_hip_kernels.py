@@ -497,7 +497,7 @@ def test_patch_embed_channels_last(ops, B, h, w):
 
 
 @pytest.mark.parametrize("B,h,w", [(2, 176, 192), (1, 240, 320), (3, 37, 53)])
-def test_pixel_dot_and_bin_head_channels_last(ops, B, h, w):
+def test_pixel_dot_and_bin_head_channels_last(ops, monkeypatch, B, h, w):
     from objcavit_amd.modules.AdaBins import bin_edges_and_centers
     feat, q = rnd("f", (B, 128, h, w), 1), rnd("q", (B, 300, 128), 2, 0.5)
     wout, bout = rnd("wo", (256, 128, 1, 1), 3, 6 / math.sqrt(128)), rnd("bo", (256,), 4, 0.5)
@@ -510,17 +510,23 @@ def test_pixel_dot_and_bin_head_channels_last(ops, B, h, w):
     assert got_ram.is_contiguous() and rel_dev(got_ram, ram) < TOL
     ref_depth, _ = restate.bin_head(widths, ram, wout, bout, 0.001, 10.0)
     _, centers = bin_edges_and_centers(dev(widths), 0.001, 10.0)
-    got = ops.bin_head(fg, qg, dev(wout), dev(bout), centers)          # NHWC default: three-term split, 256 bins in two halves
-    assert float(((got.cpu() - ref_depth).abs() / ref_depth).max()) < 1e-4
-    # ... which is fp32-faithful: against an fp64 evaluation of the same folded logits its error is that of the exact
-    # v_mfma_f32_32x32x2_f32 kernel (this input is the stress case: logit gain 6, near-one-hot softmax over 256 bins)
+    # NHWC: the two faithful split forms -- two-term fp16 with a scaled low term, all 256 bins per workgroup (the default), and
+    # three-term bf16 in two bin halves + merge -- are both held to the exact kernel's error: against an fp64 evaluation of the
+    # same folded logits (this input is the stress case: logit gain 6, near-one-hot softmax over 256 bins) within 2x of
+    # the exact v_mfma_f32_32x32x2_f32 kernel
     d64, _ = restate.bin_head(widths.double(), restate.pixel_wise_dot_product(feat.double(), q[:, 1:129, :].double()),
                               wout.double(), bout.double(), 0.001, 10.0)
     exact = ops.bin_head(fg, qg, dev(wout), dev(bout), centers, exact=True)
-    e3 = float(((got.cpu().double() - d64).abs() / d64).max())
     ex = float(((exact.cpu().double() - d64).abs() / d64).max())
-    assert e3 < 1e-4 and e3 <= 2.0 * ex + 2e-6, (e3, ex)
-    assert torch.equal(got, ops.bin_head(fg, qg, dev(wout), dev(bout), centers))
+    for mode in ("split3", "h2"):
+        monkeypatch.setenv("OCV_BINHEAD", mode)
+        got = ops.bin_head(fg, qg, dev(wout), dev(bout), centers)
+        assert float(((got.cpu() - ref_depth).abs() / ref_depth).max()) < 1e-4, mode
+        e3 = float(((got.cpu().double() - d64).abs() / d64).max())
+        assert e3 < 1e-4 and e3 <= 2.0 * ex + 2e-6, (mode, e3, ex)
+        assert torch.equal(got, ops.bin_head(fg, qg, dev(wout), dev(bout), centers))
+    monkeypatch.delenv("OCV_BINHEAD")
+    assert torch.equal(got, ops.bin_head(fg, qg, dev(wout), dev(bout), centers))          # h2 is the default
     # NCHW and NHWC paths agree to rounding
     got_nchw = ops.bin_head(dev(feat), qg, dev(wout), dev(bout), centers)
     assert float(((got - got_nchw).abs() / got_nchw).max()) < 1e-4      # different K order inside the MFMA chains
