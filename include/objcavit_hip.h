@@ -257,6 +257,15 @@ int ocv_bin_head_fwd(const float* feat, int channels_last, const float* queries,
                      const float* bout, const float* centers, float* depth, int B, int C, int Q, int n_bins, int P,
                      void* workspace, size_t workspace_bytes, ocv_stream_t stream);
 
+/* 3 x 3 convolution, stride 1, zero padding 1, of an image with 1..4 channels into Cout channels (multiple of 4): exact fp32
+ * FMA, raw result (no bias, no activation) as NHWC fp32 y [B][H][W][Cout].  x is addressed by element strides (batch,
+ * channel, row, column), so NCHW and channels_last images are read in place; w_taps [9][C][Cout] fp32 (tap t = 3 ky + kx
+ * major, 16-byte aligned) = W[co][c][ky][kx] transposed.  The skip part of the last decoder stage of do_final_upscale models
+ * (reference modules/DenseFeatureExtractor.py:99-101,116-117: the skip tensor is the input image); ocv_tap_interp_combine_fwd
+ * adds it to the low-resolution half. */
+int ocv_conv3x3_few_channels_fwd(const float* x, long stride_b, long stride_c, long stride_y, long stride_x, const float* w_taps,
+                                 float* y, int B, int C, int H, int W, int Cout, ocv_stream_t stream);
+
 /* Depthwise k x k convolution (k in {3,5}, stride in {1,2}) with explicit top/left zero padding (bottom/right
  * padding is implied by Ho/Wo -- covers TensorFlow "SAME"), per-channel bias (folded BatchNorm) and optional SiLU:
  *   out[b][c][y][x] = act( bias[c] + sum_{i,j} w[c][i][j] * in[b][c][y*stride - pad_t + i][x*stride - pad_l + j] )

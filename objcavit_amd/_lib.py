@@ -99,6 +99,7 @@ PROTOTYPES = {
     "ocv_depth_metrics_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
     "ocv_depth_metrics_fwd": (C.c_int, [_f32p, _f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_float, C.c_float] + [C.c_int] * 4 +
                               [C.c_long, _f32p, C.c_int, C.c_void_p, C.c_size_t, _stream]),
+    "ocv_conv3x3_few_channels_fwd": (C.c_int, [_f32p, C.c_long, C.c_long, C.c_long, C.c_long, _f32p, _f32p] + [C.c_int] * 5 + [_stream]),
     "ocv_stem_conv_fwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p] + [C.c_int] * 12 + [_stream]),
     "ocv_pointwise_packed_weight_elems": (C.c_size_t, [C.c_int, C.c_int]),
     "ocv_pointwise_split_set_dispatch": (C.c_int, [C.c_int, C.c_int, C.c_int]),

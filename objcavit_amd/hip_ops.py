@@ -1281,6 +1281,24 @@ def stem_conv_same(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.T
     return out
 
 
+def conv3x3_few_channels(x: torch.Tensor, w_taps: torch.Tensor) -> torch.Tensor:
+    """3x3 / stride 1 / zero padding 1 convolution of an image with at most four channels (any dense layout: read through its
+    strides) on exact fp32 FMAs; ``w_taps`` [9, C, Cout] fp32 (tap-major: weight.permute(2, 3, 1, 0)).  Raw result (no bias),
+    channels_last [B, Cout, H, W]."""
+    lib = _lib.load()
+    _req(x, "x", contiguous=False)
+    _req(w_taps, "w_taps")
+    if x.dim() != 4 or w_taps.dim() != 3 or w_taps.shape[0] != 9 or w_taps.shape[1] != x.shape[1] or not 1 <= x.shape[1] <= 4:
+        raise ValueError("conv3x3_few_channels: expected x [B, C <= 4, H, W] and w_taps [9, C, Cout]")
+    B, C, H, W = x.shape
+    Cout = int(w_taps.shape[2])
+    out = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    with timed("conv_few"):
+        check(lib.ocv_conv3x3_few_channels_fwd(x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), x.stride(3), w_taps.data_ptr(),
+                                               out.data_ptr(), B, C, H, W, Cout, _stream()), "ocv_conv3x3_few_channels_fwd")
+    return out
+
+
 def depthwise_nhwc_same(x: torch.Tensor, weight_kkc: torch.Tensor, bias: Optional[torch.Tensor], k: int, stride: int,
                         act: int = ACT_NONE) -> torch.Tensor:
     """Depthwise k x k conv, TF 'SAME' padding, channels_last in / out.  weight_kkc: [k*k, C] (tap-major)."""

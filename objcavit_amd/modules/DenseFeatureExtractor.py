@@ -126,7 +126,11 @@ class SplitConv3x3:
                 wa = (wa64 @ P.double()).float()
             a_hi, a_lo = hip_ops.prep_conv_weight(wa.reshape(9 * cout, -1, 1, 1))
             s_hi = s_lo = None
-            if cin > c1:
+            if 0 < cin - c1 <= 4:
+                # a skip tensor of at most four channels (the IMAGE, do_final_upscale): exact-fp32 direct form, tap-major fp32
+                # weight [9, C2, Cout] in the s_hi slot, s_lo None (hip_ops.conv3x3_few_channels)
+                s_hi = w[:, c1:].permute(2, 3, 1, 0).reshape(9, cin - c1, cout).contiguous()
+            elif cin > c1:
                 s_hi, s_lo = hip_ops.prep_conv_weight(w[:, c1:].contiguous())
             self._w_up = ((c1, ckey), a_hi, a_lo, s_hi, s_lo, cvec)
         return self._w_up[1:5] + (self._prep[2], self._w_up[5])
@@ -317,7 +321,10 @@ class UpSampleWithSkip(nn.Module):
                 a_hi, a_lo, s_hi, s_lo, b, border = self._split1.upconv_weights(xs.shape[1])
                 z = hip_ops.conv_nhwc_split(xs, a_hi, a_lo, None, 1, hip_ops.ACT_NONE, out_fp32=True)
             sk = None
-            if s_hi is not None:
+            if s_hi is not None and s_lo is None:
+                # <= 4 skip channels: 27 - 36 multiply-adds per output on the vector units, the image read in place
+                sk = hip_ops.conv3x3_few_channels(skip_features, s_hi)
+            elif s_hi is not None:
                 # (an encoder block of the late stages leaves the split copy of its output beside it: read in place)
                 sks = getattr(skip_features, "_ocv_hl", None)
                 if sks is None:

@@ -538,6 +538,27 @@ def test_pixel_dot_and_bin_head_channels_last(ops, monkeypatch, B, h, w):
     assert torch.equal(got_split, ops.bin_head(fg, qg, dev(wout), dev(bout), centers, split=True))
 
 
+@pytest.mark.parametrize("B,C,H,W,Cout,layout", [(2, 3, 33, 47, 128, "nchw"), (1, 3, 480, 640, 128, "nchw"), (2, 4, 16, 17, 8, "nhwc"),
+                                                (1, 1, 1, 1, 4, "nchw"), (3, 2, 5, 9, 260, "nhwc"), (2, 3, 20, 8, 132, "view")])
+def test_conv3x3_few_channels(ops, B, C, H, W, Cout, layout):
+    """ocv_conv3x3_few_channels_fwd (the skip part of the last decoder stage of do_final_upscale models: the skip tensor is the
+    image): exact fp32, zero padding, any dense layout of the image read through its strides (NCHW, channels_last, a channel
+    slice of a wider tensor), ragged tiles (8-pixel column groups, 16-row blocks, 128-channel blocks)."""
+    x, w = rnd("x", (B, C, H, W), 1), rnd("w", (Cout, C, 3, 3), 2, 0.4)
+    ref = F.conv2d(x.double(), w.double(), padding=1).float()
+    xg = dev(x)
+    if layout == "nhwc":
+        xg = xg.contiguous(memory_format=torch.channels_last)
+    elif layout == "view":
+        wide = torch.zeros(B, C + 2, H, W, device="cuda")
+        wide[:, 1:1 + C] = xg
+        xg = wide[:, 1:1 + C]
+        assert not xg.is_contiguous()
+    got = ops.conv3x3_few_channels(xg, dev(w).permute(2, 3, 1, 0).reshape(9, C, Cout).contiguous())
+    assert got.shape == (B, Cout, H, W) and got.is_contiguous(memory_format=torch.channels_last)
+    assert rel_dev(got, ref) < 2e-6
+
+
 # ------------------------------------------------------------------ depthwise convolution
 def _same_pad(x, k, s):
     ih, iw = x.shape[-2:]
