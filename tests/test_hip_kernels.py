@@ -292,6 +292,39 @@ def test_mha_few_keys_large_launch(ops, monkeypatch, form):
     assert rel_dev(got[pick], ref) < TOL
 
 
+def test_mha_few_keys_h2_random_shapes(ops):
+    """Seeded sweep of the fused few-key form over ragged shapes: 1..9 images, 1..200 queries, 1..32 live keys of 1..90 key rows
+    (kv_limit given or not, mask given or not when every key row is live), V from K's tensor or another -- against the exact-fp32
+    route at the kernels' tolerance, NaN rows (an image without a live key) in the same places."""
+    import random
+    rng = random.Random(1234)
+    E = 128
+    iw, ib = rnd("iw", (3 * E, E), 4, 2 / math.sqrt(E)), rnd("ib", (3 * E,), 5, 0.1)
+    ow, ob = rnd("ow", (E, E), 6, 1 / math.sqrt(E)), rnd("ob", (E,), 7, 0.1)
+    par = (dev(iw), dev(ib), dev(ow), dev(ob))
+    for case in range(40):
+        B, Sq = rng.randint(1, 9), rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 100, 200])
+        live_max = rng.randint(1, 32)
+        Sk = rng.choice([live_max, live_max, rng.randint(live_max, 90)])
+        counts = [rng.randint(0 if B > 1 else 1, live_max) for _ in range(B)]
+        counts[rng.randrange(B)] = live_max
+        dense = Sk == live_max and all(c == live_max for c in counts) and rng.random() < 0.5
+        qs, ks = rnd("q", (B, Sq, E), 100 + case), rnd("k", (B, Sk, E), 200 + case)
+        vs = ks if rng.random() < 0.5 else rnd("v", (B, Sk, E), 300 + case)
+        mask = None if dense else torch.arange(Sk)[None, :] >= torch.tensor(counts)[:, None]
+        kv = 0 if (dense or (Sk <= 32 and rng.random() < 0.5)) else live_max
+        args = (dev(qs), dev(ks), dev(vs)) + par + (None if mask is None else dev(mask),)
+        cache = {}
+        got = ops.mha(*args, kv_limit=kv, packed=cache).cpu()
+        assert set(cache) == {"in_proj_h2", "out_proj_h2"}, (case, B, Sq, Sk, counts, kv)
+        exact = ops.mha(*args, kv_limit=kv).cpu()
+        nan = torch.isnan(exact)
+        assert torch.equal(torch.isnan(got), nan), (case, B, Sq, Sk, counts, kv)
+        assert bool(nan.any()) == (mask is not None and 0 in counts)
+        z = lambda t: torch.where(nan, torch.zeros_like(t), t)          # noqa: E731
+        assert rel_dev(z(got), z(exact)) < TOL, (case, B, Sq, Sk, counts, kv)
+
+
 def test_split_h2_pack_layout_saturation_and_product_precision(ops):
     """ocv_pack_split_h2_fwd: the documented operand-order layout on a ragged [70, 40] matrix (zero padding to 32 rows / 16
     columns), saturation at fp16's range instead of inf, and what the two-term split is for: hi hi + 2^-11 (hi lo' + lo' hi)
