@@ -152,7 +152,11 @@ def _attn_ref(q, k, v, mask, H):
 @pytest.mark.parametrize("B,Sq,Sk", [(1, 1, 1), (2, 132, 132), (2, 300, 300), (1, 418, 418), (3, 129, 77),
                                      (1, 40, 1200), (2, 300, 513)])
 @pytest.mark.parametrize("masked", [False, True])
-def test_attention_core(ops, B, Sq, Sk, masked):
+@pytest.mark.parametrize("form", ["h2", "fp32"])
+def test_attention_core(ops, monkeypatch, B, Sq, Sk, masked, form):
+    """softmax(q k^T / sqrt(d) + mask) v per head: both contractions as two-term fp16 splits (form h2, the default:
+    attention_h2_kernel) or on exact fp32 MFMA (OCV_ATTN_FORM=fp32) -- one and several LDS chunks of keys, ragged tiles."""
+    monkeypatch.setenv("OCV_ATTN_FORM", form)
     q, k, v = rnd("q", (B, Sq, 128), 1, 1.5), rnd("k", (B, Sk, 128), 2, 1.5), rnd("v", (B, Sk, 128), 3)
     mask = None
     if masked:
@@ -172,7 +176,9 @@ def test_attention_core_strided_packed_qkv(ops):
                                   qkv[..., 256:].contiguous(), None, 4)) < TOL
 
 
-def test_attention_online_softmax_rescale_is_exercised(ops):
+@pytest.mark.parametrize("form", ["h2", "fp32"])
+def test_attention_online_softmax_rescale_is_exercised(ops, monkeypatch, form):
+    monkeypatch.setenv("OCV_ATTN_FORM", form)
     """A spike in a late key tile forces the running max to jump after earlier tiles were accumulated."""
     B, S = 1, 320
     q, k, v = rnd("q", (B, S, 128), 1), rnd("k", (B, S, 128), 2), rnd("v", (B, S, 128), 3)
@@ -182,7 +188,9 @@ def test_attention_online_softmax_rescale_is_exercised(ops):
     assert rel_dev(got, _attn_ref(q, k, v, None, 4)) < TOL
 
 
-def test_attention_fully_masked_row_is_nan_like_torch(ops):
+@pytest.mark.parametrize("form", ["h2", "fp32"])
+def test_attention_fully_masked_row_is_nan_like_torch(ops, monkeypatch, form):
+    monkeypatch.setenv("OCV_ATTN_FORM", form)
     q, k, v = rnd("q", (1, 4, 128), 1), rnd("k", (1, 40, 128), 2), rnd("v", (1, 40, 128), 3)
     mask = torch.ones(1, 40, dtype=torch.bool)
     got = ops.attention_core(dev(q), dev(k), dev(v), dev(mask), 4)
