@@ -15,6 +15,8 @@
 // instead of three (128 KB per workgroup through the vector-memory path instead of 192 KB) and half the split arithmetic.
 // (profiles/r03_cross_attention_roofline.txt holds the ablation of the split3 tile that led here.)
 //
+// Small magnitudes: the HIGH term of an operand below 6.1e-5 is an fp16 subnormal; v_mfma_f32_32x32x16_f16 honours subnormal
+// inputs on gfx950 (tools/diag/mfma_f16_denorm.hip, measured), and whatever hi loses the scaled low term carries.
 // Range: fp16 tops out at 65504.  An ACTIVATION beyond that (token, projected query / key / value) converts to hi = inf and
 // the output row turns inf / NaN -- loud, not silently saturated; tokens, projected keys / values and softmax-weighted
 // contexts of this model are O(1) .. O(100).  The weight packer saturates at +-65504 (a static matrix: checked once, not
