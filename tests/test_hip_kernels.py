@@ -333,6 +333,47 @@ def test_mha_few_keys_h2_random_shapes(ops):
         assert rel_dev(z(got), z(exact)) < TOL, (case, B, Sq, Sk, counts, kv)
 
 
+@pytest.mark.parametrize("scale", [1e-4, 1e-2, 1.0, 300.0])
+def test_two_term_fp16_kernels_hold_their_relative_error_at_any_magnitude(ops, scale):
+    """The scaled low term keeps the two-term fp16 split out of fp16's subnormals and v_mfma_f32_32x32x16_f16 honours the
+    subnormal HIGH terms of tiny operands (tools/diag/mfma_f16_denorm.hip): the self-attention core and the few-key cross-attention
+    keep the kernels' tolerance when every token is scaled by 1e-4 ... 300 (the projections' outputs scale with it; the attention
+    logits are kept O(1) by scaling the other operand back)."""
+    B, S, E = 2, 96, 128
+    q, k, v = rnd("q", (B, S, E), 1) * scale, rnd("k", (B, S, E), 2) / scale, rnd("v", (B, S, E), 3) * scale
+    got = ops.attention_core(dev(q), dev(k), dev(v), None, 4)
+    assert rel_dev(got, _attn_ref(q, k, v, None, 4)) < TOL
+    qs, ks, vs = rnd("qs", (B, 70, E), 11) * scale, rnd("ks", (B, 24, E), 12) * scale, rnd("vs", (B, 24, E), 13) * scale
+    iw = rnd("iw", (3 * E, E), 4, 2 / math.sqrt(E))
+    iw[:2 * E] /= scale                                                   # q and k projections back to O(1): logits O(1 .. 10)
+    ib, ow, ob = rnd("ib", (3 * E,), 5, 0.1), rnd("ow", (E, E), 6, 1 / math.sqrt(E)), rnd("ob", (E,), 7, 0.1) * scale
+    ib[2 * E:] *= scale
+    mask = torch.arange(24)[None, :] >= torch.tensor([24, 5])[:, None]
+    ref = restate.multi_head_attention(qs, ks, vs, iw, ib, ow, ob, mask)
+    cache = {}
+    got = ops.mha(dev(qs), dev(ks), dev(vs), dev(iw), dev(ib), dev(ow), dev(ob), dev(mask), kv_limit=24, packed=cache).cpu()
+    assert set(cache) == {"in_proj_h2", "out_proj_h2"}
+    assert rel_dev(got, ref) < TOL
+
+
+def test_two_term_fp16_kernels_turn_out_of_range_operands_into_non_finite_rows(ops):
+    """fp16's range is the documented limit of the h2 forms: a token beyond +-65504 must come out LOUD (inf / NaN in the rows it
+    feeds), never as a finite wrong number; the split3 / exact forms take the same input in their stride."""
+    import os
+    B, S, E = 1, 40, 128
+    q, k, v = rnd("q", (B, S, E), 1), rnd("k", (B, S, E), 2), rnd("v", (B, S, E), 3)
+    v[0, 7, 5] = 1.0e6                                                    # one value element beyond fp16
+    got = ops.attention_core(dev(q), dev(k), dev(v), None, 4).cpu()
+    assert not bool(torch.isfinite(got[0, :, 5]).all())                   # every query attends key 7 a little: column 5 of head 0
+    assert bool(torch.isfinite(got[0, :, 40:]).all())                     # other heads untouched
+    os.environ["OCV_ATTN_FORM"] = "fp32"
+    try:
+        exact = ops.attention_core(dev(q), dev(k), dev(v), None, 4).cpu()
+    finally:
+        del os.environ["OCV_ATTN_FORM"]
+    assert bool(torch.isfinite(exact).all()) and rel_dev(exact, _attn_ref(q, k, v, None, 4)) < TOL
+
+
 def test_split_h2_pack_layout_saturation_and_product_precision(ops):
     """ocv_pack_split_h2_fwd: the documented operand-order layout on a ragged [70, 40] matrix (zero padding to 32 rows / 16
     columns), saturation at fp16's range instead of inf, and what the two-term split is for: hi hi + 2^-11 (hi lo' + lo' hi)
