@@ -641,6 +641,25 @@ def test_conv3x3_few_channels(ops, B, C, H, W, Cout, layout):
     assert rel_dev(got, ref) < 2e-6
 
 
+@pytest.mark.parametrize("scale", [1e-3, 64.0])
+def test_bin_head_h2_on_scaled_maps(ops, monkeypatch, scale):
+    """The two-term fp16 bin head on a map scaled down / up with the queries scaled the other way (same logits): depth as for the
+    unscaled pair, to the exact kernel's noise -- tiny map values (subnormal fp16 high terms) lose nothing."""
+    from objcavit_amd.modules.AdaBins import bin_edges_and_centers
+    B, h, w = 2, 30, 40
+    feat, q = rnd("f", (B, 128, h, w), 1), rnd("q", (B, 128, 128), 2, 0.5)
+    wout, bout = rnd("wo", (256, 128, 1, 1), 3, 2 / math.sqrt(128)), rnd("bo", (256,), 4, 0.5)
+    widths = torch.rand(B, 256, generator=torch.Generator().manual_seed(5)) + 0.1
+    widths = widths / widths.sum(1, keepdim=True)
+    _, centers = bin_edges_and_centers(dev(widths), 0.001, 10.0)
+    fg = dev(feat).contiguous(memory_format=torch.channels_last)
+    monkeypatch.setenv("OCV_BINHEAD", "exact")
+    ref = ops.bin_head(fg, dev(q), dev(wout), dev(bout), centers)
+    monkeypatch.setenv("OCV_BINHEAD", "h2")
+    got = ops.bin_head((fg * scale).contiguous(memory_format=torch.channels_last), dev(q) / scale, dev(wout), dev(bout), centers)
+    assert float(((got - ref).abs() / ref).max()) < 5e-5
+
+
 # ------------------------------------------------------------------ depthwise convolution
 def _same_pad(x, k, s):
     ih, iw = x.shape[-2:]
