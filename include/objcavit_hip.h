@@ -146,6 +146,11 @@ typedef struct {
   /* optional: the four weight matrices packed by ocv_pack_split3_fwd (all four or none).  With them the projections and
    * the feed-forward block run as the three-term bf16 split (fp32-faithful, 2.7x the matrix rate); NULL = exact fp32. */
   const void *in_proj_p3, *out_proj_p3, *linear1_p3, *linear2_p3;
+  /* optional (round 3; callers built before it pass a shorter struct_size and these read as NULL): the same four matrices
+   * packed by ocv_pack_split_h2_fwd (all four or none).  With them ocv_encoder_stack_fwd runs every layer's token-local tail
+   * (output projection, both LayerNorms, feed-forward block, the next layer's q | k | v projection) as two-term fp16 splits
+   * (ocv_layer_tail_h2_fwd: half the matrix operations and two thirds of the weight stream of the three-term form; fp16's range). */
+  const void *in_proj_h2, *out_proj_h2, *linear1_h2, *linear2_h2;
 } ocv_encoder_layer_params;
 size_t ocv_encoder_layer_workspace_bytes(int B, int S, int E, int FF);
 int ocv_encoder_layer_fwd(const float* x, const ocv_encoder_layer_params* p, const uint8_t* key_padding_mask,
@@ -180,6 +185,11 @@ int ocv_ffn_residual_layernorm_split3_fwd(const float* x, const void* w1_packed,
  *   qkv_next[M][3E] = out . Wqkv_next^T + bqkv_next      when next_in_proj_p3 / next_in_proj_b / qkv_next are given
  * ctx = the attention output of the layer, x its input; p: the layer's parameters with the packed *_p3 weights set. */
 int ocv_layer_tail_split3_fwd(const float* ctx, const float* x, const ocv_encoder_layer_params* p, const void* next_in_proj_p3,
+                              const float* next_in_proj_b, float eps, const uint8_t* zero_row_mask, float* out,
+                              float* qkv_next, int M, int E, int FF, ocv_stream_t stream);
+/* The same on the two-term fp16 weights (params->out_proj_h2 / linear1_h2 / linear2_h2, next_in_proj_h2 = the NEXT layer's packed
+ * in_proj or NULL); csrc/token_h2.hip. */
+int ocv_layer_tail_h2_fwd(const float* ctx, const float* x, const ocv_encoder_layer_params* p, const void* next_in_proj_h2,
                               const float* next_in_proj_b, float eps, const uint8_t* zero_row_mask, float* out,
                               float* qkv_next, int M, int E, int FF, ocv_stream_t stream);
 /* nn.TransformerEncoder(layer, n_layers) forward (eval, post-norm, batch-first [B,S,E]) in 1 + 2 n_layers launches: the

@@ -23,7 +23,8 @@ class EncoderLayerParams(C.Structure):
     _fields_ = [("struct_size", C.c_size_t)] + [(n, C.c_void_p) for n in (
         "in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "norm1_w", "norm1_b",
         "linear1_w", "linear1_b", "linear2_w", "linear2_b", "norm2_w", "norm2_b",
-        "in_proj_p3", "out_proj_p3", "linear1_p3", "linear2_p3")]
+        "in_proj_p3", "out_proj_p3", "linear1_p3", "linear2_p3",
+        "in_proj_h2", "out_proj_h2", "linear1_h2", "linear2_h2")]
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
@@ -61,6 +62,8 @@ PROTOTYPES = {
     "ocv_ffn_residual_layernorm_split3_fwd": (C.c_int, [_f32p, C.c_void_p, _f32p, C.c_void_p, _f32p, _f32p, _f32p, C.c_float, _u8p, _f32p,
                                                         C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, _stream]),
     "ocv_layer_tail_split3_fwd": (C.c_int, [_f32p, _f32p, C.POINTER(EncoderLayerParams), C.c_void_p, _f32p, C.c_float, _u8p, _f32p, _f32p,
+                                            C.c_int, C.c_int, C.c_int, _stream]),
+    "ocv_layer_tail_h2_fwd": (C.c_int, [_f32p, _f32p, C.POINTER(EncoderLayerParams), C.c_void_p, _f32p, C.c_float, _u8p, _f32p, _f32p,
                                             C.c_int, C.c_int, C.c_int, _stream]),
     "ocv_encoder_stack_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "ocv_encoder_stack_fwd": (C.c_int, [_f32p, C.POINTER(EncoderLayerParams), C.c_int, _u8p, C.c_int, _f32p, C.c_int, C.c_int, C.c_int,

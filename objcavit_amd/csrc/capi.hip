@@ -197,7 +197,7 @@ extern "C" int ocv_encoder_layer_fwd(const float* x, const ocv_encoder_layer_par
 
 // ---------------------------------------------------------------------------
 // a whole nn.TransformerEncoder (L post-norm layers) in 1 + 2 L launches: packed projection of layer 0, then per layer
-// the attention kernel and ocv_layer_tail_split3_fwd (everything token-local + the next layer's projection).
+// the attention kernel and ocv_layer_tail_split3_fwd / ocv_layer_tail_h2_fwd (everything token-local + the next layer's projection).
 // workspace: qkv [M, 3E] | ctx [M, E] | xa [M, E] | xb [M, E]
 // ---------------------------------------------------------------------------
 extern "C" size_t ocv_encoder_stack_workspace_bytes(int B, int S, int E) {
@@ -218,6 +218,11 @@ extern "C" int ocv_encoder_stack_fwd(const float* x, const ocv_encoder_layer_par
   for (int l = 0; l < n_layers; ++l)
     OCV_CHECK_ARG(layers[l].in_proj_p3 && layers[l].out_proj_p3 && layers[l].linear1_p3 && layers[l].linear2_p3,
                   "ocv_encoder_stack_fwd: layer %d lacks its packed split3 weights (ocv_pack_split3_fwd)", l);
+  // every layer carries the two-term fp16 weights too: the token-local tails run on them (csrc/token_h2.hip); layer 0's
+  // projection stays on its three-term weights (one launch)
+  bool tails_h2 = true;
+  for (int l = 0; l < n_layers; ++l)
+    tails_h2 = tails_h2 && layers[l].in_proj_h2 && layers[l].out_proj_h2 && layers[l].linear1_h2 && layers[l].linear2_h2;
   const int M = B * S;
   char* ws = (char*)workspace;
   float* qkv = (float*)ws;
@@ -238,9 +243,13 @@ extern "C" int ocv_encoder_stack_fwd(const float* x, const ocv_encoder_layer_par
     const uint8_t* zmask = (last && zero_padded_rows && key_padding_mask) ? key_padding_mask : nullptr;
     // the tail of layer l writes the next layer's q | k | v into the buffer this layer's attention has just consumed:
     // launches on one stream run in order, so the attention above has finished reading it
-    if ((rc = ocv_layer_tail_split3_fwd(ctx, cur, &layers[l], last ? nullptr : layers[l + 1].in_proj_p3,
-                                        last ? nullptr : layers[l + 1].in_proj_b, eps, zmask, dst, last ? nullptr : qkv, M, E, FF,
-                                        stream))) return rc;
+    if (tails_h2)
+      rc = ocv_layer_tail_h2_fwd(ctx, cur, &layers[l], last ? nullptr : layers[l + 1].in_proj_h2, last ? nullptr : layers[l + 1].in_proj_b,
+                                 eps, zmask, dst, last ? nullptr : qkv, M, E, FF, stream);
+    else
+      rc = ocv_layer_tail_split3_fwd(ctx, cur, &layers[l], last ? nullptr : layers[l + 1].in_proj_p3,
+                                     last ? nullptr : layers[l + 1].in_proj_b, eps, zmask, dst, last ? nullptr : qkv, M, E, FF, stream);
+    if (rc) return rc;
     cur = dst;
   }
   return 0;

@@ -470,13 +470,20 @@ _P3_FIELDS = (("in_proj_p3", "self_attn.in_proj_weight"), ("out_proj_p3", "self_
               ("linear1_p3", "linear1.weight"), ("linear2_p3", "linear2.weight"))
 
 
+def token_mode() -> str:
+    """OCV_TOKENS: 'h2' (default: the layer tails -- output projection, LayerNorms, feed-forward block, next projection -- as
+    two-term fp16 splits, csrc/token_h2.hip; the remaining token linears as three-term bf16 splits), 'split3' (three-term bf16
+    everywhere: round 2's route, fp32's range) or 'fp32' (the exact-fp32 MFMA kernels: the A/B numerics route)."""
+    mode = os.environ.get("OCV_TOKENS", "h2")
+    if mode not in ("h2", "split3", "fp32"):
+        raise ValueError(f"OCV_TOKENS={mode!r}: expected 'h2' (default), 'split3' or 'fp32'")
+    return mode
+
+
 def token_split3_enabled() -> bool:
-    """Projections and feed-forward blocks of the transformer layers as the three-term bf16 split (default) or on the
-    exact-fp32 MFMA kernels (OCV_TOKENS=fp32: the A/B numerics route)."""
-    mode = os.environ.get("OCV_TOKENS", "split3")
-    if mode not in ("split3", "fp32"):
-        raise ValueError(f"OCV_TOKENS={mode!r}: expected 'split3' (default) or 'fp32'")
-    return mode == "split3"
+    """Whether the transformer layers' projections / feed-forward blocks run on packed split weights (OCV_TOKENS = h2 or split3)
+    rather than on the exact-fp32 MFMA kernels (OCV_TOKENS=fp32)."""
+    return token_mode() != "fp32"
 
 
 def layer_params(layer: torch.nn.Module, packed: Optional[dict] = None) -> Tuple[EncoderLayerParams, list]:
@@ -499,6 +506,16 @@ def layer_params(layer: torch.nn.Module, packed: Optional[dict] = None) -> Tuple
                 hit = packed[field] = (ver, SplitWeight3(w))
             keep.append(hit[1].packed)
             setattr(st, field, hit[1].packed.data_ptr())
+        if token_mode() == "h2":                     # + the two-term fp16 copies: the layer tails run on them
+            for field, key in _P3_FIELDS:
+                f2 = field.replace("_p3", "_h2")
+                w = sd[key]
+                ver = (w.data_ptr(), w._version)
+                hit = packed.get(f2)
+                if hit is None or hit[0] != ver:
+                    hit = packed[f2] = (ver, SplitWeightH2(w))
+                keep.append(hit[1].packed)
+                setattr(st, f2, hit[1].packed.data_ptr())
     return st, keep
 
 

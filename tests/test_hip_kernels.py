@@ -432,8 +432,12 @@ def _encoder_sd(seed, prefix="layers."):
     return enc, sd
 
 
-@pytest.mark.parametrize("B,S,counts", [(2, 132, None), (1, 300, None), (3, 40, [40, 7, 1]), (16, 32, [32] * 16)])
-def test_transformer_encoder_stack(ops, B, S, counts):
+@pytest.mark.parametrize("mode", ["h2", "split3"])
+@pytest.mark.parametrize("B,S,counts", [(2, 132, None), (1, 300, None), (3, 40, [40, 7, 1]), (16, 32, [32] * 16), (2, 1200, None)])
+def test_transformer_encoder_stack(ops, monkeypatch, B, S, counts, mode):
+    """nn.TransformerEncoder (4 post-norm layers) in 1 + 2 L launches: the layer tails as two-term fp16 splits (OCV_TOKENS=h2, the
+    default: csrc/token_h2.hip) or as three-term bf16 splits (split3), against the oracle and against the exact-fp32 route."""
+    monkeypatch.setenv("OCV_TOKENS", mode)
     from objcavit_amd.modules.layers import HipEncoderStack
     enc, sd = _encoder_sd(11)
     x = rnd("x", (B, S, 128), 12)

@@ -238,7 +238,7 @@ def test_encoder_layer_params_carry_their_size():
     import ctypes as C
     lib = _lib.load()
     p = _lib.EncoderLayerParams()
-    assert p.struct_size == C.sizeof(_lib.EncoderLayerParams) == 8 * 17
+    assert p.struct_size == C.sizeof(_lib.EncoderLayerParams) == 8 * 21       # size + 12 fp32 + 4 three-term + 4 two-term fp16 pointers
     one = C.c_void_p(256)                                   # non-null, never dereferenced: validation fails first
     for bad in (0, 8 * 12, 8 * 13 + 4, 1 << 20):
         p.struct_size = bad
