@@ -45,6 +45,9 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 cv_h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 cv_h16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 ti4 __attribute__((ext_vector_type(4)));
 
 constexpr int CBM = 256, CBN = 128, CBK = 32;
 constexpr int ROWB = 80;                                  // bytes per LDS row (64 data + 16 pad)
@@ -67,6 +70,7 @@ struct ConvArgs {
   int zbatch;                           // conv_split_dma_kernel: > 1 = that many independent GEMMs in one launch (the 16
   long xz_bytes, wz_bytes;              // Winograd positions): operand z at xhl + z xz_bytes / whi, wlo + z wz_bytes, raw fp32
                                         // result at y + (z ksplit + khalf) * M * Cout
+  int f16;                              // conv_split_dma_kernel: != 0 = the operands are fp16 (hi, lo) pairs (conv_split_dma_kernel<true>)
   unsigned rowpitch;                    // conv_split_dma_kernel: bytes between consecutive rows of the (B H) x W pixel grid of the
                                         // split input when they are not dense (0 = dense, W * 4 Cp); the patch embedding reads
                                         // every 16th image row of the feature map as one GEMM row grid this way
@@ -414,6 +418,9 @@ __device__ __forceinline__ void conv_store_rows(const ConvArgs& p, const unsigne
   }
 }
 
+// F16: the operands are fp16 (hi, lo) pairs instead of bf16 ones -- the same bytes through the same LDS-DMA pipeline, the
+// MFMA of the other 2-byte type (the Winograd F(4x4, 3x3) GEMM batch below: 22-bit products).
+template <bool F16>
 __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
 
@@ -479,9 +486,15 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          if constexpr (F16) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cv_h16x8, ah[i]), __builtin_bit_cast(cv_h16x8, bh[j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cv_h16x8, ah[i]), __builtin_bit_cast(cv_h16x8, bl[j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cv_h16x8, al[i]), __builtin_bit_cast(cv_h16x8, bh[j]), acc[i][j], 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          }
         }
       __syncthreads();
     }
@@ -701,12 +714,16 @@ int launch_conv(ConvArgs& a, int B, bool in_split, hipStream_t st) {
   if (in_split && use_dma) {
     static bool attr2 = false;
     if (!attr2) {
-      (void)hipFuncSetAttribute((const void*)conv_split_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_split_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_split_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr2 = true;
     }
     if (a.ksplit < 1) a.ksplit = 1;
     if (a.zbatch < 1) a.zbatch = 1;
-    hipLaunchKernelGGL(conv_split_dma_kernel, dim3(a.mtiles * a.ntiles * a.ksplit * a.zbatch), dim3(512), DNBUF * DBUF, st, a);
+    if (a.f16)
+      hipLaunchKernelGGL(conv_split_dma_kernel<true>, dim3(a.mtiles * a.ntiles * a.ksplit * a.zbatch), dim3(512), DNBUF * DBUF, st, a);
+    else
+      hipLaunchKernelGGL(conv_split_dma_kernel<false>, dim3(a.mtiles * a.ntiles * a.ksplit * a.zbatch), dim3(512), DNBUF * DBUF, st, a);
   } else if (in_split) hipLaunchKernelGGL(conv_igemm_kernel<true>, dim3(a.mtiles * a.ntiles), dim3(512), 2 * BUF_BYTES, st, a);
   else hipLaunchKernelGGL(conv_igemm_kernel<false>, dim3(a.mtiles * a.ntiles), dim3(512), 2 * BUF_BYTES, st, a);
   OCV_CHECK_LAUNCH("ocv_conv_nhwc");
@@ -988,6 +1005,217 @@ extern "C" int ocv_conv3x3_winograd_split_fwd(const void* x_hl, int Cin, const v
   WinoOutArgs wo{m, bias, y, (__bf16*)y_hl, B, H, W, Cout, a.Cpo, th, tw, act, T, T * (Cout / 4)};
   hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)((wo.items + 255) / 256)), dim3(256), 0, st, wo);
   OCV_CHECK_LAUNCH("ocv_conv3x3_winograd_split_fwd(output transform)");
+  return 0;
+}
+
+
+// =====================================================================================================================
+// Winograd F(4x4, 3x3) on the two-term FP16 split (round 3).  36 multiplies per 16 outputs instead of 144: 4x fewer matrix-core
+// operations than the direct form (F(2x2, 3x3): 2.25x), and a transformed input of 2.25x the activation instead of 4x.  Its
+// transforms amplify rounding ~100x, which is why round 2 stopped at F(2x2): with two bf16 terms (2^-17 products) the result
+// is 1e-4 of max |y| from fp64, five times the kernels' bar.  Two FP16 terms carry 22 bits: 2 - 3.5e-6 (CPU experiment on
+// 256 .. 1024 input channels, the figure of a three-term bf16 split) -- with ONE accumulator, i.e. on conv_split_dma_kernel
+// as it is (the MFMA of the other 2-byte type), provided no term falls into fp16's subnormals: the transformed filter
+// U = G g G^T has entries down to 1/576 of the filter's, so every position's U is scaled by a power of two that puts its
+// largest entry near 2^8 (undone on the raw GEMM result by the output transform); the transformed input is up to 7x the
+// activation (interpolation points 0, 1, -1, 2, -1/2, inf), far above the subnormals and far below 65504.
+//   1. wino43_input_kernel   V[xi][tile][c] = (B^T d B)[xi] in fp32 from the re-joined bf16 split input, written as fp16 (hi, lo)
+//                            rows, xi = 6 i + j, T = B ceil(H/4) ceil(W/4) tiles (6 x 6 input patch, stride 4, zero padded)
+//   2. conv_split_dma_kernel<true>, a batch of 36 GEMMs M[xi] = V[xi] . U'[xi]^T, raw fp32
+//   3. wino43_output_kernel  Y = A^T (M (.) 2^-k) A + bias, activation, fp32 and / or bf16 hl32 split stores
+// =====================================================================================================================
+namespace {
+
+struct Wino43InArgs {
+  const __bf16* xhl;      // [B][H][W][2 Cp] hl32 (bf16 hi | lo)
+  _Float16* v;            // [36][T][2 Cp] hl32 rows (fp16 hi | lo)
+  int B, H, W, Cp, th, tw;
+  long T, items;          // items = T * Cp / 4
+};
+
+// y = B^T x for one column of six values.  Interpolation points 0, 1, -1, 2, -1/2, inf: against the textbook set (0, +-1, +-2) the
+// transformed input is 7x the activation instead of 27x and the result 2.6x closer to fp64 (CPU experiment with fp32-accumulating
+// GEMMs, 1024 channels: 1.35e-6 against 3.46e-6 of max |y|); every coefficient is a dyadic rational, i.e. exact.
+//   B^T = [1 3/2 -2 -3/2 1 0;  0 -1 -5/2 -1/2 1 0;  0 1 1/2 -5/2 1 0;  0 -1/2 -1 1/2 1 0;  0 2 -1 -2 1 0;  0 1 3/2 -2 -3/2 1]
+__device__ __forceinline__ void w43_bt(const float (&x)[6], float (&y)[6]) {
+  y[0] = x[0] + 1.5f * (x[1] - x[3]) - 2.f * x[2] + x[4];
+  y[1] = -x[1] - 2.5f * x[2] - 0.5f * x[3] + x[4];
+  y[2] = x[1] + 0.5f * x[2] - 2.5f * x[3] + x[4];
+  y[3] = 0.5f * (x[3] - x[1]) - x[2] + x[4];
+  y[4] = 2.f * (x[1] - x[3]) - x[2] + x[4];
+  y[5] = x[1] + 1.5f * (x[2] - x[4]) - 2.f * x[3] + x[5];
+}
+
+// one thread = (tile, channel quad): 36 pixels x (4 hi + 4 lo) in, 36 positions x (4 hi + 4 lo) out
+__global__ __launch_bounds__(256) void wino43_input_kernel(Wino43InArgs p) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.items) return;
+  const int nq = p.Cp >> 2;
+  const long t = i / nq;
+  const int c = (int)(i - t * nq) * 4;
+  const int tx = (int)(t % p.tw);
+  const long r = t / p.tw;
+  const int ty = (int)(r % p.th), b = (int)(r / p.th);
+  const long coff = (long)(c >> 5) * 64 + (c & 31);                       // hi quad; lo quad at + 32
+  float w[6][6][4];                                                        // (B^T d): row index ii, column xx
+#pragma unroll
+  for (int xx = 0; xx < 6; ++xx) {
+    const int x = 4 * tx - 1 + xx;
+    float col[4][6];
+#pragma unroll
+    for (int yy = 0; yy < 6; ++yy) {
+      const int y = 4 * ty - 1 + yy;
+      const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+      const __bf16* src = ok ? p.xhl + (((long)b * p.H + y) * p.W + x) * 2 * p.Cp + coff
+                             : reinterpret_cast<const __bf16*>(ocv_zero_page);
+      const ti4 h = *reinterpret_cast<const ti4*>(src);
+      const ti4 l = *reinterpret_cast<const ti4*>(src + (ok ? 32 : 4));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) col[e][yy] = (float)h[e] + (float)l[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float o[6];
+      w43_bt(col[e], o);
+#pragma unroll
+      for (int ii = 0; ii < 6; ++ii) w[ii][xx][e] = o[ii];
+    }
+  }
+#pragma unroll
+  for (int ii = 0; ii < 6; ++ii) {
+    float v6[4][6];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float rowv[6];
+#pragma unroll
+      for (int xx = 0; xx < 6; ++xx) rowv[xx] = w[ii][xx][e];
+      w43_bt(rowv, v6[e]);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 6; ++jj) {
+      cv_h16x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const _Float16 hb = (_Float16)v6[e][jj];
+        hi[e] = hb;
+        lo[e] = (_Float16)(v6[e][jj] - (float)hb);
+      }
+      _Float16* dst = p.v + (((long)(6 * ii + jj) * p.T + t) * 2 * p.Cp) + coff;
+      *reinterpret_cast<cv_h16x4*>(dst) = hi;
+      *reinterpret_cast<cv_h16x4*>(dst + 32) = lo;
+    }
+  }
+}
+
+struct Wino43OutArgs {
+  const float* m;         // [36][T][Cout] raw GEMM results
+  const float* fscale;    // [36]: 2^-k of each position's filter scaling
+  const float* bias;
+  float* y;               // [B][H][W][Cout] fp32 (nullable)
+  __bf16* yhl;            // hl32 split copy, bf16 (nullable)
+  int B, H, W, Cout, Cpo, th, tw, act;
+  long T, items;          // items = T * Cout / 4
+};
+
+// one thread = (tile, 4 channels): Y = A^T M A (A^T = [1 1 1 1 1 0; 0 1 -1 2 -1/2 0; 0 1 1 4 1/4 0; 0 1 -1 8 -1/8 1]), bias,
+// activation, up to 4 x 4 pixel stores
+__global__ __launch_bounds__(256) void wino43_output_kernel(Wino43OutArgs p) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.items) return;
+  const int nq = p.Cout >> 2;
+  const long t = i / nq;
+  const int n = (int)(i - t * nq) * 4;
+  const int tx = (int)(t % p.tw);
+  const long r = t / p.tw;
+  const int ty = (int)(r % p.th), b = (int)(r / p.th);
+  f32x4 s[4][6];                                                           // A^T M: rows dy, columns jj
+#pragma unroll
+  for (int jj = 0; jj < 6; ++jj) {
+    f32x4 m[6];
+#pragma unroll
+    for (int ii = 0; ii < 6; ++ii)
+      m[ii] = *reinterpret_cast<const f32x4*>(p.m + ((long)(6 * ii + jj) * p.T + t) * p.Cout + n) * p.fscale[6 * ii + jj];
+    s[0][jj] = m[0] + m[1] + m[2] + m[3] + m[4];
+    s[1][jj] = m[1] - m[2] + 2.f * m[3] - 0.5f * m[4];
+    s[2][jj] = m[1] + m[2] + 4.f * m[3] + 0.25f * m[4];
+    s[3][jj] = m[1] - m[2] + 8.f * m[3] - 0.125f * m[4] + m[5];
+  }
+  const f32x4 bv = p.bias != nullptr ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int dy = 0; dy < 4; ++dy) {
+    const int y = 4 * ty + dy;
+    if (y >= p.H) continue;
+    f32x4 o[4];
+    o[0] = s[dy][0] + s[dy][1] + s[dy][2] + s[dy][3] + s[dy][4] + bv;
+    o[1] = s[dy][1] - s[dy][2] + 2.f * s[dy][3] - 0.5f * s[dy][4] + bv;
+    o[2] = s[dy][1] + s[dy][2] + 4.f * s[dy][3] + 0.25f * s[dy][4] + bv;
+    o[3] = s[dy][1] - s[dy][2] + 8.f * s[dy][3] - 0.125f * s[dy][4] + s[dy][5] + bv;
+#pragma unroll
+    for (int dx = 0; dx < 4; ++dx) {
+      const int x = 4 * tx + dx;
+      if (x >= p.W) continue;
+      f32x4 v = o[dx];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = conv_act(v[e], p.act);
+      const long px = ((long)b * p.H + y) * p.W + x;
+      if (p.y != nullptr) *reinterpret_cast<f32x4*>(p.y + px * p.Cout + n) = v;
+      if (p.yhl != nullptr) {
+        __bf16 hi[4], lo[4];
+        split4(v, hi, lo);
+        const long oh = hl_index(px, n, p.Cpo);
+        *reinterpret_cast<uint2*>(p.yhl + oh) = *reinterpret_cast<uint2*>(hi);
+        *reinterpret_cast<uint2*>(p.yhl + oh + 32) = *reinterpret_cast<uint2*>(lo);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t ocv_conv3x3_winograd43_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+  if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return 0;
+  const long T = (long)B * ((H + 3) / 4) * ((W + 3) / 4);
+  const int Cp = (Cin + 31) / 32 * 32;
+  return wino_align((size_t)36 * T * 2 * Cp * sizeof(_Float16)) + wino_align((size_t)36 * T * Cout * sizeof(float));
+}
+
+extern "C" int ocv_conv3x3_winograd43_split_fwd(const void* x_hl, int Cin, const void* u_hi, const void* u_lo, const float* fscale,
+                                                const float* bias, float* y, void* y_hl, int B, int H, int W, int Cout,
+                                                int act, void* workspace, size_t workspace_bytes, ocv_stream_t stream) {
+  OCV_CHECK_ARG(x_hl && u_hi && u_lo && fscale && (y || y_hl) && workspace, "ocv_conv3x3_winograd43_split_fwd: null pointer");
+  OCV_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 8 && Cout % 8 == 0,
+                "ocv_conv3x3_winograd43_split_fwd: bad sizes (Cout must be a multiple of 8, got %d)", Cout);
+  OCV_CHECK_ARG(act >= 0 && act <= 3, "ocv_conv3x3_winograd43_split_fwd: unknown activation %d", act);
+  OCV_CHECK_ARG((reinterpret_cast<uintptr_t>(x_hl) & 127) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0 &&
+                    ocv_aligned16(u_hi) && ocv_aligned16(u_lo) && ocv_aligned16(y) && ocv_aligned16(y_hl) && ocv_aligned16(bias),
+                "ocv_conv3x3_winograd43_split_fwd: x_hl must be 128-byte, workspace 256-byte, the rest 16-byte aligned");
+  OCV_CHECK_ARG(workspace_bytes >= ocv_conv3x3_winograd43_workspace_bytes(B, H, W, Cin, Cout),
+                "ocv_conv3x3_winograd43_split_fwd: workspace too small");
+  const int th = (H + 3) / 4, tw = (W + 3) / 4, Cp = (Cin + 31) / 32 * 32;
+  const long T = (long)B * th * tw;
+  OCV_CHECK_ARG(T * (Cin + 32) * 4 < (1L << 32) && (long)Cout * (Cin + 32) * 2 < (1L << 32),
+                "ocv_conv3x3_winograd43_split_fwd: one transformed operand must stay below 4 GiB");
+  hipStream_t st = (hipStream_t)stream;
+  _Float16* v = (_Float16*)workspace;
+  float* m = (float*)((char*)workspace + wino_align((size_t)36 * T * 2 * Cp * sizeof(_Float16)));
+  if (y_hl != nullptr && Cout % 32 != 0) {
+    const hipError_t e = hipMemsetAsync(y_hl, 0, ocv_split_act_elems(B, H, W, Cout) * sizeof(__bf16), st);
+    OCV_CHECK_ARG(e == hipSuccess, "ocv_conv3x3_winograd43_split_fwd: hipMemsetAsync failed: %s", hipGetErrorString(e));
+  }
+  Wino43InArgs wi{(const __bf16*)x_hl, v, B, H, W, Cp, th, tw, T, T * (Cp / 4)};
+  hipLaunchKernelGGL(wino43_input_kernel, dim3((unsigned)((wi.items + 255) / 256)), dim3(256), 0, st, wi);
+  OCV_CHECK_LAUNCH("ocv_conv3x3_winograd43_split_fwd(input transform)");
+  ConvArgs a{};
+  a.xhl = (const __bf16*)v; a.whi = (const __bf16*)u_hi; a.wlo = (const __bf16*)u_lo; a.y = m;
+  a.C1 = Cin; a.Cin = Cin; a.Cout = Cout; a.H = 1; a.W = (int)T; a.ks = 1; a.act = OCV_ACT_NONE; a.ksplit = 1;
+  a.zbatch = 36; a.xz_bytes = T * 2 * Cp * (long)sizeof(_Float16); a.wz_bytes = (long)Cout * Cp * (long)sizeof(_Float16);
+  a.Cpo = (Cout + 31) / 32 * 32;
+  a.f16 = 1;
+  const int rc = launch_conv(a, 1, true, st);
+  if (rc != 0) return rc;
+  Wino43OutArgs wo{m, fscale, bias, y, (__bf16*)y_hl, B, H, W, Cout, a.Cpo, th, tw, act, T, T * (Cout / 4)};
+  hipLaunchKernelGGL(wino43_output_kernel, dim3((unsigned)((wo.items + 255) / 256)), dim3(256), 0, st, wo);
+  OCV_CHECK_LAUNCH("ocv_conv3x3_winograd43_split_fwd(output transform)");
   return 0;
 }
 

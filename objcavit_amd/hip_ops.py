@@ -975,19 +975,96 @@ def prep_winograd_weight(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tens
     return hi.contiguous(), lo.contiguous()
 
 
+# F(4x4, 3x3) with the interpolation points 0, 1, -1, 2, -1/2, inf (csrc/conv_igemm.hip, w43_bt): G rows [1, a, a^2] / prod_{j != i}(a_i - a_j)
+_WINO43_G = ((1.0, 0.0, 0.0), (-1 / 3, -1 / 3, -1 / 3), (1 / 3, -1 / 3, 1 / 3), (1 / 15, 2 / 15, 4 / 15), (-16 / 15, 8 / 15, -4 / 15), (0.0, 0.0, 1.0))
+
+
+def prep_winograd43_weight(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """[Cout, Cin, 3, 3] fp32 -> (u_hi, u_lo fp16 [36, Cout, Cp], fscale fp32 [36]): the Winograd F(4x4, 3x3) filter transform
+    U[6 i + j] = (G g G^T)[i][j] in fp64, every position scaled by the power of two 2^k that puts its largest entry in
+    [2^7.5, 2^8.5) (the transform's entries go down to 1/576 of the filter's: unscaled, their low terms fall into fp16's
+    subnormals and the result is 100x less accurate), then split hi = fp16(U'), lo = fp16(U' - hi); fscale = 2^-k is applied to
+    the raw GEMM results by the output transform.  Cp = Cin rounded up to 32.  Once per weight version (cached by the callers)."""
+    Cout, Cin, kh, kw = weight.shape
+    if (kh, kw) != (3, 3):
+        raise ValueError("prep_winograd43_weight: kernel must be 3x3")
+    G = torch.tensor(_WINO43_G, dtype=torch.float64, device=weight.device)
+    u = torch.einsum("ia,ocab,jb->ijoc", G, weight.detach().double(), G).reshape(36, Cout, Cin)
+    amax = u.abs().amax(dim=(1, 2)).clamp_min(1e-30)
+    k = torch.round(8.0 - torch.log2(amax))
+    u = (u * torch.exp2(k)[:, None, None]).float()
+    Cp = (Cin + 31) // 32 * 32
+    if Cp != Cin:
+        u = torch.nn.functional.pad(u, (0, Cp - Cin))
+    hi = u.to(torch.float16)
+    lo = (u - hi.float()).to(torch.float16)
+    return hi.contiguous(), lo.contiguous(), torch.exp2(-k).float().contiguous()
+
+
+def winograd_tile(B: int, H: int, W: int, Cin: int, Cout: int) -> int:
+    """Which Winograd form a 3x3 convolution that ``winograd_pays`` takes: 4 = F(4x4, 3x3) on two-term fp16 splits (default:
+    4x fewer matrix operations than direct, 36 GEMMs), 2 = F(2x2, 3x3) on two-term bf16 splits (round 2's: 2.25x, 16 GEMMs).
+    OCV_CONV_WINOGRAD_TILE=2|4 forces one."""
+    mode = os.environ.get("OCV_CONV_WINOGRAD_TILE", "4")
+    if mode not in ("2", "4"):
+        raise ValueError(f"OCV_CONV_WINOGRAD_TILE={mode!r}: expected 2 or 4")
+    return int(mode)
+
+
+def conv3x3_winograd43_split(x: "SplitAct", u_hi: torch.Tensor, u_lo: torch.Tensor, fscale: torch.Tensor, bias: Optional[torch.Tensor],
+                             act: int = ACT_NONE, out_fp32: bool = True, out_split: bool = False):
+    """3x3 convolution (stride 1, padding 1) of a pre-split activation in Winograd F(4x4, 3x3) form on two-term fp16 splits
+    (ocv_conv3x3_winograd43_split_fwd).  Returns fp32 tensor, SplitAct, or (fp32, SplitAct) like conv_nhwc_split."""
+    lib = _lib.load()
+    if not (out_fp32 or out_split):
+        raise ValueError("conv3x3_winograd43_split: nothing to output")
+    _req(x.hl, "x.hl", torch.bfloat16)
+    B, Cin, H, W = x.shape
+    Cp = (Cin + 31) // 32 * 32
+    if x.hl.dim() != 4 or x.hl.shape[3] != 2 * Cp:
+        raise ValueError("conv3x3_winograd43_split: x.hl must be [B, H, W, 2 * ceil32(C)] bf16")
+    for n, t in (("u_hi", u_hi), ("u_lo", u_lo)):
+        _req(t, n, torch.float16)
+    _req(fscale, "fscale")
+    if u_hi.dim() != 3 or u_hi.shape[0] != 36 or u_hi.shape[2] != Cp or u_lo.shape != u_hi.shape or fscale.numel() != 36:
+        raise ValueError(f"conv3x3_winograd43_split: transformed weights {tuple(u_hi.shape)} do not match {Cin} input channels")
+    Cout = u_hi.shape[1]
+    if Cout % 8 != 0:
+        raise ValueError("conv3x3_winograd43_split: Cout must be a multiple of 8")
+    if bias is not None:
+        _req(bias, "bias")
+        if bias.numel() != Cout:
+            raise ValueError("conv3x3_winograd43_split: bias size mismatch")
+    y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.hl.device, memory_format=torch.channels_last) if out_fp32 else None
+    ys = SplitAct.empty(B, Cout, H, W, x.hl.device) if out_split else None
+    nws = int(lib.ocv_conv3x3_winograd43_workspace_bytes(B, H, W, Cin, Cout))
+    ws = workspace(nws, x.hl.device, "conv_winograd")
+    with timed(f"conv3x3w|{B},{H},{W},{Cin},{Cout}"):
+        check(lib.ocv_conv3x3_winograd43_split_fwd(x.hl.data_ptr(), Cin, u_hi.data_ptr(), u_lo.data_ptr(), fscale.data_ptr(), _ptr(bias),
+                                                   _ptr(y), ys.hl.data_ptr() if out_split else None, B, H, W, Cout, act,
+                                                   ws.data_ptr(), ws.numel(), _stream()), "ocv_conv3x3_winograd43_split_fwd")
+    if out_fp32 and out_split:
+        return y, ys
+    return y if out_fp32 else ys
+
+
 def winograd_pays(B: int, H: int, W: int, Cin: int, Cout: int) -> bool:
-    """Where the Winograd form of a 3x3 convolution beats the direct split-bf16 kernel: its transformed input is 4x the
-    activation and its raw result 4x the output, both through HBM, so the arithmetic must dominate -- the decoder's two
-    30 x 40 stages (2224 / 1024 -> 1024 at bs = 16: 16 GEMMs 0.87 / 0.45 ms + transforms against 1.85 / 0.87 ms direct,
-    tools/exp_winograd_gemm.py); at 60 x 80 (1088 / 512 -> 512) the transforms' traffic already eats the gain.
-    OCV_CONV_WINOGRAD=0 / =1 in the environment forces never / whenever the kernel supports the shape."""
+    """Where a Winograd form of a 3x3 convolution beats the direct split-bf16 kernel: the transformed input and the raw result go
+    through HBM, so the arithmetic must dominate.  F(4x4, 3x3) on two-term fp16 splits (the default form, ``winograd_tile``): the
+    decoder's 30 x 40 and 60 x 80 second convolutions (1024 -> 1024: 413 us against 1000 direct and 632 for F(2x2, 3x3); 512 -> 512:
+    557 against 882; 256 -> 256 at 120 x 160 is a tie and stays direct -- tools/run_wino43.py, profiles/r03_winograd43.txt).
+    F(2x2, 3x3) (OCV_CONV_WINOGRAD_TILE=2, round 2's): the 30 x 40 stage only (its 4x transformed input eats the gain at 60 x 80).
+    OCV_CONV_WINOGRAD=0 / =1 in the environment forces never / whenever the kernel supports the shape; OCV_WINO_MIN_CIN /
+    OCV_WINO_MIN_COUT / OCV_WINO_MAX_PIX move the thresholds."""
     mode = os.environ.get("OCV_CONV_WINOGRAD", "auto")
     if mode == "0" or Cout % 8 != 0:
         return False
     if mode == "1":
         return True
-    return Cin >= int(os.environ.get("OCV_WINO_MIN_CIN", "768")) and Cout >= int(os.environ.get("OCV_WINO_MIN_COUT", "512")) \
-        and B * H * W <= int(os.environ.get("OCV_WINO_MAX_PIX", "32768"))
+    f43 = winograd_tile(B, H, W, Cin, Cout) == 4
+    return Cin >= int(os.environ.get("OCV_WINO_MIN_CIN", "512" if f43 else "768")) \
+        and Cout >= int(os.environ.get("OCV_WINO_MIN_COUT", "512")) \
+        and B * H * W <= int(os.environ.get("OCV_WINO_MAX_PIX", "131072" if f43 else "32768"))
 
 
 def conv3x3_winograd_split(x: "SplitAct", u_hi: torch.Tensor, u_lo: torch.Tensor, bias: Optional[torch.Tensor],

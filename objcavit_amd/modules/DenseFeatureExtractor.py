@@ -142,11 +142,15 @@ class SplitConv3x3:
         B, Cin, H, W = x.shape
         if self.conv.kernel_size[0] == 3 and hip_ops.winograd_pays(B, H, W, Cin, self.conv.out_channels):
             # the deep stages: Winograd F(2x2, 3x3), 2.25x fewer matrix-core operations (csrc/conv_igemm.hip)
-            if self._wino is None:
+            tile = hip_ops.winograd_tile(B, H, W, Cin, self.conv.out_channels)
+            if self._wino is None or self._wino[0] != tile:
                 if torch.cuda.is_current_stream_capturing():
                     raise RuntimeError("weight preparation during graph capture: run one eager warm-up call first")
-                self._wino = hip_ops.prep_winograd_weight(self._w_folded)
-            return hip_ops.conv3x3_winograd_split(x, self._wino[0], self._wino[1], b, act, out_fp32=out_fp32, out_split=out_split)
+                prep = hip_ops.prep_winograd43_weight if tile == 4 else hip_ops.prep_winograd_weight
+                self._wino = (tile,) + tuple(prep(self._w_folded))
+            if tile == 4:      # F(4x4, 3x3) on two-term fp16 splits: 4x fewer matrix-core operations
+                return hip_ops.conv3x3_winograd43_split(x, self._wino[1], self._wino[2], self._wino[3], b, act, out_fp32=out_fp32, out_split=out_split)
+            return hip_ops.conv3x3_winograd_split(x, self._wino[1], self._wino[2], b, act, out_fp32=out_fp32, out_split=out_split)
         return hip_ops.conv_nhwc_split(x, hi, lo, b, self.conv.kernel_size[0], act, out_fp32=out_fp32, out_split=out_split)
 
 # skip-connection table: encoder-name fragment -> (feature_select, skip channels 3..0)

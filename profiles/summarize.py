@@ -27,7 +27,7 @@ OURS = ("bin_head_kernel", "pixel_dot_kernel", "patch_embed_partial_kernel", "pa
         "conv_split_dma_kernel", "upsample_concat_split_kernel", "pw_rows_kernel", "pw_tile_kernel", "pw_stream_kernel",
         "bin_head_split_kernel", "bin_head_split3_kernel", "bin_head_combine_kernel", "wino_input_kernel", "wino_output_kernel", "conv_exact_kernel", "tap_interp_kernel", "lin3_kernel", "ffn3_kernel", "ffn3_finish_kernel", "layer_tail3_kernel", "pack3_kernel", "cross_attn_fused_kernel", "depth_metrics_partial_kernel", "depth_metrics_finish_kernel", "dw_slide_kernel", "se_hidden_partials_kernel", "se_gate_hid_kernel", "stem_conv_kernel",
         "mbconv_expand_dw_kernel", "pos_sample_kernel", "pw_big_kernel", "pw_hl_kernel", "se_gate_weights_kernel", "xattn_kv3_kernel", "xattn_main3_kernel", "encoder_stack_kernel", "upsample_concat_split8_kernel", "upsample_concat_split_2x2_kernel", "conv_splitk_finish_kernel", "ffn_finish_kernel", "upsample_concat_split_lds_kernel",
-        "xattn_main_h2_kernel", "xattn_kv_h2_kernel", "pack_h2_kernel", "bin_head_h2_kernel", "conv_few_kernel", "attention_h2_kernel", "layer_tail_h2_kernel")
+        "xattn_main_h2_kernel", "xattn_kv_h2_kernel", "pack_h2_kernel", "bin_head_h2_kernel", "conv_few_kernel", "attention_h2_kernel", "layer_tail_h2_kernel", "wino43_input_kernel", "wino43_output_kernel")
 
 
 def is_step_end(name):

@@ -1147,6 +1147,46 @@ def test_conv3x3_winograd_split(ops, B, H, W, Cin, Cout, act):
     assert rel_dev(y, direct) < SPLIT_TOL
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,act", [
+    (2, 30, 40, 96, 64, 2),        # H not a multiple of 4 (last tile row half outside), LeakyReLU
+    (1, 7, 9, 40, 72, 0),          # odd H and W, Cin % 32 != 0, Cout % 32 != 0
+    (3, 1, 1, 32, 8, 1),           # a single pixel: every tap but the centre is padding
+    (1, 4, 4, 8, 16, 3),           # one tile, SiLU
+    (1, 16, 20, 1024, 512, 2),     # long K: 32 channel chunks per position
+    (2, 13, 16, 300, 136, 2),      # ragged everything
+    (16, 30, 40, 1024, 1024, 2),   # the decoder's 30 x 40 stage at full size (1280 tiles per position, 36 GEMMs of K = 1024)
+])
+def test_conv3x3_winograd43_split(ops, B, H, W, Cin, Cout, act):
+    """ocv_conv3x3_winograd43_split_fwd (F(4x4, 3x3): input transform, 36 batched two-term-fp16 GEMMs on filters scaled out of
+    fp16's subnormals, output transform) against an fp64 convolution at the SAME bar as the direct kernel (2e-5 of max |y|),
+    and against the direct kernel itself."""
+    x = rnd("x", (B, Cin, H, W), 1)
+    w, b = rnd("w", (Cout, Cin, 3, 3), 3, 1 / math.sqrt(Cin * 9)), rnd("b", (Cout,), 4, 0.2)
+    if B * H * W * Cout > 4e6:                                  # the full-size case: reference on the GPU in fp64
+        ref = F.conv2d(dev(x).double(), dev(w).double(), dev(b).double(), padding=1).cpu()
+    else:
+        ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    ref = [ref, torch.relu(ref), F.leaky_relu(ref, 0.01), F.silu(ref)][act]
+    u_hi, u_lo, fs = ops.prep_winograd43_weight(dev(w))
+    assert tuple(u_hi.shape) == (36, Cout, (Cin + 31) // 32 * 32) and u_hi.dtype == torch.float16 and fs.numel() == 36
+    assert float(u_hi.float().abs().amax()) < 1024.0 and bool(torch.isfinite(u_lo.float()).all())
+    xs = ops.upsample_concat_split(dev(x), None, (H, W))
+    poison = [torch.full((1 << 22,), float("nan"), device="cuda") for _ in range(8)]
+    del poison                                                  # workspace and outputs come out of NaN-filled memory
+    y, ys = ops.conv3x3_winograd43_split(xs, u_hi, u_lo, fs, dev(b), act, out_fp32=True, out_split=True)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    assert rel_dev(y, ref) < SPLIT_TOL
+    assert rel_dev(ys.float(), y) < 1e-5
+    Cpo = (Cout + 31) // 32 * 32
+    blocks = ys.hl.view(B, H, W, Cpo // 32, 2, 32).permute(0, 1, 2, 4, 3, 5).reshape(B, H, W, 2, Cpo)
+    assert not bool(blocks[..., Cout:].any())                  # pad channels of the split output are zero
+    y2 = ops.conv3x3_winograd43_split(xs, u_hi, u_lo, fs, dev(b), act, out_fp32=True, out_split=False)
+    assert torch.equal(y, y2)
+    hi, lo = ops.prep_conv_weight(dev(w))
+    direct = ops.conv_nhwc_split(xs, hi, lo, dev(b), 3, act)
+    assert rel_dev(y, direct) < SPLIT_TOL
+
+
 def test_conv3x3_winograd_keeps_fp32_range_and_rejects_bad_operands(ops):
     x = rnd("x", (1, 64, 12, 12), 1) * torch.logspace(-3, 3, 64).view(1, 64, 1, 1)
     w = rnd("w", (32, 64, 3, 3), 2, 0.05) / torch.logspace(-3, 3, 64).view(1, 64, 1, 1)
@@ -1159,7 +1199,15 @@ def test_conv3x3_winograd_keeps_fp32_range_and_rejects_bad_operands(ops):
     with pytest.raises(ValueError):
         ops.prep_winograd_weight(dev(rnd("w1", (8, 8, 1, 1), 1)))
     assert ops.winograd_pays(16, 30, 40, 2224, 1024) and ops.winograd_pays(16, 30, 40, 1024, 1024)
-    assert not ops.winograd_pays(16, 60, 80, 1088, 512) and not ops.winograd_pays(16, 240, 320, 280, 128)
+    assert ops.winograd_tile(16, 30, 40, 1024, 1024) == 4                 # default form: F(4x4, 3x3) on two-term fp16 splits ...
+    assert ops.winograd_pays(16, 60, 80, 512, 512) and not ops.winograd_pays(16, 120, 160, 256, 256)     # ... which also takes 60 x 80
+    assert not ops.winograd_pays(16, 240, 320, 280, 128)
+    import os
+    os.environ["OCV_CONV_WINOGRAD_TILE"] = "2"                            # round 2's F(2x2, 3x3): the 30 x 40 stage only
+    try:
+        assert ops.winograd_pays(16, 30, 40, 1024, 1024) and not ops.winograd_pays(16, 60, 80, 1088, 512)
+    finally:
+        del os.environ["OCV_CONV_WINOGRAD_TILE"]
 
 
 @pytest.mark.parametrize("B,H,W,C1,C2,Cout,k,act", [
