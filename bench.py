@@ -660,8 +660,8 @@ def main():
         if not a.stub_cpu:
             res["dtype_note"] = ("fp32 results; contractions of the 3x3 / 1x1 / 16x16-patch convolutions run as split-bf16 (hi*hi + hi*lo + "
                                  "lo*hi on v_mfma_*_bf16, fp32 accumulate: product error <= 2^-17; the first convolution of every decoder "
-                                 "stage at the low resolution = an exact re-association; the 30x40 second convolution in Winograd "
-                                 "F(2x2,3x3) form with fp32 transforms, same parity bar); layer 0's projection of each transformer stack as a "
+                                 "stage at the low resolution = an exact re-association; the 30x40 and 60x80 second convolutions in Winograd "
+                                 "F(4x4,3x3) form with fp32 transforms and two-term fp16 products, same parity bar); layer 0's projection of each transformer stack as a "
                                  "three-term bf16 split (six products, dropped terms <= 2^-24: fp32-faithful); the layers' projections and "
                                  "feed-forward blocks, the attention cores (QK^T, PV), the image <- object cross-attention and the bin head as a two-term fp16 split with a "
                                  "scaled low term (x = hi + 2^-11 lo', three v_mfma_*_f16 per product block: 22-bit products = the error of "
