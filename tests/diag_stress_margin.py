@@ -1,0 +1,45 @@
+"""Diagnostic (run by hand on the GPU box; lives under tests/ because it calls the oracle): the stress-case error that
+tests/test_hip_models.py::test_config2_full_size_properties pins below 6e-4 -- N(0,1) "images", 6x logit gain, fp32 rounding
+amplified ~2000x -- under the arithmetic routes of the rounds.  python tests/diag_stress_margin.py"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import torch
+import gen
+from oracle import restate
+from objcavit_amd.config import make_args
+from objcavit_amd.modules.GraphBins import GraphBins, SyntheticObjectProvider
+
+ROUTES = {
+    "round 3 default (fp16 two-term attention / cross-attention / bin head / layer tails, Winograd F(4,3) fp16)": {},
+    "Winograd F(2,2) bf16 instead of F(4,3) fp16": {"OCV_CONV_WINOGRAD_TILE": "2"},
+    "round 2 arithmetic (three-term tokens / bin head, exact-fp32 attention, F(2,2))": {
+        "OCV_CONV_WINOGRAD_TILE": "2", "OCV_TOKENS": "split3", "OCV_BINHEAD": "split3", "OCV_ATTN_FORM": "fp32", "OCV_XATTN_FORM": "split3"},
+    "no Winograd": {"OCV_CONV_WINOGRAD": "0"},
+    "exact-fp32 convolutions, default tokens / heads": {"OCV_CONV": "exact"},
+}
+torch.set_grad_enabled(False)
+img = gen.randn("img", (8, 3, 480, 640), 5)
+ref = None
+for name, env in ROUTES.items():
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        args = make_args(strategy="learned", language="control_obj_zeros_512")
+        m = GraphBins(args, object_provider=SyntheticObjectProvider(16, "control_obj_zeros_512")).eval()
+        gen.load_into(m, 5, gen.PEAKY)
+        m = m.cuda()
+        d = m(img.cuda()).depth_pred
+        if ref is None:
+            feats, boxes, _ = m.object_provider(img.cuda())
+            sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+            ref, _ = restate.graphbins_forward(img[3:4], [feats[3].cpu()], [boxes[3].cpu()], sd, 0.001, 10, strategy="learned")
+        e = ((d[3:4].cpu() - ref).abs() / ref.abs())
+        print(f"{name}: max-rel {float(e.max()):.2e}  mean-rel {float(e.mean()):.2e}", flush=True)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
