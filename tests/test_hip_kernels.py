@@ -1187,6 +1187,24 @@ def test_conv3x3_winograd43_split(ops, B, H, W, Cin, Cout, act):
     assert rel_dev(y, direct) < SPLIT_TOL
 
 
+def test_conv3x3_winograd43_random_shapes(ops):
+    """Seeded sweep of the F(4x4, 3x3) form over ragged shapes (1..3 images, 1..23 rows / columns, 4..132 input channels, 8..200
+    output channels, every activation) against an fp64 convolution."""
+    import random
+    rng = random.Random(4343)
+    for case in range(16):
+        B, H, W = rng.randint(1, 3), rng.randint(1, 23), rng.randint(1, 23)
+        Cin, Cout, act = rng.choice([4, 8, 12, 28, 32, 36, 64, 132]), 8 * rng.randint(1, 25), rng.randint(0, 3)     # (the splitter takes channel quads)
+        x = rnd("x", (B, Cin, H, W), 500 + case)
+        w, b = rnd("w", (Cout, Cin, 3, 3), 600 + case, 1 / math.sqrt(Cin * 9)), rnd("b", (Cout,), 700 + case, 0.2)
+        ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+        ref = [ref, torch.relu(ref), F.leaky_relu(ref, 0.01), F.silu(ref)][act]
+        u_hi, u_lo, fs = ops.prep_winograd43_weight(dev(w))
+        xs = ops.upsample_concat_split(dev(x), None, (H, W))
+        y = ops.conv3x3_winograd43_split(xs, u_hi, u_lo, fs, dev(b), act)
+        assert rel_dev(y, ref) < SPLIT_TOL, (case, B, H, W, Cin, Cout, act)
+
+
 def test_conv3x3_winograd_keeps_fp32_range_and_rejects_bad_operands(ops):
     x = rnd("x", (1, 64, 12, 12), 1) * torch.logspace(-3, 3, 64).view(1, 64, 1, 1)
     w = rnd("w", (32, 64, 3, 3), 2, 0.05) / torch.logspace(-3, 3, 64).view(1, 64, 1, 1)
