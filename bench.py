@@ -47,11 +47,10 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32, dense
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16, dense (the split-bf16 convolutions issue 3 of these per product)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16 / _f16, dense: the same peak for both 2-byte types (the split convolutions issue 3 MFMAs per product)
 
 E, NBINS = 128, 256
 
@@ -89,7 +88,7 @@ class Workload:
         self.stacks = 2 if self.kw.get("use_2_saca") else 1
 
     def gains(self):
-        import gen
+        from objcavit_amd import synth as gen
         return gen.PEAKY if self.gains_name == "PEAKY" else KITTI_GAINS
 
 
@@ -118,7 +117,7 @@ def kernel_model(B, wl):
 
 
 def build_model(device, wl):
-    import gen
+    from objcavit_amd import synth as gen
     from objcavit_amd.config import make_args
     from objcavit_amd.modules.GraphBins import GraphBins, SyntheticObjectProvider
     args = make_args(dataset=wl.dataset, language=wl.language, dimensions_train=[wl.H, wl.W], dimensions_test=[wl.H, wl.W], **wl.kw)
@@ -234,21 +233,26 @@ def kernel_report(timing, a, B, wl):
     km = kernel_model(B, wl)
     kernels, convs = {}, []
     for name, (cnt, ms) in timing.items():
-        if name.startswith("conv3x3|") or name.startswith("conv1x1|") or name.startswith("conv3x3w|"):
+        if name.startswith(("conv3x3|", "conv1x1|", "conv3x3w2|", "conv3x3w4|")):
             k = 1 if name.startswith("conv1x1") else 3
-            wino = name.startswith("conv3x3w|")          # Winograd F(2x2,3x3): 16 multiplies per 4 outputs instead of 36
+            # Winograd launches are priced by the tile ACTUALLY dispatched (the timing name carries it): F(2x2,3x3) = 16 multiplies per
+            # 4 outputs on two-term bf16 splits, F(4x4,3x3) = 36 per 16 outputs on two-term fp16 splits; direct = 9 per output, bf16
+            wino = 2 if name.startswith("conv3x3w2|") else 4 if name.startswith("conv3x3w4|") else 0
+            per_out = {0: 1.0, 2: 16.0 / 36.0, 4: 36.0 / 144.0}[wino]
+            mfma_dtype = "f16" if wino == 4 else "bf16"
             b_, h_, w_, ci, co = (int(v) for v in name.split("|")[1].split(","))
             m_ = b_ * h_ * w_
             flops = 2.0 * m_ * co * ci * k * k                      # algorithmic (fp32-equivalent, direct-form) FLOPs
-            issued = 3 * flops * (16.0 / 36.0 if wino else 1.0)      # bf16 matrix-core FLOPs the launch(es) actually issue
+            issued = 3 * flops * per_out                             # 2-byte matrix-core FLOPs the launch(es) actually issue (3 MFMAs per product)
             byts = m_ * ci * 4 + m_ * co * 4 + k * k * co * ci * 4   # read input once, write output once, weights
-            convs.append(dict(shape=f"B{b_} {h_}x{w_} {ci}->{co} k{k}", form="winograd F(2x2,3x3), 3 launches" if wino else "direct",
+            form = {0: "direct", 2: "winograd F(2x2,3x3), 3 launches", 4: "winograd F(4x4,3x3), 3 launches"}[wino]
+            convs.append(dict(shape=f"B{b_} {h_}x{w_} {ci}->{co} k{k}", form=form, mfma_dtype=mfma_dtype,
                               launches_per_step=cnt / a.steps, ms=round(ms, 4),
                               alg_GFLOP=round(flops / 1e9, 1), alg_MB=round(byts / 1e6, 1),
                               alg_TFLOPs=round(flops / (ms * 1e-3) / 1e12, 1),
-                              issued_bf16_TFLOPs=round(issued / (ms * 1e-3) / 1e12, 1),
-                              frac_bf16_mfma_algorithmic=round(flops / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
-                              frac_bf16_mfma_issued=round(issued / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+                              issued_mfma_TFLOPs=round(issued / (ms * 1e-3) / 1e12, 1),
+                              frac_mfma_algorithmic=round(flops / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+                              frac_mfma_issued=round(issued / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
                               GBps=round(byts / (ms * 1e-3) / 1e9, 1)))
             continue
         if name.startswith("tap_interp|"):
@@ -285,13 +289,13 @@ def kernel_report(timing, a, B, wl):
         # three bf16 MFMAs per algorithmic product, so the matrix pipe's own utilisation is 3x that (frac_issued).
         roofline = dict(kernel="conv_split_dma_kernel " + conv_dom["shape"], bound="mfma",
                         achieved=conv_dom["alg_TFLOPs"], peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=conv_dom["frac_bf16_mfma_algorithmic"],
+                        frac=conv_dom["frac_mfma_algorithmic"],
                         traffic=traffic_all.get("conv3x3") if (wl.idx == 2 and B == 16) else None,
                         traffic_source=("profiles/roofline_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE of this launch from separate rocprofv3 "
                                         "--pmc passes of this command (tools/profile_round.sh), committed -- NOT measured in this run"
                                         if (wl.idx == 2 and B == 16) else "no PMC pass committed for this workload"),
-                        frac_algorithmic=conv_dom["frac_bf16_mfma_algorithmic"], frac_issued=conv_dom["frac_bf16_mfma_issued"],
-                        issued_bf16_TFLOPs=conv_dom["issued_bf16_TFLOPs"],
+                        frac_algorithmic=conv_dom["frac_mfma_algorithmic"], frac_issued=conv_dom["frac_mfma_issued"],
+                        issued_bf16_TFLOPs=conv_dom["issued_mfma_TFLOPs"],
                         x_over_fp32_mfma_peak=round(conv_dom["alg_TFLOPs"] / F32_MFMA_PEAK_TFLOPS, 2),
                         ms=conv_dom["ms"], alg_GFLOP=conv_dom["alg_GFLOP"], alg_MB=conv_dom["alg_MB"],
                         note="achieved / frac = algorithmic fp32-equivalent FLOPs (2*M*N*K*9) per launch over the dense bf16 "

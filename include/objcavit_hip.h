@@ -460,14 +460,20 @@ int ocv_conv3x3_winograd_split_fwd(const void* x_hl, int Cin, const void* u_hi, 
  * direct form (F(2x2, 3x3): 2.25x), a transformed input of 2.25x the activation instead of 4x.  Input and output are the bf16
  * hl32 split / fp32 tensors of ocv_conv3x3_winograd_split_fwd; inside, the transformed input and filter are fp16 (hi, lo) pairs
  * (22-bit products: the transforms' ~100x error amplification stays at 2 - 3.5e-6 of max |y|, where two bf16 terms give 1e-4).
- *   u_hi, u_lo [36][Cout][Cp] fp16: U'[6 i + j] = (G g G^T)[i][j] * 2^k[6 i + j] (fp64 transform; the power of two puts the
- *   position's largest entry near 2^8, out of fp16's subnormals), hi = fp16(U'), lo = fp16(U' - hi); fscale [36] fp32 = 2^-k.
- * Interpolation points 0, 1, -1, 2, -1/2, inf (G rows [1, a, a^2] / prod_{j != i}(a_i - a_j), last row [0 0 1]).  fp16's range
- * applies to the transformed input (up to 7x the activation): activations beyond ~9000 overflow. */
+ *   u_hi, u_lo [36][Cout][Cp] fp16: U'[6 i + j][n][c] = (G g G^T)[i][j][n][c] * 2^k[6 i + j] * 2^-a[c] (fp64 transform; the
+ *   power of two per POSITION puts the position's largest entry near 2^8, out of fp16's subnormals; the power of two per INPUT
+ *   CHANNEL equalises the filters' columns), hi = fp16(U'), lo = fp16(U' - hi); fscale [36] fp32 = 2^-k; cscale [Cp] fp32 = 2^a
+ *   (1 for pad channels; NULL = all ones), applied to the activations by the input transform.
+ * Interpolation points 0, 1, -1, 2, -1/2, inf (G rows [1, a, a^2] / prod_{j != i}(a_i - a_j), last row [0 0 1]).  The
+ * transformed input is up to 49x the activation (7x per 1-D pass) with an unscaled low term, so the input transform scales every
+ * TILE by a power of two taken from that tile's largest input (49 amax 2^s in [2^14, 2^15); a GEMM row: undone exactly by the
+ * output transform): no overflow and no subnormal low terms at ANY activation magnitude fp32 holds; inf / NaN inputs give
+ * non-finite outputs.  What remains of fp16's range is the spread INSIDE one tile and channel: values 2^-13 below the tile's
+ * largest lose low-term bits gradually (their products are that much smaller than the tile's result, too). */
 size_t ocv_conv3x3_winograd43_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int ocv_conv3x3_winograd43_split_fwd(const void* x_hl, int Cin, const void* u_hi, const void* u_lo, const float* fscale,
-                                     const float* bias, float* y, void* y_hl, int B, int H, int W, int Cout, int act,
-                                     void* workspace, size_t workspace_bytes, ocv_stream_t stream);
+                                     const float* cscale, const float* bias, float* y, void* y_hl, int B, int H, int W, int Cout,
+                                     int act, void* workspace, size_t workspace_bytes, ocv_stream_t stream);
 
 /* Second half of "3 x 3 convolution of an up-sampled tensor, computed at the low resolution" (first convolution of every
  * UpSampleWithSkip stage: F.interpolate(bilinear, align_corners=True) + torch.cat + Conv2d(k=3) + BatchNorm + LeakyReLU,

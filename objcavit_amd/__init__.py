@@ -17,8 +17,10 @@ import os as _os
 # ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4: the first two streams a process creates get
 # queues of their own, later ones share the last) and streams that share a queue run one after the other.  Several
 # GraphedGraphBins instances in flight (one stream each, bench.py --inflight) need queues of their own: measured 781 instead
-# of 840 img/s on shared queues.  Only a default, only effective when this package is imported before the HIP runtime
-# initialises (first GPU call); INTEGRATION.md says so too.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# of 840 img/s on shared queues.  A library must not change runtime-wide policy behind its host's back, so importing this
+# package touches the environment ONLY when the host asks for it (OCV_SET_HW_QUEUES=<n>, effective when set before the
+# HIP runtime initialises); bench.py sets GPU_MAX_HW_QUEUES itself, INTEGRATION.md holds the recommendation.
+if _os.environ.get("OCV_SET_HW_QUEUES"):
+    _os.environ.setdefault("GPU_MAX_HW_QUEUES", str(int(_os.environ["OCV_SET_HW_QUEUES"])))
 
-__version__ = "0.3.0"
+__version__ = "0.4.0"

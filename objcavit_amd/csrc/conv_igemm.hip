@@ -1017,8 +1017,13 @@ extern "C" int ocv_conv3x3_winograd_split_fwd(const void* x_hl, int Cin, const v
 // 256 .. 1024 input channels, the figure of a three-term bf16 split) -- with ONE accumulator, i.e. on conv_split_dma_kernel
 // as it is (the MFMA of the other 2-byte type), provided no term falls into fp16's subnormals: the transformed filter
 // U = G g G^T has entries down to 1/576 of the filter's, so every position's U is scaled by a power of two that puts its
-// largest entry near 2^8 (undone on the raw GEMM result by the output transform); the transformed input is up to 7x the
-// activation (interpolation points 0, 1, -1, 2, -1/2, inf), far above the subnormals and far below 65504.
+// largest entry near 2^8 (undone on the raw GEMM result by the output transform).  The transformed INPUT is up to 49x the
+// activation (7x per 1-D pass with the interpolation points 0, 1, -1, 2, -1/2, inf) and its low term is unscaled, so as it stands
+// it would overflow from activations of ~1.3e3 and lose its low terms to fp16's subnormals below ~0.1: every TILE's
+// transformed input is therefore scaled by a power of two taken from the tile's own largest input (49 amax 2^s in [2^14, 2^15):
+// a row of the GEMM, so it factors out and is undone exactly by the output transform), and every input CHANNEL by a static power
+// of two that equalises the filters' columns (a channel with tiny weights and huge activations -- or the reverse -- has BOTH
+// factors moved to the middle of fp16's range; hip_ops.prep_winograd43_weight).  All scalings are exact.
 //   1. wino43_input_kernel   V[xi][tile][c] = (B^T d B)[xi] in fp32 from the re-joined bf16 split input, written as fp16 (hi, lo)
 //                            rows, xi = 6 i + j, T = B ceil(H/4) ceil(W/4) tiles (6 x 6 input patch, stride 4, zero padded)
 //   2. conv_split_dma_kernel<true>, a batch of 36 GEMMs M[xi] = V[xi] . U'[xi]^T, raw fp32
@@ -1029,13 +1034,16 @@ namespace {
 struct Wino43InArgs {
   const __bf16* xhl;      // [B][H][W][2 Cp] hl32 (bf16 hi | lo)
   _Float16* v;            // [36][T][2 Cp] hl32 rows (fp16 hi | lo)
+  const float* cscale;    // [Cp] per-input-channel power of two 2^a_c (1 for pad channels): the filters carry 2^-a_c
+  float* tinv;            // [T] out: 2^-s_t, the inverse of the power of two this tile's transformed input was scaled by
   int B, H, W, Cp, th, tw;
-  long T, items;          // items = T * Cp / 4
+  long T;
 };
 
 // y = B^T x for one column of six values.  Interpolation points 0, 1, -1, 2, -1/2, inf: against the textbook set (0, +-1, +-2) the
-// transformed input is 7x the activation instead of 27x and the result 2.6x closer to fp64 (CPU experiment with fp32-accumulating
-// GEMMs, 1024 channels: 1.35e-6 against 3.46e-6 of max |y|); every coefficient is a dyadic rational, i.e. exact.
+// transformed input is at most 49x the activation (7x per 1-D pass: the largest absolute row sum of B^T) instead of 27^2 x, and the
+// result 2.6x closer to fp64 (CPU experiment with fp32-accumulating GEMMs, 1024 channels: 1.35e-6 against 3.46e-6 of max |y|);
+// every coefficient is a dyadic rational, i.e. exact.
 //   B^T = [1 3/2 -2 -3/2 1 0;  0 -1 -5/2 -1/2 1 0;  0 1 1/2 -5/2 1 0;  0 -1/2 -1 1/2 1 0;  0 2 -1 -2 1 0;  0 1 3/2 -2 -3/2 1]
 __device__ __forceinline__ void w43_bt(const float (&x)[6], float (&y)[6]) {
   y[0] = x[0] + 1.5f * (x[1] - x[3]) - 2.f * x[2] + x[4];
@@ -1046,18 +1054,15 @@ __device__ __forceinline__ void w43_bt(const float (&x)[6], float (&y)[6]) {
   y[5] = x[1] + 1.5f * (x[2] - x[4]) - 2.f * x[3] + x[5];
 }
 
-// one thread = (tile, channel quad): 36 pixels x (4 hi + 4 lo) in, 36 positions x (4 hi + 4 lo) out
-__global__ __launch_bounds__(256) void wino43_input_kernel(Wino43InArgs p) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= p.items) return;
-  const int nq = p.Cp >> 2;
-  const long t = i / nq;
-  const int c = (int)(i - t * nq) * 4;
+// The 6 x 6 input patch of tile t, channel quad c (re-joined hi + lo, times the channels' static power of two), after the COLUMN
+// pass of the transform: w[ii][xx][e] = (B^T d)[ii][xx].  Returns the largest |d| of the quad's 36 x 4 inputs.
+__device__ __forceinline__ float w43_load_patch(const Wino43InArgs& p, long t, int c, float (&w)[6][6][4]) {
   const int tx = (int)(t % p.tw);
   const long r = t / p.tw;
   const int ty = (int)(r % p.th), b = (int)(r / p.th);
   const long coff = (long)(c >> 5) * 64 + (c & 31);                       // hi quad; lo quad at + 32
-  float w[6][6][4];                                                        // (B^T d): row index ii, column xx
+  const f32x4 cs = p.cscale != nullptr ? *reinterpret_cast<const f32x4*>(p.cscale + c) : f32x4{1.f, 1.f, 1.f, 1.f};
+  float amax = 0.f;
 #pragma unroll
   for (int xx = 0; xx < 6; ++xx) {
     const int x = 4 * tx - 1 + xx;
@@ -1071,7 +1076,10 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(Wino43InArgs p) {
       const ti4 h = *reinterpret_cast<const ti4*>(src);
       const ti4 l = *reinterpret_cast<const ti4*>(src + (ok ? 32 : 4));
 #pragma unroll
-      for (int e = 0; e < 4; ++e) col[e][yy] = (float)h[e] + (float)l[e];
+      for (int e = 0; e < 4; ++e) {
+        col[e][yy] = ((float)h[e] + (float)l[e]) * cs[e];
+        amax = fmaxf(amax, fabsf(col[e][yy]));                             // (a NaN input is dropped here and still reaches V below)
+      }
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -1081,6 +1089,37 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(Wino43InArgs p) {
       for (int ii = 0; ii < 6; ++ii) w[ii][xx][e] = o[ii];
     }
   }
+  return amax;
+}
+
+// the largest |d| alone (first round of the many-channel path)
+__device__ __forceinline__ float w43_patch_amax(const Wino43InArgs& p, long t, int c) {
+  const int tx = (int)(t % p.tw);
+  const long r = t / p.tw;
+  const int ty = (int)(r % p.th), b = (int)(r / p.th);
+  const long coff = (long)(c >> 5) * 64 + (c & 31);
+  const f32x4 cs = p.cscale != nullptr ? *reinterpret_cast<const f32x4*>(p.cscale + c) : f32x4{1.f, 1.f, 1.f, 1.f};
+  float amax = 0.f;
+  for (int yy = 0; yy < 6; ++yy) {
+    const int y = 4 * ty - 1 + yy;
+    if ((unsigned)y >= (unsigned)p.H) continue;
+#pragma unroll
+    for (int xx = 0; xx < 6; ++xx) {
+      const int x = 4 * tx - 1 + xx;
+      if ((unsigned)x >= (unsigned)p.W) continue;
+      const __bf16* src = p.xhl + (((long)b * p.H + y) * p.W + x) * 2 * p.Cp + coff;
+      const ti4 h = *reinterpret_cast<const ti4*>(src);
+      const ti4 l = *reinterpret_cast<const ti4*>(src + 32);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(((float)h[e] + (float)l[e]) * cs[e]));
+    }
+  }
+  return amax;
+}
+
+// row pass of the transform, scaled by the tile's power of two, split into fp16 (hi, lo) and stored
+__device__ __forceinline__ void w43_store_patch(const Wino43InArgs& p, long t, int c, const float (&w)[6][6][4], float sc) {
+  const long coff = (long)(c >> 5) * 64 + (c & 31);
 #pragma unroll
   for (int ii = 0; ii < 6; ++ii) {
     float v6[4][6];
@@ -1096,9 +1135,10 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(Wino43InArgs p) {
       cv_h16x4 hi, lo;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const _Float16 hb = (_Float16)v6[e][jj];
+        const float v = v6[e][jj] * sc;
+        const _Float16 hb = (_Float16)v;
         hi[e] = hb;
-        lo[e] = (_Float16)(v6[e][jj] - (float)hb);
+        lo[e] = (_Float16)(v - (float)hb);
       }
       _Float16* dst = p.v + (((long)(6 * ii + jj) * p.T + t) * 2 * p.Cp) + coff;
       *reinterpret_cast<cv_h16x4*>(dst) = hi;
@@ -1107,9 +1147,62 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(Wino43InArgs p) {
   }
 }
 
+// The power of two a tile's transformed input is multiplied by: |V| <= 49 amax (two passes of B^T, row sums <= 7), scaled so that
+// 49 amax 2^s lands in [2^14, 2^15) -- under fp16's 65504 whatever the activations' magnitude, and with the low terms of everything
+// within 2^-13 of the tile's maximum outside fp16's subnormals.  amax = 0 (an all-zero tile) and non-finite amax (an inf input: the
+// result must be non-finite, not silently clipped) leave the data unscaled.
+__device__ __forceinline__ float w43_tile_scale(float amax) {
+  if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
+  int e;
+  (void)frexpf(49.f * amax, &e);                                           // 49 amax = m 2^e, m in [0.5, 1)
+  e = 15 - e;
+  e = e < -100 ? -100 : (e > 100 ? 100 : e);
+  return ldexpf(1.f, e);
+}
+
+// Workgroup of 256 threads; thread = (tile, channel quad).  Cp <= 1024 (the shapes the dispatcher sends here): a workgroup owns
+// G = 256 / (Cp / 4) whole tiles, every thread holds its quad's patch in registers while the tile's largest input is found (LDS
+// atomic max on the bit pattern: exact and order-independent).  Cp > 1024: one tile per workgroup, the quads in rounds of 256 --
+// one round for the maximum, a second (re-reading the patch from L2) for the transform.
+template <bool ROUNDS>
+// (two wavefronts per SIMD: forcing the three of round 3's kernel spills 18 registers and measured 1.5 - 2.5 % slower per convolution)
+__global__ __launch_bounds__(256, ROUNDS ? 1 : 2) void wino43_input_kernel(Wino43InArgs p) {
+  __shared__ unsigned gmax[32];
+  const int tid = threadIdx.x;
+  const int nq = p.Cp >> 2;
+  if (tid < 32) gmax[tid] = 0u;
+  __syncthreads();
+  float w[6][6][4];
+  if (!ROUNDS) {
+    const int G = 256 / nq;
+    const int g = tid / nq, q = tid - g * nq;
+    const long t = (long)blockIdx.x * G + g;
+    const bool on = g < G && t < p.T;
+    if (on) atomicMax(&gmax[g], __float_as_uint(w43_load_patch(p, t, 4 * q, w)));
+    __syncthreads();
+    if (!on) return;
+    const float sc = w43_tile_scale(__uint_as_float(gmax[g]));
+    if (q == 0) p.tinv[t] = 1.f / sc;                                      // a power of two: exact
+    w43_store_patch(p, t, 4 * q, w, sc);
+  } else {
+    const long t = blockIdx.x;
+    float amax = 0.f;
+    for (int q = tid; q < nq; q += 256) amax = fmaxf(amax, w43_patch_amax(p, t, 4 * q));
+    atomicMax(&gmax[0], __float_as_uint(amax));
+    __syncthreads();
+    const float sc = w43_tile_scale(__uint_as_float(gmax[0]));
+    if (tid == 0) p.tinv[t] = 1.f / sc;
+    for (int q = tid; q < nq; q += 256) {
+      (void)w43_load_patch(p, t, 4 * q, w);
+      w43_store_patch(p, t, 4 * q, w, sc);
+    }
+  }
+}
+
 struct Wino43OutArgs {
   const float* m;         // [36][T][Cout] raw GEMM results
   const float* fscale;    // [36]: 2^-k of each position's filter scaling
+  const float* tinv;      // [T]: 2^-s of each tile's input scaling (wino43_input_kernel)
   const float* bias;
   float* y;               // [B][H][W][Cout] fp32 (nullable)
   __bf16* yhl;            // hl32 split copy, bf16 (nullable)
@@ -1129,12 +1222,13 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(Wino43OutArgs p) {
   const long r = t / p.tw;
   const int ty = (int)(r % p.th), b = (int)(r / p.th);
   f32x4 s[4][6];                                                           // A^T M: rows dy, columns jj
+  const float ti = p.tinv[t];
 #pragma unroll
   for (int jj = 0; jj < 6; ++jj) {
     f32x4 m[6];
 #pragma unroll
     for (int ii = 0; ii < 6; ++ii)
-      m[ii] = *reinterpret_cast<const f32x4*>(p.m + ((long)(6 * ii + jj) * p.T + t) * p.Cout + n) * p.fscale[6 * ii + jj];
+      m[ii] = *reinterpret_cast<const f32x4*>(p.m + ((long)(6 * ii + jj) * p.T + t) * p.Cout + n) * (p.fscale[6 * ii + jj] * ti);
     s[0][jj] = m[0] + m[1] + m[2] + m[3] + m[4];
     s[1][jj] = m[1] - m[2] + 2.f * m[3] - 0.5f * m[4];
     s[2][jj] = m[1] + m[2] + 4.f * m[3] + 0.25f * m[4];
@@ -1176,18 +1270,20 @@ extern "C" size_t ocv_conv3x3_winograd43_workspace_bytes(int B, int H, int W, in
   if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return 0;
   const long T = (long)B * ((H + 3) / 4) * ((W + 3) / 4);
   const int Cp = (Cin + 31) / 32 * 32;
-  return wino_align((size_t)36 * T * 2 * Cp * sizeof(_Float16)) + wino_align((size_t)36 * T * Cout * sizeof(float));
+  return wino_align((size_t)36 * T * 2 * Cp * sizeof(_Float16)) + wino_align((size_t)36 * T * Cout * sizeof(float)) +
+         wino_align((size_t)T * sizeof(float));
 }
 
 extern "C" int ocv_conv3x3_winograd43_split_fwd(const void* x_hl, int Cin, const void* u_hi, const void* u_lo, const float* fscale,
-                                                const float* bias, float* y, void* y_hl, int B, int H, int W, int Cout,
-                                                int act, void* workspace, size_t workspace_bytes, ocv_stream_t stream) {
+                                                const float* cscale, const float* bias, float* y, void* y_hl, int B, int H, int W,
+                                                int Cout, int act, void* workspace, size_t workspace_bytes, ocv_stream_t stream) {
   OCV_CHECK_ARG(x_hl && u_hi && u_lo && fscale && (y || y_hl) && workspace, "ocv_conv3x3_winograd43_split_fwd: null pointer");
   OCV_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 8 && Cout % 8 == 0,
                 "ocv_conv3x3_winograd43_split_fwd: bad sizes (Cout must be a multiple of 8, got %d)", Cout);
   OCV_CHECK_ARG(act >= 0 && act <= 3, "ocv_conv3x3_winograd43_split_fwd: unknown activation %d", act);
   OCV_CHECK_ARG((reinterpret_cast<uintptr_t>(x_hl) & 127) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0 &&
-                    ocv_aligned16(u_hi) && ocv_aligned16(u_lo) && ocv_aligned16(y) && ocv_aligned16(y_hl) && ocv_aligned16(bias),
+                    ocv_aligned16(u_hi) && ocv_aligned16(u_lo) && ocv_aligned16(y) && ocv_aligned16(y_hl) && ocv_aligned16(bias) &&
+                    ocv_aligned16(cscale),
                 "ocv_conv3x3_winograd43_split_fwd: x_hl must be 128-byte, workspace 256-byte, the rest 16-byte aligned");
   OCV_CHECK_ARG(workspace_bytes >= ocv_conv3x3_winograd43_workspace_bytes(B, H, W, Cin, Cout),
                 "ocv_conv3x3_winograd43_split_fwd: workspace too small");
@@ -1197,13 +1293,20 @@ extern "C" int ocv_conv3x3_winograd43_split_fwd(const void* x_hl, int Cin, const
                 "ocv_conv3x3_winograd43_split_fwd: one transformed operand must stay below 4 GiB");
   hipStream_t st = (hipStream_t)stream;
   _Float16* v = (_Float16*)workspace;
-  float* m = (float*)((char*)workspace + wino_align((size_t)36 * T * 2 * Cp * sizeof(_Float16)));
+  const size_t v_bytes = wino_align((size_t)36 * T * 2 * Cp * sizeof(_Float16));
+  const size_t m_bytes = wino_align((size_t)36 * T * Cout * sizeof(float));
+  float* m = (float*)((char*)workspace + v_bytes);
+  float* tinv = (float*)((char*)workspace + v_bytes + m_bytes);
   if (y_hl != nullptr && Cout % 32 != 0) {
     const hipError_t e = hipMemsetAsync(y_hl, 0, ocv_split_act_elems(B, H, W, Cout) * sizeof(__bf16), st);
     OCV_CHECK_ARG(e == hipSuccess, "ocv_conv3x3_winograd43_split_fwd: hipMemsetAsync failed: %s", hipGetErrorString(e));
   }
-  Wino43InArgs wi{(const __bf16*)x_hl, v, B, H, W, Cp, th, tw, T, T * (Cp / 4)};
-  hipLaunchKernelGGL(wino43_input_kernel, dim3((unsigned)((wi.items + 255) / 256)), dim3(256), 0, st, wi);
+  Wino43InArgs wi{(const __bf16*)x_hl, v, cscale, tinv, B, H, W, Cp, th, tw, T};
+  const int nq = Cp / 4;
+  const long in_wgs = nq <= 256 ? (T + 256 / nq - 1) / (256 / nq) : T;
+  OCV_CHECK_ARG(in_wgs < (1L << 31), "ocv_conv3x3_winograd43_split_fwd: too many tiles");
+  if (nq <= 256) hipLaunchKernelGGL(wino43_input_kernel<false>, dim3((unsigned)in_wgs), dim3(256), 0, st, wi);
+  else hipLaunchKernelGGL(wino43_input_kernel<true>, dim3((unsigned)in_wgs), dim3(256), 0, st, wi);
   OCV_CHECK_LAUNCH("ocv_conv3x3_winograd43_split_fwd(input transform)");
   ConvArgs a{};
   a.xhl = (const __bf16*)v; a.whi = (const __bf16*)u_hi; a.wlo = (const __bf16*)u_lo; a.y = m;
@@ -1213,7 +1316,7 @@ extern "C" int ocv_conv3x3_winograd43_split_fwd(const void* x_hl, int Cin, const
   a.f16 = 1;
   const int rc = launch_conv(a, 1, true, st);
   if (rc != 0) return rc;
-  Wino43OutArgs wo{m, fscale, bias, y, (__bf16*)y_hl, B, H, W, Cout, a.Cpo, th, tw, act, T, T * (Cout / 4)};
+  Wino43OutArgs wo{m, fscale, tinv, bias, y, (__bf16*)y_hl, B, H, W, Cout, a.Cpo, th, tw, act, T, T * (Cout / 4)};
   hipLaunchKernelGGL(wino43_output_kernel, dim3((unsigned)((wo.items + 255) / 256)), dim3(256), 0, st, wo);
   OCV_CHECK_LAUNCH("ocv_conv3x3_winograd43_split_fwd(output transform)");
   return 0;

@@ -979,26 +979,38 @@ def prep_winograd_weight(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tens
 _WINO43_G = ((1.0, 0.0, 0.0), (-1 / 3, -1 / 3, -1 / 3), (1 / 3, -1 / 3, 1 / 3), (1 / 15, 2 / 15, 4 / 15), (-16 / 15, 8 / 15, -4 / 15), (0.0, 0.0, 1.0))
 
 
-def prep_winograd43_weight(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """[Cout, Cin, 3, 3] fp32 -> (u_hi, u_lo fp16 [36, Cout, Cp], fscale fp32 [36]): the Winograd F(4x4, 3x3) filter transform
-    U[6 i + j] = (G g G^T)[i][j] in fp64, every position scaled by the power of two 2^k that puts its largest entry in
-    [2^7.5, 2^8.5) (the transform's entries go down to 1/576 of the filter's: unscaled, their low terms fall into fp16's
-    subnormals and the result is 100x less accurate), then split hi = fp16(U'), lo = fp16(U' - hi); fscale = 2^-k is applied to
-    the raw GEMM results by the output transform.  Cp = Cin rounded up to 32.  Once per weight version (cached by the callers)."""
+def prep_winograd43_weight(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """[Cout, Cin, 3, 3] fp32 -> (u_hi, u_lo fp16 [36, Cout, Cp], fscale fp32 [36], cscale fp32 [Cp]): the Winograd F(4x4, 3x3)
+    filter transform U[6 i + j] = (G g G^T)[i][j] in fp64, scaled by two sets of powers of two before it is split:
+    per POSITION 2^k (the transform's entries go down to 1/576 of the filter's: unscaled, their low terms fall into fp16's
+    subnormals and the result is 100x less accurate) and per INPUT CHANNEL 2^-a (a channel whose weights are tiny because its
+    activations are huge -- or the reverse -- would otherwise have one of the two operands at the edge of fp16's range; the
+    input transform multiplies the channel's activations by cscale = 2^a, so products are unchanged).  Both are chosen so that the
+    largest entry of every position and of every channel sits near 2^8; hi = fp16(U'), lo = fp16(U' - hi); fscale = 2^-k is
+    applied to the raw GEMM results by the output transform.  Cp = Cin rounded up to 32 (cscale 1 on the pad channels).
+    Once per weight version (cached by the callers)."""
     Cout, Cin, kh, kw = weight.shape
     if (kh, kw) != (3, 3):
         raise ValueError("prep_winograd43_weight: kernel must be 3x3")
     G = torch.tensor(_WINO43_G, dtype=torch.float64, device=weight.device)
     u = torch.einsum("ia,ocab,jb->ijoc", G, weight.detach().double(), G).reshape(36, Cout, Cin)
+    # channel equalisation first (on the position-normalised magnitudes), then the position scale on what is left
+    pmax = u.abs().amax(dim=(1, 2), keepdim=True).clamp_min(1e-300)
+    cmax = (u.abs() / pmax).amax(dim=(0, 1))                                   # [Cin], <= 1
+    a = torch.where(cmax > 0, torch.round(torch.log2(cmax.clamp_min(1e-300))), torch.zeros_like(cmax)).clamp(-60.0, 60.0)
+    a = a - a.max()                                                            # the largest channel keeps its scale
+    u = u * torch.exp2(-a)[None, None, :]
     amax = u.abs().amax(dim=(1, 2)).clamp_min(1e-30)
     k = torch.round(8.0 - torch.log2(amax))
     u = (u * torch.exp2(k)[:, None, None]).float()
     Cp = (Cin + 31) // 32 * 32
+    cscale = torch.exp2(a).float()
     if Cp != Cin:
         u = torch.nn.functional.pad(u, (0, Cp - Cin))
+        cscale = torch.nn.functional.pad(cscale, (0, Cp - Cin), value=1.0)
     hi = u.to(torch.float16)
     lo = (u - hi.float()).to(torch.float16)
-    return hi.contiguous(), lo.contiguous(), torch.exp2(-k).float().contiguous()
+    return hi.contiguous(), lo.contiguous(), torch.exp2(-k).float().contiguous(), cscale.contiguous()
 
 
 def winograd_tile(B: int, H: int, W: int, Cin: int, Cout: int) -> int:
@@ -1012,7 +1024,7 @@ def winograd_tile(B: int, H: int, W: int, Cin: int, Cout: int) -> int:
 
 
 def conv3x3_winograd43_split(x: "SplitAct", u_hi: torch.Tensor, u_lo: torch.Tensor, fscale: torch.Tensor, bias: Optional[torch.Tensor],
-                             act: int = ACT_NONE, out_fp32: bool = True, out_split: bool = False):
+                             act: int = ACT_NONE, out_fp32: bool = True, out_split: bool = False, cscale: Optional[torch.Tensor] = None):
     """3x3 convolution (stride 1, padding 1) of a pre-split activation in Winograd F(4x4, 3x3) form on two-term fp16 splits
     (ocv_conv3x3_winograd43_split_fwd).  Returns fp32 tensor, SplitAct, or (fp32, SplitAct) like conv_nhwc_split."""
     lib = _lib.load()
@@ -1026,6 +1038,10 @@ def conv3x3_winograd43_split(x: "SplitAct", u_hi: torch.Tensor, u_lo: torch.Tens
     for n, t in (("u_hi", u_hi), ("u_lo", u_lo)):
         _req(t, n, torch.float16)
     _req(fscale, "fscale")
+    if cscale is not None:
+        _req(cscale, "cscale")
+        if cscale.numel() != Cp:
+            raise ValueError(f"conv3x3_winograd43_split: cscale must hold {Cp} values (Cin rounded up to 32)")
     if u_hi.dim() != 3 or u_hi.shape[0] != 36 or u_hi.shape[2] != Cp or u_lo.shape != u_hi.shape or fscale.numel() != 36:
         raise ValueError(f"conv3x3_winograd43_split: transformed weights {tuple(u_hi.shape)} do not match {Cin} input channels")
     Cout = u_hi.shape[1]
@@ -1039,8 +1055,8 @@ def conv3x3_winograd43_split(x: "SplitAct", u_hi: torch.Tensor, u_lo: torch.Tens
     ys = SplitAct.empty(B, Cout, H, W, x.hl.device) if out_split else None
     nws = int(lib.ocv_conv3x3_winograd43_workspace_bytes(B, H, W, Cin, Cout))
     ws = workspace(nws, x.hl.device, "conv_winograd")
-    with timed(f"conv3x3w|{B},{H},{W},{Cin},{Cout}"):
-        check(lib.ocv_conv3x3_winograd43_split_fwd(x.hl.data_ptr(), Cin, u_hi.data_ptr(), u_lo.data_ptr(), fscale.data_ptr(), _ptr(bias),
+    with timed(f"conv3x3w4|{B},{H},{W},{Cin},{Cout}"):
+        check(lib.ocv_conv3x3_winograd43_split_fwd(x.hl.data_ptr(), Cin, u_hi.data_ptr(), u_lo.data_ptr(), fscale.data_ptr(), _ptr(cscale), _ptr(bias),
                                                    _ptr(y), ys.hl.data_ptr() if out_split else None, B, H, W, Cout, act,
                                                    ws.data_ptr(), ws.numel(), _stream()), "ocv_conv3x3_winograd43_split_fwd")
     if out_fp32 and out_split:
@@ -1094,7 +1110,7 @@ def conv3x3_winograd_split(x: "SplitAct", u_hi: torch.Tensor, u_lo: torch.Tensor
     ys = SplitAct.empty(B, Cout, H, W, x.hl.device) if out_split else None
     nws = int(lib.ocv_conv3x3_winograd_workspace_bytes(B, H, W, Cin, Cout))
     ws = workspace(nws, x.hl.device, "conv_winograd")
-    with timed(f"conv3x3w|{B},{H},{W},{Cin},{Cout}"):
+    with timed(f"conv3x3w2|{B},{H},{W},{Cin},{Cout}"):
         check(lib.ocv_conv3x3_winograd_split_fwd(x.hl.data_ptr(), Cin, u_hi.data_ptr(), u_lo.data_ptr(), _ptr(bias), _ptr(y),
                                                  ys.hl.data_ptr() if out_split else None, B, H, W, Cout, act,
                                                  ws.data_ptr(), ws.numel(), _stream()), "ocv_conv3x3_winograd_split_fwd")

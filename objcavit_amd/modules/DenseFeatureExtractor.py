@@ -149,7 +149,8 @@ class SplitConv3x3:
                 prep = hip_ops.prep_winograd43_weight if tile == 4 else hip_ops.prep_winograd_weight
                 self._wino = (tile,) + tuple(prep(self._w_folded))
             if tile == 4:      # F(4x4, 3x3) on two-term fp16 splits: 4x fewer matrix-core operations
-                return hip_ops.conv3x3_winograd43_split(x, self._wino[1], self._wino[2], self._wino[3], b, act, out_fp32=out_fp32, out_split=out_split)
+                return hip_ops.conv3x3_winograd43_split(x, self._wino[1], self._wino[2], self._wino[3], b, act, out_fp32=out_fp32, out_split=out_split,
+                                                        cscale=self._wino[4])
             return hip_ops.conv3x3_winograd_split(x, self._wino[1], self._wino[2], b, act, out_fp32=out_fp32, out_split=out_split)
         return hip_ops.conv_nhwc_split(x, hi, lo, b, self.conv.kernel_size[0], act, out_fp32=out_fp32, out_split=out_split)
 

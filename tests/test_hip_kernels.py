@@ -1167,20 +1167,21 @@ def test_conv3x3_winograd43_split(ops, B, H, W, Cin, Cout, act):
     else:
         ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
     ref = [ref, torch.relu(ref), F.leaky_relu(ref, 0.01), F.silu(ref)][act]
-    u_hi, u_lo, fs = ops.prep_winograd43_weight(dev(w))
+    u_hi, u_lo, fs, cs = ops.prep_winograd43_weight(dev(w))
     assert tuple(u_hi.shape) == (36, Cout, (Cin + 31) // 32 * 32) and u_hi.dtype == torch.float16 and fs.numel() == 36
+    assert cs.numel() == (Cin + 31) // 32 * 32 and bool((torch.log2(cs) == torch.round(torch.log2(cs))).all())     # powers of two
     assert float(u_hi.float().abs().amax()) < 1024.0 and bool(torch.isfinite(u_lo.float()).all())
     xs = ops.upsample_concat_split(dev(x), None, (H, W))
     poison = [torch.full((1 << 22,), float("nan"), device="cuda") for _ in range(8)]
     del poison                                                  # workspace and outputs come out of NaN-filled memory
-    y, ys = ops.conv3x3_winograd43_split(xs, u_hi, u_lo, fs, dev(b), act, out_fp32=True, out_split=True)
+    y, ys = ops.conv3x3_winograd43_split(xs, u_hi, u_lo, fs, dev(b), act, out_fp32=True, out_split=True, cscale=cs)
     assert y.is_contiguous(memory_format=torch.channels_last)
     assert rel_dev(y, ref) < SPLIT_TOL
     assert rel_dev(ys.float(), y) < 1e-5
     Cpo = (Cout + 31) // 32 * 32
     blocks = ys.hl.view(B, H, W, Cpo // 32, 2, 32).permute(0, 1, 2, 4, 3, 5).reshape(B, H, W, 2, Cpo)
     assert not bool(blocks[..., Cout:].any())                  # pad channels of the split output are zero
-    y2 = ops.conv3x3_winograd43_split(xs, u_hi, u_lo, fs, dev(b), act, out_fp32=True, out_split=False)
+    y2 = ops.conv3x3_winograd43_split(xs, u_hi, u_lo, fs, dev(b), act, out_fp32=True, out_split=False, cscale=cs)
     assert torch.equal(y, y2)
     hi, lo = ops.prep_conv_weight(dev(w))
     direct = ops.conv_nhwc_split(xs, hi, lo, dev(b), 3, act)
@@ -1199,10 +1200,47 @@ def test_conv3x3_winograd43_random_shapes(ops):
         w, b = rnd("w", (Cout, Cin, 3, 3), 600 + case, 1 / math.sqrt(Cin * 9)), rnd("b", (Cout,), 700 + case, 0.2)
         ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
         ref = [ref, torch.relu(ref), F.leaky_relu(ref, 0.01), F.silu(ref)][act]
-        u_hi, u_lo, fs = ops.prep_winograd43_weight(dev(w))
+        u_hi, u_lo, fs, cs = ops.prep_winograd43_weight(dev(w))
         xs = ops.upsample_concat_split(dev(x), None, (H, W))
-        y = ops.conv3x3_winograd43_split(xs, u_hi, u_lo, fs, dev(b), act)
+        y = ops.conv3x3_winograd43_split(xs, u_hi, u_lo, fs, dev(b), act, cscale=cs)
         assert rel_dev(y, ref) < SPLIT_TOL, (case, B, H, W, Cin, Cout, act)
+
+
+@pytest.mark.parametrize("Cin", [64, 1024, 1056])     # tiles sharing a workgroup / one tile per workgroup / the two-round path (Cp > 1024)
+def test_conv3x3_winograd43_keeps_fp32_range(ops, Cin):
+    """the F(4x4, 3x3) form's transformed input is up to 49x the activation with an UNSCALED fp16 low term.  Its input
+    transform now scales every tile by a power of two from the tile's own largest input and every channel by a static power of two
+    from the filters' columns, so the result keeps SPLIT_TOL at every magnitude fp32 activations take -- x * 1e-4 (was 3e-4 of
+    max |y|: low terms in fp16's subnormals), x * 1e3, x * 1e6 (was NaN: overflow from ~1.3e3 on), per-channel scales spanning
+    2^-10 ... 2^10 against inverse weights (was 3e-4), tiles of very different magnitude side by side -- and that an inf / NaN
+    activation comes out non-finite (loud), never clipped."""
+    B, H, W, Cout = 2, 12, 13, 32
+    x0 = rnd("x", (B, Cin, H, W), 11)
+    w0 = rnd("w", (Cout, Cin, 3, 3), 12, 1 / math.sqrt(Cin * 9))
+    span = torch.logspace(-3, 3, Cin).view(1, Cin, 1, 1)
+    ramp = torch.logspace(-4, 4, W).view(1, 1, 1, W)                       # neighbouring tiles differ by orders of magnitude
+    cases = [("unit", x0, w0), ("x 1e-4", x0 * 1e-4, w0), ("x 1e3", x0 * 1e3, w0), ("x 1e6", x0 * 1e6, w0),
+             ("per-channel 1e-3 .. 1e3 against inverse weights", x0 * span, w0 / span), ("per-channel activations only", x0 * span, w0),
+             ("column ramp 1e-4 .. 1e4", x0 * ramp, w0)]
+    for name, x, w in cases:
+        ref = F.conv2d(x.double(), w.double(), padding=1)
+        u_hi, u_lo, fs, cs = ops.prep_winograd43_weight(dev(w))
+        assert bool(torch.isfinite(u_hi.float()).all()) and float(u_hi.float().abs().amax()) < 1024.0
+        xs = ops.upsample_concat_split(dev(x), None, (H, W))
+        y = ops.conv3x3_winograd43_split(xs, u_hi, u_lo, fs, None, 0, cscale=cs)
+        assert bool(torch.isfinite(y).all()), name
+        if name.startswith("column ramp"):                                  # error relative to each column's own magnitude
+            err = ((y.cpu().double() - ref).abs().amax(dim=(0, 1, 2)) / ref.abs().amax(dim=(0, 1, 2))).max()
+            assert float(err) < 4 * SPLIT_TOL, (name, float(err))         # a tile holds four columns: 10x steps inside it
+        else:
+            assert rel_dev(y, ref) < SPLIT_TOL, (name, rel_dev(y, ref))
+    for bad in (float("inf"), float("nan")):
+        x = x0.clone()
+        x[0, 3, 5, 6] = bad
+        u_hi, u_lo, fs, cs = ops.prep_winograd43_weight(dev(w0))
+        y = ops.conv3x3_winograd43_split(ops.upsample_concat_split(dev(x), None, (H, W)), u_hi, u_lo, fs, None, 0, cscale=cs)
+        assert not bool(torch.isfinite(y[0, :, 4:7, 5:8]).all())           # loud where the bad value enters
+        assert bool(torch.isfinite(y[1]).all())                            # and nowhere else: the other image is untouched
 
 
 def test_conv3x3_winograd_keeps_fp32_range_and_rejects_bad_operands(ops):

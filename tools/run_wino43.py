@@ -29,7 +29,7 @@ for (B, H, W, Ci, Co) in ((16, 30, 40, 1024, 1024), (8, 22, 76, 1024, 1024), (16
     u4 = hip_ops.prep_winograd43_weight(w)
     forms = (("direct", lambda: hip_ops.conv_nhwc_split(xs, hi, lo, b, 3, 2, out_fp32=False, out_split=True)),
              ("F(2,2) bf16x2", lambda: hip_ops.conv3x3_winograd_split(xs, u2[0], u2[1], b, 2, out_fp32=False, out_split=True)),
-             ("F(4,3) fp16x2", lambda: hip_ops.conv3x3_winograd43_split(xs, u4[0], u4[1], u4[2], b, 2, out_fp32=False, out_split=True)))
+             ("F(4,3) fp16x2", lambda: hip_ops.conv3x3_winograd43_split(xs, u4[0], u4[1], u4[2], b, 2, out_fp32=False, out_split=True, cscale=u4[3])))
     row = []
     for name, fn in forms:
         us = timeit(fn)
