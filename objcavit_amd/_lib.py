@@ -119,6 +119,12 @@ PROTOTYPES = {
     "ocv_conv_nhwc_exact_fwd": (C.c_int, [_f32p, C.c_int, _f32p, C.c_int, _f32p, _f32p, _f32p, _f32p] + [C.c_int] * 6 + [_stream]),
     "ocv_mbconv_expand_dw_tiles": (C.c_int, [C.c_int] * 4),
     "ocv_mbconv_expand_dw_fwd": (C.c_int, [_f32p, C.c_void_p, _f32p, _f32p, _f32p, _f32p, _f32p] + [C.c_int] * 11 + [_stream]),
+    "ocv_se_tail_supported": (C.c_int, [C.c_int, C.c_int]),
+    "ocv_depthwise_conv_nhwc_se_fwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_void_p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, _f32p, C.c_void_p]
+                                       + [C.c_int] * 10 + [_stream]),
+    "ocv_mbconv_expand_dw_se_fwd": (C.c_int, [_f32p, C.c_void_p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, _f32p, C.c_void_p]
+                                    + [C.c_int] * 11 + [_stream]),
+    "ocv_se_fold_gate_weights_fwd": (C.c_int, [_f32p, _f32p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, _stream]),
     "ocv_split_act_elems": (C.c_size_t, [C.c_int] * 4),
     "ocv_conv_nhwc_split_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p, C.c_void_p]
                                 + [C.c_int] * 6 + [_stream]),

@@ -177,7 +177,9 @@ class workspace_scope:
         return False
 
 
-def workspace(nbytes: int, device: torch.device, tag: str = "default") -> torch.Tensor:
+def workspace(nbytes: int, device: torch.device, tag: str = "default", zero: bool = False) -> torch.Tensor:
+    """``zero``: the buffer is zero-filled when it is (re)allocated -- for words a kernel finds zero and leaves zero (the
+    arrival counters of the in-launch squeeze-excite tail), which must never come out of recycled, dirty memory."""
     store = _ws_stack()[-1]
     idx = device.index if device.index is not None else torch.cuda.current_device()
     key = (idx, torch.cuda.current_stream(idx).cuda_stream, tag)
@@ -188,7 +190,7 @@ def workspace(nbytes: int, device: torch.device, tag: str = "default") -> torch.
         if store.frozen and buf is not None:
             raise RuntimeError(f"workspace {key} of a captured graph would have to grow from {buf.numel()} to {nbytes} "
                                "bytes: the graph's nodes hold the old address -- capture a new graph for the new shapes")
-        buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        buf = (torch.zeros if zero else torch.empty)(max(nbytes, 1), dtype=torch.uint8, device=device)
         store[key] = buf
     return buf
 
@@ -1431,10 +1433,33 @@ def depthwise_nhwc_same(x: torch.Tensor, weight_kkc: torch.Tensor, bias: Optiona
     return out
 
 
+def se_tail_pays(C: int, R: int) -> bool:
+    """Whether a block's squeeze-excite gate is computed INSIDE the launch that produces the pooled tensor, by the image's last
+    workgroup to finish (csrc/se_tail.hpp), instead of by the two launches behind it.  OPT-IN (OCV_SE_TAIL=1): built for VERDICT
+    r3 item 1b, correct under load (tests), 50 launches fewer per forward (271 -> 221) -- and NOT faster, measured
+    (profiles/r04_se_tail.txt): every depthwise workgroup pays ~1 us for draining its stores and drawing its ticket, and the one
+    workgroup that does the tail reads the partials (written through to memory) and 8 C R bytes of weights at a single
+    workgroup's ~60 - 100 GB/s: +10 ... +24 us per depthwise launch against the 13 - 17 us of the two launches it replaces;
+    sum of the depthwise + squeeze-excite kernels 3.06 -> 3.19 ms per step at bs 16, 1.13 -> 1.14 at bs 1.
+    OCV_SE_TAIL_MAX_BYTES bounds the squeeze-excite weight bytes of the blocks that take it (default 400 000: B5's stages 1 - 5)."""
+    mode = os.environ.get("OCV_SE_TAIL", "0")
+    if mode not in ("0", "1"):
+        raise ValueError(f"OCV_SE_TAIL={mode!r}: expected '0' (default) or '1'")
+    return (mode == "1" and bool(_lib.load().ocv_se_tail_supported(int(C), int(R)))
+            and 8 * C * R <= int(os.environ.get("OCV_SE_TAIL_MAX_BYTES", "400000")))
+
+
+def _se_counters(B: int, device: torch.device) -> torch.Tensor:
+    """uint32 [B] arrival counters of the squeeze-excite tail: zero-filled when allocated, found zero and left zero by every
+    launch (one buffer per (device, stream): launches of one stream run one after the other)."""
+    return workspace(4 * B, device, "se_counters", zero=True)
+
+
 def depthwise_se_gate(x: torch.Tensor, weight_kkc: torch.Tensor, bias: Optional[torch.Tensor], k: int, stride: int,
                       w1: torch.Tensor, b1: torch.Tensor, w2t: torch.Tensor, b2: torch.Tensor):
-    """silu(depthwise k x k (TF 'SAME') + bias) of a channels_last tensor AND the squeeze-excite gate of that output,
-    in two launches: returns (y [B, C, Ho, Wo] channels_last, gate [B, C])."""
+    """silu(depthwise k x k (TF 'SAME') + bias) of a channels_last tensor AND the squeeze-excite gate of that output: three
+    launches (depthwise, hidden layer, gate), or ONE where ``se_tail_pays`` (opt-in: the image's last workgroup forms the gate).
+    Returns (y [B, C, Ho, Wo] channels_last, gate [B, C])."""
     lib = _lib.load()
     x = _nhwc(x, "x")
     _req(weight_kkc, "weight")
@@ -1456,6 +1481,14 @@ def depthwise_se_gate(x: torch.Tensor, weight_kkc: torch.Tensor, bias: Optional[
     out = torch.empty(B, Cc, Ho, Wo, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     part = workspace(B * tiles * Cc * 4, x.device, "dw_part")
     gate = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
+    if se_tail_pays(Cc, R):
+        cnt = _se_counters(B, x.device)
+        with timed(f"depthwise_se|{B},{H},{W},{Cc},k{k}s{stride}"):
+            check(lib.ocv_depthwise_conv_nhwc_se_fwd(x.data_ptr(), weight_kkc.data_ptr(), _ptr(bias), out.data_ptr(), None,
+                                                     part.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), R,
+                                                     gate.data_ptr(), cnt.data_ptr(), B, Cc, H, W, k, stride, ph // 2, pw // 2, Ho, Wo,
+                                                     _stream()), "ocv_depthwise_conv_nhwc_se_fwd")
+        return out, gate
     hid = workspace(B * R * 4, x.device, "se_hidden")
     with timed(f"depthwise|{B},{H},{W},{Cc},k{k}s{stride}"):
         check(lib.ocv_depthwise_conv_nhwc_sum_fwd(x.data_ptr(), weight_kkc.data_ptr(), _ptr(bias), out.data_ptr(),
@@ -1498,6 +1531,20 @@ def depthwise_se_gate_weights(x: torch.Tensor, weight_kkc: torch.Tensor, bias: O
     hid = workspace(B * R * 4, x.device, "se_hidden")
     img_elems = int(lib.ocv_pointwise_packed_weight_elems(Cc, N))
     wpk = torch.empty(B * img_elems, dtype=torch.bfloat16, device=x.device)
+    if se_tail_pays(Cc, R):
+        # two launches: the depthwise launch's last workgroups form the gate, the second folds it into the weights
+        gate = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
+        cnt = _se_counters(B, x.device)
+        with timed(f"depthwise_se|{B},{H},{W},{Cc},k{k}s{stride}"):
+            check(lib.ocv_depthwise_conv_nhwc_se_fwd(x.data_ptr(), weight_kkc.data_ptr(), _ptr(bias), None, ys.hl.data_ptr(),
+                                                     part.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), R,
+                                                     gate.data_ptr(), cnt.data_ptr(), B, Cc, H, W, k, stride, ph // 2, pw // 2, Ho, Wo,
+                                                     _stream()), "ocv_depthwise_conv_nhwc_se_fwd")
+        with timed("se_gate_weights"):
+            check(lib.ocv_se_fold_gate_weights_fwd(gate.data_ptr(), w_proj.data_ptr(), wpk.data_ptr(), img_elems, B, Cc, N, _stream()),
+                  "ocv_se_fold_gate_weights_fwd")
+        wg = PerImageSplitWeight(wpk, N, Cc, img_elems, B)
+        return (ys, wg, gate) if want_gate else (ys, wg)
     gate = torch.empty(B, Cc, dtype=torch.float32, device=x.device) if want_gate else None
     with timed(f"depthwise|{B},{H},{W},{Cc},k{k}s{stride}"):
         check(lib.ocv_depthwise_conv_nhwc_sum_hl_fwd(x.data_ptr(), weight_kkc.data_ptr(), _ptr(bias), None, ys.hl.data_ptr(),
@@ -1555,6 +1602,14 @@ def expand_depthwise_se_gate(x: torch.Tensor, w_expand: "SplitWeight", b_expand:
     out = torch.empty(B, mid, Ho, Wo, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     part = workspace(B * tiles * mid * 4, x.device, "dw_part")
     gate = torch.empty(B, mid, dtype=torch.float32, device=x.device)
+    if se_tail_pays(mid, R):
+        cnt = _se_counters(B, x.device)
+        with timed(f"expand_dw_se|{B},{H},{W},{Cin},{mid},k{k}s{stride}"):
+            check(lib.ocv_mbconv_expand_dw_se_fwd(x.data_ptr(), w_expand.packed.data_ptr(), _ptr(b_expand), weight_kkc.data_ptr(),
+                                                  _ptr(bias), out.data_ptr(), part.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2t.data_ptr(),
+                                                  b2.data_ptr(), R, gate.data_ptr(), cnt.data_ptr(), B, H, W, Cin, mid, k, stride,
+                                                  ph // 2, pw // 2, Ho, Wo, _stream()), "ocv_mbconv_expand_dw_se_fwd")
+        return out, gate
     hid = workspace(B * R * 4, x.device, "se_hidden")
     with timed(f"expand_dw|{B},{H},{W},{Cin},{mid},k{k}s{stride}"):
         check(lib.ocv_mbconv_expand_dw_fwd(x.data_ptr(), w_expand.packed.data_ptr(), _ptr(b_expand), weight_kkc.data_ptr(),

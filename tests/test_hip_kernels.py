@@ -903,11 +903,13 @@ def test_pointwise_hl(ops, cfg, B, H, W, Cin, Cout, act, use_res, outs):
 @pytest.mark.parametrize("cfg", [(0, 0), (1, 1), (2, 2), (4, 1)])
 @pytest.mark.parametrize("k,s,B,C,H,W,R,N", [(5, 1, 2, 1056, 30, 40, 44, 176), (3, 1, 3, 768, 9, 11, 32, 128),
                                              (5, 2, 2, 96, 13, 17, 4, 24), (3, 2, 16, 384, 15, 20, 16, 128)])
-def test_depthwise_hl_gate_weights_project(ops, cfg, k, s, B, C, H, W, R, N):
+@pytest.mark.parametrize("tail", ["0", "1"])
+def test_depthwise_hl_gate_weights_project(ops, monkeypatch, tail, cfg, k, s, B, C, H, W, R, N):
     """The late-stage MBConv tail on the pre-split route: depthwise + SiLU written ONCE in the hl32 layout, the
     squeeze-excite gate folded into per-image packed project weights (ocv_se_gate_weights_fwd), the project 1x1 on the
     LDS-DMA kernel with tiles that never span images -- against the definition (gate applied to the rows) in float64, and
-    piece by piece against the fp32-row kernels."""
+    piece by piece against the fp32-row kernels.  tail = OCV_SE_TAIL: the gate by the hidden-layer launch / inside the depthwise launch."""
+    monkeypatch.setenv("OCV_SE_TAIL", tail)
     x, w, b = rnd("x", (B, C, H, W), 1), rnd("w", (C, 1, k, k), 2, 0.3), rnd("b", (C,), 3, 0.2)
     w1, b1 = rnd("w1", (R, C), 4, 1 / math.sqrt(C)), rnd("b1", (R,), 5, 0.3)
     w2, b2 = rnd("w2", (C, R), 6, 1 / math.sqrt(R)), rnd("b2", (C,), 7, 0.3)
@@ -991,7 +993,9 @@ def test_depthwise_nhwc_same(ops, k, s, B, C, H, W):
 @pytest.mark.parametrize("k,s", [(3, 1), (3, 2), (5, 1), (5, 2)])
 @pytest.mark.parametrize("B,C,H,W,R", [(2, 48, 60, 80, 12), (1, 8, 15, 20, 2), (3, 12, 33, 47, 4), (1, 4, 1, 1, 1),
                                        (2, 144, 30, 41, 6), (2, 1056, 9, 11, 44), (1, 3072, 4, 5, 128), (16, 240, 30, 40, 10)])
-def test_depthwise_se_gate(ops, k, s, B, C, H, W, R):
+@pytest.mark.parametrize("tail", ["0", "1"])          # OCV_SE_TAIL: the gate by two launches behind the depthwise one / inside it
+def test_depthwise_se_gate(ops, monkeypatch, tail, k, s, B, C, H, W, R):
+    monkeypatch.setenv("OCV_SE_TAIL", tail)
     x, w, b = rnd("x", (B, C, H, W), 1), rnd("w", (C, 1, k, k), 2, 0.3), rnd("b", (C,), 3, 0.2)
     w1, b1 = rnd("w1", (R, C), 4, 1 / math.sqrt(C)), rnd("b1", (R,), 5, 0.3)
     w2, b2 = rnd("w2", (C, R), 6, 1 / math.sqrt(R)), rnd("b2", (C,), 7, 0.3)
@@ -1006,13 +1010,48 @@ def test_depthwise_se_gate(ops, k, s, B, C, H, W, R):
     assert torch.equal(y, y2) and torch.equal(g, g2)        # fixed-order pooling sums
 
 
+@pytest.mark.parametrize("B,C,H,W,R,k,s", [(16, 240, 30, 40, 10, 5, 1), (1, 240, 60, 80, 10, 5, 2), (4, 1056, 30, 40, 44, 5, 1), (2, 48, 120, 160, 12, 3, 1)])
+def test_se_tail_handoff_under_load_against_the_two_launch_route(ops, monkeypatch, B, C, H, W, R, k, s):
+    """The in-launch squeeze-excite tail (csrc/se_tail.hpp: every depthwise workgroup publishes its pooling partial write-through,
+    the image's last workgroup acquires and forms the gate) against the two-launch route on the SAME inputs, forty times in a row
+    on new data while the partial buffer is recycled (the consumer's L1 / its XCD's L2 hold the PREVIOUS iteration's lines: a
+    missing release or acquire reads those) and while a second stream keeps the chip unevenly busy.  Both routes sum the partials
+    in fp32 in different orders: 1e-5.  The counters must read zero after every launch."""
+    monkeypatch.setenv("OCV_SE_TAIL", "1")
+    assert ops.se_tail_pays(C, R)
+    w, b = rnd("w", (C, 1, k, k), 2, 0.3), rnd("b", (C,), 3, 0.2)
+    w1, b1 = rnd("w1", (R, C), 4, 1 / math.sqrt(C)), rnd("b1", (R,), 5, 0.3)
+    w2, b2 = rnd("w2", (C, R), 6, 1 / math.sqrt(R)), rnd("b2", (C,), 7, 0.3)
+    par = (dev(w).flatten(1).t().contiguous(), dev(b), k, s, dev(w1), dev(b1), dev(w2).t().contiguous(), dev(b2))
+    side = torch.cuda.Stream()
+    load_x = torch.randn(8, 64, 120, 160, device="cuda").contiguous(memory_format=torch.channels_last)
+    load_w = torch.randn(25, 64, device="cuda") * 0.2
+    xs = [(torch.randn(B, C, H, W, device="cuda") * (0.2 + 0.1 * i)).contiguous(memory_format=torch.channels_last) for i in range(4)]
+    for it in range(40):
+        x = xs[it % 4] + 0.01 * it
+        if it % 3 != 2:                                          # uneven: two iterations out of three share the chip
+            with torch.cuda.stream(side):
+                ops.depthwise_nhwc_same(load_x, load_w, None, 5, 1, 3)
+        monkeypatch.setenv("OCV_SE_TAIL", "1")
+        y, g = ops.depthwise_se_gate(x, *par)
+        cnt = ops._se_counters(B, x.device)
+        monkeypatch.setenv("OCV_SE_TAIL", "0")
+        y0, g0 = ops.depthwise_se_gate(x, *par)
+        assert torch.equal(y, y0), it
+        assert rel_dev(g, g0) < 1e-5, (it, rel_dev(g, g0))
+        assert not bool(cnt.view(torch.int32)[:B].any()), it     # restored by the last workgroup of every image
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("k,s", [(3, 1), (3, 2), (5, 1), (5, 2)])
 @pytest.mark.parametrize("B,H,W,Cin,mid", [(2, 17, 23, 24, 144), (1, 30, 40, 40, 240), (2, 33, 47, 64, 384), (1, 8, 32, 40, 48),
                                            (1, 3, 2, 24, 36), (3, 64, 70, 32, 100)])
-def test_expand_depthwise_fused(ops, k, s, B, H, W, Cin, mid):
+@pytest.mark.parametrize("tail", ["0", "1"])
+def test_expand_depthwise_fused(ops, monkeypatch, tail, k, s, B, H, W, Cin, mid):
     """Fused expand 1x1 + depthwise (+ squeeze-excite gate) against the fp32 formulation and against the two-launch
     path: image sizes that are not multiples of the 8 x 32 / 8 x 16 tiles, channel counts that do not fill the last
     32-channel chunk, images smaller than one tile, asymmetric 'SAME' padding at stride 2."""
+    monkeypatch.setenv("OCV_SE_TAIL", tail)
     R = max(1, Cin // 4)
     x = rnd("x", (B, Cin, H, W), 1)
     we, be = rnd("we", (mid, Cin), 2, 1 / math.sqrt(Cin)), rnd("be", (mid,), 3, 0.3)
