@@ -33,7 +33,8 @@ extern "C" {
 
 typedef void* ocv_stream_t;
 
-#define OCV_ABI_VERSION 2 /* 2: ocv_encoder_layer_params starts with struct_size (round 3) */
+#define OCV_ABI_VERSION 3 /* 2: ocv_encoder_layer_params starts with struct_size (round 3); 3: ocv_patch_embed_split_fwd and
+                           ocv_conv3x3_winograd43_split_fwd take the split operands' element type (+ cscale / oscale), round 4 */
 int ocv_abi_version(void);
 const char* ocv_last_error(void);
 
@@ -223,11 +224,13 @@ int ocv_patch_embed_fwd(const float* fmap, int channels_last, const float* W, co
  * Products hi*hi + hi*lo + lo*hi (error <= 2^-17 per product, as in every convolution of the path), fp32 accumulation.
  *   x_hl  [B][h][w][2 C] bf16 (C a multiple of 32);   w_hi / w_lo [16 (ky)][E][16 C] bf16, column kx*C + c =
  *   bf16 split of W[e][c][ky][kx];   pos / pos_bs / out as above;   E a multiple of 8;   h a multiple of 16 when B > 1.
- *   workspace: ocv_patch_embed_split_workspace_bytes (the 16 raw results). */
+ *   workspace: ocv_patch_embed_split_workspace_bytes (the 16 raw results).
+ *   f16 / oscale: the element type of x_hl, w_hi, w_lo (0 = bf16 pairs, 1 = fp16 pairs) and the nullable per-output-channel
+ *   factor [E] on the raw sums, as ocv_conv_nhwc_split_x_fwd (ABI 3). */
 size_t ocv_patch_embed_split_workspace_bytes(int B, int C, int h, int w, int E);
-int ocv_patch_embed_split_fwd(const void* x_hl, int C, const void* w_hi, const void* w_lo, const float* bias,
-                              const float* pos, long pos_bs, float* out, int B, int h, int w, int E, void* workspace,
-                              size_t workspace_bytes, ocv_stream_t stream);
+int ocv_patch_embed_split_fwd(const void* x_hl, int C, const void* w_hi, const void* w_lo, const float* oscale, int f16,
+                              const float* bias, const float* pos, long pos_bs, float* out, int B, int h, int w, int E,
+                              void* workspace, size_t workspace_bytes, ocv_stream_t stream);
 
 /* PixelWiseDotProduct (modules/layers.py:31-36): ram[b][q][p] = sum_c feat[b][c][p] * queries[b][q][c].
  * feat [B,C,P] (NCHW with P = h*w), queries addressed as ptr + b*q_bs + q*q_ld + c, ram [B,Q,P].  C == Q == 128. */
@@ -465,6 +468,21 @@ size_t ocv_conv_nhwc_split_workspace_bytes(int B, int H, int W, int Cin, int Cou
 int ocv_conv_nhwc_split_ws_fwd(const void* x_hl, int Cin, const void* w_hi, const void* w_lo, const float* bias,
                                const float* residual, float* y, void* y_hl, int B, int H, int W, int Cout, int ksize,
                                int act, void* workspace, size_t workspace_bytes, ocv_stream_t stream);
+/* Round 4: the same convolution with the element type of the split operands as a parameter.
+ *   f16 = 0: x_hl, w_hi, w_lo, y_hl hold bf16 (hi, lo) pairs -- products good to 2^-17, fp32's range (ocv_conv_nhwc_split_ws_fwd).
+ *   f16 = 1: they hold FP16 pairs (hi = fp16(v), lo = fp16(v - hi), the low term unscaled): the same three matrix-core products
+ *     per block on v_mfma_f32_16x16x32_f16, good to 2^-22 -- the stress-case margin of the depth map (4.5e-4 of the 1e-3 bar
+ *     with bf16 pairs) was these products' alone.  fp16's range is handled explicitly: WEIGHTS are scaled per output channel by
+ *     a power of two that puts the row's largest entry near 2^8 (out of the subnormals; hip_ops.prep_conv_weight) and
+ *     oscale [Cout] (nullable = ones) = the inverse powers, applied to the raw accumulators in front of bias / activation (exact);
+ *     ACTIVATIONS are stored unscaled: beyond +-65504 they become inf (the output is non-finite: loud), below ~0.1 their low
+ *     term is subnormal, an ABSOLUTE error floor of 2^-25 per value that only matters for a tensor whose every entry is tiny
+ *     (objcavit_amd.hip_ops.fp16_range_report checks a model's activations against both ends).
+ * The producers of hl32 tensors take the same flag: ocv_upsample_concat_split_x_fwd, ocv_tap_interp_combine_x_fwd,
+ * ocv_conv3x3_winograd43_split_fwd (hl_f16: its input AND its split output), ocv_patch_embed_split_fwd (reads). */
+int ocv_conv_nhwc_split_x_fwd(const void* x_hl, int Cin, const void* w_hi, const void* w_lo, const float* oscale, int f16,
+                              const float* bias, const float* residual, float* y, void* y_hl, int B, int H, int W, int Cout,
+                              int ksize, int act, void* workspace, size_t workspace_bytes, ocv_stream_t stream);
 
 /* The same 3 x 3 convolution (stride 1, zero padding 1) in Winograd F(2x2, 3x3) form, for shapes where the arithmetic
  * dominates the transforms' traffic (Cin, Cout in the thousands at <= ~30 x 40 pixels: the two deepest decoder stages):
@@ -497,7 +515,7 @@ int ocv_conv3x3_winograd_split_fwd(const void* x_hl, int Cin, const void* u_hi, 
 size_t ocv_conv3x3_winograd43_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int ocv_conv3x3_winograd43_split_fwd(const void* x_hl, int Cin, const void* u_hi, const void* u_lo, const float* fscale,
                                      const float* cscale, const float* bias, float* y, void* y_hl, int B, int H, int W, int Cout,
-                                     int act, void* workspace, size_t workspace_bytes, ocv_stream_t stream);
+                                     int act, int hl_f16, void* workspace, size_t workspace_bytes, ocv_stream_t stream);
 
 /* Second half of "3 x 3 convolution of an up-sampled tensor, computed at the low resolution" (first convolution of every
  * UpSampleWithSkip stage: F.interpolate(bilinear, align_corners=True) + torch.cat + Conv2d(k=3) + BatchNorm + LeakyReLU,
@@ -516,6 +534,9 @@ int ocv_conv3x3_winograd43_split_fwd(const void* x_hl, int Cin, const void* u_hi
 int ocv_tap_interp_supported(int h, int w, int H, int W, int Cout);
 int ocv_tap_interp_combine_fwd(const float* z, int h, int w, int zpad, const float* zborder, const float* s, const float* bias,
                                float* y, void* y_hl, int B, int H, int W, int Cout, int act, ocv_stream_t stream);
+/* the same with the element type of y_hl as a parameter (0 = bf16 pairs, 1 = fp16 pairs: ocv_conv_nhwc_split_x_fwd) */
+int ocv_tap_interp_combine_x_fwd(const float* z, int h, int w, int zpad, const float* zborder, const float* s, const float* bias,
+                                 float* y, void* y_hl, int hl_f16, int B, int H, int W, int Cout, int act, ocv_stream_t stream);
 
 /* Bilinear resize of x [B,h,w,C1] (NHWC fp32) to H x W with align_corners = True, concatenated along channels with
  * skip [B,H,W,C2] (nullable, then C2 = 0), written in the hl32 split layout for C1+C2 channels (out_hl,
@@ -524,6 +545,9 @@ int ocv_tap_interp_combine_fwd(const float* z, int h, int w, int zpad, const flo
  * ocv_conv_nhwc_split_fwd. */
 int ocv_upsample_concat_split_fwd(const float* x, int h, int w, int C1, const float* skip, int C2, void* out_hl, int B,
                                   int H, int W, ocv_stream_t stream);
+/* the same with the element type of out_hl as a parameter (0 = bf16 pairs, 1 = fp16 pairs: ocv_conv_nhwc_split_x_fwd) */
+int ocv_upsample_concat_split_x_fwd(const float* x, int h, int w, int C1, const float* skip, int C2, void* out_hl, int f16, int B,
+                                    int H, int W, ocv_stream_t stream);
 
 /* Validation-step arithmetic in one pass (next row N2: modules/GraphBinsLM.py:154-212, metrics/MetricsPreprocess.py:14-45,
  * metrics/AbsRel.py:44-52, SqRel.py:45-52, RMSE.py:48-55, RMSELog.py:45-52, Log10.py:52-61, AccThresh.py:59-66).
@@ -539,6 +563,29 @@ int ocv_depth_metrics_fwd(const float* pred, const float* pred_mirror, int h, in
                           float min_depth, float max_depth, int crop_y0, int crop_y1, int crop_x0, int crop_x1,
                           long first_image_id, float* records, int B, void* workspace, size_t workspace_bytes,
                           ocv_stream_t stream);
+
+/* Tail of mViT / ObjCAViT.forward + glue of AdaBins / GraphBins.forward in one launch (modules/miniViT.py:33-42, modules/AdaBins.py:79-83):
+ *   y = raw [B][n_bins] (the regressor's last Linear) -> OCV_BINNORM_LINEAR: relu(y) + 0.1 | OCV_BINNORM_SIGMOID: sigmoid(y) |
+ *   OCV_BINNORM_NONE: y (already normalised, e.g. a softmax);  widths_normed = y / sum_row(y) (NONE: y);
+ *   edges [B][n_bins + 1] = cumsum([min_depth, (max_depth - min_depth) * widths_normed]);  centers [B][n_bins] = edge midpoints. */
+#define OCV_BINNORM_LINEAR 0
+#define OCV_BINNORM_SIGMOID 1
+#define OCV_BINNORM_NONE 2
+int ocv_bin_edges_fwd(const float* raw, int mode, float min_depth, float max_depth, float* widths_normed, float* edges,
+                      float* centers, int B, int n_bins, ocv_stream_t stream);
+
+/* Ragged object lists with the per-image COUNT in device memory (shape-static: a captured graph serves any object set up to its
+ * capacity; replaces pad_sequence / F.pad / mask building of SelfAttnCrossAttn.forward, modules/ObjCAViT.py:180-183,192-194).
+ *   ocv_object_tokens_pad_fwd: tokens [B][capacity][E] (rows >= counts[b] arbitrary) -> out = rows < count kept, the rest
+ *     pad_value (1e-4); mask[b][j] = (j >= counts[b]).  out may alias tokens.
+ *   ocv_object_front_pad_fwd: objects [B][capacity][E] -> out [B][S][E] = [ pad_value x (S - Nmax) | rows 0 .. Nmax-1 ] (rows
+ *     padded at the FRONT), key_padding_mask [B][S] = (j >= counts[b]) (mask padded at the BACK).  Nmax = nmax
+ *     when nmax > 0 (the global batch's longest list, data-parallel shards), else the largest count within the image's group
+ *     of `group` consecutive images (one group = one call of the reference: its Nmax is that call's longest list, Q3). */
+int ocv_object_tokens_pad_fwd(const float* tokens, const int* counts, float pad_value, float* out, uint8_t* mask, int B,
+                              int capacity, int E, ocv_stream_t stream);
+int ocv_object_front_pad_fwd(const float* objects, const int* counts, int group, int nmax, float pad_value, float* out,
+                             uint8_t* key_padding_mask, int B, int capacity, int S, int E, ocv_stream_t stream);
 
 /* Positional-embedding samplers of GridRandomPositionalEmbeddings.forward (modules/ObjCAViT.py:50-147) on the learnable
  * table `table` [>= gh*gw][E], viewed as a gh x gw grid of E-vectors (row y*gw + x; reference :82-83).  One output row

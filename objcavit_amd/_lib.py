@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("OCV_LIB_PATH") or os.path.join(_HERE, "lib", "libobjc
 _f32p = C.c_void_p      # device pointers travel as integers
 _u8p = C.c_void_p
 _stream = C.c_void_p
-ABI_VERSION = 2          # include/objcavit_hip.h: OCV_ABI_VERSION
+ABI_VERSION = 3          # include/objcavit_hip.h: OCV_ABI_VERSION
 
 
 class EncoderLayerParams(C.Structure):
@@ -81,7 +81,7 @@ PROTOTYPES = {
                                           _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
     "ocv_patch_embed_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ocv_patch_embed_split_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
-    "ocv_patch_embed_split_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _f32p, _f32p, C.c_long, _f32p, C.c_int,
+    "ocv_patch_embed_split_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _f32p, C.c_int, _f32p, _f32p, C.c_long, _f32p, C.c_int,
                                             C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, _stream]),
     "ocv_patch_embed_fwd": (C.c_int, [_f32p, C.c_int, _f32p, _f32p, _f32p, C.c_long, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_void_p, C.c_size_t, _stream]),
@@ -119,6 +119,9 @@ PROTOTYPES = {
     "ocv_conv_nhwc_exact_fwd": (C.c_int, [_f32p, C.c_int, _f32p, C.c_int, _f32p, _f32p, _f32p, _f32p] + [C.c_int] * 6 + [_stream]),
     "ocv_mbconv_expand_dw_tiles": (C.c_int, [C.c_int] * 4),
     "ocv_mbconv_expand_dw_fwd": (C.c_int, [_f32p, C.c_void_p, _f32p, _f32p, _f32p, _f32p, _f32p] + [C.c_int] * 11 + [_stream]),
+    "ocv_bin_edges_fwd": (C.c_int, [_f32p, C.c_int, C.c_float, C.c_float, _f32p, _f32p, _f32p, C.c_int, C.c_int, _stream]),
+    "ocv_object_tokens_pad_fwd": (C.c_int, [_f32p, C.c_void_p, C.c_float, _f32p, _u8p, C.c_int, C.c_int, C.c_int, _stream]),
+    "ocv_object_front_pad_fwd": (C.c_int, [_f32p, C.c_void_p, C.c_int, C.c_int, C.c_float, _f32p, _u8p] + [C.c_int] * 4 + [_stream]),
     "ocv_se_tail_supported": (C.c_int, [C.c_int, C.c_int]),
     "ocv_depthwise_conv_nhwc_se_fwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_void_p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, _f32p, C.c_void_p]
                                        + [C.c_int] * 10 + [_stream]),
@@ -131,13 +134,18 @@ PROTOTYPES = {
     "ocv_conv_nhwc_split_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
     "ocv_conv_nhwc_split_ws_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p, C.c_void_p]
                                    + [C.c_int] * 6 + [C.c_void_p, C.c_size_t, _stream]),
+    "ocv_conv_nhwc_split_x_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _f32p, C.c_int, _f32p, _f32p, _f32p, C.c_void_p]
+                                  + [C.c_int] * 6 + [C.c_void_p, C.c_size_t, _stream]),
+    "ocv_upsample_concat_split_x_fwd": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_void_p, C.c_int,
+                                                  C.c_int, C.c_int, C.c_int, _stream]),
+    "ocv_tap_interp_combine_x_fwd": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_void_p] + [C.c_int] * 6 + [_stream]),
     "ocv_pos_grid_sample_fwd": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                           C.c_int, _f32p, _f32p, _stream]),
     "ocv_conv3x3_winograd_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
     "ocv_conv3x3_winograd_split_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _f32p, _f32p, C.c_void_p] + [C.c_int] * 5 +
                                        [C.c_void_p, C.c_size_t, _stream]),
     "ocv_conv3x3_winograd43_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
-    "ocv_conv3x3_winograd43_split_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p, _f32p, C.c_void_p] + [C.c_int] * 5 +
+    "ocv_conv3x3_winograd43_split_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p, _f32p, C.c_void_p] + [C.c_int] * 6 +
                                          [C.c_void_p, C.c_size_t, _stream]),
     "ocv_tap_interp_supported": (C.c_int, [C.c_int] * 5),
     "ocv_tap_interp_combine_fwd": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_void_p] + [C.c_int] * 5 + [_stream]),

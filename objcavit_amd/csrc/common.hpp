@@ -42,6 +42,23 @@ __device__ __forceinline__ float fast_silu(float x) { return x * fast_sigmoid(x)
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// Two-term split of an fp32 value into the 2-byte (hi, lo) bit patterns of the "hl32" activation layout (csrc/conv_igemm.hip):
+// F16 = fp16 terms (hi = fp16(v), lo = fp16(v - hi): 22 bits down to an absolute floor of 2^-25, range +-65504 -- beyond it inf,
+// loud), else bf16 terms (16 bits, fp32's range).  Which one a tensor holds is the producing call's ``f16`` flag; consumers are
+// told the same flag.
+template <bool F16>
+__device__ __forceinline__ void ocv_split1(float v, unsigned short& hi, unsigned short& lo) {
+  if constexpr (F16) {
+    const _Float16 h = (_Float16)v;
+    hi = __builtin_bit_cast(unsigned short, h);
+    lo = __builtin_bit_cast(unsigned short, (_Float16)(v - (float)h));
+  } else {
+    const __bf16 h = (__bf16)v;
+    hi = __builtin_bit_cast(unsigned short, h);
+    lo = __builtin_bit_cast(unsigned short, (__bf16)(v - (float)h));
+  }
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------

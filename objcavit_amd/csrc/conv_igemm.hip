@@ -71,6 +71,9 @@ struct ConvArgs {
   long xz_bytes, wz_bytes;              // Winograd positions): operand z at xhl + z xz_bytes / whi, wlo + z wz_bytes, raw fp32
                                         // result at y + (z ksplit + khalf) * M * Cout
   int f16;                              // conv_split_dma_kernel: != 0 = the operands are fp16 (hi, lo) pairs (conv_split_dma_kernel<true>)
+                                        // and so is the split copy of the output (yhl)
+  const float* oscale;                  // nullable [Cout]: raw accumulators are multiplied by it before bias / activation (the
+                                        // per-output-channel power of two the fp16 weights were scaled by, inverted)
   unsigned rowpitch;                    // conv_split_dma_kernel: bytes between consecutive rows of the (B H) x W pixel grid of the
                                         // split input when they are not dense (0 = dense, W * 4 Cp); the patch embedding reads
                                         // every 16th image row of the feature map as one GEMM row grid this way
@@ -90,6 +93,47 @@ __device__ __forceinline__ void split4(const f32x4 v, __bf16* hi, __bf16* lo) {
     hi[i] = h;
     lo[i] = (__bf16)(f[i] - (float)h);
   }
+}
+
+// The same split with FP16 terms (round 4: the decoder's convolutions as two-term fp16 products, 2^-22 instead of 2^-17): hi =
+// fp16(v), lo = fp16(v - hi), UNSCALED low term (one accumulator in the GEMM kernel): for |v| below ~0.1 the low term is an fp16
+// subnormal (honoured by the MFMA), i.e. the pair's ABSOLUTE error has a floor of 2^-25 ~ 3e-8 -- harmless next to O(1)
+// activations, and the reason the weights are scaled per output channel (oscale) while activations are range-checked, not scaled.
+// Values beyond +-65504 become inf (loud), never clipped.
+__device__ __forceinline__ void split4h(const f32x4 v, _Float16* hi, _Float16* lo) {
+  const float f[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const _Float16 h = (_Float16)f[i];
+    hi[i] = h;
+    lo[i] = (_Float16)(f[i] - (float)h);
+  }
+}
+// two-byte (hi, lo) parts of four values as raw bits, either element type
+template <bool F16>
+__device__ __forceinline__ void split4_bits(const f32x4 v, unsigned short* hi, unsigned short* lo) {
+  if constexpr (F16) split4h(v, reinterpret_cast<_Float16*>(hi), reinterpret_cast<_Float16*>(lo));
+  else split4(v, reinterpret_cast<__bf16*>(hi), reinterpret_cast<__bf16*>(lo));
+}
+__device__ __forceinline__ void split4_bits(const f32x4 v, unsigned short* hi, unsigned short* lo, bool f16) {
+  if (f16) split4_bits<true>(v, hi, lo);
+  else split4_bits<false>(v, hi, lo);
+}
+// hi + lo of four consecutive (hi at p, lo at p + lo_off) two-byte pairs, either element type
+__device__ __forceinline__ f32x4 join4_bits(const void* p, int lo_off, bool f16) {
+  f32x4 r;
+  if (f16) {
+    const cv_h16x4 h = *reinterpret_cast<const cv_h16x4*>(p);
+    const cv_h16x4 l = *reinterpret_cast<const cv_h16x4*>(reinterpret_cast<const _Float16*>(p) + lo_off);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = (float)h[e] + (float)l[e];
+  } else {
+    const ti4 h = *reinterpret_cast<const ti4*>(p);
+    const ti4 l = *reinterpret_cast<const ti4*>(reinterpret_cast<const __bf16*>(p) + lo_off);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = (float)h[e] + (float)l[e];
+  }
+  return r;
 }
 
 // "hl32" layout of a split activation: per pixel, per block of 32 channels, 32 hi values followed by their 32 lo values
@@ -375,6 +419,7 @@ __device__ __forceinline__ float conv_act(float v, int act) {
   if (act == OCV_ACT_RELU) return fmaxf(v, 0.f);
   return v;
 }
+template <bool F16>
 __device__ __forceinline__ void conv_store_rows(const ConvArgs& p, const unsigned char* lds, int wave, int lane, long m0, int n0,
                                                 long yoff) {
   const int cw = wave & 3, half = wave >> 2;
@@ -383,9 +428,12 @@ __device__ __forceinline__ void conv_store_rows(const ConvArgs& p, const unsigne
   const int oct = lane & 7, rsub = lane >> 3;
   const int ncol = n0 + wn * 64 + oct * 8;
   if (ncol >= p.Cout) return;
-  float bv[8];
+  float bv[8], sv[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) bv[e] = p.bias != nullptr ? p.bias[ncol + e] : 0.f;
+  for (int e = 0; e < 8; ++e) {
+    bv[e] = p.bias != nullptr ? p.bias[ncol + e] : 0.f;
+    sv[e] = p.oscale != nullptr ? p.oscale[ncol + e] : 1.f;
+  }
 #pragma unroll 4
   for (int it = 0; it < 8; ++it) {
     const int row = half * 64 + it * 8 + rsub;
@@ -395,8 +443,8 @@ __device__ __forceinline__ void conv_store_rows(const ConvArgs& p, const unsigne
     f32x4 c = *reinterpret_cast<const f32x4*>(tile + row * ERS + oct * 8 + 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      a[e] = conv_act(a[e] + bv[e], p.act);
-      c[e] = conv_act(c[e] + bv[4 + e], p.act);
+      a[e] = conv_act(fmaf(a[e], sv[e], bv[e]), p.act);            // (sv = 1: exact, the product of round 3)
+      c[e] = conv_act(fmaf(c[e], sv[4 + e], bv[4 + e]), p.act);
     }
     const long o = m * p.Cout + ncol;
     if (p.res != nullptr) {
@@ -408,9 +456,9 @@ __device__ __forceinline__ void conv_store_rows(const ConvArgs& p, const unsigne
       *reinterpret_cast<f32x4*>(p.y + yoff + o + 4) = c;
     }
     if (p.yhl != nullptr) {
-      __bf16 hi[8], lo[8];
-      split4(a, hi, lo);
-      split4(c, hi + 4, lo + 4);
+      __attribute__((aligned(16))) unsigned short hi[8], lo[8];
+      split4_bits<F16>(a, hi, lo);
+      split4_bits<F16>(c, hi + 4, lo + 4);
       const long oh = hl_index(m, ncol, p.Cpo);          // ncol % 8 == 0: the octet stays inside one 32-block
       *reinterpret_cast<bf16x8*>(p.yhl + oh) = *reinterpret_cast<bf16x8*>(hi);
       *reinterpret_cast<bf16x8*>(p.yhl + oh + 32) = *reinterpret_cast<bf16x8*>(lo);
@@ -513,7 +561,7 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) tile[(16 * i + 4 * q4 + r) * ERS + 16 * j + l15] = acc[i][j][r];
       __syncthreads();
-      conv_store_rows(p, lds, wave, lane, m0, n0, yoff);
+      conv_store_rows<F16>(p, lds, wave, lane, m0, n0, yoff);
       return;
     }
     // Cout not a multiple of 8: element-wise stores
@@ -522,22 +570,30 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
       const int n = n0 + wn * 64 + j * 16 + l15;
       const bool nok = n < p.Cout;
       const float bv = (p.bias != nullptr && nok) ? p.bias[n] : 0.f;
+      const float sv = (p.oscale != nullptr && nok) ? p.oscale[n] : 1.f;
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const long m = m0 + wm * 128 + i * 16 + 4 * q4 + r;
           if (nok && m < p.M) {
-            float v = acc[i][j][r] + bv;
+            float v = fmaf(acc[i][j][r], sv, bv);
             if (p.act == OCV_ACT_LEAKY_RELU) v = v > 0.f ? v : 0.01f * v;
             else if (p.act == OCV_ACT_SILU) v = fast_silu(v);
             else if (p.act == OCV_ACT_RELU) v = fmaxf(v, 0.f);
             if (p.res != nullptr) v += p.res[m * p.Cout + n];
             if (p.y != nullptr) p.y[yoff + m * p.Cout + n] = v;
             if (p.yhl != nullptr) {
-              const __bf16 hb = (__bf16)v;
-              p.yhl[hl_index(m, n, p.Cpo)] = hb;
-              p.yhl[hl_index(m, n, p.Cpo) + 32] = (__bf16)(v - (float)hb);
+              if constexpr (F16) {
+                _Float16* yh = reinterpret_cast<_Float16*>(p.yhl);
+                const _Float16 hb = (_Float16)v;
+                yh[hl_index(m, n, p.Cpo)] = hb;
+                yh[hl_index(m, n, p.Cpo) + 32] = (_Float16)(v - (float)hb);
+              } else {
+                const __bf16 hb = (__bf16)v;
+                p.yhl[hl_index(m, n, p.Cpo)] = hb;
+                p.yhl[hl_index(m, n, p.Cpo) + 32] = (__bf16)(v - (float)hb);
+              }
             }
           }
         }
@@ -636,7 +692,7 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
 #undef OCV_WAIT_VM
   if ((p.Cout & 7) == 0) {                             // the consumers park their accumulators in LDS; all eight waves store
     __syncthreads();
-    conv_store_rows(p, lds, wave, lane, m0, n0, yoff);
+    conv_store_rows<F16>(p, lds, wave, lane, m0, n0, yoff);
   }
 }
 
@@ -649,6 +705,8 @@ struct FinArgs {
   __bf16* yhl;
   long M, items;         // items = M * Cout / 8
   int Cout, Cpo, act, ksplit;
+  const float* oscale;   // nullable [Cout] (ConvArgs::oscale)
+  int f16;               // element type of yhl
 };
 
 __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(FinArgs p) {
@@ -665,8 +723,8 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(FinArgs p) {
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    a[e] = conv_act(a[e] + (p.bias != nullptr ? p.bias[n + e] : 0.f), p.act);
-    c[e] = conv_act(c[e] + (p.bias != nullptr ? p.bias[n + 4 + e] : 0.f), p.act);
+    a[e] = conv_act(fmaf(a[e], p.oscale != nullptr ? p.oscale[n + e] : 1.f, p.bias != nullptr ? p.bias[n + e] : 0.f), p.act);
+    c[e] = conv_act(fmaf(c[e], p.oscale != nullptr ? p.oscale[n + 4 + e] : 1.f, p.bias != nullptr ? p.bias[n + 4 + e] : 0.f), p.act);
   }
   if (p.res != nullptr) {
     a += *reinterpret_cast<const f32x4*>(p.res + o);
@@ -677,9 +735,9 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(FinArgs p) {
     *reinterpret_cast<f32x4*>(p.y + o + 4) = c;
   }
   if (p.yhl != nullptr) {
-    __bf16 hi[8], lo[8];
-    split4(a, hi, lo);
-    split4(c, hi + 4, lo + 4);
+    __attribute__((aligned(16))) unsigned short hi[8], lo[8];
+    split4_bits(a, hi, lo, p.f16 != 0);
+    split4_bits(c, hi + 4, lo + 4, p.f16 != 0);
     const long oh = hl_index(m, n, p.Cpo);
     *reinterpret_cast<bf16x8*>(p.yhl + oh) = *reinterpret_cast<bf16x8*>(hi);
     *reinterpret_cast<bf16x8*>(p.yhl + oh + 32) = *reinterpret_cast<bf16x8*>(lo);
@@ -743,9 +801,10 @@ extern "C" size_t ocv_conv_nhwc_split_workspace_bytes(int B, int H, int W, int C
   return ks > 1 ? (size_t)ks * M * Cout * sizeof(float) : 0;
 }
 
-extern "C" int ocv_conv_nhwc_split_ws_fwd(const void* x_hl, int Cin, const void* w_hi, const void* w_lo, const float* bias,
-                                          const float* residual, float* y, void* y_hl, int B, int H, int W, int Cout,
-                                          int ksize, int act, void* workspace, size_t workspace_bytes, ocv_stream_t stream) {
+extern "C" int ocv_conv_nhwc_split_x_fwd(const void* x_hl, int Cin, const void* w_hi, const void* w_lo, const float* oscale,
+                                         int f16, const float* bias, const float* residual, float* y, void* y_hl, int B, int H,
+                                         int W, int Cout, int ksize, int act, void* workspace, size_t workspace_bytes,
+                                         ocv_stream_t stream) {
   OCV_CHECK_ARG(x_hl && w_hi && w_lo && (y || y_hl), "ocv_conv_nhwc_split_fwd: null pointer");
   OCV_CHECK_ARG(ocv_aligned16(y) && ocv_aligned16(y_hl) && ocv_aligned16(residual) && ocv_aligned16(workspace), "ocv_conv_nhwc_split_fwd: outputs, residual and workspace must be 16-byte aligned");
   OCV_CHECK_ARG(ksize == 1 || ksize == 3, "ocv_conv_nhwc_split_fwd: kernel size must be 1 or 3 (got %d)", ksize);
@@ -753,10 +812,12 @@ extern "C" int ocv_conv_nhwc_split_ws_fwd(const void* x_hl, int Cin, const void*
   OCV_CHECK_ARG(act >= 0 && act <= 3, "ocv_conv_nhwc_split_fwd: unknown activation %d", act);
   OCV_CHECK_ARG((reinterpret_cast<uintptr_t>(x_hl) & 127) == 0 && ocv_aligned16(w_hi) && ocv_aligned16(w_lo), "ocv_conv_nhwc_split_fwd: x_hl must be 128-byte aligned, weights 16-byte aligned");
   OCV_CHECK_ARG((long)B * H * W * (Cin + 32) * 4 < (1L << 32) && 9L * Cout * (Cin + 32) * 2 < (1L << 32), "ocv_conv_nhwc_split_fwd: each operand must be smaller than 4 GiB");
+  OCV_CHECK_ARG(f16 == 0 || f16 == 1, "ocv_conv_nhwc_split_fwd: f16 must be 0 (bf16 pairs) or 1 (fp16 pairs)");
   ConvArgs a{};
   a.xhl = (const __bf16*)x_hl; a.yhl = (__bf16*)y_hl; a.Cpo = (Cout + 31) / 32 * 32;
   a.whi = (const __bf16*)w_hi; a.wlo = (const __bf16*)w_lo; a.bias = bias; a.res = residual; a.y = y;
   a.C1 = Cin; a.C2 = 0; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.ks = ksize; a.act = act; a.ksplit = 1;
+  a.f16 = f16; a.oscale = oscale;
   if (y_hl != nullptr && Cout % 32 != 0) {       // the kernels write channels < Cout only: pad channels must read as zero
     const hipError_t e = hipMemsetAsync(y_hl, 0, ocv_split_act_elems(B, H, W, Cout) * sizeof(__bf16), (hipStream_t)stream);
     OCV_CHECK_ARG(e == hipSuccess, "ocv_conv_nhwc_split_fwd: hipMemsetAsync failed: %s", hipGetErrorString(e));
@@ -764,18 +825,26 @@ extern "C" int ocv_conv_nhwc_split_ws_fwd(const void* x_hl, int Cin, const void*
   const long M = (long)B * H * W;
   const int ks = conv_ksplit(M, Cout, Cin, ksize);
   static const bool use_dma = getenv("OCV_CONV_NO_DMA") == nullptr;
+  OCV_CHECK_ARG(use_dma || f16 == 0, "ocv_conv_nhwc_split_fwd: OCV_CONV_NO_DMA (the register-staged diagnostic kernel) takes bf16 pairs only");
   if (ks > 1 && use_dma && workspace != nullptr && workspace_bytes >= (size_t)ks * M * Cout * sizeof(float)) {
     // two workgroups per tile, each over half of the channel chunks -> raw partial sums -> finish pass
     ConvArgs h = a;
-    h.bias = nullptr; h.res = nullptr; h.yhl = nullptr; h.act = OCV_ACT_NONE; h.y = (float*)workspace; h.ksplit = ks;
+    h.bias = nullptr; h.res = nullptr; h.yhl = nullptr; h.act = OCV_ACT_NONE; h.y = (float*)workspace; h.ksplit = ks; h.oscale = nullptr;
     const int rc = launch_conv(h, B, true, (hipStream_t)stream);
     if (rc != 0) return rc;
-    FinArgs f{(const float*)workspace, bias, residual, y, (__bf16*)y_hl, M, M * Cout / 8, Cout, a.Cpo, act, ks};
+    FinArgs f{(const float*)workspace, bias, residual, y, (__bf16*)y_hl, M, M * Cout / 8, Cout, a.Cpo, act, ks, oscale, f16};
     hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)((f.items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, f);
     OCV_CHECK_LAUNCH("ocv_conv_nhwc_split_fwd(finish)");
     return 0;
   }
   return launch_conv(a, B, true, (hipStream_t)stream);
+}
+
+extern "C" int ocv_conv_nhwc_split_ws_fwd(const void* x_hl, int Cin, const void* w_hi, const void* w_lo, const float* bias,
+                                          const float* residual, float* y, void* y_hl, int B, int H, int W, int Cout,
+                                          int ksize, int act, void* workspace, size_t workspace_bytes, ocv_stream_t stream) {
+  return ocv_conv_nhwc_split_x_fwd(x_hl, Cin, w_hi, w_lo, nullptr, 0, bias, residual, y, y_hl, B, H, W, Cout, ksize, act, workspace,
+                                   workspace_bytes, stream);
 }
 
 extern "C" int ocv_conv_nhwc_split_fwd(const void* x_hl, int Cin, const void* w_hi, const void* w_lo, const float* bias,
@@ -1032,12 +1101,13 @@ extern "C" int ocv_conv3x3_winograd_split_fwd(const void* x_hl, int Cin, const v
 namespace {
 
 struct Wino43InArgs {
-  const __bf16* xhl;      // [B][H][W][2 Cp] hl32 (bf16 hi | lo)
+  const __bf16* xhl;      // [B][H][W][2 Cp] hl32 (bf16 hi | lo; fp16 pairs with in_f16)
   _Float16* v;            // [36][T][2 Cp] hl32 rows (fp16 hi | lo)
   const float* cscale;    // [Cp] per-input-channel power of two 2^a_c (1 for pad channels): the filters carry 2^-a_c
   float* tinv;            // [T] out: 2^-s_t, the inverse of the power of two this tile's transformed input was scaled by
   int B, H, W, Cp, th, tw;
   long T;
+  int in_f16;             // element type of xhl
 };
 
 // y = B^T x for one column of six values.  Interpolation points 0, 1, -1, 2, -1/2, inf: against the textbook set (0, +-1, +-2) the
@@ -1073,11 +1143,10 @@ __device__ __forceinline__ float w43_load_patch(const Wino43InArgs& p, long t, i
       const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
       const __bf16* src = ok ? p.xhl + (((long)b * p.H + y) * p.W + x) * 2 * p.Cp + coff
                              : reinterpret_cast<const __bf16*>(ocv_zero_page);
-      const ti4 h = *reinterpret_cast<const ti4*>(src);
-      const ti4 l = *reinterpret_cast<const ti4*>(src + (ok ? 32 : 4));
+      const f32x4 d4 = join4_bits(src, ok ? 32 : 4, p.in_f16 != 0);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        col[e][yy] = ((float)h[e] + (float)l[e]) * cs[e];
+        col[e][yy] = d4[e] * cs[e];
         amax = fmaxf(amax, fabsf(col[e][yy]));                             // (a NaN input is dropped here and still reaches V below)
       }
     }
@@ -1108,10 +1177,9 @@ __device__ __forceinline__ float w43_patch_amax(const Wino43InArgs& p, long t, i
       const int x = 4 * tx - 1 + xx;
       if ((unsigned)x >= (unsigned)p.W) continue;
       const __bf16* src = p.xhl + (((long)b * p.H + y) * p.W + x) * 2 * p.Cp + coff;
-      const ti4 h = *reinterpret_cast<const ti4*>(src);
-      const ti4 l = *reinterpret_cast<const ti4*>(src + 32);
+      const f32x4 d4 = join4_bits(src, 32, p.in_f16 != 0);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(((float)h[e] + (float)l[e]) * cs[e]));
+      for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(d4[e] * cs[e]));
     }
   }
   return amax;
@@ -1205,9 +1273,10 @@ struct Wino43OutArgs {
   const float* tinv;      // [T]: 2^-s of each tile's input scaling (wino43_input_kernel)
   const float* bias;
   float* y;               // [B][H][W][Cout] fp32 (nullable)
-  __bf16* yhl;            // hl32 split copy, bf16 (nullable)
+  __bf16* yhl;            // hl32 split copy (nullable): bf16 pairs, fp16 pairs with out_f16
   int B, H, W, Cout, Cpo, th, tw, act;
   long T, items;          // items = T * Cout / 4
+  int out_f16;
 };
 
 // one thread = (tile, 4 channels): Y = A^T M A (A^T = [1 1 1 1 1 0; 0 1 -1 2 -1/2 0; 0 1 1 4 1/4 0; 0 1 -1 8 -1/8 1]), bias,
@@ -1254,8 +1323,8 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(Wino43OutArgs p) {
       const long px = ((long)b * p.H + y) * p.W + x;
       if (p.y != nullptr) *reinterpret_cast<f32x4*>(p.y + px * p.Cout + n) = v;
       if (p.yhl != nullptr) {
-        __bf16 hi[4], lo[4];
-        split4(v, hi, lo);
+        __attribute__((aligned(8))) unsigned short hi[4], lo[4];
+        split4_bits(v, hi, lo, p.out_f16 != 0);
         const long oh = hl_index(px, n, p.Cpo);
         *reinterpret_cast<uint2*>(p.yhl + oh) = *reinterpret_cast<uint2*>(hi);
         *reinterpret_cast<uint2*>(p.yhl + oh + 32) = *reinterpret_cast<uint2*>(lo);
@@ -1276,7 +1345,9 @@ extern "C" size_t ocv_conv3x3_winograd43_workspace_bytes(int B, int H, int W, in
 
 extern "C" int ocv_conv3x3_winograd43_split_fwd(const void* x_hl, int Cin, const void* u_hi, const void* u_lo, const float* fscale,
                                                 const float* cscale, const float* bias, float* y, void* y_hl, int B, int H, int W,
-                                                int Cout, int act, void* workspace, size_t workspace_bytes, ocv_stream_t stream) {
+                                                int Cout, int act, int hl_f16, void* workspace, size_t workspace_bytes,
+                                                ocv_stream_t stream) {
+  OCV_CHECK_ARG(hl_f16 == 0 || hl_f16 == 1, "ocv_conv3x3_winograd43_split_fwd: hl_f16 must be 0 (bf16 pairs) or 1 (fp16 pairs)");
   OCV_CHECK_ARG(x_hl && u_hi && u_lo && fscale && (y || y_hl) && workspace, "ocv_conv3x3_winograd43_split_fwd: null pointer");
   OCV_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 8 && Cout % 8 == 0,
                 "ocv_conv3x3_winograd43_split_fwd: bad sizes (Cout must be a multiple of 8, got %d)", Cout);
@@ -1301,7 +1372,7 @@ extern "C" int ocv_conv3x3_winograd43_split_fwd(const void* x_hl, int Cin, const
     const hipError_t e = hipMemsetAsync(y_hl, 0, ocv_split_act_elems(B, H, W, Cout) * sizeof(__bf16), st);
     OCV_CHECK_ARG(e == hipSuccess, "ocv_conv3x3_winograd43_split_fwd: hipMemsetAsync failed: %s", hipGetErrorString(e));
   }
-  Wino43InArgs wi{(const __bf16*)x_hl, v, cscale, tinv, B, H, W, Cp, th, tw, T};
+  Wino43InArgs wi{(const __bf16*)x_hl, v, cscale, tinv, B, H, W, Cp, th, tw, T, hl_f16};
   const int nq = Cp / 4;
   const long in_wgs = nq <= 256 ? (T + 256 / nq - 1) / (256 / nq) : T;
   OCV_CHECK_ARG(in_wgs < (1L << 31), "ocv_conv3x3_winograd43_split_fwd: too many tiles");
@@ -1316,7 +1387,7 @@ extern "C" int ocv_conv3x3_winograd43_split_fwd(const void* x_hl, int Cin, const
   a.f16 = 1;
   const int rc = launch_conv(a, 1, true, st);
   if (rc != 0) return rc;
-  Wino43OutArgs wo{m, fscale, tinv, bias, y, (__bf16*)y_hl, B, H, W, Cout, a.Cpo, th, tw, act, T, T * (Cout / 4)};
+  Wino43OutArgs wo{m, fscale, tinv, bias, y, (__bf16*)y_hl, B, H, W, Cout, a.Cpo, th, tw, act, T, T * (Cout / 4), hl_f16};
   hipLaunchKernelGGL(wino43_output_kernel, dim3((unsigned)((wo.items + 255) / 256)), dim3(256), 0, st, wo);
   OCV_CHECK_LAUNCH("ocv_conv3x3_winograd43_split_fwd(output transform)");
   return 0;
@@ -1358,10 +1429,11 @@ extern "C" size_t ocv_patch_embed_split_workspace_bytes(int B, int C, int h, int
   return (size_t)16 * B * (h / 16) * (w / 16) * E * sizeof(float);
 }
 
-extern "C" int ocv_patch_embed_split_fwd(const void* x_hl, int C, const void* w_hi, const void* w_lo, const float* bias,
-                                         const float* pos, long pos_bs, float* out, int B, int h, int w, int E,
+extern "C" int ocv_patch_embed_split_fwd(const void* x_hl, int C, const void* w_hi, const void* w_lo, const float* oscale, int f16,
+                                         const float* bias, const float* pos, long pos_bs, float* out, int B, int h, int w, int E,
                                          void* workspace, size_t workspace_bytes, ocv_stream_t stream) {
   OCV_CHECK_ARG(x_hl && w_hi && w_lo && out && workspace, "ocv_patch_embed_split_fwd: null pointer");
+  OCV_CHECK_ARG(f16 == 0 || f16 == 1, "ocv_patch_embed_split_fwd: f16 must be 0 (bf16 pairs) or 1 (fp16 pairs)");
   const size_t need = ocv_patch_embed_split_workspace_bytes(B, C, h, w, E);
   OCV_CHECK_ARG(need != 0, "ocv_patch_embed_split_fwd: needs C a multiple of 32 (got %d), E a multiple of 8 (got %d), a map of at "
                 "least one 16 x 16 patch (got %d x %d)", C, E, h, w);
@@ -1376,6 +1448,7 @@ extern "C" int ocv_patch_embed_split_fwd(const void* x_hl, int C, const void* w_
   a.xhl = (const __bf16*)x_hl; a.whi = (const __bf16*)w_hi; a.wlo = (const __bf16*)w_lo; a.y = (float*)workspace;
   a.C1 = 16 * C; a.Cin = 16 * C; a.Cout = E; a.H = B * gh; a.W = gw; a.ks = 1; a.act = OCV_ACT_NONE; a.ksplit = 1;
   a.Cpo = (E + 31) / 32 * 32;
+  a.f16 = f16; a.oscale = oscale;                                             // (the 16 GEMMs share their output channels' scales)
   a.zbatch = 16;
   a.xz_bytes = (long)w * 2 * C * (long)sizeof(__bf16);                        // one image row down
   a.wz_bytes = (long)E * 16 * C * (long)sizeof(__bf16);

@@ -42,11 +42,12 @@ struct TIArgs {
   const float* s;        // [B][H][W][Cout] skip-part convolution (raw), nullable
   const float* bias;     // nullable
   float* y;              // [B][H][W][Cout] fp32, nullable
-  __bf16* yhl;           // hl32 split, nullable
+  __bf16* yhl;           // hl32 split, nullable (bf16 pairs; fp16 pairs with f16)
   int h, w, H, W, Cout, Cpo, act, zpad;
   float sh, sw;
   int tiles_x, tiles_y;
   int fq_cap;            // pixels per staging buffer (multiple of 32: whole 256-lane rounds)
+  int f16;               // element type of yhl
 };
 
 template <int ACT>
@@ -235,11 +236,18 @@ __device__ __forceinline__ void ti_store(const TIArgs& p, const float4 (&acc)[4]
     if (p.yhl != nullptr) {
       const float f[4] = {v.x, v.y, v.z, v.w};
       ti_bf16x4 hi, lo;
+      unsigned short hb_[4], lb_[4];
+      if (p.f16) {                                                 // (uniform: one scalar branch per store)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ocv_split1<true>(f[e], hb_[e], lb_[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ocv_split1<false>(f[e], hb_[e], lb_[e]);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const __bf16 hb = (__bf16)f[e];
-        hi[e] = hb;
-        lo[e] = (__bf16)(f[e] - (float)hb);
+        hi[e] = __builtin_bit_cast(__bf16, hb_[e]);
+        lo[e] = __builtin_bit_cast(__bf16, lb_[e]);
       }
       __bf16* d = p.yhl + pix * 2 * p.Cpo + (n >> 5) * 64 + (n & 31);
       *reinterpret_cast<ti_bf16x4*>(d) = hi;
@@ -279,7 +287,14 @@ extern "C" int ocv_tap_interp_supported(int h, int w, int H, int W, int Cout) {
 extern "C" int ocv_tap_interp_combine_fwd(const float* z, int h, int w, int zpad, const float* zborder, const float* s,
                                           const float* bias, float* y, void* y_hl, int B, int H, int W, int Cout, int act,
                                           ocv_stream_t stream) {
+  return ocv_tap_interp_combine_x_fwd(z, h, w, zpad, zborder, s, bias, y, y_hl, 0, B, H, W, Cout, act, stream);
+}
+
+extern "C" int ocv_tap_interp_combine_x_fwd(const float* z, int h, int w, int zpad, const float* zborder, const float* s,
+                                            const float* bias, float* y, void* y_hl, int hl_f16, int B, int H, int W, int Cout,
+                                            int act, ocv_stream_t stream) {
   OCV_CHECK_ARG(z && (y || y_hl), "ocv_tap_interp_combine_fwd: null pointer");
+  OCV_CHECK_ARG(hl_f16 == 0 || hl_f16 == 1, "ocv_tap_interp_combine_fwd: hl_f16 must be 0 (bf16 pairs) or 1 (fp16 pairs)");
   OCV_CHECK_ARG((zpad == 0 && zborder == nullptr) || (zpad == 1 && zborder != nullptr && h >= 3 && w >= 3 && ocv_aligned16(zborder)),
                 "ocv_tap_interp_combine_fwd: zpad must be 0 (no border vector) or 1 (with a 16-byte aligned border vector, h, w >= 3)");
   OCV_CHECK_ARG(B >= 1 && h >= 1 && w >= 1 && H >= 1 && W >= 1 && Cout >= 4 && Cout % 4 == 0,
@@ -294,7 +309,7 @@ extern "C" int ocv_tap_interp_combine_fwd(const float* z, int h, int w, int zpad
   const int nj = ocv_cdiv(ti_footprint(h, w, H, W) + 1, 32);       // 1..6 staging rounds per tap (footprint + one spare slot)
   TIArgs a{z, zborder, s, bias, y, (__bf16*)y_hl, h, w, H, W, Cout, (Cout + 31) / 32 * 32, act, zpad,
            H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f,
-           ocv_cdiv(W, TX), ocv_cdiv(H, TY), nj * 32};
+           ocv_cdiv(W, TX), ocv_cdiv(H, TY), nj * 32, hl_f16};
   const long nwg = (long)a.tiles_x * a.tiles_y * B;
   OCV_CHECK_ARG(nwg < (1L << 31) && ocv_cdiv(Cout, CB) <= 65535, "ocv_tap_interp_combine_fwd: grid too large");
   if (y_hl != nullptr && Cout % 32 != 0) {

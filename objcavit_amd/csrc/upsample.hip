@@ -43,24 +43,21 @@ struct UpArgs {
 };
 
 // 4 consecutive channels c .. c + 3 (c % 4 == 0: inside one 32-block) of pixel pix
+template <bool F16>
 __device__ __forceinline__ void store_split4(unsigned short* hl, long pix, int c, int Cp, float4 v) {
   unsigned short* hi = hl + pix * 2 * Cp + (c >> 5) * 64 + (c & 31);
   unsigned short* lo = hi + 32;
   const float f[4] = {v.x, v.y, v.z, v.w};
   unsigned short h[4], l[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const __bf16 hb = (__bf16)f[i];
-    const __bf16 lb = (__bf16)(f[i] - (float)hb);
-    h[i] = __builtin_bit_cast(unsigned short, hb);
-    l[i] = __builtin_bit_cast(unsigned short, lb);
-  }
+  for (int i = 0; i < 4; ++i) ocv_split1<F16>(f[i], h[i], l[i]);
   *reinterpret_cast<uint2*>(hi) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
   *reinterpret_cast<uint2*>(lo) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
 }
 
 constexpr int UP_ITEMS = 8;
 
+template <bool F16>
 __global__ __launch_bounds__(256) void upsample_concat_split_kernel(UpArgs p) {
   const int C = p.C1 + p.C2, c4n = p.Cp >> 2;
   // XCD-aware, bijective workgroup -> work map: consecutive workgroup ids go round-robin to the 8 XCDs, and the four
@@ -101,7 +98,7 @@ __global__ __launch_bounds__(256) void upsample_concat_split_kernel(UpArgs p) {
     } else {
       v = ld4(p.skip + ((b * p.H + Y) * (long)p.W + X) * p.C2 + (c - p.C1));
     }
-    store_split4(p.hl, (b * p.H + Y) * (long)p.W + X, c, p.Cp, v);
+    store_split4<F16>(p.hl, (b * p.H + Y) * (long)p.W + X, c, p.Cp, v);
   }
 }
 
@@ -134,6 +131,7 @@ __device__ __forceinline__ float4 up_lerp(const float4 a, const float4 b, const 
 
 constexpr int UP8_ITEMS = 4;          // items per thread, all loaded before the first store
 
+template <bool F16>
 __global__ __launch_bounds__(256) void upsample_concat_split8_kernel(Up8Args p) {
   const int C = p.C1 + p.C2;
   long wg = blockIdx.x;
@@ -180,9 +178,10 @@ __global__ __launch_bounds__(256) void upsample_concat_split8_kernel(Up8Args p) 
     const float f[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const __bf16 hb = (__bf16)f[i];
-      hi[u][i] = hb;
-      lo[u][i] = (__bf16)(f[i] - (float)hb);
+      unsigned short hb_, lb_;
+      ocv_split1<F16>(f[i], hb_, lb_);
+      hi[u][i] = __builtin_bit_cast(__bf16, hb_);
+      lo[u][i] = __builtin_bit_cast(__bf16, lb_);
     }
     dst[u] = p.hl + ((b * p.H + Y) * (long)p.W + X) * 2 * p.Cp + (c >> 5) * 64 + (c & 31);
   }
@@ -213,6 +212,7 @@ __device__ __forceinline__ float4 up_sel(bool second, const float4 a, const floa
   return make_float4(second ? b.x : a.x, second ? b.y : a.y, second ? b.z : a.z, second ? b.w : a.w);
 }
 
+template <bool F16>
 __global__ __launch_bounds__(256) void upsample_concat_split_2x2_kernel(UpBArgs p) {
   const int C = p.C1 + p.C2;
   long wg = blockIdx.x;
@@ -297,9 +297,10 @@ __global__ __launch_bounds__(256) void upsample_concat_split_2x2_kernel(UpBArgs 
       const float f[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const __bf16 hb = (__bf16)f[e];
-        hi[2 * j + i][e] = hb;
-        lo[2 * j + i][e] = (__bf16)(f[e] - (float)hb);
+        unsigned short hb_, lb_;
+        ocv_split1<F16>(f[e], hb_, lb_);
+        hi[2 * j + i][e] = __builtin_bit_cast(__bf16, hb_);
+        lo[2 * j + i][e] = __builtin_bit_cast(__bf16, lb_);
       }
     }
 #pragma unroll
@@ -339,6 +340,7 @@ struct UpLArgs {
   int tiles_x, tiles_per_image, nup;     // nup = C1 / 64 resize chunks; further chunks: 64 skip / pad channels each
 };
 
+template <bool F16>
 __global__ __launch_bounds__(256) void upsample_concat_split_lds_kernel(UpLArgs p) {
   __shared__ __attribute__((aligned(16))) float4 src[ULS_H * ULS_W][ULC / 4];
   const int tid = threadIdx.x;
@@ -377,9 +379,10 @@ __global__ __launch_bounds__(256) void upsample_concat_split_lds_kernel(UpLArgs 
       up_bf16x8 hi, lo;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const __bf16 hb = (__bf16)f[e];
-        hi[e] = hb;
-        lo[e] = (__bf16)(f[e] - (float)hb);
+        unsigned short hb_, lb_;
+        ocv_split1<F16>(f[e], hb_, lb_);
+        hi[e] = __builtin_bit_cast(__bf16, hb_);
+        lo[e] = __builtin_bit_cast(__bf16, lb_);
       }
       const int c = chunk * ULC + oct * 8;
       __bf16* dst = p.hl + ((b * p.H + Y) * (long)p.W + X) * 2 * p.Cp + (c >> 5) * 64 + (c & 31);
@@ -407,9 +410,10 @@ __global__ __launch_bounds__(256) void upsample_concat_split_lds_kernel(UpLArgs 
     up_bf16x8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const __bf16 hb = (__bf16)f[e];
-      hi[e] = hb;
-      lo[e] = (__bf16)(f[e] - (float)hb);
+      unsigned short hb_, lb_;
+      ocv_split1<F16>(f[e], hb_, lb_);
+      hi[e] = __builtin_bit_cast(__bf16, hb_);
+      lo[e] = __builtin_bit_cast(__bf16, lb_);
     }
     __bf16* dst = p.hl + ((b * p.H + Y) * (long)p.W + X) * 2 * p.Cp + (c >> 5) * 64 + (c & 31);
     *reinterpret_cast<up_bf16x8*>(dst) = hi;
@@ -419,8 +423,9 @@ __global__ __launch_bounds__(256) void upsample_concat_split_lds_kernel(UpLArgs 
 
 }  // namespace
 
-extern "C" int ocv_upsample_concat_split_fwd(const float* x, int h, int w, int C1, const float* skip, int C2, void* out_hl,
-                                             int B, int H, int W, ocv_stream_t stream) {
+extern "C" int ocv_upsample_concat_split_x_fwd(const float* x, int h, int w, int C1, const float* skip, int C2, void* out_hl,
+                                               int f16, int B, int H, int W, ocv_stream_t stream) {
+  OCV_CHECK_ARG(f16 == 0 || f16 == 1, "ocv_upsample_concat_split_fwd: f16 must be 0 (bf16 pairs) or 1 (fp16 pairs)");
   OCV_CHECK_ARG(x && out_hl, "ocv_upsample_concat_split_fwd: null pointer");
   OCV_CHECK_ARG(B >= 1 && h >= 1 && w >= 1 && H >= 1 && W >= 1 && C1 >= 4 && C1 % 4 == 0, "ocv_upsample_concat_split_fwd: bad sizes (C1 must be a multiple of 4)");
   OCV_CHECK_ARG(skip == nullptr ? C2 == 0 : (C2 >= 4 && C2 % 4 == 0), "ocv_upsample_concat_split_fwd: C2 must be a multiple of 4 (0 without a skip tensor)");
@@ -437,7 +442,8 @@ extern "C" int ocv_upsample_concat_split_fwd(const float* x, int h, int w, int C
     const long nb = (long)B * g.tiles_per_image;
     const int nchunk = g.nup + (Cp - C1 + ULC - 1) / ULC;
     OCV_CHECK_ARG(nb < (1L << 31) && nchunk < 65536, "ocv_upsample_concat_split_fwd: tensor too large");
-    hipLaunchKernelGGL(upsample_concat_split_lds_kernel, dim3((unsigned)nb, (unsigned)nchunk), dim3(256), 0, (hipStream_t)stream, g);
+    if (f16) hipLaunchKernelGGL(upsample_concat_split_lds_kernel<true>, dim3((unsigned)nb, (unsigned)nchunk), dim3(256), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(upsample_concat_split_lds_kernel<false>, dim3((unsigned)nb, (unsigned)nchunk), dim3(256), 0, (hipStream_t)stream, g);
     OCV_CHECK_LAUNCH("ocv_upsample_concat_split_fwd");
     return 0;
   }
@@ -452,7 +458,8 @@ extern "C" int ocv_upsample_concat_split_fwd(const float* x, int h, int w, int C
     g.PB = threads / g.noct;
     const long nb = (g.nblk + g.PB - 1) / g.PB;
     OCV_CHECK_ARG(nb < (1L << 31), "ocv_upsample_concat_split_fwd: tensor too large");
-    hipLaunchKernelGGL(upsample_concat_split_2x2_kernel, dim3((unsigned)nb), dim3(threads), 0, (hipStream_t)stream, g);
+    if (f16) hipLaunchKernelGGL(upsample_concat_split_2x2_kernel<true>, dim3((unsigned)nb), dim3(threads), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(upsample_concat_split_2x2_kernel<false>, dim3((unsigned)nb), dim3(threads), 0, (hipStream_t)stream, g);
     OCV_CHECK_LAUNCH("ocv_upsample_concat_split_fwd");
     return 0;
   }
@@ -462,13 +469,20 @@ extern "C" int ocv_upsample_concat_split_fwd(const float* x, int h, int w, int C
     g.PB = (256 * UP8_ITEMS) / g.noct;                           // a workgroup's items fit one pass of its threads
     const long nb = (g.npix + g.PB - 1) / g.PB;
     OCV_CHECK_ARG(nb < (1L << 31), "ocv_upsample_concat_split_fwd: tensor too large");
-    hipLaunchKernelGGL(upsample_concat_split8_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, g);
+    if (f16) hipLaunchKernelGGL(upsample_concat_split8_kernel<true>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(upsample_concat_split8_kernel<false>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, g);
     OCV_CHECK_LAUNCH("ocv_upsample_concat_split_fwd");
     return 0;
   }
   const long blocks = (a.total + 256L * UP_ITEMS - 1) / (256L * UP_ITEMS);
   OCV_CHECK_ARG(blocks < (1L << 31), "ocv_upsample_concat_split_fwd: tensor too large");
-  hipLaunchKernelGGL(upsample_concat_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  if (f16) hipLaunchKernelGGL(upsample_concat_split_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(upsample_concat_split_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   OCV_CHECK_LAUNCH("ocv_upsample_concat_split_fwd");
   return 0;
+}
+
+extern "C" int ocv_upsample_concat_split_fwd(const float* x, int h, int w, int C1, const float* skip, int C2, void* out_hl,
+                                             int B, int H, int W, ocv_stream_t stream) {
+  return ocv_upsample_concat_split_x_fwd(x, h, w, C1, skip, C2, out_hl, 0, B, H, W, stream);
 }

@@ -6,9 +6,14 @@ Every C-ABI entry point only enqueues on the caller's stream (no allocation, no 
 against 25.9 ms for eager dispatch -- the ~1 ms the GPU idles between dependent launches of the eager stream.  (While
 the decoder still ran on MIOpen / ATen kernels replay was SLOWER than eager, 77 vs 51 ms; that went away with them.)
 
-``GraphedGraphBins`` captures ``GraphBins.forward_until_head`` (shapes fixed by the example image; object boxes /
-features come from the model's provider and are baked in as static device tensors) and runs the fused bin-head
-kernel eagerly after each replay.  Launches named in ``eager_ops`` (timing names of hip_ops, e.g.
+``GraphedGraphBins`` captures ``GraphBins.forward_until_head`` (shapes fixed by the example image) and runs the fused bin-head
+kernel eagerly after each replay.  Objects: by default whatever the model's provider returned at capture time is baked in as
+static device tensors (the benchmark's synthetic objects).  With ``object_capacity = N`` the graph owns static PADDED object
+buffers ([B, N, 512] features, [B, N, 4] boxes, int32 counts[B]) and every replay takes LIVE objects -- ``g(image, features_list,
+xywh_list)`` / ``g(image, PaddedObjects)`` / the provider's output for ``image`` -- copied into those buffers first: the masks and
+the front-padding of the key rows are formed on the device from ``counts`` (csrc/objects_pad.hip), nothing on the captured path
+depends on a count on the host, so ONE capture per (B, N) serves any ragged object set (BASELINE configs[4]: a detector + CLIP
+in front of a hipGraph-captured forward, modules/GraphBins.py:90-107, modules/ObjCAViT.py:311-330,180-194).  Launches named in ``eager_ops`` (timing names of hip_ops, e.g.
 ``"conv3x3|16,240,320,280,128"``) are kept out of the graph as EAGER ISLANDS: capture ends in front of them and a new
 graph segment starts behind them, so a step is  segment, island, segment, ..., head  -- that is how bench.py times
 its roofline kernel live with HIP events inside the timed region (events recorded inside a captured graph cannot be
@@ -16,13 +21,15 @@ read back on ROCm 7.2).
 """
 from __future__ import annotations
 
+import ctypes
 import threading
 import warnings
-from typing import Callable, List, Sequence, Tuple, Union
+from typing import Callable, List, Optional, Sequence, Tuple, Union
 
 import torch
 
 from . import hip_ops
+from .modules.ObjCAViT import PaddedObjects
 
 # Stream capture is a process-wide affair on ROCm 7.2: two threads capturing at the same time abort inside capture_end
 # (measured: tests, round 3), whatever capture_error_mode says.  Captures are therefore serialised; everything a capture
@@ -30,12 +37,45 @@ from . import hip_ops
 _CAPTURE_LOCK = threading.Lock()
 
 
+_HIP = None
+
+
+def _graph_node_count(g: "torch.cuda.CUDAGraph") -> Optional[int]:
+    """Number of nodes of a captured (kept, not yet instantiated) graph, asked of the HIP runtime itself
+    (hipGraphGetNodes); None when the runtime library or the raw handle is not reachable."""
+    global _HIP
+    try:
+        if _HIP is None:
+            _HIP = ctypes.CDLL("libamdhip64.so")
+            _HIP.hipGraphGetNodes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+            _HIP.hipGraphGetNodes.restype = ctypes.c_int
+        n = ctypes.c_size_t(0)
+        if _HIP.hipGraphGetNodes(ctypes.c_void_p(int(g.raw_cuda_graph())), None, ctypes.byref(n)) != 0:
+            return None
+        return int(n.value)
+    except (OSError, AttributeError, RuntimeError, TypeError):
+        return None
+
+
 class GraphedGraphBins:
-    def __init__(self, model, example_image: torch.Tensor, warmup: int = 2, eager_ops: Sequence[str] = ()):
+    images_are_independent = True      # an image's result does not depend on its batch mates (per object group: SURVEY.md Q3)
+
+    def __init__(self, model, example_image: torch.Tensor, warmup: int = 2, eager_ops: Sequence[str] = (),
+                 object_capacity: Optional[int] = None, object_group: Optional[int] = None):
         if example_image.device.type != "cuda":
             raise RuntimeError("graph capture needs a GPU tensor")
         self.model = model
         self.static_image = example_image.clone()
+        self.object_group = object_group
+        self.objects: Optional[PaddedObjects] = None
+        if object_capacity is not None:
+            B, dev = example_image.shape[0], example_image.device
+            cap, fdim = int(object_capacity), int(model.objcavit.obj_feature_dim)
+            if cap < 1:
+                raise ValueError("object_capacity must be >= 1")
+            self.objects = PaddedObjects(torch.zeros(B, cap, fdim, device=dev), torch.full((B, cap, 4), -1.0, device=dev),
+                                         torch.ones(B, dtype=torch.int32, device=dev))
+            self.load_objects(None, None)          # the provider's objects for the example image: warm-up on real values
         self.stream = torch.cuda.Stream()
         self.stream.wait_stream(torch.cuda.current_stream())
         # the graph OWNS its scratch: every workspace requested during warm-up, capture and replay comes from this
@@ -43,7 +83,7 @@ class GraphedGraphBins:
         self.scratch = hip_ops.WorkspaceStore()
         with hip_ops.workspace_scope(self.scratch), torch.cuda.stream(self.stream), torch.no_grad():
             for _ in range(warmup):                      # sizes every workspace / weight cache before capture
-                model(self.static_image)
+                model(self.static_image, self.objects, None, None, self.object_group)
         torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
 
@@ -52,26 +92,34 @@ class GraphedGraphBins:
         state = {"g": None}
 
         def begin():
-            g = torch.cuda.CUDAGraph()
+            # keep_graph: the captured hipGraph_t stays alive behind capture_end, so its node count can be read from the
+            # runtime before it is instantiated
+            g = torch.cuda.CUDAGraph(keep_graph=True)
             # thread_local: calls made by OTHER threads while we capture (the RCCL watchdog of a data-parallel job
             # polls events) must not invalidate the capture
             g.capture_begin(pool=pool, capture_error_mode="thread_local")
             state["g"] = g
 
         def end():
-            # a segment without a single node (two adjacent islands, or nothing behind the last one) is DROPPED: torch
-            # reports it with a warning at capture_end, and replaying an empty hipGraph on every step is pure overhead
+            # a segment without a single node (two adjacent islands, or nothing behind the last one) is DROPPED: replaying an
+            # empty hipGraph on every step is pure overhead.  Emptiness is read from the capture itself (hipGraphGetNodes);
+            # torch's "graph is empty" warning -- process-global warning state, wording of one torch version -- is only the
+            # fallback when the runtime cannot be asked.
+            g = state["g"]
             with warnings.catch_warnings(record=True) as seen:
                 warnings.simplefilter("always")
-                state["g"].capture_end()
-            empty = any("empty" in str(w.message).lower() for w in seen)
+                g.capture_end()
             for w in seen:
                 if "empty" not in str(w.message).lower():
                     warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
+            n = _graph_node_count(g)
+            empty = n == 0 if n is not None else any("empty" in str(w.message).lower() for w in seen)
             if empty:
                 self.empty_segments_dropped += 1
             else:
-                self.segments.append(state["g"])
+                g.instantiate()
+                self.segments.append(g)
+            self.segment_nodes.append(n)
             state["g"] = None
 
         def on_break(name, call):
@@ -82,11 +130,12 @@ class GraphedGraphBins:
             begin()
 
         self.empty_segments_dropped = 0
+        self.segment_nodes: List[Optional[int]] = []      # nodes per captured segment (dropped ones included), None = not readable
         # the hook is an object handed to hip_ops for the duration of THIS capture on THIS thread (thread-local scope)
         with _CAPTURE_LOCK, hip_ops.island_scope(hip_ops.IslandHook(eager_ops, on_break)), hip_ops.workspace_scope(self.scratch), \
                 torch.cuda.stream(self.stream), torch.no_grad():
             begin()
-            parts = model.forward_until_head(self.static_image)
+            parts = model.forward_until_head(self.static_image, self.objects, None, None, self.object_group)
             end()
         torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
@@ -96,11 +145,43 @@ class GraphedGraphBins:
         self.islands = [s[0] for s in self.segments if isinstance(s, tuple)]
 
     @torch.no_grad()
-    def __call__(self, image: torch.Tensor):
+    def load_objects(self, object_features, object_xywh_list=None, image: Optional[torch.Tensor] = None) -> None:
+        """Copy one batch's objects into the graph's static buffers (current stream): a ``PaddedObjects`` of at most the graph's
+        capacity, the reference's two lists, or None = ask the model's provider (for ``image``, default the static image)."""
+        if self.objects is None:
+            raise RuntimeError("this graph was captured with its objects baked in (no object_capacity): it takes only the image")
+        st = self.objects
+        B, cap = st.features.shape[:2]
+        if object_features is None:
+            img = self.static_image if image is None else image
+            padded = getattr(self.model.object_provider, "padded", None)
+            if padded is not None:
+                object_features = padded(img)
+            else:
+                object_features, object_xywh_list, _ = self.model.object_provider(img)
+        if not isinstance(object_features, PaddedObjects):
+            lens = [int(f.shape[0]) for f in object_features]
+            if len(lens) != B or max(lens) > cap:
+                raise ValueError(f"captured for {B} images of at most {cap} objects, got {len(lens)} lists, the longest of {max(lens)}")
+            object_features = PaddedObjects.from_lists([f.float() for f in object_features], object_xywh_list, st.features.device)
+        po = object_features
+        n, k = po.features.shape[1], min(po.xywh.shape[2], 4)
+        if po.features.shape[0] != B or n > cap or po.features.shape[2] != st.features.shape[2]:
+            raise ValueError(f"captured for objects [{B}, <= {cap}, {st.features.shape[2]}], got {tuple(po.features.shape)}")
+        st.features[:, :n].copy_(po.features)
+        st.xywh[:, :n, :k].copy_(po.xywh[:, :, :k])
+        st.counts.copy_(po.counts)
+
+    @torch.no_grad()
+    def __call__(self, image: torch.Tensor, object_features=None, object_xywh_list=None):
         if image.shape != self.static_image.shape:
             raise ValueError(f"captured for {tuple(self.static_image.shape)}, got {tuple(image.shape)}")
+        if self.objects is None and object_features is not None:
+            raise RuntimeError("this graph was captured with its objects baked in (no object_capacity): it takes only the image")
         if image.data_ptr() != self.static_image.data_ptr():
             self.static_image.copy_(image)
+        if self.objects is not None:
+            self.load_objects(object_features, object_xywh_list, image)
         with hip_ops.workspace_scope(self.scratch):
             for seg in self.segments:
                 if isinstance(seg, tuple):

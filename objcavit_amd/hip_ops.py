@@ -648,12 +648,12 @@ class PatchEmbedSplitWeight:
         self._key = None
         self._val = None
 
-    def get(self, w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        key = (w.data_ptr(), w._version, tuple(w.shape))
+    def get(self, w: torch.Tensor, f16: bool = False):
+        key = (w.data_ptr(), w._version, tuple(w.shape), bool(f16))
         if key != self._key:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("weight preparation during graph capture: run one eager warm-up call first")
-            self._val = prep_patch_embed_weight(w)
+            self._val = prep_patch_embed_weight(w, f16)
             self._key = key
         return self._val
 
@@ -669,21 +669,34 @@ def patch_embed_auto(fmap: torch.Tensor, weight: torch.Tensor, bias: Optional[to
         raise ValueError(f"OCV_PATCH_EMBED={mode!r}: expected 'split' (default) or 'exact'")
     if (pre is not None and mode == "split" and split_cache is not None and tuple(pre.shape) == tuple(fmap.shape)
             and patch_embed_split_supported(fmap.shape[0], fmap.shape[1], fmap.shape[2], fmap.shape[3], weight.shape[0])):
-        hi, lo = split_cache.get(weight)
-        return patch_embed_split(pre, hi, lo, bias, pos)
+        if not pre.f16:
+            hi, lo = split_cache.get(weight, False)
+            return patch_embed_split(pre, hi, lo, bias, pos)
+        if fp16_weight_safe(weight.detach().flatten(1)):
+            hi, lo, osc = split_cache.get(weight, True)
+            return patch_embed_split(pre, hi, lo, bias, pos, oscale=osc)
+        ROUTE_REPORT["patch_embed"] = "weights do not fit fp16 pairs (column spread > 2^17): exact-fp32 kernel on the fp32 map"
     return patch_embed(fmap, weight, bias, pos, cl_cache=cl_cache)
 
 
-def prep_patch_embed_weight(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """[E, C, 16, 16] fp32 -> (w_hi, w_lo) bf16 [16 (ky), E, 16 C] with column kx * C + c, w_hi = bf16(W), w_lo = bf16(W - w_hi):
-    the operand order of ocv_patch_embed_split_fwd.  Done once per weight version by the callers (cached there)."""
+def prep_patch_embed_weight(weight: torch.Tensor, f16: bool = False):
+    """[E, C, 16, 16] fp32 -> the two-term split [16 (ky), E, 16 C] with column kx * C + c: the operand order of
+    ocv_patch_embed_split_fwd.  f16 = False: (w_hi, w_lo) bf16; f16 = True: (w_hi, w_lo, oscale) fp16 pairs of W * 2^k[e] and
+    oscale [E] = 2^-k, as ``prep_conv_weight``.  Done once per weight version by the callers (cached there)."""
     E, Cc, kh, kw = weight.shape
     if (kh, kw) != (16, 16) or Cc % 32 != 0:
         raise ValueError("prep_patch_embed_weight: needs a 16x16 kernel and a multiple of 32 input channels")
     w = weight.detach().float().permute(2, 0, 3, 1).reshape(16, E, 16 * Cc)
-    hi = w.to(torch.bfloat16)
-    lo = (w - hi.float()).to(torch.bfloat16)
-    return hi.contiguous(), lo.contiguous()
+    if not f16:
+        hi = w.to(torch.bfloat16)
+        lo = (w - hi.float()).to(torch.bfloat16)
+        return hi.contiguous(), lo.contiguous()
+    amax = w.abs().amax(dim=(0, 2))
+    k = torch.where(amax > 0, torch.round(8.0 - torch.log2(amax.clamp_min(1e-30))), torch.zeros_like(amax)).clamp(-100.0, 100.0)
+    w = w * torch.exp2(k)[None, :, None]
+    hi = w.to(torch.float16)
+    lo = (w - hi.float()).to(torch.float16)
+    return hi.contiguous(), lo.contiguous(), torch.exp2(-k).float().contiguous()
 
 
 def patch_embed_split_supported(B: int, Cc: int, h: int, w: int, E: int) -> bool:
@@ -691,18 +704,23 @@ def patch_embed_split_supported(B: int, Cc: int, h: int, w: int, E: int) -> bool
 
 
 def patch_embed_split(fmap: "SplitAct", w_hi: torch.Tensor, w_lo: torch.Tensor, bias: Optional[torch.Tensor],
-                      pos: Optional[torch.Tensor]) -> torch.Tensor:
+                      pos: Optional[torch.Tensor], oscale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """tokens [B, S, E] = conv16x16/16(fmap) flattened + bias + pos on a feature map held in the hl32 split layout
-    (ocv_patch_embed_split_fwd: 16 split-bf16 GEMMs in one launch of the convolution kernel + a fixed-order sum).
-    w_hi / w_lo from ``prep_patch_embed_weight``; pos is [S, E] or [B, S, E]."""
+    (ocv_patch_embed_split_fwd: 16 two-term-split GEMMs in one launch of the convolution kernel + a fixed-order sum).
+    w_hi / w_lo (/ oscale) from ``prep_patch_embed_weight`` in the map's element type; pos is [S, E] or [B, S, E]."""
     lib = _lib.load()
-    _req(fmap.hl, "fmap.hl", torch.bfloat16)
+    dt = fmap.hl.dtype
+    _req(fmap.hl, "fmap.hl", dt)
     B, Cc, h, w = fmap.shape
     for n, t in (("w_hi", w_hi), ("w_lo", w_lo)):
-        _req(t, n, torch.bfloat16)
+        _req(t, n, dt)
     if w_hi.dim() != 3 or w_hi.shape[0] != 16 or w_hi.shape[2] != 16 * Cc or w_lo.shape != w_hi.shape:
         raise ValueError(f"patch_embed_split: weights {tuple(w_hi.shape)} do not match {Cc} channels / 16x16 patches")
     E = w_hi.shape[1]
+    if oscale is not None:
+        _req(oscale, "oscale")
+        if oscale.numel() != E:
+            raise ValueError("patch_embed_split: oscale size mismatch")
     gh, gw = h // 16, w // 16
     S = gh * gw
     nb = int(lib.ocv_patch_embed_split_workspace_bytes(B, Cc, h, w, E))
@@ -724,9 +742,9 @@ def patch_embed_split(fmap: "SplitAct", w_hi: torch.Tensor, w_lo: torch.Tensor, 
     ws = workspace(nb, fmap.hl.device, "patch_embed_split")
     out = torch.empty(B, S, E, dtype=torch.float32, device=fmap.hl.device)
     with timed("patch_embed"):
-        check(lib.ocv_patch_embed_split_fwd(fmap.hl.data_ptr(), Cc, w_hi.data_ptr(), w_lo.data_ptr(), _ptr(bias), _ptr(pos), pos_bs,
-                                            out.data_ptr(), B, h, w, E, ws.data_ptr(), ws.numel(), _stream()),
-              "ocv_patch_embed_split_fwd")
+        check(lib.ocv_patch_embed_split_fwd(fmap.hl.data_ptr(), Cc, w_hi.data_ptr(), w_lo.data_ptr(), _ptr(oscale), int(fmap.f16),
+                                            _ptr(bias), _ptr(pos), pos_bs, out.data_ptr(), B, h, w, E, ws.data_ptr(), ws.numel(),
+                                            _stream()), "ocv_patch_embed_split_fwd")
     return out
 
 
@@ -788,6 +806,76 @@ def bin_head(feat: torch.Tensor, queries: torch.Tensor, w_out: torch.Tensor, b_o
                                              centers.data_ptr(), depth.data_ptr(), B, Cc, nbins, h * w, _ptr(part), npart,
                                              _stream()), "ocv_bin_head_folded_ws_fwd")
     return depth
+
+
+# ---------------------------------------------------------------------------
+# bin widths -> edges -> centres (csrc/bin_edges.hip)
+# ---------------------------------------------------------------------------
+BINNORM = {"linear": 0, "sigmoid": 1, "none": 2}
+
+
+def bin_edges(raw: torch.Tensor, norm: str, min_depth: float, max_depth: float) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """raw [B, n_bins] (the regressor's output; ``norm`` = 'linear' | 'sigmoid', or 'none' for rows that are normalised already) ->
+    (bin_widths_normed [B, n_bins], bin_edges [B, n_bins + 1], centers [B, n_bins]) in one launch."""
+    lib = _lib.load()
+    _req(raw, "raw")
+    if raw.dim() != 2 or norm not in BINNORM:
+        raise ValueError("bin_edges: raw must be [B, n_bins] and norm one of " + ", ".join(BINNORM))
+    B, n = raw.shape
+    w = torch.empty_like(raw)
+    e = torch.empty(B, n + 1, dtype=torch.float32, device=raw.device)
+    c = torch.empty_like(raw)
+    check(lib.ocv_bin_edges_fwd(raw.data_ptr(), BINNORM[norm], float(min_depth), float(max_depth), w.data_ptr(), e.data_ptr(),
+                                c.data_ptr(), B, n, _stream()), "ocv_bin_edges_fwd")
+    return w, e, c
+
+
+# ---------------------------------------------------------------------------
+# ragged object lists with device-resident counts (csrc/objects_pad.hip)
+# ---------------------------------------------------------------------------
+def _counts_i32(counts: torch.Tensor, B: int) -> torch.Tensor:
+    _req(counts, "counts", torch.int32)
+    if counts.shape != (B,):
+        raise ValueError(f"counts: expected int32 [{B}], got {tuple(counts.shape)}")
+    return counts
+
+
+def object_tokens_pad(tokens: torch.Tensor, counts: torch.Tensor, pad_value: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """tokens [B, cap, E] (rows >= counts[b] arbitrary) -> (tokens with those rows set to ``pad_value``, uint8 mask [B, cap] with
+    1 = padding): pad_sequence(..., padding_value) + the key-padding mask of modules/ObjCAViT.py:180-183, counts on the device."""
+    lib = _lib.load()
+    _req(tokens, "tokens")
+    if tokens.dim() != 3:
+        raise ValueError("object_tokens_pad: tokens must be [B, capacity, E]")
+    B, cap, E = tokens.shape
+    _counts_i32(counts, B)
+    out = torch.empty_like(tokens)
+    mask = torch.empty(B, cap, dtype=torch.uint8, device=tokens.device)
+    check(lib.ocv_object_tokens_pad_fwd(tokens.data_ptr(), counts.data_ptr(), float(pad_value), out.data_ptr(), mask.data_ptr(),
+                                        B, cap, E, _stream()), "ocv_object_tokens_pad_fwd")
+    return out, mask
+
+
+def object_front_pad(objects: torch.Tensor, counts: torch.Tensor, S: int, pad_value: float, group: Optional[int] = None,
+                     nmax: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """objects [B, cap, E] -> (keys [B, S, E] with the rows padded at the FRONT to S, uint8 mask [B, S] = (j >= counts[b])):
+    modules/ObjCAViT.py:192-194 with Nmax = the longest list of the image's group (``group`` consecutive images = one call of
+    the reference; None = the whole batch) or ``nmax`` when given (> 0)."""
+    lib = _lib.load()
+    _req(objects, "objects")
+    if objects.dim() != 3:
+        raise ValueError("object_front_pad: objects must be [B, capacity, E]")
+    B, cap, E = objects.shape
+    _counts_i32(counts, B)
+    if cap > S:
+        raise ValueError(f"more objects per image ({cap}) than image tokens ({S})")
+    if nmax < 0 or nmax > cap:
+        raise ValueError(f"object_front_pad: nmax = {nmax} outside [0, capacity = {cap}]")
+    out = torch.empty(B, S, E, dtype=torch.float32, device=objects.device)
+    kpm = torch.empty(B, S, dtype=torch.uint8, device=objects.device)
+    check(lib.ocv_object_front_pad_fwd(objects.data_ptr(), counts.data_ptr(), int(group or B), int(nmax), float(pad_value),
+                                       out.data_ptr(), kpm.data_ptr(), B, cap, int(S), E, _stream()), "ocv_object_front_pad_fwd")
+    return out, kpm
 
 
 # ---------------------------------------------------------------------------
@@ -858,19 +946,59 @@ def depthwise_conv_same(x: torch.Tensor, weight: torch.Tensor, bias: Optional[to
 # ---------------------------------------------------------------------------
 # split-bf16 implicit-GEMM convolution on NHWC activations
 # ---------------------------------------------------------------------------
-def prep_conv_weight(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """[Cout, Cin, k, k] fp32 -> (w_hi, w_lo) bf16 [k*k, Cout, Cp] with Cp = Cin rounded up to 32 (zero padded),
-    w_hi = bf16(W), w_lo = bf16(W - w_hi).  Done once per weight version by the callers (cached there)."""
+def conv_split_f16() -> bool:
+    """Element type of the two-term split of the decoder's / heads' convolutions (the "hl32" activations between them and their
+    weights): OCV_CONV_SPLIT = 'f16' (default, round 4: fp16 pairs, products good to 2^-22 on v_mfma_*_f16; weights scaled per
+    output channel out of fp16's subnormals, activations range-checked -- ``range_check`` / ``fp16_range_report``) or 'bf16'
+    (rounds 1 - 3: bf16 pairs, 2^-17, fp32's range: the A/B route, and what a model falls back to -- reported in
+    ``ROUTE_REPORT`` -- when its weights do not fit fp16 pairs)."""
+    mode = os.environ.get("OCV_CONV_SPLIT", "f16")
+    if mode not in ("f16", "bf16"):
+        raise ValueError(f"OCV_CONV_SPLIT={mode!r}: expected 'f16' (default) or 'bf16'")
+    return mode == "f16"
+
+
+ROUTE_REPORT: Dict[str, str] = {}        # layer / model name -> why it left the default route (never silent: bench.py prints it)
+
+
+def fp16_weight_safe(w2d: torch.Tensor) -> bool:
+    """Whether a weight matrix [N, K] keeps at least bf16-pair precision (16 bits) on EVERY entry as fp16 pairs after its rows have
+    been scaled to a largest entry near 2^8: an entry more than 2^17 below its row's largest has fewer than five low-term bits
+    left above fp16's subnormal step.  Judged per input column (a column that is small in every row = an input channel whose
+    weights are tiny next to the others', which matters exactly when its activations are huge); all-zero columns are fine."""
+    w = w2d.detach().abs().double()
+    rmax = w.amax(dim=1, keepdim=True).clamp_min(1e-300)
+    col = (w / rmax).amax(dim=0)
+    col = col[col > 0]
+    return bool(col.numel() == 0 or float(col.min()) >= 2.0 ** -17)
+
+
+def prep_conv_weight(weight: torch.Tensor, f16: bool = False):
+    """[Cout, Cin, k, k] fp32 -> the two-term split in the kernels' order [k*k, Cout, Cp], Cp = Cin rounded up to 32 (zero padded).
+    f16 = False: (w_hi, w_lo) bf16, w_hi = bf16(W), w_lo = bf16(W - w_hi).
+    f16 = True:  (w_hi, w_lo, oscale): fp16 pairs of W * 2^k[n], k[n] the power of two that puts output channel n's largest entry
+      in [2^7.5, 2^8.5) (out of fp16's subnormals: BN-folded weights of ~0.02 would otherwise have low terms of 1e-5, below the
+      6e-5 where fp16 stops being normal), and oscale [Cout] fp32 = 2^-k for the kernel's epilogue (exact).
+    Done once per weight version by the callers (cached there)."""
     Cout, Cin, kh, kw = weight.shape
     if kh != kw or kh not in (1, 3):
         raise ValueError("prep_conv_weight: kernel must be 1x1 or 3x3")
     w = weight.detach().float().permute(2, 3, 0, 1).reshape(kh * kw, Cout, Cin)
     Cp = (Cin + 31) // 32 * 32
+    if not f16:
+        if Cp != Cin:
+            w = torch.nn.functional.pad(w, (0, Cp - Cin))
+        hi = w.to(torch.bfloat16)
+        lo = (w - hi.float()).to(torch.bfloat16)
+        return hi.contiguous(), lo.contiguous()
+    amax = w.abs().amax(dim=(0, 2))                                            # [Cout]
+    k = torch.where(amax > 0, torch.round(8.0 - torch.log2(amax.clamp_min(1e-30))), torch.zeros_like(amax)).clamp(-100.0, 100.0)
+    w = w * torch.exp2(k)[None, :, None]
     if Cp != Cin:
         w = torch.nn.functional.pad(w, (0, Cp - Cin))
-    hi = w.to(torch.bfloat16)
-    lo = (w - hi.float()).to(torch.bfloat16)
-    return hi.contiguous(), lo.contiguous()
+    hi = w.to(torch.float16)
+    lo = (w - hi.float()).to(torch.float16)
+    return hi.contiguous(), lo.contiguous(), torch.exp2(-k).float().contiguous()
 
 
 def conv_nhwc_exact(x1: torch.Tensor, x2: Optional[torch.Tensor], w_tap_major: torch.Tensor, bias: Optional[torch.Tensor],
@@ -911,7 +1039,7 @@ def tap_interp_supported(h: int, w: int, H: int, W: int, Cout: int) -> bool:
 
 def tap_interp_combine(z: torch.Tensor, s: Optional[torch.Tensor], bias: Optional[torch.Tensor], size: Tuple[int, int],
                        act: int = ACT_NONE, out_fp32: bool = True, out_split: bool = False,
-                       border: Optional[torch.Tensor] = None):
+                       border: Optional[torch.Tensor] = None, split_f16: bool = False):
     """act(bias + s + sum over the 9 taps of the bilinear (align_corners) interpolation of z's tap products at the tap
     position): ocv_tap_interp_combine_fwd.  z [B, 9 Cout, h, w] channels_last (tap-major columns), s [B, Cout, H, W]
     channels_last or None.  ``border`` [9 Cout]: z is the interior of an (h+2) x (w+2) grid whose border ring holds this
@@ -942,19 +1070,20 @@ def tap_interp_combine(z: torch.Tensor, s: Optional[torch.Tensor], bias: Optiona
     if not tap_interp_supported(h, w, H, W, Cout):
         raise ValueError(f"tap_interp_combine: unsupported resize {h}x{w} -> {H}x{W} / channel count {Cout}")
     y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=z.device, memory_format=torch.channels_last) if out_fp32 else None
-    ys = SplitAct.empty(B, Cout, H, W, z.device) if out_split else None
+    ys = SplitAct.empty(B, Cout, H, W, z.device, f16=split_f16) if out_split else None
     with timed(f"tap_interp|{B},{H},{W},{Cout}"):
-        check(lib.ocv_tap_interp_combine_fwd(z.data_ptr(), h, w, zpad, _ptr(border), _ptr(s), _ptr(bias), _ptr(y),
-                                             ys.hl.data_ptr() if out_split else None, B, H, W, Cout, act, _stream()),
-              "ocv_tap_interp_combine_fwd")
+        check(lib.ocv_tap_interp_combine_x_fwd(z.data_ptr(), h, w, zpad, _ptr(border), _ptr(s), _ptr(bias), _ptr(y),
+                                               ys.hl.data_ptr() if out_split else None, int(bool(split_f16)), B, H, W, Cout, act,
+                                               _stream()), "ocv_tap_interp_combine_fwd")
+    _note_range(f"tap_interp|{B},{H},{W},{Cout}", ys)
     if out_fp32 and out_split:
         return y, ys
     return y if out_fp32 else ys
 
 
-def split_act(x: torch.Tensor) -> "SplitAct":
-    """fp32 channels_last activation -> hl32 split (the resize kernel at scale 1)."""
-    return upsample_concat_split(x, None, tuple(x.shape[-2:]))
+def split_act(x: torch.Tensor, f16: bool = False) -> "SplitAct":
+    """fp32 channels_last activation -> hl32 split (the resize kernel at scale 1); ``f16``: fp16 pairs instead of bf16 pairs."""
+    return upsample_concat_split(x, None, tuple(x.shape[-2:]), f16=f16)
 
 
 _WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
@@ -1032,11 +1161,11 @@ def conv3x3_winograd43_split(x: "SplitAct", u_hi: torch.Tensor, u_lo: torch.Tens
     lib = _lib.load()
     if not (out_fp32 or out_split):
         raise ValueError("conv3x3_winograd43_split: nothing to output")
-    _req(x.hl, "x.hl", torch.bfloat16)
+    _req(x.hl, "x.hl", x.hl.dtype)
     B, Cin, H, W = x.shape
     Cp = (Cin + 31) // 32 * 32
     if x.hl.dim() != 4 or x.hl.shape[3] != 2 * Cp:
-        raise ValueError("conv3x3_winograd43_split: x.hl must be [B, H, W, 2 * ceil32(C)] bf16")
+        raise ValueError("conv3x3_winograd43_split: x.hl must be [B, H, W, 2 * ceil32(C)]")
     for n, t in (("u_hi", u_hi), ("u_lo", u_lo)):
         _req(t, n, torch.float16)
     _req(fscale, "fscale")
@@ -1054,13 +1183,14 @@ def conv3x3_winograd43_split(x: "SplitAct", u_hi: torch.Tensor, u_lo: torch.Tens
         if bias.numel() != Cout:
             raise ValueError("conv3x3_winograd43_split: bias size mismatch")
     y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.hl.device, memory_format=torch.channels_last) if out_fp32 else None
-    ys = SplitAct.empty(B, Cout, H, W, x.hl.device) if out_split else None
+    ys = SplitAct.empty(B, Cout, H, W, x.hl.device, f16=x.f16) if out_split else None
     nws = int(lib.ocv_conv3x3_winograd43_workspace_bytes(B, H, W, Cin, Cout))
     ws = workspace(nws, x.hl.device, "conv_winograd")
     with timed(f"conv3x3w4|{B},{H},{W},{Cin},{Cout}"):
         check(lib.ocv_conv3x3_winograd43_split_fwd(x.hl.data_ptr(), Cin, u_hi.data_ptr(), u_lo.data_ptr(), fscale.data_ptr(), _ptr(cscale), _ptr(bias),
-                                                   _ptr(y), ys.hl.data_ptr() if out_split else None, B, H, W, Cout, act,
+                                                   _ptr(y), ys.hl.data_ptr() if out_split else None, B, H, W, Cout, act, int(x.f16),
                                                    ws.data_ptr(), ws.numel(), _stream()), "ocv_conv3x3_winograd43_split_fwd")
+    _note_range(f"conv3x3w4|{B},{H},{W},{Cin},{Cout}", ys)
     if out_fp32 and out_split:
         return y, ys
     return y if out_fp32 else ys
@@ -1659,9 +1789,9 @@ def se_gate(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2t: torch.Tens
 # split-bf16 activations between our convolutions
 # ---------------------------------------------------------------------------
 class SplitAct:
-    """An activation of logical shape [B, C, H, W] held in the "hl32" split-bf16 layout of include/objcavit_hip.h: one
-    bf16 buffer ``hl`` [B, H, W, 2 * Cp] (Cp = C rounded up to 32) with, per pixel and per 32-channel block, the 32
-    hi = bf16(v) values followed by the 32 lo = bf16(v - hi) values; pad channels are zero.  Produced by
+    """An activation of logical shape [B, C, H, W] held in the "hl32" two-term split layout of include/objcavit_hip.h: one
+    2-byte buffer ``hl`` [B, H, W, 2 * Cp] (Cp = C rounded up to 32; dtype bfloat16 or float16 = the element type of the pairs)
+    with, per pixel and per 32-channel block, the 32 hi = t(v) values followed by the 32 lo = t(v - hi) values; pad channels are zero.  Produced by
     ``upsample_concat_split`` / ``conv_nhwc_split(..., out_split=True)``, consumed by ``conv_nhwc_split`` with no
     per-tap conversion work."""
     __slots__ = ("hl", "C")
@@ -1670,12 +1800,17 @@ class SplitAct:
         self.hl, self.C = hl, int(C)
 
     @staticmethod
-    def empty(B: int, C: int, H: int, W: int, device) -> "SplitAct":
+    def empty(B: int, C: int, H: int, W: int, device, f16: bool = False) -> "SplitAct":
         Cp = (C + 31) // 32 * 32
         n = int(_lib.load().ocv_split_act_elems(B, H, W, C))
         if n != B * H * W * 2 * Cp:
             raise ValueError(f"SplitAct: bad sizes {(B, C, H, W)}")
-        return SplitAct(torch.empty(B, H, W, 2 * Cp, dtype=torch.bfloat16, device=device), C)
+        return SplitAct(torch.empty(B, H, W, 2 * Cp, dtype=torch.float16 if f16 else torch.bfloat16, device=device), C)
+
+    @property
+    def f16(self) -> bool:
+        """Whether the pairs are fp16 (2^-22 products, +-65504) rather than bf16 (2^-17, fp32's range)."""
+        return self.hl.dtype == torch.float16
 
     @property
     def shape(self):
@@ -1703,8 +1838,9 @@ class SplitAct:
         return hi.float() + lo.float()
 
 
-def upsample_concat_split(x: torch.Tensor, skip: Optional[torch.Tensor], size: Tuple[int, int]) -> SplitAct:
-    """split(cat([bilinear_resize(x, size, align_corners=True), skip], dim=1)); x / skip channels_last fp32."""
+def upsample_concat_split(x: torch.Tensor, skip: Optional[torch.Tensor], size: Tuple[int, int], f16: bool = False) -> SplitAct:
+    """split(cat([bilinear_resize(x, size, align_corners=True), skip], dim=1)); x / skip channels_last fp32; the split as bf16
+    pairs, or fp16 pairs with ``f16``."""
     lib = _lib.load()
     x = _nhwc(x, "x")
     B, C1, h, w = x.shape
@@ -1715,25 +1851,29 @@ def upsample_concat_split(x: torch.Tensor, skip: Optional[torch.Tensor], size: T
         if skip.shape[0] != B or tuple(skip.shape[2:]) != (H, W):
             raise ValueError("upsample_concat_split: skip must be [B, C2, H, W] at the target size")
         C2 = skip.shape[1]
-    out = SplitAct.empty(B, C1 + C2, H, W, x.device)
+    out = SplitAct.empty(B, C1 + C2, H, W, x.device, f16=f16)
     with timed("upsample_concat_split"):
-        check(lib.ocv_upsample_concat_split_fwd(x.data_ptr(), h, w, C1, _ptr(skip), C2, out.hl.data_ptr(), B, H, W,
-                                                _stream()), "ocv_upsample_concat_split_fwd")
+        check(lib.ocv_upsample_concat_split_x_fwd(x.data_ptr(), h, w, C1, _ptr(skip), C2, out.hl.data_ptr(), int(bool(f16)), B, H, W,
+                                                  _stream()), "ocv_upsample_concat_split_fwd")
+    _note_range(f"split|{B},{H},{W},{C1 + C2}", out)
     return out
 
 
 def conv_nhwc_split(x: SplitAct, w_hi: torch.Tensor, w_lo: torch.Tensor, bias: Optional[torch.Tensor], ksize: int,
-                    act: int = ACT_NONE, out_fp32: bool = True, out_split: bool = False):
-    """Split-bf16 convolution on a pre-split input.  Returns fp32 tensor, SplitAct, or (fp32, SplitAct)."""
+                    act: int = ACT_NONE, out_fp32: bool = True, out_split: bool = False, oscale: Optional[torch.Tensor] = None):
+    """Two-term-split convolution on a pre-split input; the weights' element type must be the input's (bf16 pairs, or fp16 pairs
+    with their per-output-channel ``oscale``: prep_conv_weight(f16=True)), the split output has it too.
+    Returns fp32 tensor, SplitAct, or (fp32, SplitAct)."""
     lib = _lib.load()
     if not (out_fp32 or out_split):
         raise ValueError("conv_nhwc_split: nothing to output")
-    _req(x.hl, "x.hl", torch.bfloat16)
+    dt = x.hl.dtype
+    _req(x.hl, "x.hl", dt)
     B, Cin, H, W = x.shape
     if x.hl.dim() != 4 or x.hl.shape[3] != 2 * ((Cin + 31) // 32 * 32):
-        raise ValueError("conv_nhwc_split: x.hl must be [B, H, W, 2 * ceil32(C)] bf16")
+        raise ValueError("conv_nhwc_split: x.hl must be [B, H, W, 2 * ceil32(C)]")
     for n, t in (("w_hi", w_hi), ("w_lo", w_lo)):
-        _req(t, n, torch.bfloat16)
+        _req(t, n, dt)
     taps, Cout, Cp = w_hi.shape
     if w_lo.shape != w_hi.shape or taps != ksize * ksize or Cp != (Cin + 31) // 32 * 32:
         raise ValueError(f"conv_nhwc_split: weights {tuple(w_hi.shape)} do not match {Cin} input channels, k={ksize}")
@@ -1741,15 +1881,57 @@ def conv_nhwc_split(x: SplitAct, w_hi: torch.Tensor, w_lo: torch.Tensor, bias: O
         _req(bias, "bias")
         if bias.numel() != Cout:
             raise ValueError("conv_nhwc_split: bias size mismatch")
+    if oscale is not None:
+        _req(oscale, "oscale")
+        if oscale.numel() != Cout:
+            raise ValueError("conv_nhwc_split: oscale size mismatch")
     y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.hl.device, memory_format=torch.channels_last) if out_fp32 else None
-    ys = SplitAct.empty(B, Cout, H, W, x.hl.device) if out_split else None
+    ys = SplitAct.empty(B, Cout, H, W, x.hl.device, f16=x.f16) if out_split else None
     nws = int(lib.ocv_conv_nhwc_split_workspace_bytes(B, H, W, Cin, Cout, ksize))      # split-K partial sums (most shapes: 0)
     ws = workspace(nws, x.hl.device, "conv_splitk") if nws else None
-    ptrs = (x.hl.data_ptr(), Cin, w_hi.data_ptr(), w_lo.data_ptr(), _ptr(bias), None, _ptr(y),
+    ptrs = (x.hl.data_ptr(), Cin, w_hi.data_ptr(), w_lo.data_ptr(), _ptr(oscale), int(x.f16), _ptr(bias), None, _ptr(y),
             ys.hl.data_ptr() if out_split else None, B, H, W, Cout, ksize, act, _ptr(ws), nws)
-    keep = (x, w_hi, w_lo, bias, y, ys, ws)      # an eager island re-issues this launch on every replay
+    keep = (x, w_hi, w_lo, oscale, bias, y, ys, ws)      # an eager island re-issues this launch on every replay
     launch(f"conv{ksize}x{ksize}|{B},{H},{W},{Cin},{Cout}",
-           lambda: (keep, check(lib.ocv_conv_nhwc_split_ws_fwd(*ptrs, _stream()), "ocv_conv_nhwc_split_ws_fwd"))[1])
+           lambda: (keep, check(lib.ocv_conv_nhwc_split_x_fwd(*ptrs, _stream()), "ocv_conv_nhwc_split_x_fwd"))[1])
+    _note_range(f"conv{ksize}x{ksize}|{B},{H},{W},{Cin},{Cout}", ys)
     if out_fp32 and out_split:
         return y, ys
     return y if out_fp32 else ys
+
+
+# ---------------------------------------------------------------------------
+# fp16 range check of the split activations (diagnostic: host synchronisation per tensor)
+# ---------------------------------------------------------------------------
+class _Range:
+    enabled = False
+    seen: Dict[str, Tuple[float, float]] = {}
+
+
+def range_check(on: bool = True) -> None:
+    """Start (and reset) / stop recording the largest and the smallest-nonzero-block magnitude of every fp16 hl32 tensor the
+    path produces.  Diagnostic: every record is a host synchronisation -- run ONE eager forward under it (bench.py does, before
+    its timed region), never a captured or timed one."""
+    _Range.enabled = on
+    if on:
+        _Range.seen = {}
+
+
+def _note_range(name: str, ys: Optional["SplitAct"]) -> None:
+    if not _Range.enabled or ys is None or not ys.f16 or torch.cuda.is_current_stream_capturing():
+        return
+    hi = ys.hi.float().abs()
+    amax = float(hi.amax()) if hi.numel() else 0.0
+    finite = bool(torch.isfinite(hi).all())
+    old = _Range.seen.get(name)
+    _Range.seen[name] = (max(amax, old[0]) if old else amax, (old[1] if old else True) and finite)
+
+
+def fp16_range_report() -> dict:
+    """What ``range_check`` saw: per fp16 hl32 tensor its largest magnitude; ``ok`` = every tensor finite, its largest entry below
+    fp16's 65504 with a factor 16 to spare and above 2^-6 (a tensor whose LARGEST entry is below that has every low term in fp16's
+    subnormals: its pairs are then good to ~2^-17 instead of 2^-22, still the bf16 pairs' precision)."""
+    t = {k: v[0] for k, v in _Range.seen.items()}
+    bad = {k: v[0] for k, v in _Range.seen.items() if not v[1] or v[0] > 65504.0 / 16 or (0.0 < v[0] < 2.0 ** -6)}
+    return {"tensors": len(t), "max_amax": max(t.values()) if t else None, "min_amax": min(t.values()) if t else None,
+            "ok": not bad, "out_of_range": bad}

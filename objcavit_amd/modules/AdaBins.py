@@ -20,7 +20,14 @@ from .miniViT import mViT
 
 
 def bin_edges_and_centers(bin_widths_normed: torch.Tensor, min_depth: float, max_depth: float):
-    """widths -> edges -> centres (reference modules/AdaBins.py:79-83 == modules/GraphBins.py:111-115)."""
+    """widths -> edges -> centres (reference modules/AdaBins.py:79-83 == modules/GraphBins.py:111-115): what
+    ``regress_bin_widths(..., depth_range)`` already left on the tensor (one launch with the normalisation), one launch of
+    csrc/bin_edges.hip for other GPU tensors, the reference's torch formulation on the CPU."""
+    stash = getattr(bin_widths_normed, "_ocv_bins", None)
+    if stash is not None and stash[0] == (float(min_depth), float(max_depth)):
+        return stash[1], stash[2]
+    if bin_widths_normed.is_cuda:
+        return hip_ops.bin_edges(bin_widths_normed.contiguous(), "none", min_depth, max_depth)[1:]
     widths = (max_depth - min_depth) * bin_widths_normed
     widths = nn.functional.pad(widths, (1, 0), mode='constant', value=min_depth)
     edges = torch.cumsum(widths, dim=1)
@@ -29,6 +36,8 @@ def bin_edges_and_centers(bin_widths_normed: torch.Tensor, min_depth: float, max
 
 
 class AdaBins(nn.Module):
+    images_are_independent = True      # an image's result does not depend on its batch mates (per object group: SURVEY.md Q3)
+
     def __init__(self, args, backbone: nn.Module = None):
         super().__init__()
         self.args = args
@@ -66,8 +75,8 @@ class AdaBins(nn.Module):
 
     def forward(self, image):
         unet_out = self.dense_feature_extractor(image)
-        bin_widths_normed, feat, queries = self.adaptive_bins_layer.forward_parts(unet_out)
         ds = self.args[self.args.basic.dataset]
+        bin_widths_normed, feat, queries = self.adaptive_bins_layer.forward_parts(unet_out, (ds.min_depth, ds.max_depth))
         bin_edges, centers = bin_edges_and_centers(bin_widths_normed, ds.min_depth, ds.max_depth)
         conv = self.conv_out[0]
         depth_pred = hip_ops.bin_head(feat, queries, conv.weight.detach(), conv.bias.detach(), centers)

@@ -39,9 +39,15 @@ def split_bf16_convs_enabled() -> bool:
     return mode != "exact"
 
 
+class Fp16Unsafe(Exception):
+    """A convolution's (possibly composed) weight does not fit fp16 pairs (hip_ops.fp16_weight_safe): the decoder then runs its
+    whole split pipeline on bf16 pairs instead and says so in hip_ops.ROUTE_REPORT."""
+
+
 class SplitConv3x3:
-    """Inference-time plan for one 3x3 (or 1x1) convolution [+ folded BatchNorm]: weights split into bf16 hi/lo
-    once per parameter version, then ``ocv_conv_nhwc_fwd``."""
+    """Inference-time plan for one 3x3 (or 1x1) convolution [+ folded BatchNorm]: weights split into two 2-byte terms once per
+    parameter version -- bf16 pairs, or fp16 pairs scaled per output channel (round 4), whichever the pre-split input it is
+    handed holds -- then ``ocv_conv_nhwc_split_x_fwd`` / the Winograd forms."""
 
     def __init__(self, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d] = None):
         self.conv, self.bn = conv, bn
@@ -51,6 +57,20 @@ class SplitConv3x3:
         self._w_folded = None
         self._w_exact = None
         self._w_up = None
+        self._prep16 = None
+
+    def prep_for(self, f16: bool):
+        """(w_hi, w_lo, bias, oscale) in the element type of the input: bf16 pairs (oscale None) or fp16 pairs."""
+        self._ensure_prepared()
+        if not f16:
+            return self._prep[0], self._prep[1], self._prep[2], None
+        if self._prep16 is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("weight preparation during graph capture: run one eager warm-up call first")
+            if not hip_ops.fp16_weight_safe(self._w_folded.flatten(1)):
+                raise Fp16Unsafe(f"{self.conv}: column spread beyond 2^17")
+            self._prep16 = hip_ops.prep_conv_weight(self._w_folded, f16=True)
+        return self._prep16[0], self._prep16[1], self._prep[2], self._prep16[2]
 
     def usable(self, c1: int, c2: int = 0) -> bool:
         k = self.conv.kernel_size
@@ -99,20 +119,22 @@ class SplitConv3x3:
                 self._wino = None                                      # transformed / tap-major weights: built on first use
                 self._w_exact = None
                 self._w_up = None
+                self._prep16 = None
                 self._w_folded = w.detach()
             self._key = key
 
-    def upconv_weights(self, c1: int, compose=None):
+    def upconv_weights(self, c1: int, compose=None, f16: bool = False):
         """The weight of a convolution over cat([up(x), skip]) re-arranged for the low-resolution form
         (csrc/tap_interp.hip): the up-sampled half as ONE 1x1 weight with the nine taps stacked tap-major
         ([9 Cout, C1]: row t Cout + co, t = 3 ky + kx), the skip half as an ordinary 3x3 weight (None when C2 = 0).
         ``compose`` = (key, fn): x itself is a bias-only-affine image of an earlier tensor, x = P x0 + pb with
         (P [C1, K], pb [C1] or None) = fn() in float64 -- the tap-stacked weight is then composed with P in float64
-        ([9 Cout, K], applied to x0 directly) and the sixth return value is the tap-stacked image of pb ([9 Cout] fp32,
-        what z holds where x = pb), None without ``compose``."""
+        ([9 Cout, K], applied to x0 directly) and ``border`` is the tap-stacked image of pb ([9 Cout] fp32, what z holds
+        where x = pb), None without ``compose``.  ``f16``: the two-term splits as fp16 pairs with per-row scales (a_osc / s_osc)
+        instead of bf16 pairs.  -> dict(a_hi, a_lo, a_osc, s_hi, s_lo, s_osc, bias, border)."""
         self._ensure_prepared()
         ckey = None if compose is None else compose[0]
-        if self._w_up is None or self._w_up[0] != (c1, ckey):
+        if self._w_up is None or self._w_up[0] != (c1, ckey, bool(f16)):
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("weight preparation during graph capture: run one eager warm-up call first")
             w = self._w_folded
@@ -124,35 +146,43 @@ class SplitConv3x3:
                 wa64 = wa.double()
                 cvec = (wa64 @ pb.double()).float().contiguous() if pb is not None else torch.zeros(9 * cout, device=w.device)
                 wa = (wa64 @ P.double()).float()
-            a_hi, a_lo = hip_ops.prep_conv_weight(wa.reshape(9 * cout, -1, 1, 1))
-            s_hi = s_lo = None
+            if f16 and not hip_ops.fp16_weight_safe(wa):
+                raise Fp16Unsafe(f"{self.conv} (tap-stacked{', composed' if compose is not None else ''}): column spread beyond 2^17")
+            pa = hip_ops.prep_conv_weight(wa.reshape(9 * cout, -1, 1, 1), f16=f16)
+            d = dict(a_hi=pa[0], a_lo=pa[1], a_osc=pa[2] if f16 else None, s_hi=None, s_lo=None, s_osc=None, border=cvec)
             if 0 < cin - c1 <= 4:
                 # a skip tensor of at most four channels (the IMAGE, do_final_upscale): exact-fp32 direct form, tap-major fp32
                 # weight [9, C2, Cout] in the s_hi slot, s_lo None (hip_ops.conv3x3_few_channels)
-                s_hi = w[:, c1:].permute(2, 3, 1, 0).reshape(9, cin - c1, cout).contiguous()
+                d["s_hi"] = w[:, c1:].permute(2, 3, 1, 0).reshape(9, cin - c1, cout).contiguous()
             elif cin > c1:
-                s_hi, s_lo = hip_ops.prep_conv_weight(w[:, c1:].contiguous())
-            self._w_up = ((c1, ckey), a_hi, a_lo, s_hi, s_lo, cvec)
-        return self._w_up[1:5] + (self._prep[2], self._w_up[5])
+                ws = w[:, c1:].contiguous()
+                if f16 and not hip_ops.fp16_weight_safe(ws.flatten(1)):
+                    raise Fp16Unsafe(f"{self.conv} (skip part): column spread beyond 2^17")
+                ps = hip_ops.prep_conv_weight(ws, f16=f16)
+                d.update(s_hi=ps[0], s_lo=ps[1], s_osc=ps[2] if f16 else None)
+            self._w_up = ((c1, ckey, bool(f16)), d)
+        return dict(self._w_up[1], bias=self._prep[2])
 
     def run_split(self, x: "hip_ops.SplitAct", act=hip_ops.ACT_NONE, out_fp32=True, out_split=False):
-        """Same convolution on a pre-split activation (no per-tap fp32 -> bf16 work in the kernel)."""
-        self._ensure_prepared()
-        hi, lo, b = self._prep
+        """Same convolution on a pre-split activation (no per-tap fp32 -> 2-byte work in the kernel), in the element type of
+        ``x`` (bf16 or fp16 pairs)."""
+        hi, lo, b, osc = self.prep_for(x.f16)
         B, Cin, H, W = x.shape
         if self.conv.kernel_size[0] == 3 and hip_ops.winograd_pays(B, H, W, Cin, self.conv.out_channels):
-            # the deep stages: Winograd F(2x2, 3x3), 2.25x fewer matrix-core operations (csrc/conv_igemm.hip)
+            # the deep stages: Winograd F(4x4, 3x3) on fp16 pairs, 4x fewer matrix-core operations (csrc/conv_igemm.hip);
+            # F(2x2, 3x3) (OCV_CONV_WINOGRAD_TILE=2) exists for bf16 pairs only
             tile = hip_ops.winograd_tile(B, H, W, Cin, self.conv.out_channels)
-            if self._wino is None or self._wino[0] != tile:
-                if torch.cuda.is_current_stream_capturing():
-                    raise RuntimeError("weight preparation during graph capture: run one eager warm-up call first")
-                prep = hip_ops.prep_winograd43_weight if tile == 4 else hip_ops.prep_winograd_weight
-                self._wino = (tile,) + tuple(prep(self._w_folded))
-            if tile == 4:      # F(4x4, 3x3) on two-term fp16 splits: 4x fewer matrix-core operations
-                return hip_ops.conv3x3_winograd43_split(x, self._wino[1], self._wino[2], self._wino[3], b, act, out_fp32=out_fp32, out_split=out_split,
-                                                        cscale=self._wino[4])
-            return hip_ops.conv3x3_winograd_split(x, self._wino[1], self._wino[2], b, act, out_fp32=out_fp32, out_split=out_split)
-        return hip_ops.conv_nhwc_split(x, hi, lo, b, self.conv.kernel_size[0], act, out_fp32=out_fp32, out_split=out_split)
+            if tile == 4 or not x.f16:
+                if self._wino is None or self._wino[0] != tile:
+                    if torch.cuda.is_current_stream_capturing():
+                        raise RuntimeError("weight preparation during graph capture: run one eager warm-up call first")
+                    prep = hip_ops.prep_winograd43_weight if tile == 4 else hip_ops.prep_winograd_weight
+                    self._wino = (tile,) + tuple(prep(self._w_folded))
+                if tile == 4:
+                    return hip_ops.conv3x3_winograd43_split(x, self._wino[1], self._wino[2], self._wino[3], b, act, out_fp32=out_fp32,
+                                                            out_split=out_split, cscale=self._wino[4])
+                return hip_ops.conv3x3_winograd_split(x, self._wino[1], self._wino[2], b, act, out_fp32=out_fp32, out_split=out_split)
+        return hip_ops.conv_nhwc_split(x, hi, lo, b, self.conv.kernel_size[0], act, out_fp32=out_fp32, out_split=out_split, oscale=osc)
 
 # skip-connection table: encoder-name fragment -> (feature_select, skip channels 3..0)
 # (reference modules/DenseFeatureExtractor.py:62-85)
@@ -303,46 +333,52 @@ class UpSampleWithSkip(nn.Module):
         return (c1 % 32 == 0 and cout % 8 == 0 and x.shape[2] < skip_features.shape[2] and x.shape[3] < skip_features.shape[3]
                 and hip_ops.tap_interp_supported(x.shape[2], x.shape[3], skip_features.shape[2], skip_features.shape[3], cout))
 
-    def forward_split(self, x, skip_features, out_fp32=True, out_split=False, affine_of=None):
+    def forward_split(self, x, skip_features, out_fp32=True, out_split=False, affine_of=None, f16=False):
         """GPU inference plan.  ``x``: the stage input, fp32 channels_last or already split (hip_ops.SplitAct).
         ``affine_of`` = (x0, key, fn, (h, w)): the stage input is NOT materialised -- it is the h x w grid whose interior is
         P x0 + pb (per pixel, (P, pb) = fn() in float64) and whose one-pixel border ring is pb (Decoder.conv2's padded
         1x1 convolution, optionally behind the backbone's bias-free conv_head): the tap-stacked weight is composed with P
         once per weight version and the 1x1 GEMM reads x0 (``x`` is then only consulted for its shape).
+        ``f16``: the element type of every split tensor of the stage (fp16 pairs / bf16 pairs: hip_ops.conv_split_f16).
         First convolution, low-resolution form (default): conv3x3(cat(up(x), skip)) = sum over the nine taps of the
         bilinear interpolation of (W_tap x) -- formed once per LOW-resolution pixel by one 1x1 GEMM with 9 Cout columns,
         ~4x fewer matrix-core operations for the up-sampled channels -- + conv3x3 over the skip channels, combined,
-        biased, activated and split by ocv_tap_interp_combine_fwd.  Otherwise: resize + concat + fp32->split-bf16 in ONE
+        biased, activated and split by ocv_tap_interp_combine_fwd.  Otherwise: resize + concat + fp32->split in ONE
         pass, then the direct 3x3 convolution.  The second convolution hands the next stage fp32 and / or the split pair."""
         H, W = skip_features.shape[-2:]
+
+        def as_split(t):
+            if isinstance(t, hip_ops.SplitAct):
+                return t if t.f16 == f16 else hip_ops.split_act(t.float().contiguous(memory_format=torch.channels_last), f16=f16)
+            ride = getattr(t, "_ocv_hl", None)          # (an encoder block of the late stages may leave its split copy beside it)
+            return ride if ride is not None and ride.f16 == f16 else hip_ops.split_act(t, f16=f16)
+
         if affine_of is not None or self.lowres_ready(x, skip_features):
             if affine_of is not None:
                 x0, key, fn, _ = affine_of
-                xs = x0 if isinstance(x0, hip_ops.SplitAct) else (getattr(x0, "_ocv_hl", None) or hip_ops.split_act(x0))
-                a_hi, a_lo, s_hi, s_lo, b, border = self._split1.upconv_weights(x.shape[1], compose=(key, fn))
-                z = hip_ops.conv_nhwc_split(xs, a_hi, a_lo, border, 1, hip_ops.ACT_NONE, out_fp32=True)
+                xs = as_split(x0)
+                wt = self._split1.upconv_weights(x.shape[1], compose=(key, fn), f16=f16)
+                z = hip_ops.conv_nhwc_split(xs, wt["a_hi"], wt["a_lo"], wt["border"], 1, hip_ops.ACT_NONE, out_fp32=True, oscale=wt["a_osc"])
             else:
-                xs = x if isinstance(x, hip_ops.SplitAct) else hip_ops.split_act(x)
-                a_hi, a_lo, s_hi, s_lo, b, border = self._split1.upconv_weights(xs.shape[1])
-                z = hip_ops.conv_nhwc_split(xs, a_hi, a_lo, None, 1, hip_ops.ACT_NONE, out_fp32=True)
+                xs = as_split(x)
+                wt = self._split1.upconv_weights(xs.shape[1], f16=f16)
+                z = hip_ops.conv_nhwc_split(xs, wt["a_hi"], wt["a_lo"], None, 1, hip_ops.ACT_NONE, out_fp32=True, oscale=wt["a_osc"])
             sk = None
-            if s_hi is not None and s_lo is None:
+            if wt["s_hi"] is not None and wt["s_lo"] is None:
                 # <= 4 skip channels: 27 - 36 multiply-adds per output on the vector units, the image read in place
-                sk = hip_ops.conv3x3_few_channels(skip_features, s_hi)
-            elif s_hi is not None:
-                # (an encoder block of the late stages leaves the split copy of its output beside it: read in place)
-                sks = getattr(skip_features, "_ocv_hl", None)
-                if sks is None:
-                    c2 = skip_features.shape[1]
-                    if c2 % 4:                       # 3-channel image: one zero channel more (the weight's pad columns are zero too)
-                        skip_features = F.pad(skip_features, (0, 0, 0, 0, 0, 4 - c2 % 4))
-                    sks = hip_ops.split_act(skip_features)
-                sk = hip_ops.conv_nhwc_split(sks, s_hi, s_lo, None, 3, hip_ops.ACT_NONE, out_fp32=True)
-            f = hip_ops.tap_interp_combine(z, sk, b, (H, W), hip_ops.ACT_LEAKY_RELU, out_fp32=False, out_split=True, border=border)
+                sk = hip_ops.conv3x3_few_channels(skip_features, wt["s_hi"])
+            elif wt["s_hi"] is not None:
+                c2 = skip_features.shape[1]
+                if c2 % 4 and getattr(skip_features, "_ocv_hl", None) is None:      # 3-channel image: one zero channel more (the weight's pad columns are zero too)
+                    skip_features = F.pad(skip_features, (0, 0, 0, 0, 0, 4 - c2 % 4))
+                sk = hip_ops.conv_nhwc_split(as_split(skip_features), wt["s_hi"], wt["s_lo"], None, 3, hip_ops.ACT_NONE, out_fp32=True,
+                                             oscale=wt["s_osc"])
+            f = hip_ops.tap_interp_combine(z, sk, wt["bias"], (H, W), hip_ops.ACT_LEAKY_RELU, out_fp32=False, out_split=True,
+                                           border=wt["border"], split_f16=f16)
         else:
             if isinstance(x, hip_ops.SplitAct):
                 x = x.float()
-            cat = hip_ops.upsample_concat_split(x, skip_features, (H, W))
+            cat = hip_ops.upsample_concat_split(x, skip_features, (H, W), f16=f16)
             f = self._split1.run_split(cat, hip_ops.ACT_LEAKY_RELU, out_fp32=False, out_split=True)
         return self._split2.run_split(f, hip_ops.ACT_LEAKY_RELU, out_fp32=out_fp32, out_split=out_split)
 
@@ -359,7 +395,11 @@ class UpSampleWithSkip(nn.Module):
 
     def forward(self, x, skip_features):
         if self.split_ready(x, skip_features):
-            return self.forward_split(x, skip_features)
+            try:
+                return self.forward_split(x, skip_features, f16=hip_ops.conv_split_f16())
+            except Fp16Unsafe as e:
+                hip_ops.ROUTE_REPORT[f"UpSampleWithSkip({self._net[0].in_channels}->{self._net[0].out_channels})"] = f"bf16 pairs: {e}"
+                return self.forward_split(x, skip_features, f16=False)
         up = F.interpolate(x, size=skip_features.shape[-2:], mode="bilinear", align_corners=True)
         if not self.training and not torch.is_grad_enabled() and up.device.type == "cuda":
             # hand-written convolutions on fp32 operands: the channel concat is virtual (two A-operand sources), BN is
@@ -492,19 +532,38 @@ class Decoder(nn.Module):
                 and self._split3.usable(self.conv3.in_channels) and self.conv3.in_channels % 8 == 0
                 and (fin is None or fin.split_ready(_ShapeOnly(b0.shape[0], self.up4._net[3].out_channels, b0.shape[2], b0.shape[3], device=b0.device), features[0]))):
             # all-split pipeline: the last stage hands conv3 its input pre-split; conv3 returns the fp32 feature map
-            # (patch embedding reads it) AND its split copy, which rides along for the heads' 3x3 convolution
-            for i, (up, skip) in enumerate(stages[:-1]):
-                # the next stage's low-resolution first convolution reads its input in split form, its resize kernel fp32
-                nxt, nskip = stages[i + 1]
-                want_split = nxt.lowres_ready(_ShapeOnly(x.shape[0], up._net[3].out_channels, skip.shape[2], skip.shape[3]), nskip)
-                x = up.forward_split(x, skip, out_fp32=not want_split, out_split=want_split,
-                                     affine_of=affine[1] if i == 0 and affine is not None else None)
-            xs = self.up4.forward_split(x, b0, out_fp32=False, out_split=True)
-            if fin is not None:
-                # do_final_upscale (reference :99-101,116-117): a fifth stage against the IMAGE, in the same low-resolution form
-                # (tap GEMM at half resolution, a 3 x 3 convolution over the image's three channels, tap interpolation)
-                xs = fin.forward_split(xs, features[0], out_fp32=False, out_split=True)
-            out, out_split = self._split3.run_split(xs, hip_ops.ACT_NONE, out_fp32=True, out_split=True)
+            # (patch embedding reads it) AND its split copy, which rides along for the heads' 3x3 convolution.  Element type of
+            # every split tensor: fp16 pairs (round 4) unless a weight of the pipeline does not fit them -- then bf16 pairs for
+            # the whole pipeline, decided once per weight version and REPORTED (hip_ops.ROUTE_REPORT), never silent.
+            wkey = (hip_ops.conv_split_f16(),) + tuple((p.data_ptr(), p._version) for p in self.parameters()) + \
+                tuple((b.data_ptr(), b._version) for b in self.buffers())
+            mode = self.__dict__.get("_f16_mode")
+            if mode is None or mode[0] != wkey:
+                mode = self.__dict__["_f16_mode"] = (wkey, hip_ops.conv_split_f16())
+
+            def pipeline(f16):
+                x_ = x
+                for i, (up, skip) in enumerate(stages[:-1]):
+                    # the next stage's low-resolution first convolution reads its input in split form, its resize kernel fp32
+                    nxt, nskip = stages[i + 1]
+                    want_split = nxt.lowres_ready(_ShapeOnly(x_.shape[0], up._net[3].out_channels, skip.shape[2], skip.shape[3]), nskip)
+                    x_ = up.forward_split(x_, skip, out_fp32=not want_split, out_split=want_split,
+                                          affine_of=affine[1] if i == 0 and affine is not None else None, f16=f16)
+                xs = self.up4.forward_split(x_, b0, out_fp32=False, out_split=True, f16=f16)
+                if fin is not None:
+                    # do_final_upscale (reference :99-101,116-117): a fifth stage against the IMAGE, in the same low-resolution form
+                    # (tap GEMM at half resolution, a 3 x 3 convolution over the image's three channels, tap interpolation)
+                    xs = fin.forward_split(xs, features[0], out_fp32=False, out_split=True, f16=f16)
+                return self._split3.run_split(xs, hip_ops.ACT_NONE, out_fp32=True, out_split=True)
+
+            try:
+                out, out_split = pipeline(mode[1])
+            except Fp16Unsafe as e:
+                if torch.cuda.is_current_stream_capturing():
+                    raise
+                hip_ops.ROUTE_REPORT["Decoder"] = f"split pipeline on bf16 pairs instead of fp16 pairs: {e}"
+                self.__dict__["_f16_mode"] = (wkey, False)
+                out, out_split = pipeline(False)
             out._ocv_split = out_split
             return out
         for up, skip in stages:

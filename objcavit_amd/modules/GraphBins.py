@@ -30,7 +30,7 @@ import torch.nn as nn
 from .. import hip_ops
 from .AdaBins import bin_edges_and_centers
 from .DenseFeatureExtractor import DenseFeatureExtractor
-from .ObjCAViT import ObjCAViT
+from .ObjCAViT import ObjCAViT, PaddedObjects
 
 
 class SyntheticObjectProvider:
@@ -62,8 +62,21 @@ class SyntheticObjectProvider:
         feats, boxes = self._cache[key]
         return [f for f in feats], [b for b in boxes], None
 
+    def padded(self, image: torch.Tensor) -> PaddedObjects:
+        """The same objects in the shape-static form (built once per (batch, size), counts on the device): GraphBins prefers
+        this entry point when a provider has one -- no per-forward stack / pad / copy launches."""
+        B = image.shape[0]
+        key = ("padded", B, image.shape[2], image.shape[3], image.device)
+        if key not in self._cache:
+            self(image)
+            feats, boxes = self._cache[(B, image.shape[2], image.shape[3], image.device)]
+            self._cache[key] = PaddedObjects(feats, boxes, torch.full((B,), self.n, dtype=torch.int32, device=image.device))
+        return self._cache[key]
+
 
 class GraphBins(nn.Module):
+    images_are_independent = True      # an image's result does not depend on its batch mates (per object group: SURVEY.md Q3)
+
     def __init__(self, args, object_provider: Optional[Callable] = None, backbone: nn.Module = None):
         super().__init__()
         self.args = args
@@ -103,15 +116,23 @@ class GraphBins(nn.Module):
         for m in self._frozen_params_module_list:
             yield from m.parameters()
 
-    def forward_until_head(self, image, object_features: Optional[List[torch.Tensor]] = None,
-                           object_xywh_list: Optional[List[Optional[torch.Tensor]]] = None, pad_objects_to: Optional[int] = None):
+    def forward_until_head(self, image, object_features=None, object_xywh_list: Optional[List[Optional[torch.Tensor]]] = None,
+                           pad_objects_to: Optional[int] = None, object_group: Optional[int] = None):
         """Everything up to the inputs of the fused bin head: (feat, queries, centers, bin_edges, detections).
-        Split out so that a hipGraph can capture it while the head kernel stays individually timeable."""
+        Split out so that a hipGraph can capture it while the head kernel stays individually timeable.
+        ``object_features``: None (ask the provider), the reference's list of N_i x 512 tensors (with ``object_xywh_list``), or a
+        ``PaddedObjects`` (shape-static, counts on the device: what a captured graph holds).  ``object_group``: images per
+        reference call when the batch is several calls' batches at once (ValidationStep: image + mirror)."""
         detections = None
         if object_features is None:
             with torch.no_grad():
-                object_features, object_xywh_list, detections = self.object_provider(image)
-        object_features = [nf.float() for nf in object_features]
+                padded = getattr(self.object_provider, "padded", None)
+                if padded is not None:
+                    object_features = padded(image)
+                else:
+                    object_features, object_xywh_list, detections = self.object_provider(image)
+        if not isinstance(object_features, PaddedObjects):
+            object_features = [nf.float() for nf in object_features]
         pre = None
         if image.is_cuda and self.objcavit.can_prepass() and os.environ.get("OCV_OBJ_OVERLAP", "0") == "1":
             # Opt-in (OCV_OBJ_OVERLAP=1).  The object branch (embedding, positional MLP, first self-attention stack:
@@ -133,7 +154,7 @@ class GraphBins(nn.Module):
         else:
             dense_features = self.dense_feature_extractor(image)
         bin_widths_normed, feat, queries = self.objcavit.forward_parts(dense_features, object_features, object_xywh_list, pre=pre,
-                                                                     pad_objects_to=pad_objects_to)
+                                                                     pad_objects_to=pad_objects_to, object_group=object_group)
         ds = self.args[self.args.basic.dataset]
         bin_edges, centers = bin_edges_and_centers(bin_widths_normed, ds.min_depth, ds.max_depth)
         return feat, queries, centers, bin_edges, detections
@@ -142,10 +163,12 @@ class GraphBins(nn.Module):
         conv = self.conv_out[0]
         return hip_ops.bin_head(feat, queries, conv.weight.detach(), conv.bias.detach(), centers)
 
-    def forward(self, image, object_features: Optional[List[torch.Tensor]] = None,
-                object_xywh_list: Optional[List[Optional[torch.Tensor]]] = None, pad_objects_to: Optional[int] = None):
+    def forward(self, image, object_features=None, object_xywh_list: Optional[List[Optional[torch.Tensor]]] = None,
+                pad_objects_to: Optional[int] = None, object_group: Optional[int] = None):
         """``pad_objects_to``: the longest object list of the GLOBAL batch when ``image`` is one rank's shard of it
-        (objcavit_amd/dp.py ``sharded_forward``); None = this batch's own maximum, as the reference pads."""
-        feat, queries, centers, bin_edges, detections = self.forward_until_head(image, object_features, object_xywh_list, pad_objects_to)
+        (objcavit_amd/dp.py ``sharded_forward``); None = this batch's own maximum, as the reference pads.
+        ``object_group``: see ``forward_until_head``."""
+        feat, queries, centers, bin_edges, detections = self.forward_until_head(image, object_features, object_xywh_list, pad_objects_to,
+                                                                                object_group)
         depth_pred = self.head(feat, queries, centers)
         return self.ReturnType(depth_pred=depth_pred, bin_edges=bin_edges, detections=detections)

@@ -71,6 +71,53 @@ class _PerDevice:
 
 _NO_BOX = _PerDevice(lambda dev: torch.full((1, 4), -1.0, device=dev))                      # reference :313
 _RAGGED_MASK = _PerDevice(lambda dev, counts, nmax: (torch.arange(nmax)[None, :] >= torch.tensor(counts)[:, None]).to(dev))
+_COUNTS = _PerDevice(lambda dev, counts: torch.tensor(counts, dtype=torch.int32).to(dev), capacity=64)
+
+
+class PaddedObjects:
+    """The object inputs of a batch in shape-static form: ``features`` [B, cap, F] fp32, ``xywh`` [B, cap, >= 2 | 4] fp32,
+    ``counts`` int32 [B] ON THE DEVICE with 1 <= counts[b] <= cap (rows beyond an image's count are ignored; an image without
+    detections has ONE row, the <UNK> feature with the box (-1, -1, -1, -1): reference :311-315).  Nothing on the path reads the
+    counts on the host, so a captured hipGraph replays with whatever the buffers hold (objcavit_amd/graph.py); an object provider
+    may return one directly instead of the reference's two lists."""
+    __slots__ = ("features", "xywh", "counts", "max_count")
+
+    def __init__(self, features: torch.Tensor, xywh: torch.Tensor, counts: torch.Tensor, max_count: Optional[int] = None):
+        if features.dim() != 3 or xywh.dim() != 3 or xywh.shape[:2] != features.shape[:2] or counts.shape != features.shape[:1]:
+            raise ValueError("PaddedObjects: expected features [B, cap, F], xywh [B, cap, k], counts [B]")
+        if counts.dtype != torch.int32:
+            raise TypeError("PaddedObjects: counts must be int32")
+        self.features, self.xywh, self.counts = features, xywh, counts
+        self.max_count = max_count          # the longest list, when the host knows it (built from lists): argument checks only
+
+    @property
+    def capacity(self) -> int:
+        return int(self.features.shape[1])
+
+    @staticmethod
+    def from_lists(object_features, object_xywh_list, device, capacity: Optional[int] = None) -> "PaddedObjects":
+        """The reference's two lists (N_i x F features, N_i x 4 boxes or None) -> padded tensors + device counts.  The counts
+        tensor comes from a small LRU keyed on the tuple of counts (a host -> device copy: not inside a graph capture)."""
+        B = len(object_features)
+        if len(object_xywh_list) != B:
+            raise ValueError("object_features / object_xywh_list must have one entry per image")
+        boxes = [_NO_BOX.get(device) if b is None else b.to(device, torch.float32) for b in object_xywh_list]    # :313
+        counts = [int(f.shape[0]) for f in object_features]
+        for c, b in zip(counts, boxes):
+            if b.dim() != 2 or b.shape[0] != c or c < 1:
+                raise ValueError("object_features and object_xywh_list disagree on the number of objects (or an image has none: "
+                                 "the reference hands such an image ONE <UNK> row)")
+        cap = max(max(counts), int(capacity or 0))
+        width = min(b.shape[1] for b in boxes)
+        feats = [f.to(device, torch.float32) for f in object_features]
+        if all(c == cap for c in counts):
+            f3, b3 = torch.stack(feats, 0), torch.stack([b[:, :width] for b in boxes], 0)
+        else:
+            f3 = nn.utils.rnn.pad_sequence(feats, batch_first=True)
+            b3 = nn.utils.rnn.pad_sequence([b[:, :width] for b in boxes], batch_first=True)
+            if f3.shape[1] < cap:
+                f3, b3 = F.pad(f3, (0, 0, 0, cap - f3.shape[1])), F.pad(b3, (0, 0, 0, cap - b3.shape[1]))
+        return PaddedObjects(f3.contiguous(), b3.contiguous(), _COUNTS.get(device, tuple(counts)), max(counts))
 
 
 # ---------------------------------------------------------------------------
@@ -175,31 +222,57 @@ class SelfAttnCrossAttn(nn.Module):
             feats = F.pad(feats, (0, 0, 0, nmax - feats.shape[1]), value=PAD_VALUE)
         return feats, _RAGGED_MASK.get(device, tuple(counts), nmax)     # True = padding (:180-181)
 
-    def object_self_attention(self, object_features, device, pad_to: Optional[int] = None):
-        """The object half of ``forward`` -- pad + mask, self-attention stack -- which does not depend on the image
-        tokens: (att_obj [B, Nmax, E], mask [B, Nmax]).  May be issued ahead of time on another stream."""
-        feats, mask = self._pad_objects(object_features, device, pad_to)
+    def object_self_attention(self, object_features, device, pad_to: Optional[int] = None, counts: Optional[torch.Tensor] = None):
+        """The object half of ``forward`` -- pad + mask, self-attention stack -- which does not depend on the image tokens:
+        (att_obj [B, cap, E], mask [B, cap], counts or None).  May be issued ahead of time on another stream.
+        ``object_features``: the reference's list of N_i x E tensors; or a [B, cap, E] tensor with ``counts`` (int32 [B] on the
+        device; rows >= counts[b] arbitrary): the same thing shape-static, nothing read on the host; or a B x S x E tensor
+        without counts (what saca_2 receives, SURVEY.md Q3: every row counts as an object)."""
+        if not isinstance(object_features, torch.Tensor):
+            lens = [int(o.shape[0]) for o in object_features]
+            cap = max(lens)
+            if pad_to is not None:
+                if int(pad_to) < cap:
+                    raise ValueError(f"pad_to = {pad_to} is smaller than the longest object list of the batch ({cap})")
+                cap = int(pad_to)
+            object_features = self._pad_objects(object_features, device, cap)[0]
+            counts = _COUNTS.get(device, tuple(lens))
+        if counts is None:
+            feats, mask = self._pad_objects(object_features, device, pad_to)               # tensor input: nothing is padding
+        else:
+            feats, mask = hip_ops.object_tokens_pad(object_features.contiguous(), counts, PAD_VALUE)    # :180-183
         if self._obj_stack is None:
-            return feats, mask                                                            # :186
-        return self._obj_stack(feats, mask), mask                                         # :188 (padded rows -> 0)
+            return feats, mask, counts                                                    # :186
+        return self._obj_stack(feats, mask), mask, counts                                 # :188 (padded rows -> 0)
 
     def forward(self, image_patch_embeddings, object_features, want_object_output: bool = True, pre_obj=None,
-                pad_objects_to: Optional[int] = None):
+                pad_objects_to: Optional[int] = None, counts: Optional[torch.Tensor] = None, group: Optional[int] = None):
+        """``counts`` / ``group``: see ``object_self_attention`` and hip_ops.object_front_pad -- ``group`` consecutive images
+        form one call of the reference (their longest list is the Nmax the key rows are front-padded to); None = the batch."""
         x = image_patch_embeddings.contiguous()
         B, S, E = x.shape
         att_img = self._img_stack(x)                                                      # reference :169
-        att_obj, mask = pre_obj if pre_obj is not None else self.object_self_attention(object_features, x.device, pad_objects_to)
-        amt = S - att_obj.shape[1]                                                        # :192
+        att_obj, mask, counts = pre_obj if pre_obj is not None else \
+            self.object_self_attention(object_features, x.device, pad_objects_to, counts)
+        cap = att_obj.shape[1]
+        amt = S - cap                                                                     # :192
         if amt < 0:
-            raise ValueError(f"more objects per image ({att_obj.shape[1]}) than image tokens ({S})")
-        kpm = F.pad(mask, (0, amt), value=True)                                           # :193  mask padded at the BACK
-        att_obj_p = F.pad(att_obj, (0, 0, amt, 0), value=PAD_VALUE).contiguous()          # :194  rows padded at the FRONT
+            raise ValueError(f"more objects per image ({cap}) than image tokens ({S})")
+        if counts is not None:
+            # mask padded at the BACK, rows padded at the FRONT to the longest list of the (group's) batch -- on the device
+            att_obj_p, kpm = hip_ops.object_front_pad(att_obj, counts, S, PAD_VALUE, group=group,
+                                                      nmax=int(pad_objects_to or 0))     # :193-194
+        elif amt == 0:
+            att_obj_p, kpm = att_obj.contiguous(), mask
+        else:
+            kpm = F.pad(mask, (0, amt), value=True)                                       # :193  mask padded at the BACK
+            att_obj_p = F.pad(att_obj, (0, 0, amt, 0), value=PAD_VALUE).contiguous()      # :194  rows padded at the FRONT
         ca1 = self.cross_attn_obj_im
-        # every key at position >= Nmax is masked (mask is True beyond each image's object count, and was padded with
-        # True at the back): the kernel only projects / scores the first Nmax keys -- same result, ~10x less work
+        # every key at position >= cap is masked (the mask is True beyond each image's object count): the kernel only projects /
+        # scores the first cap keys -- same result, ~10x less work
         final_img = hip_ops.mha(att_img, att_obj_p, att_img, ca1.in_proj_weight.detach(), ca1.in_proj_bias.detach(),
                                 ca1.out_proj.weight.detach(), ca1.out_proj.bias.detach(), kpm, ca1.num_heads,
-                                kv_limit=int(mask.shape[1]), packed=self._ca1_p3)                             # :195-201
+                                kv_limit=int(cap), packed=self._ca1_p3)                                       # :195-201
         final_obj = None
         if want_object_output:
             ca2 = self.cross_attn_im_obj
@@ -291,57 +364,66 @@ class ObjCAViT(nn.Module):
         return self._img_pos_cache["v"]
 
     # -- forward ---------------------------------------------------------------
-    def _embed_objects(self, object_features, object_xywh_list, dev, image_features):
-        """Linear(512 -> E) + positional embedding of all objects of the batch as ONE flattened [sum N_i, .] problem
-        (reference :311-330: a Python loop over images); overwrites the caller's list like the reference (:330).
-        ``image_features`` is only read (for its shape) by the grid strategies."""
-        B = len(object_features)
-        boxes = [_NO_BOX.get(dev) if b is None else b.to(dev, torch.float32) for b in object_xywh_list]    # :313
-        counts = [int(f.shape[0]) for f in object_features]
+    def _embed_objects(self, po: PaddedObjects, image_features) -> torch.Tensor:
+        """Linear(512 -> E) + positional embedding of every object row of the batch as ONE flattened [B * cap, .] problem
+        (reference :311-330: a Python loop over images) -> [B, cap, E]; rows beyond an image's count hold garbage (possibly
+        NaN: a zero box under roi_align) that the padding kernel replaces.  ``image_features`` is only read (for its shape)
+        by the grid strategies."""
+        B, cap = po.features.shape[:2]
         need = 2 if self.strategy in ("learned", "grid_random") else 4
-        for c, b in zip(counts, boxes):
-            if b.dim() != 2 or b.shape[0] != c or b.shape[1] < need:
-                raise ValueError("object_features and object_xywh_list disagree on the number of objects "
-                                 f"(or boxes have fewer than {need} columns)")
-        all_feat = torch.cat([f.to(dev, torch.float32) for f in object_features], dim=0)
-        width = min(b.shape[1] for b in boxes)
-        all_box = torch.cat([b[:, :width] for b in boxes], dim=0)
-        emb = hip_ops.linear(all_feat.contiguous(), self.obj_embedding_layer.weight.detach(),
+        if po.xywh.shape[2] < need:
+            raise ValueError(f"object boxes have fewer than {need} columns")
+        emb = hip_ops.linear(po.features.reshape(B * cap, -1), self.obj_embedding_layer.weight.detach(),
                              self.obj_embedding_layer.bias.detach())
-        emb = self._object_pos(all_box, image_features, emb)
-        objs = list(torch.split(emb, counts, dim=0))
-        for i in range(B):
-            object_features[i] = objs[i]                       # the reference overwrites the caller's list (:330)
-        return objs
+        emb = self._object_pos(po.xywh.reshape(B * cap, -1), image_features, emb)
+        return emb.view(B, cap, -1)
 
     def can_prepass(self) -> bool:
         """Whether the object branch (embedding + first self-attention stack) is independent of the image features --
         true for the MLP positional strategies -- so that it can run beside the encoder on a second stream."""
         return self.strategy in _MLP_IN and not self.training
 
-    def object_prepass(self, object_features, object_xywh_list, dev, pad_objects_to: Optional[int] = None):
-        """Steps of ``forward_parts`` that do not need the dense features: (embedded objects, (att_obj, mask))."""
-        if len(object_features) != len(object_xywh_list):
-            raise ValueError("object_features / object_xywh_list must have one entry per image")
-        objs = self._embed_objects(object_features, object_xywh_list, dev, None)
-        return objs, self.saca_1.object_self_attention(objs, dev, pad_objects_to)
+    def _padded(self, object_features, object_xywh_list, dev, capacity: Optional[int]) -> PaddedObjects:
+        if isinstance(object_features, PaddedObjects):
+            if capacity is not None and object_features.capacity < int(capacity):
+                raise ValueError(f"PaddedObjects of capacity {object_features.capacity} where {capacity} rows were asked for")
+            return object_features
+        return PaddedObjects.from_lists(object_features, object_xywh_list, dev, capacity)
 
-    def forward_parts(self, image_features, object_features, object_xywh_list, pre=None, pad_objects_to: Optional[int] = None):
-        """-> (bin_widths_normed, conv3x3 features, queries view B x n_query x E).  ``pre``: result of
-        ``object_prepass`` when the caller has already issued the object branch.  ``pad_objects_to``: see
-        ``SelfAttnCrossAttn._pad_objects`` (the batch's Nmax when this batch is a shard of a larger one)."""
+    def object_prepass(self, object_features, object_xywh_list, dev, pad_objects_to: Optional[int] = None):
+        """Steps of ``forward_parts`` that do not need the dense features: (padded inputs, embedded objects, (att_obj, mask, counts))."""
+        po = self._padded(object_features, object_xywh_list, dev, pad_objects_to)
+        emb = self._embed_objects(po, None)
+        return po, emb, self.saca_1.object_self_attention(emb, dev, None, po.counts)
+
+    def forward_parts(self, image_features, object_features, object_xywh_list, pre=None, pad_objects_to: Optional[int] = None,
+                      object_group: Optional[int] = None):
+        """-> (bin_widths_normed, conv3x3 features, queries view B x n_query x E).
+        ``object_features`` / ``object_xywh_list``: the reference's two lists, or a ``PaddedObjects`` (then the second argument is
+        ignored).  ``pre``: result of ``object_prepass`` when the caller has already issued the object branch.
+        ``pad_objects_to``: the Nmax of the batch when this batch is a shard of a larger one (SelfAttnCrossAttn._pad_objects).
+        ``object_group``: images per reference call when several calls' batches run as one (hip_ops.object_front_pad)."""
         if self.training:
             raise RuntimeError("the HIP path implements inference (eval mode) only")
         dev = image_features.device
         B = image_features.shape[0]
-        if len(object_features) != B or len(object_xywh_list) != B:
-            raise ValueError("object_features / object_xywh_list must have one entry per image")
         # 1. objects: Linear(512 -> E) + positional embedding, all images in one launch (reference :311-330)
         if pre is None:
-            objs = self._embed_objects(object_features, object_xywh_list, dev, image_features)
+            po = self._padded(object_features, object_xywh_list, dev, pad_objects_to)
+            emb = self._embed_objects(po, image_features)
             pre_obj = None
         else:
-            objs, pre_obj = pre
+            po, emb, pre_obj = pre
+        if po.features.shape[0] != B:
+            raise ValueError("object_features / object_xywh_list must have one entry per image")
+        if pad_objects_to is not None and int(pad_objects_to) > po.capacity:
+            raise ValueError(f"pad_objects_to = {pad_objects_to} exceeds the object capacity {po.capacity}")
+        if pad_objects_to is not None and po.max_count is not None and int(pad_objects_to) < po.max_count:
+            raise ValueError(f"pad_to = {pad_objects_to} is smaller than the longest object list of the batch ({po.max_count})")
+        if isinstance(object_features, list):
+            # the reference overwrites the caller's list with the embedded objects (:330)
+            for i in range(min(B, len(object_features))):
+                object_features[i] = emb[i, :int(object_features[i].shape[0])]
 
         # 2. image tokens: patch conv + bias + positional embedding, token-major (reference :333-364)
         if self.patch_size != 16:
@@ -354,13 +436,15 @@ class ObjCAViT(nn.Module):
                                        self._w_cl, self._w_pe)
 
         # 3. self-attention / cross-attention stacks (reference :366-368)
-        tok, obj = self.saca_1(tok, objs, want_object_output=self.use_2_saca, pre_obj=pre_obj, pad_objects_to=pad_objects_to)
+        tok, obj = self.saca_1(tok, emb, want_object_output=self.use_2_saca, pre_obj=pre_obj, pad_objects_to=pad_objects_to,
+                               counts=po.counts, group=object_group)
         if self.use_2_saca:
             tok, obj = self.saca_2(tok, obj, want_object_output=False)
 
         # 4. heads (reference :373-388)
         feat = self._conv3x3_nhwc(image_features)
-        y = regress_bin_widths(self.regressor, tok[:, 0, :], self.norm)
+        ds = self.args[self.args.basic.dataset]
+        y = regress_bin_widths(self.regressor, tok[:, 0, :], self.norm, (ds.min_depth, ds.max_depth))
         return y, feat, tok[:, 1:self.n_query_channels + 1, :]
 
     def _conv3x3_nhwc(self, x):
@@ -371,7 +455,13 @@ class ObjCAViT(nn.Module):
         if plan.usable(x.shape[1]):
             pre = getattr(x, "_ocv_split", None)                      # the decoder's conv3 leaves its split copy here
             if pre is not None and tuple(pre.shape) == tuple(x.shape):
-                return plan.run_split(pre)
+                from .DenseFeatureExtractor import Fp16Unsafe
+                try:
+                    return plan.run_split(pre)
+                except Fp16Unsafe as e:                                # (reported, not silent; the fp32 map takes the bf16-pair kernel)
+                    if torch.cuda.is_current_stream_capturing():
+                        raise
+                    hip_ops.ROUTE_REPORT["heads.conv3x3"] = f"bf16 pairs on the fp32 map: {e}"
             return plan(x)                                            # split-bf16 implicit GEMM, NHWC in / out
         return plan.exact(x)                                          # OCV_CONV=exact, or channels not a multiple of 4
 

@@ -16,12 +16,20 @@ from .. import hip_ops
 from .layers import PatchTransformerEncoder, PixelWiseDotProduct
 
 
-def regress_bin_widths(regressor: nn.Sequential, head: torch.Tensor, norm: str) -> torch.Tensor:
+def regress_bin_widths(regressor: nn.Sequential, head: torch.Tensor, norm: str, depth_range=None) -> torch.Tensor:
     """regressor MLP (Linear, LeakyReLU, Linear, LeakyReLU, Linear) + normalisation
-    (reference modules/miniViT.py:33-42 == modules/ObjCAViT.py:378-388)."""
+    (reference modules/miniViT.py:33-42 == modules/ObjCAViT.py:378-388).  ``depth_range`` = (min_depth, max_depth): the
+    normalisation, the bin edges and the bin centres come out of ONE launch (csrc/bin_edges.hip); edges and centres ride along
+    on the returned tensor for ``AdaBins.bin_edges_and_centers`` (reference modules/AdaBins.py:79-83)."""
     y = hip_ops.linear(head.contiguous(), regressor[0].weight.detach(), regressor[0].bias.detach(), hip_ops.ACT_LEAKY_RELU)
     y = hip_ops.linear(y, regressor[2].weight.detach(), regressor[2].bias.detach(), hip_ops.ACT_LEAKY_RELU)
     y = hip_ops.linear(y, regressor[4].weight.detach(), regressor[4].bias.detach(), hip_ops.ACT_NONE)
+    if depth_range is not None:
+        lo, hi = float(depth_range[0]), float(depth_range[1])
+        mode = "linear" if norm == "linear" else ("none" if norm == "softmax" else "sigmoid")
+        w, edges, centers = hip_ops.bin_edges(torch.softmax(y, dim=1) if norm == "softmax" else y, mode, lo, hi)
+        w._ocv_bins = ((lo, hi), edges, centers)
+        return w
     if norm == "linear":
         y = torch.relu(y) + 0.1
     elif norm == "softmax":
@@ -44,14 +52,14 @@ class mViT(nn.Module):
                                        nn.Linear(256, 256), nn.LeakyReLU(),
                                        nn.Linear(256, dim_out))
 
-    def forward_parts(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    def forward_parts(self, x: torch.Tensor, depth_range=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """-> (bin_widths_normed B x dim_out, conv3x3 features B x E x h x w, queries B x n_query x E (view)).
-        Used by AdaBins.forward so that the range-attention maps are never materialised."""
+        Used by AdaBins.forward so that the range-attention maps are never materialised (``depth_range``: regress_bin_widths)."""
         tok = self.patch_transformer.forward_batch_first(x)           # B x S x E
         if tok.shape[1] < self.n_query_channels + 1:
             raise ValueError(f"need at least {self.n_query_channels + 1} patches, got {tok.shape[1]}")
         feat = self._conv3x3_nhwc(x)
-        y = regress_bin_widths(self.regressor, tok[:, 0, :], self.norm)
+        y = regress_bin_widths(self.regressor, tok[:, 0, :], self.norm, depth_range)
         return y, feat, tok[:, 1:self.n_query_channels + 1, :]
 
     def _conv3x3_nhwc(self, x):
@@ -62,7 +70,13 @@ class mViT(nn.Module):
         if plan.usable(x.shape[1]):
             pre = getattr(x, "_ocv_split", None)                      # the decoder's conv3 leaves its split copy here
             if pre is not None and tuple(pre.shape) == tuple(x.shape):
-                return plan.run_split(pre)
+                from .DenseFeatureExtractor import Fp16Unsafe
+                try:
+                    return plan.run_split(pre)
+                except Fp16Unsafe as e:                                # (reported, not silent; the fp32 map takes the bf16-pair kernel)
+                    if torch.cuda.is_current_stream_capturing():
+                        raise
+                    hip_ops.ROUTE_REPORT["heads.conv3x3"] = f"bf16 pairs on the fp32 map: {e}"
             return plan(x)                                            # split-bf16 implicit GEMM, NHWC in / out
         return plan.exact(x)                                          # OCV_CONV=exact, or channels not a multiple of 4
 
