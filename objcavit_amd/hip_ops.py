@@ -653,7 +653,8 @@ class PatchEmbedSplitWeight:
         if key != self._key:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("weight preparation during graph capture: run one eager warm-up call first")
-            self._val = prep_patch_embed_weight(w, f16)
+            # (None: the weight does not fit fp16 pairs -- judged once per weight version, a host synchronisation)
+            self._val = prep_patch_embed_weight(w, f16) if not f16 or fp16_weight_safe(w.detach().flatten(1)) else None
             self._key = key
         return self._val
 
@@ -672,9 +673,9 @@ def patch_embed_auto(fmap: torch.Tensor, weight: torch.Tensor, bias: Optional[to
         if not pre.f16:
             hi, lo = split_cache.get(weight, False)
             return patch_embed_split(pre, hi, lo, bias, pos)
-        if fp16_weight_safe(weight.detach().flatten(1)):
-            hi, lo, osc = split_cache.get(weight, True)
-            return patch_embed_split(pre, hi, lo, bias, pos, oscale=osc)
+        prep = split_cache.get(weight, True)
+        if prep is not None:
+            return patch_embed_split(pre, prep[0], prep[1], bias, pos, oscale=prep[2])
         ROUTE_REPORT["patch_embed"] = "weights do not fit fp16 pairs (column spread > 2^17): exact-fp32 kernel on the fp32 map"
     return patch_embed(fmap, weight, bias, pos, cl_cache=cl_cache)
 

@@ -556,13 +556,28 @@ class Decoder(nn.Module):
                     xs = fin.forward_split(xs, features[0], out_fp32=False, out_split=True, f16=f16)
                 return self._split3.run_split(xs, hip_ops.ACT_NONE, out_fp32=True, out_split=True)
 
+            calibrate = mode[1] and len(mode) == 2 and not torch.cuda.is_current_stream_capturing()
             try:
+                if calibrate:
+                    # FIRST eager forward of this weight version on fp16 pairs: the activations' range is measured once (host
+                    # synchronisations, this call only).  The pairs' error floor is absolute (2^-25 per value) and their ceiling
+                    # 65504: a tensor whose largest entry lies outside [2^-6, 4094] sends the pipeline to bf16 pairs -- reported.
+                    hip_ops.range_check(True)
                 out, out_split = pipeline(mode[1])
+                if calibrate:
+                    rep = hip_ops.fp16_range_report()
+                    hip_ops.range_check(False)
+                    mode = self.__dict__["_f16_mode"] = (wkey, rep["ok"], rep)
+                    if not rep["ok"]:
+                        hip_ops.ROUTE_REPORT["Decoder"] = ("split pipeline on bf16 pairs instead of fp16 pairs: activation range "
+                                                           f"{rep['out_of_range']} outside [2^-6, 65504 / 16] on the first batch")
+                        out, out_split = pipeline(False)
             except Fp16Unsafe as e:
+                hip_ops.range_check(False)
                 if torch.cuda.is_current_stream_capturing():
                     raise
                 hip_ops.ROUTE_REPORT["Decoder"] = f"split pipeline on bf16 pairs instead of fp16 pairs: {e}"
-                self.__dict__["_f16_mode"] = (wkey, False)
+                self.__dict__["_f16_mode"] = (wkey, False, None)
                 out, out_split = pipeline(False)
             out._ocv_split = out_split
             return out
