@@ -227,9 +227,10 @@ def cpu_baseline(sd, img_cpu, feats, boxes, gpu_depth, wl, budget_s=60.0):
 # ---------------------------------------------------------------------------
 # per-kernel report and the roofline object
 # ---------------------------------------------------------------------------
-def kernel_report(timing, a, B, wl):
+def kernel_report(timing, a, B, wl, split_f16=True):
     """{"roofline": ..., "kernels": ..., "convs": ...} from the HIP-event durations of the entry points
-    (name -> (launches, mean ms)) and the algorithmic bytes / flops of ``kernel_model``."""
+    (name -> (launches, mean ms)) and the algorithmic bytes / flops of ``kernel_model``.  ``split_f16``: the element type of
+    the direct convolutions' two-term splits (fp16 pairs since round 4; bf16 pairs on the fallback / A-B route)."""
     km = kernel_model(B, wl)
     kernels, convs = {}, []
     for name, (cnt, ms) in timing.items():
@@ -239,7 +240,7 @@ def kernel_report(timing, a, B, wl):
             # 4 outputs on two-term bf16 splits, F(4x4,3x3) = 36 per 16 outputs on two-term fp16 splits; direct = 9 per output, bf16
             wino = 2 if name.startswith("conv3x3w2|") else 4 if name.startswith("conv3x3w4|") else 0
             per_out = {0: 1.0, 2: 16.0 / 36.0, 4: 36.0 / 144.0}[wino]
-            mfma_dtype = "f16" if wino == 4 else "bf16"
+            mfma_dtype = "f16" if (wino == 4 or split_f16) else "bf16"
             b_, h_, w_, ci, co = (int(v) for v in name.split("|")[1].split(","))
             m_ = b_ * h_ * w_
             flops = 2.0 * m_ * co * ci * k * k                      # algorithmic (fp32-equivalent, direct-form) FLOPs
@@ -295,15 +296,16 @@ def kernel_report(timing, a, B, wl):
                                         "--pmc passes of this command (tools/profile_round.sh), committed -- NOT measured in this run"
                                         if (wl.idx == 2 and B == 16) else "no PMC pass committed for this workload"),
                         frac_algorithmic=conv_dom["frac_mfma_algorithmic"], frac_issued=conv_dom["frac_mfma_issued"],
-                        issued_bf16_TFLOPs=conv_dom["issued_mfma_TFLOPs"],
+                        issued_mfma_TFLOPs=conv_dom["issued_mfma_TFLOPs"], mfma_dtype=conv_dom["mfma_dtype"],
                         x_over_fp32_mfma_peak=round(conv_dom["alg_TFLOPs"] / F32_MFMA_PEAK_TFLOPS, 2),
                         ms=conv_dom["ms"], alg_GFLOP=conv_dom["alg_GFLOP"], alg_MB=conv_dom["alg_MB"],
-                        note="achieved / frac = algorithmic fp32-equivalent FLOPs (2*M*N*K*9) per launch over the dense bf16 "
-                             "MFMA peak; the split-bf16 scheme issues 3 bf16 MFMAs per product (frac_issued = matrix-pipe "
-                             "utilisation); x_over_fp32_mfma_peak = the same rate over the 157.3 TF fp32-MFMA peak the "
-                             "reference's arithmetic would be priced on.  The launch runs at the package power cap "
-                             "(rocm-smi: 1385-1397 W of 1400 W, sclk 2.02-2.08 GHz; tools/power_probe_conv.sh): `peak` "
-                             "assumes 2.4 GHz")
+                        note="achieved / frac = algorithmic fp32-equivalent FLOPs (2*M*N*K*9) per launch over the dense 2-byte "
+                             "MFMA peak (2.5 PF for bf16 and for fp16); the two-term split issues 3 MFMAs per product "
+                             "(frac_issued = matrix-pipe utilisation); x_over_fp32_mfma_peak = the same rate over the 157.3 TF "
+                             "fp32-MFMA peak the reference's arithmetic would be priced on.  The launch runs at the package "
+                             "power cap (rocm-smi: 1385-1397 W of 1400 W, sclk 2.02-2.08 GHz; tools/power_probe_conv.sh): "
+                             "`peak` assumes 2.4 GHz; fp16 pairs (round 4: 2^-22 products instead of 2^-17) draw more power "
+                             "per MFMA than bf16 pairs and run ~4 % slower under that cap (same box: 0.940 vs 0.902 ms)")
     elif dom:
         k = kernels[dom]
         # fp32 contraction kernels sit above the ridge point (157.3 TF / 8 TB/s = 19.7 flop/B): matrix-pipe bound
@@ -475,11 +477,12 @@ def main():
     island = f"conv3x3|{B},{wl.h},{wl.w},128,128"
     gt = box = None
     if a.stub_cpu:
-        work = StubWorkload(B)
+        # the slot bookkeeping of the pipelined mode (slots take the steps round-robin after the first ROOFLINE_STEPS) without a GPU
+        work = [StubWorkload(B) for _ in range(max(1, a.inflight))]
         launch_mode = "stub"
 
-        def step(first_id):
-            return work.step(img, first_id)
+        def step(first_id, slot=0):
+            return work[slot].step(img, first_id)
     else:
         from objcavit_amd import hip_ops
         from objcavit_amd.validation import crop_box
@@ -524,10 +527,11 @@ def main():
                 return out.depth_pred, hip_ops.depth_metrics(out.depth_pred, gt, wl.min_depth, wl.max_depth, crop=box,
                                                              first_image_id=first_id)
 
-    nslot = 1 if a.stub_cpu else len(slots)
+    nslot = len(work) if a.stub_cpu else len(slots)
+    slot_steps = [0] * nslot
     for i in range(a.warmup):
         for k in range(nslot):
-            step(0, k) if not a.stub_cpu else step(0)  # also warms the metric kernel (lazy code loading)
+            step(0, k)                                 # also warms the metric kernel (lazy code loading)
         barrier() if world == 1 else (None if a.stub_cpu else torch.cuda.synchronize())
         log(f"warm-up step {i} done")
     barrier()
@@ -543,18 +547,18 @@ def main():
     t0 = time.perf_counter()
     for s_ in range(a.steps):
         first_id = (s_ * world + rank) * B
-        if a.stub_cpu:
-            depth, rec = step(first_id)
-        elif nslot == 1:
-            depth, rec = step(first_id, 0)
+        if nslot == 1:
+            slot = 0
         else:
-            if s_ == ROOFLINE_STEPS:
+            if s_ == ROOFLINE_STEPS and not a.stub_cpu:
                 hip_ops.pause_timing(True)
                 ev = torch.cuda.Event()
                 ev.record(streams[0])
                 for st_ in streams[1:]:
                     st_.wait_event(ev)
-            depth, rec = step(first_id, 0 if s_ < ROOFLINE_STEPS else s_ % nslot)
+            slot = 0 if s_ < ROOFLINE_STEPS else s_ % nslot
+        depth, rec = step(first_id, slot)
+        slot_steps[slot] += 1
         records.append(rec)
     t_issue = time.perf_counter() - t0                 # host time to ISSUE the K steps (<< the steps' GPU time: not host-bound)
     if not a.stub_cpu:
@@ -641,7 +645,7 @@ def main():
             "value": value, "unit": "images/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "stub" if a.stub_cpu else "f32 (bf16 / fp16 split contractions)",
+            "dtype": "stub" if a.stub_cpu else "f32 (fp16 / bf16 split contractions)",
             "data": "stub" if a.stub_cpu else "synthetic",
             # like-for-like with round 1 and with a caller that submits one batch at a time: value_sequential;
             # `value` is the timed region as the driver clocks it (= value_pipelined when inflight > 1)
@@ -650,6 +654,11 @@ def main():
             "sustained_images_per_s": None if sustained_ips is None else round(sustained_ips * world, 1),
             "sustained_seconds": None if sustained_s is None else round(sustained_s, 2),
             "launch": launch_mode.replace("ROOFLINE_STEPS", str(ROOFLINE_STEPS)), "inflight": nslot, "launcher": launcher,
+            "slot_steps": slot_steps,                 # timed steps each slot of THIS rank served (first ROOFLINE_STEPS on slot 0, then round-robin)
+            # host threads per rank: the main thread issues every launch (one Python thread per process, captures serialised by
+            # graph._CAPTURE_LOCK); torch's intra-op pool is not used by the hot path (no CPU tensor math in a step) -- a rank
+            # needs ONE busy CPU while it issues and idles in synchronize(); 8 ranks fit the 16-CPU quota of the driver's box
+            "host_threads": {"issuing": 1, "torch_intra_op": torch.get_num_threads(), "cpus_allowed": len(os.sched_getaffinity(0))},
             "ranks_seen": ranks_seen, "host_issue_ms_per_step": round(t_issue / a.steps * 1e3, 3),
             "step_latency_ms": None if step_latency_ms is None else round(step_latency_ms, 3),
             "sequential_images_per_s_this_rank": None if sequential_ips is None else round(sequential_ips, 1),
@@ -658,20 +667,33 @@ def main():
                                    f"parity tests' gains on attention / bin-head layers (gen.{'PEAKY' if wl.gains_name == 'PEAKY' else 'KITTI_GAINS'}: "
                                    "a non-degenerate bin softmax, SURVEY Q12) -- no trained checkpoint exists offline",
                        "baseline_config": wl.idx, "global_batch": world * B, "image": [H, W], "objects_per_image": wl.n_obj,
-                       "tokens": wl.S, "sa_ca_stacks": wl.stacks, "parallelism": f"dp{world}"},
+                       "tokens": wl.S, "sa_ca_stacks": wl.stacks, "parallelism": f"dp{world}",
+                       # the like-for-like rates travel inside `config` too (the driver's parsed line keeps it): `value` is
+                       # `inflight` batches overlapped on the chip, value_sequential one batch after the other
+                       "inflight": nslot, "value_pipelined": value if nslot > 1 else None,
+                       "value_sequential": (None if sequential_ips is None else round(sequential_ips * world, 1)) if nslot > 1 else value},
             "metrics_gathered": dp.summarise(table),
         }
         if not a.stub_cpu:
-            res["dtype_note"] = ("fp32 results; contractions of the 3x3 / 1x1 / 16x16-patch convolutions run as split-bf16 (hi*hi + hi*lo + "
-                                 "lo*hi on v_mfma_*_bf16, fp32 accumulate: product error <= 2^-17; the first convolution of every decoder "
-                                 "stage at the low resolution = an exact re-association; the 30x40 and 60x80 second convolutions in Winograd "
-                                 "F(4x4,3x3) form with fp32 transforms and two-term fp16 products, same parity bar); layer 0's projection of each transformer stack as a "
+            res["dtype_note"] = ("fp32 results; the decoder's / heads' 3x3, tap-GEMM and 16x16-patch convolutions run as two-term FP16 splits "
+                                 "(round 4: hi*hi + hi*lo + lo*hi on v_mfma_*_f16, fp32 accumulate, product error <= 2^-22; weights scaled per "
+                                 "output channel by a power of two, activations range-checked on the first batch, bf16 pairs as the REPORTED "
+                                 "fallback: conv_split); the encoder's 1x1 convolutions as two-term bf16 splits (2^-17); the first convolution "
+                                 "of every decoder stage at the low resolution = an exact re-association; the 30x40 and 60x80 second convolutions in Winograd "
+                                 "F(4x4,3x3) form with fp32 transforms, per-tile scaled two-term fp16 products, same parity bar); layer 0's projection of each transformer stack as a "
                                  "three-term bf16 split (six products, dropped terms <= 2^-24: fp32-faithful); the layers' projections and "
                                  "feed-forward blocks, the attention cores (QK^T, PV), the image <- object cross-attention and the bin head as a two-term fp16 split with a "
                                  "scaled low term (x = hi + 2^-11 lo', three v_mfma_*_f16 per product block: 22-bit products = the error of "
                                  "an fp32 FMA chain); depthwise and squeeze-excite on exact fp32 FMA.  exact_fp32_* = the same workload with "
                                  "every contraction on exact-fp32 arithmetic (" + " ".join(f"{k}={v}" for k, v in EXACT_ENV.items()) + ")")
-            res.update(kernel_report(timing, a, B, wl))
+            from objcavit_amd import hip_ops as _ops
+            fmode = model.dense_feature_extractor.decoder.__dict__.get("_f16_mode")
+            split_f16 = bool(fmode[1]) if fmode else _ops.conv_split_f16()
+            res["conv_split"] = {"pairs": "fp16" if split_f16 else "bf16",
+                                 # the decoder measured its activations' range on its first eager batch (host syncs, that call only)
+                                 "fp16_range_first_batch": (fmode[2] if fmode and len(fmode) > 2 else None),
+                                 "route_report": dict(_ops.ROUTE_REPORT)}
+            res.update(kernel_report(timing, a, B, wl, split_f16))
             if exact is not None:
                 res["exact_fp32_images_per_s"] = exact["images_per_s"]
                 res["exact_fp32_max_rel_vs_default_route"] = exact["max_rel_vs_default_route"]

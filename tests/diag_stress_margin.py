@@ -4,19 +4,17 @@ amplified ~2000x -- under the arithmetic routes of the rounds.  python tests/dia
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import torch
-import gen
+from objcavit_amd import synth as gen
 from oracle import restate
 from objcavit_amd.config import make_args
 from objcavit_amd.modules.GraphBins import GraphBins, SyntheticObjectProvider
 
 ROUTES = {
-    "round 3 default (fp16 two-term attention / cross-attention / bin head / layer tails, Winograd F(4,3) fp16)": {},
-    "Winograd F(2,2) bf16 instead of F(4,3) fp16": {"OCV_CONV_WINOGRAD_TILE": "2"},
-    "round 2 arithmetic (three-term tokens / bin head, exact-fp32 attention, F(2,2))": {
-        "OCV_CONV_WINOGRAD_TILE": "2", "OCV_TOKENS": "split3", "OCV_BINHEAD": "split3", "OCV_ATTN_FORM": "fp32", "OCV_XATTN_FORM": "split3"},
-    "no Winograd": {"OCV_CONV_WINOGRAD": "0"},
+    "round 4 default (decoder / heads convolutions on two-term FP16 splits, weights scaled per output channel)": {},
+    "round 3 default (the same convolutions on two-term BF16 splits; fp16 two-term attention / bin head / layer tails, Winograd F(4,3))": {"OCV_CONV_SPLIT": "bf16"},
+    "fp16 pairs, no Winograd": {"OCV_CONV_WINOGRAD": "0"},
+    "fp16 pairs + the encoder's 1x1 convolutions on exact fp32 (OCV_PW=fp32)": {"OCV_PW": "fp32"},
     "exact-fp32 convolutions, default tokens / heads": {"OCV_CONV": "exact"},
 }
 torch.set_grad_enabled(False)

@@ -34,6 +34,23 @@ def test_bench_gpus_2_launches_its_own_ranks():
 
 
 @pytest.mark.timeout(300)
+def test_bench_gpus_2_with_three_slots_in_flight_per_rank():
+    """the pipelined mode's slot bookkeeping under a process group -- two ranks, three slots each, the first
+    ROOFLINE_STEPS steps of the timed region on slot 0 alone, the rest round-robin; every step's records reach the ONE all-gather
+    exactly once (unique image ids over ranks x steps x batch) and the JSON says which slot served how many steps."""
+    r = _run(["--gpus", "2", "--steps", "20", "--warmup", "1", "--batch", "2", "--inflight", "3", "--stub-cpu"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["inflight"] == 3 and j["config"]["inflight"] == 3
+    assert j["metrics_gathered"]["images"] == 2 * 20 * 2               # bench.py itself asserts the ids are 0 .. N-1, each once
+    assert sum(j["slot_steps"]) == 20 and j["slot_steps"] == [8, 6, 6]  # steps 0, 1 alone on slot 0, then s % 3
+    assert j["host_threads"]["issuing"] == 1
+    assert j["config"]["value_sequential"] is None or j["config"]["value_sequential"] > 0
+
+
+@pytest.mark.timeout(300)
 def test_bench_rank_failure_is_a_nonzero_exit():
     # --gpus 2 inside a 3-rank launcher environment: every rank refuses, the job fails loudly
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2", "--stub-cpu"],

@@ -41,9 +41,13 @@ print("RCCL_SINGLE_RANK_OK", torch.cuda.nccl.version() if hasattr(torch.cuda, "n
 
 @pytest.mark.timeout(300)
 def test_rccl_initialises_and_runs_the_jobs_collectives_on_one_rank(tmp_path):
+    import socket
     script = tmp_path / "child.py"
     script.write_text(CHILD)
-    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29731")
+    with socket.socket() as sk:                                   # a free port, as tests/test_dp_gloo.py picks one
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0 and "RCCL_SINGLE_RANK_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
