@@ -225,18 +225,35 @@ __global__ __launch_bounds__(1024) void se_hidden_partials_kernel(const float* _
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long b = blockIdx.y;
   const float* pb = part + b * tiles * (long)C;
-  // pooling: TG thread groups share the tiles of a channel (all 1024 threads busy for C <= 1024), summed in group order
-  const int TG = C >= 1024 ? 1 : 1024 / C;
-  for (int idx = tid; idx < TG * C; idx += 1024) {
-    const int c = idx % C, tg = idx / C;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int t = tg;
-    for (; t + 3 * TG < tiles; t += 4 * TG) {
-      s0 += pb[(long)t * C + c]; s1 += pb[(long)(t + TG) * C + c];
-      s2 += pb[(long)(t + 2 * TG) * C + c]; s3 += pb[(long)(t + 3 * TG) * C + c];
+  // pooling: item = (channel QUAD, row group); every thread keeps eight independent 16-byte loads in flight.  (Round 4: the first
+  // version summed one float per load, four in flight -- at bs 1, where a depthwise launch leaves up to 600 partial rows per
+  // image, that was 38 dependent round trips and 10.7 us per launch, 0.42 ms of a 4 ms forward; profiles/r04a_*.)  Out-of-range
+  // rows are clamped to a valid address and selected away: no branch around a load.  Fixed order: rows ascending within a group,
+  // groups ascending.
+  const int nq = C >> 2;                    // C % 4 == 0 (the depthwise kernels' contract)
+  const int TG = nq >= 1024 ? 1 : min(tiles, 1024 / nq);
+  for (int idx = tid; idx < TG * nq; idx += 1024) {
+    const int q = idx % nq, tg = idx / nq;
+    float4 a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* src = pb + 4 * q;
+    for (int t0 = tg; t0 < tiles; t0 += 8 * TG) {
+      float4 u[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) u[j] = ld4(src + (long)min(t0 + j * TG, tiles - 1) * C);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool ok = t0 + j * TG < tiles;
+        a[j].x += ok ? u[j].x : 0.f; a[j].y += ok ? u[j].y : 0.f; a[j].z += ok ? u[j].z : 0.f; a[j].w += ok ? u[j].w : 0.f;
+      }
     }
-    for (; t < tiles; t += TG) s0 += pb[(long)t * C + c];
-    red[idx] = (s0 + s1) + (s2 + s3);
+    float4 r;
+    r.x = ((a[0].x + a[1].x) + (a[2].x + a[3].x)) + ((a[4].x + a[5].x) + (a[6].x + a[7].x));
+    r.y = ((a[0].y + a[1].y) + (a[2].y + a[3].y)) + ((a[4].y + a[5].y) + (a[6].y + a[7].y));
+    r.z = ((a[0].z + a[1].z) + (a[2].z + a[3].z)) + ((a[4].z + a[5].z) + (a[6].z + a[7].z));
+    r.w = ((a[0].w + a[1].w) + (a[2].w + a[3].w)) + ((a[4].w + a[5].w) + (a[6].w + a[7].w));
+    *reinterpret_cast<float4*>(red + tg * C + 4 * q) = r;
   }
   __syncthreads();
   for (int c = tid; c < C; c += 1024) {
@@ -247,16 +264,25 @@ __global__ __launch_bounds__(1024) void se_hidden_partials_kernel(const float* _
   __syncthreads();
   const int r = blockIdx.x * 16 + wave;
   if (r >= R) return;
+  // one wavefront per hidden unit: a lane takes channel QUADS lane, lane + 64, ... -- 16-byte loads, four of them in flight
+  // (C <= 1024: the whole row of W1 in one round trip; one float per load took C / 256 dependent rounds)
   const float* wr = w1 + (long)r * C;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int c = lane;
-  for (; c + 192 < C; c += 256) {
-    s0 = fmaf(wr[c], mean[c], s0);
-    s1 = fmaf(wr[c + 64], mean[c + 64], s1);
-    s2 = fmaf(wr[c + 128], mean[c + 128], s2);
-    s3 = fmaf(wr[c + 192], mean[c + 192], s3);
+  int q = lane;
+  for (; q + 192 < nq; q += 256) {
+    const float4 u0 = ld4(wr + 4 * q), u1 = ld4(wr + 4 * (q + 64)), u2 = ld4(wr + 4 * (q + 128)), u3 = ld4(wr + 4 * (q + 192));
+    const float4 m0 = *reinterpret_cast<const float4*>(mean + 4 * q), m1 = *reinterpret_cast<const float4*>(mean + 4 * (q + 64));
+    const float4 m2 = *reinterpret_cast<const float4*>(mean + 4 * (q + 128)), m3 = *reinterpret_cast<const float4*>(mean + 4 * (q + 192));
+    s0 = fmaf(u0.x, m0.x, fmaf(u0.y, m0.y, fmaf(u0.z, m0.z, fmaf(u0.w, m0.w, s0))));
+    s1 = fmaf(u1.x, m1.x, fmaf(u1.y, m1.y, fmaf(u1.z, m1.z, fmaf(u1.w, m1.w, s1))));
+    s2 = fmaf(u2.x, m2.x, fmaf(u2.y, m2.y, fmaf(u2.z, m2.z, fmaf(u2.w, m2.w, s2))));
+    s3 = fmaf(u3.x, m3.x, fmaf(u3.y, m3.y, fmaf(u3.z, m3.z, fmaf(u3.w, m3.w, s3))));
   }
-  for (; c < C; c += 64) s0 = fmaf(wr[c], mean[c], s0);
+  for (; q < nq; q += 64) {
+    const float4 u0 = ld4(wr + 4 * q);
+    const float4 m0 = *reinterpret_cast<const float4*>(mean + 4 * q);
+    s0 = fmaf(u0.x, m0.x, fmaf(u0.y, m0.y, fmaf(u0.z, m0.z, fmaf(u0.w, m0.w, s0))));
+  }
   const float s = wave_sum((s0 + s1) + (s2 + s3));
   if (lane == 0) hid[b * R + r] = fast_silu(s + b1[r]);
 }
@@ -273,6 +299,18 @@ __global__ __launch_bounds__(256) void se_gate_hid_kernel(const float* __restric
   const float* w = w2t + c;
   float s0 = b2[c], s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int r = 0;
+  for (; r + 15 < R; r += 16) {                       // sixteen loads in flight (four were: R / 4 dependent round trips)
+    float u[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) u[j] = w[(long)(r + j) * C];
+#pragma unroll
+    for (int j = 0; j < 16; j += 4) {
+      s0 = fmaf(u[j], hs[r + j], s0);
+      s1 = fmaf(u[j + 1], hs[r + j + 1], s1);
+      s2 = fmaf(u[j + 2], hs[r + j + 2], s2);
+      s3 = fmaf(u[j + 3], hs[r + j + 3], s3);
+    }
+  }
   for (; r + 3 < R; r += 4) {
     s0 = fmaf(w[(long)r * C], hs[r], s0);
     s1 = fmaf(w[(long)(r + 1) * C], hs[r + 1], s1);
@@ -310,6 +348,18 @@ __global__ __launch_bounds__(256) void se_gate_weights_kernel(const float* __res
       const float* w = w2t + c;
       float s0 = b2[c], s1 = 0.f, s2 = 0.f, s3 = 0.f;
       int r = 0;
+      for (; r + 15 < R; r += 16) {                   // sixteen loads in flight, the summation order of se_gate_hid_kernel
+        float u[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) u[j] = w[(long)(r + j) * C];
+#pragma unroll
+        for (int j = 0; j < 16; j += 4) {
+          s0 = fmaf(u[j], hs[r + j], s0);
+          s1 = fmaf(u[j + 1], hs[r + j + 1], s1);
+          s2 = fmaf(u[j + 2], hs[r + j + 2], s2);
+          s3 = fmaf(u[j + 3], hs[r + j + 3], s3);
+        }
+      }
       for (; r + 3 < R; r += 4) {
         s0 = fmaf(w[(long)r * C], hs[r], s0);
         s1 = fmaf(w[(long)(r + 1) * C], hs[r + 1], s1);
@@ -444,9 +494,9 @@ extern "C" int ocv_se_gate_partials_fwd(const float* part, int tiles, long pixel
                                         int B, int C, int R, ocv_stream_t stream) {
   OCV_CHECK_ARG(part && w1 && b1 && w2t && b2 && gate && hidden_ws, "ocv_se_gate_partials_fwd: null pointer");
   OCV_CHECK_ARG(B >= 1 && B <= 65535 && C >= 1 && R >= 1 && R <= 256 && tiles >= 1 && pixels_per_image >= 1, "ocv_se_gate_partials_fwd: bad sizes (R <= 256)");
-  OCV_CHECK_ARG(C <= 8192, "ocv_se_gate_partials_fwd: C too large (%d)", C);
+  OCV_CHECK_ARG(C <= 8192 && C % 4 == 0, "ocv_se_gate_partials_fwd: C must be a multiple of 4, at most 8192 (got %d)", C);
   hipStream_t st = (hipStream_t)stream;
-  const size_t lds = (size_t)(C + (C >= 1024 ? C : (1024 / C) * C)) * sizeof(float);
+  const size_t lds = (size_t)(C + (C >= 4096 ? C : 4096)) * sizeof(float);      // mean[C] | red[TG][C], TG * C <= 4096
   hipLaunchKernelGGL(se_hidden_partials_kernel, dim3((R + 15) / 16, B), dim3(1024), lds, st, part, tiles,
                      1.0f / (float)pixels_per_image, w1, b1, hidden_ws, C, R);
   OCV_CHECK_LAUNCH("ocv_se_gate_partials_fwd(hidden)");
@@ -465,7 +515,7 @@ extern "C" int ocv_se_gate_weights_fwd(const float* part, int tiles, long pixels
   OCV_CHECK_ARG(w_image_elems >= (long)ocv_pointwise_packed_weight_elems(C, N) && (w_image_elems & 7) == 0 && ocv_aligned16(w_packed) && ocv_aligned16(W),
                 "ocv_se_gate_weights_fwd: w_image_elems must hold one packed matrix (ocv_pointwise_packed_weight_elems) and keep 16-byte alignment");
   hipStream_t st = (hipStream_t)stream;
-  const size_t lds = (size_t)(C + (C >= 1024 ? C : (1024 / C) * C)) * sizeof(float);
+  const size_t lds = (size_t)(C + (C >= 4096 ? C : 4096)) * sizeof(float);      // mean[C] | red[TG][C], TG * C <= 4096
   hipLaunchKernelGGL(se_hidden_partials_kernel, dim3((R + 15) / 16, B), dim3(1024), lds, st, part, tiles,
                      1.0f / (float)pixels_per_image, w1, b1, hidden_ws, C, R);
   OCV_CHECK_LAUNCH("ocv_se_gate_weights_fwd(hidden)");

@@ -407,6 +407,7 @@ int launch_tile(const PSArgs& a, hipStream_t st) {
 
 template <int WN>
 int launch_tile_wn(const PSArgs& a, int wk, hipStream_t st) {
+  if (wk >= 4) return launch_tile<WN, 4, 1>(a, st);
   return wk >= 2 ? launch_tile<WN, 2, 1>(a, st) : launch_tile<WN, 1, 1>(a, st);
 }
 
@@ -573,7 +574,9 @@ extern "C" int ocv_pointwise_conv_nhwc_split_hl_fwd(const float* x, const float*
   int wn = Cout > 64 ? 4 : 2;
   if (cfg.wn == 2 || cfg.wn == 4) wn = cfg.wn;
   const long wgs = ((M + 31) / 32) * ocv_cdiv(Cout, 32 * wn);
-  int wk = (wgs < 512 && Kp >= 512) ? 2 : 1;
+  // (round 4, the reference's own batch of 1 - 2: a stage 6 - 7 layer is then 10 - 40 workgroups walking K = 1824 ... 3072 in a
+  // chain of 14 - 24 slabs, ~1 us each, on a chip that is otherwise idle: FOUR K groups per workgroup halve the chain)
+  int wk = (wgs < 512 && Kp >= 512) ? ((wgs < 128 && Kp >= 1024) ? 4 : 2) : 1;
   if (cfg.wk) wk = cfg.wk;
   return wn == 4 ? launch_tile_wn<4>(a, wk, st) : launch_tile_wn<2>(a, wk, st);
 }

@@ -789,7 +789,7 @@ def test_pointwise_nhwc_split(ops, B, H, W, Cin, Cout, act, use_gate, use_res):
     assert torch.equal(got, ops.pointwise_nhwc(xg, sw, dev(b), act, **kw))      # fixed-order K-group reduction
 
 
-@pytest.mark.parametrize("cfg", [(3, 4, 1), (3, 4, 2), (3, 2, 1), (3, 2, 2)])
+@pytest.mark.parametrize("cfg", [(3, 4, 1), (3, 4, 2), (3, 2, 1), (3, 2, 2), (3, 4, 4), (3, 2, 4)])      # (.., 4): four K groups, round 4
 @pytest.mark.parametrize("B,H,W,Cin,Cout,act,use_gate,use_res", [
     (2, 30, 40, 176, 1056, 3, False, False),    # stage-5 expand: 11 K steps, 33 channel tiles
     (2, 30, 40, 1056, 176, 0, True, True),      # stage-5 project: ragged channel block, rows spanning two images per tile
@@ -798,7 +798,7 @@ def test_pointwise_nhwc_split(ops, B, H, W, Cin, Cout, act, use_gate, use_res):
     (1, 4, 5, 128, 102, 1, False, True),        # N % 4 != 0: the per-element store path
 ])
 def test_pointwise_nhwc_split_pinned_tile_shapes(ops, cfg, B, H, W, Cin, Cout, act, use_gate, use_res):
-    """Every shape of the 32-row tile kernel (2 | 4 wavefronts across channels x 1 | 2 K groups), pinned through
+    """Every shape of the 32-row tile kernel (2 | 4 wavefronts across channels x 1 | 2 | 4 K groups), pinned through
     ocv_pointwise_split_set_dispatch instead of left to the automatic choice, on late-stage layer shapes and ragged
     M / N / K; the automatic dispatch must agree with each of them to fp32 summation order."""
     x, w, b = rnd("x", (B, Cin, H, W), 1), rnd("w", (Cout, Cin, 1, 1), 2, 1 / math.sqrt(Cin)), rnd("b", (Cout,), 3, 0.2)
