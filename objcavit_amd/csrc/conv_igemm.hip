@@ -119,19 +119,22 @@ __device__ __forceinline__ void split4_bits(const f32x4 v, unsigned short* hi, u
   if (f16) split4_bits<true>(v, hi, lo);
   else split4_bits<false>(v, hi, lo);
 }
-// hi + lo of four consecutive (hi at p, lo at p + lo_off) two-byte pairs, either element type
+// hi + lo of four consecutive (hi at p, lo at p + lo_off) two-byte pairs, either element type.  The two 8-byte loads are issued
+// UNCONDITIONALLY and only the conversion depends on the type: a branch around a load makes hipcc wait for every load on its own
+// (the first version of this function did, and the Winograd input transform went from 95 to 120 us per launch).
 __device__ __forceinline__ f32x4 join4_bits(const void* p, int lo_off, bool f16) {
+  const uint2 hb = *reinterpret_cast<const uint2*>(p);
+  const uint2 lb = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p) + lo_off);
   f32x4 r;
   if (f16) {
-    const cv_h16x4 h = *reinterpret_cast<const cv_h16x4*>(p);
-    const cv_h16x4 l = *reinterpret_cast<const cv_h16x4*>(reinterpret_cast<const _Float16*>(p) + lo_off);
+    const cv_h16x4 h = __builtin_bit_cast(cv_h16x4, hb), l = __builtin_bit_cast(cv_h16x4, lb);
 #pragma unroll
     for (int e = 0; e < 4; ++e) r[e] = (float)h[e] + (float)l[e];
   } else {
-    const ti4 h = *reinterpret_cast<const ti4*>(p);
-    const ti4 l = *reinterpret_cast<const ti4*>(reinterpret_cast<const __bf16*>(p) + lo_off);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] = (float)h[e] + (float)l[e];
+    r[0] = __uint_as_float(hb.x << 16) + __uint_as_float(lb.x << 16);
+    r[1] = __uint_as_float(hb.x & 0xffff0000u) + __uint_as_float(lb.x & 0xffff0000u);
+    r[2] = __uint_as_float(hb.y << 16) + __uint_as_float(lb.y << 16);
+    r[3] = __uint_as_float(hb.y & 0xffff0000u) + __uint_as_float(lb.y & 0xffff0000u);
   }
   return r;
 }
@@ -1242,11 +1245,21 @@ __global__ __launch_bounds__(256, ROUNDS ? 1 : 2) void wino43_input_kernel(Wino4
   __syncthreads();
   float w[6][6][4];
   if (!ROUNDS) {
-    const int G = 256 / nq;
+    // (the workgroup is only as large as its tiles need -- 64, 128 or 256 threads: the barrier below then holds back two or four
+    // wavefronts, not always four, and more workgroups interleave their load and store phases on a CU)
+    const int nt = blockDim.x;
+    const int G = nt / nq;
     const int g = tid / nq, q = tid - g * nq;
     const long t = (long)blockIdx.x * G + g;
     const bool on = g < G && t < p.T;
-    if (on) atomicMax(&gmax[g], __float_as_uint(w43_load_patch(p, t, 4 * q, w)));
+    float amax = on ? w43_load_patch(p, t, 4 * q, w) : 0.f;
+    if ((nq & 63) == 0) {                                                  // whole wavefronts per tile: one LDS atomic per wavefront
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+      if (on && (tid & 63) == 0) atomicMax(&gmax[g], __float_as_uint(amax));
+    } else if (on) {
+      atomicMax(&gmax[g], __float_as_uint(amax));
+    }
     __syncthreads();
     if (!on) return;
     const float sc = w43_tile_scale(__uint_as_float(gmax[g]));
@@ -1374,9 +1387,10 @@ extern "C" int ocv_conv3x3_winograd43_split_fwd(const void* x_hl, int Cin, const
   }
   Wino43InArgs wi{(const __bf16*)x_hl, v, cscale, tinv, B, H, W, Cp, th, tw, T, hl_f16};
   const int nq = Cp / 4;
-  const long in_wgs = nq <= 256 ? (T + 256 / nq - 1) / (256 / nq) : T;
+  const int in_threads = nq <= 64 ? 64 : (nq <= 128 ? 128 : 256);          // tiles of <= 64 / <= 128 / more channel quads
+  const long in_wgs = nq <= 256 ? (T + in_threads / nq - 1) / (in_threads / nq) : T;
   OCV_CHECK_ARG(in_wgs < (1L << 31), "ocv_conv3x3_winograd43_split_fwd: too many tiles");
-  if (nq <= 256) hipLaunchKernelGGL(wino43_input_kernel<false>, dim3((unsigned)in_wgs), dim3(256), 0, st, wi);
+  if (nq <= 256) hipLaunchKernelGGL(wino43_input_kernel<false>, dim3((unsigned)in_wgs), dim3(in_threads), 0, st, wi);
   else hipLaunchKernelGGL(wino43_input_kernel<true>, dim3((unsigned)in_wgs), dim3(256), 0, st, wi);
   OCV_CHECK_LAUNCH("ocv_conv3x3_winograd43_split_fwd(input transform)");
   ConvArgs a{};

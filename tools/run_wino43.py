@@ -23,7 +23,7 @@ for (B, H, W, Ci, Co) in ((16, 30, 40, 1024, 1024), (8, 22, 76, 1024, 1024), (16
     w = torch.randn(Co, Ci, 3, 3, device="cuda") / (Ci * 9) ** 0.5
     b = torch.randn(Co, device="cuda") * 0.1
     ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), padding=1), 0.01)
-    xs = hip_ops.split_act(x)
+    xs = hip_ops.split_act(x)  # bf16 pairs (the F(2,2) form takes no others); the model feeds the F(4,3) form fp16 pairs: same kernel, other conversion
     hi, lo = hip_ops.prep_conv_weight(w)
     u2 = hip_ops.prep_winograd_weight(w)
     u4 = hip_ops.prep_winograd43_weight(w)
