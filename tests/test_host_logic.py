@@ -305,3 +305,73 @@ def test_island_hook_and_workspace_scope_are_thread_local():
     t.join()
     assert not err, err
     assert seen["diverted"] == ["conv3x3|x"] and seen["ran"] == ["holder-other", "main"]
+
+
+def test_padded_objects_from_lists_and_weight_preparation_on_the_host():
+    """Round 4 host logic without a GPU: the reference's two object lists -> padded tensors + int32 counts (an image without
+    detections keeps ONE row with the box (-1, -1, -1, -1)); fp16 weight pairs scaled per output channel by exact powers of two;
+    the fp16-fit test of a weight matrix; the Winograd F(4x4,3x3) filters' per-position and per-channel powers of two."""
+    from objcavit_amd import hip_ops
+    from objcavit_amd.modules.ObjCAViT import PaddedObjects
+    feats = [torch.ones(3, 512), torch.full((1, 512), 2.0), torch.full((5, 512), 3.0)]
+    boxes = [torch.rand(3, 4), None, torch.rand(5, 4)]
+    po = PaddedObjects.from_lists(feats, boxes, torch.device("cpu"), capacity=8)
+    assert po.features.shape == (3, 8, 512) and po.xywh.shape == (3, 8, 4) and po.counts.dtype == torch.int32
+    assert po.counts.tolist() == [3, 1, 5] and po.max_count == 5 and po.capacity == 8
+    assert po.xywh[1, 0].tolist() == [-1.0] * 4 and float(po.features[2, 4, 0]) == 3.0 and float(po.features[0, 3:].abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        PaddedObjects.from_lists([torch.ones(2, 512)], [torch.rand(3, 4)], torch.device("cpu"))       # counts disagree
+    with pytest.raises(ValueError):
+        PaddedObjects.from_lists([torch.ones(0, 512)], [torch.rand(0, 4)], torch.device("cpu"))       # no row at all
+
+    w = torch.randn(24, 40, 3, 3) * torch.logspace(-3, 3, 24).view(24, 1, 1, 1)                      # heavy-tailed OUTPUT channels
+    hi, lo, osc = hip_ops.prep_conv_weight(w, f16=True)
+    assert hi.dtype == lo.dtype == torch.float16 and hi.shape == (9, 24, 64) and osc.shape == (24,)
+    assert bool((torch.log2(osc) == torch.round(torch.log2(osc))).all())                             # exact powers of two
+    rowmax = hi.float().abs().amax(dim=(0, 2))
+    assert float(rowmax.min()) >= 2.0 ** 7.4 and float(rowmax.max()) <= 2.0 ** 8.6                   # every row's largest entry near 2^8
+    back = (hi.float() + lo.float()) * osc.view(1, 24, 1)
+    ref = w.permute(2, 3, 0, 1).reshape(9, 24, 40)
+    assert float(((back[:, :, :40] - ref).abs() / ref.abs().amax(dim=(0, 2), keepdim=True)).max()) < 2.0 ** -21   # 22-bit pairs per row
+    assert not bool(back[:, :, 40:].any())
+    bh, bl = hip_ops.prep_conv_weight(w)                                                               # bf16 pairs: unchanged contract
+    assert bh.dtype == torch.bfloat16 and bh.shape == (9, 24, 64)
+
+    flat = torch.randn(16, 72)
+    assert hip_ops.fp16_weight_safe(flat)
+    flat[:, 5] *= 2.0 ** -20
+    assert not hip_ops.fp16_weight_safe(flat)
+    flat[:, 5] = 0.0
+    assert hip_ops.fp16_weight_safe(flat)                                                              # an all-zero column is fine
+
+    span = torch.logspace(-3, 3, 40).view(1, 40, 1, 1)
+    u_hi, u_lo, fs, cs = hip_ops.prep_winograd43_weight(torch.randn(24, 40, 3, 3) / span)
+    assert u_hi.shape == (36, 24, 64) and fs.shape == (36,) and cs.shape == (64,) and bool((cs[40:] == 1).all())
+    assert bool((torch.log2(cs) == torch.round(torch.log2(cs))).all()) and float(cs.max()) == 1.0
+    colmax = u_hi.float().abs().amax(dim=(0, 1))[:40]
+    assert float(colmax.max() / colmax.min()) < 8.0                                                    # columns equalised (were 10^6 apart)
+
+
+def test_validation_step_joint_forward_on_a_stand_in_model():
+    """ValidationStep(joint=True) on a model that declares its images independent: ONE call on [batch | mirrored batch], the
+    un-mirrored half returned, the mirrored depth handed to the metric kernel (checked here up to the kernel call)."""
+    import collections
+    from objcavit_amd.config import make_args
+    from objcavit_amd.validation import ValidationStep
+    Out = collections.namedtuple("Out", ["depth_pred", "bin_edges"])
+    calls = []
+
+    class Toy(torch.nn.Module):
+        images_are_independent = True
+
+        def forward(self, image):
+            calls.append(tuple(image.shape))
+            return Out(image[:, :1, ::2, ::2].abs() + torch.linspace(0.5, 4.0, image.shape[3] // 2), image.mean(dim=(1, 2, 3), keepdim=False)[:, None])
+
+    img = torch.randn(3, 3, 8, 12)
+    vs = ValidationStep(Toy(), make_args(), joint=True)
+    out, mirror = vs._forward_pair(img)
+    assert calls == [(6, 3, 8, 12)] and out.depth_pred.shape == (3, 1, 4, 6) and mirror.shape == (3, 1, 4, 6) and out.bin_edges.shape == (3, 1)
+    two = ValidationStep(Toy(), make_args(), joint=False)
+    o2, m2 = two._forward_pair(img)
+    assert torch.equal(out.depth_pred, o2.depth_pred) and torch.equal(mirror, m2)
