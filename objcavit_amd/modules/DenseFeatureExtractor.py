@@ -563,17 +563,19 @@ class Decoder(nn.Module):
                     # synchronisations, this call only).  The pairs' error floor is absolute (2^-25 per value) and their ceiling
                     # 65504: a tensor whose largest entry lies outside [2^-6, 4094] sends the pipeline to bf16 pairs -- reported.
                     hip_ops.range_check(True)
-                out, out_split = pipeline(mode[1])
+                try:
+                    out, out_split = pipeline(mode[1])
+                    rep = hip_ops.fp16_range_report() if calibrate else None
+                finally:
+                    if calibrate:
+                        hip_ops.range_check(False)          # whatever happened: never leave the synchronising recorder on
                 if calibrate:
-                    rep = hip_ops.fp16_range_report()
-                    hip_ops.range_check(False)
                     mode = self.__dict__["_f16_mode"] = (wkey, rep["ok"], rep)
                     if not rep["ok"]:
                         hip_ops.ROUTE_REPORT["Decoder"] = ("split pipeline on bf16 pairs instead of fp16 pairs: activation range "
                                                            f"{rep['out_of_range']} outside [2^-6, 65504 / 16] on the first batch")
                         out, out_split = pipeline(False)
             except Fp16Unsafe as e:
-                hip_ops.range_check(False)
                 if torch.cuda.is_current_stream_capturing():
                     raise
                 hip_ops.ROUTE_REPORT["Decoder"] = f"split pipeline on bf16 pairs instead of fp16 pairs: {e}"
