@@ -79,6 +79,74 @@ def _takes_group(model) -> bool:
         return False
 
 
+class PipelinedValidation:
+    """The reference's validation loop -- one image at a time (main.py:58), model(image) and model(mirror) per image
+    (modules/GraphBinsLM.py:159,173) -- with ``slots`` validation steps IN FLIGHT: each slot is a hipGraph of the joint
+    [batch | mirrored batch] forward captured on a stream of its own (objcavit_amd/graph.py; live objects with
+    ``object_capacity``), the steps go to the slots round-robin, the per-image records are collected at the end (or whenever the
+    caller asks).  At bs 1 every launch is latency, so consecutive images overlap almost freely: measured on MI355X
+    (bench.py --batch 1: the same slot mechanism) 261 img/s one after the other, **575 img/s with three in flight**; bs 2
+    (= image + mirror) 433 -> 796.  Results are those of ``ValidationStep(joint=True)``: same kernels, same order per step.
+
+        pv = PipelinedValidation(model, args, example_image, slots=3)
+        for i, (image, depth_gt) in enumerate(loader):      # bs 1, as the reference
+            pv.submit(image.cuda(non_blocking=True), depth_gt.cuda(non_blocking=True), first_image_id=i)
+        records = pv.collect()                                # [N, 10] per-image records, submission order
+    """
+
+    def __init__(self, model, args, example_image: torch.Tensor, slots: int = 3, object_capacity: Optional[int] = None,
+                 flip_tta: bool = True):
+        from .graph import GraphedGraphBins
+        if slots < 1:
+            raise ValueError("PipelinedValidation: slots must be >= 1")
+        self.args, self.flip_tta = args, flip_tta
+        ds = args[args.basic.dataset]
+        self.min_depth, self.max_depth = float(ds.min_depth), float(ds.max_depth)
+        self.B = int(example_image.shape[0])
+        both = torch.cat([example_image, example_image.flip(dims=[3])], 0) if flip_tta else example_image
+        self.graphs = [GraphedGraphBins(model, both, object_capacity=object_capacity, object_group=self.B if flip_tta else None)
+                       for _ in range(slots)]
+        self._next = 0
+        self._pending = []
+
+    @torch.no_grad()
+    def submit(self, image: torch.Tensor, depth_gt: torch.Tensor, first_image_id: int = 0, object_features=None, object_xywh_list=None) -> None:
+        """Enqueue one validation step (image [B, 3, H, W] as captured, ground truth [B, 1, H', W']) on the next slot's stream;
+        returns at once.  ``object_features`` / ``object_xywh_list``: the objects of the 2B images [batch | mirrored batch] for a
+        graph with ``object_capacity`` (default: the model's provider is asked, on the slot's stream)."""
+        if tuple(image.shape[1:]) != tuple(self.graphs[0].static_image.shape[1:]) or image.shape[0] != self.B:
+            raise ValueError(f"captured for images {(self.B,) + tuple(self.graphs[0].static_image.shape[1:])}, got {tuple(image.shape)}")
+        g = self.graphs[self._next]
+        self._next = (self._next + 1) % len(self.graphs)
+        caller = torch.cuda.current_stream(image.device)
+        g.stream.wait_stream(caller)                         # image / ground truth were produced on the caller's stream
+        with torch.cuda.stream(g.stream):
+            both = torch.cat([image, image.flip(dims=[3])], 0) if self.flip_tta else image
+            out = g(both, object_features, object_xywh_list) if g.objects is not None else g(both)
+            H, W = depth_gt.shape[2:]
+            B = self.B
+            rec = hip_ops.depth_metrics(out.depth_pred[:B].contiguous(), depth_gt.contiguous(), self.min_depth, self.max_depth,
+                                        crop=crop_box(self.args, H, W),
+                                        pred_mirror=out.depth_pred[B:].contiguous() if self.flip_tta else None,
+                                        first_image_id=first_image_id)
+        for t in (image, depth_gt):
+            t.record_stream(g.stream)                        # the caching allocator must not recycle them under the slot's launches
+        self._pending.append((rec, g.stream))
+
+    def collect(self) -> torch.Tensor:
+        """Wait for every submitted step; -> records [N * B, 10] in submission order (and forget them)."""
+        cur = None
+        for _, st in self._pending:
+            st.synchronize()
+            cur = st
+        if not self._pending:
+            return torch.empty(0, 10)
+        out = torch.cat([r for r, _ in self._pending], 0)
+        del cur
+        self._pending = []
+        return out
+
+
 def totals(records: torch.Tensor) -> Dict[str, float]:
     """Pixel-total metrics over all images of a record table (the reference's non-running metric classes after an
     epoch): weights n_valid, the two RMSEs recombined through their squares."""

@@ -201,3 +201,35 @@ def test_baseline_config_at_the_reference_validation_batch(B):
         assert rel_dev(e[i:i + 1], ref_e) < 1e-4 and max_rel(d[i:i + 1], ref) < 1e-3, i
     g = GraphedGraphBins(m, img)
     assert torch.equal(g(img).depth_pred, d)
+
+
+def test_pipelined_validation_equals_the_sequential_step():
+    """PipelinedValidation: the reference's bs-1 validation loop with three steps in flight (one captured joint image + mirror graph
+    per slot, own stream each) gives the records of ValidationStep(joint=True) issued one after the other -- seven images, more
+    than two rounds of the three slots, live objects from the model's provider (different per image and for the mirror)."""
+    from objcavit_amd.validation import PipelinedValidation, ValidationStep
+    H, W, B, N = 352, 384, 1, 7
+
+    class Prov:                                             # a "detector": objects follow from the image content
+        def __call__(self, image):
+            f, b = [], []
+            for i in range(image.shape[0]):
+                n = 1 + int(float(image[i, 0, 0, :8].abs().sum()) * 7) % 20
+                seed = int(float(image[i, 1, 1, :8].abs().sum()) * 1000) % 97
+                fs, bs = _objects([n], 200 + seed, H, W)
+                f.append(fs[0].to(image.device))
+                b.append(bs[0].to(image.device))
+            return f, b, None
+
+    m, _, args = _model(dict(strategy="learned_bbox_wh", use_2_saca=True), H, W, 29, provider=Prov())
+    imgs = [gen.randn(f"im{i}", (B, 3, H, W), 300 + i).cuda() for i in range(N)]
+    gts = [(torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(i)) * 9.0 + 0.5).cuda() for i in range(N)]
+    seq = ValidationStep(m, args, joint=True)
+    ref = torch.cat([seq(imgs[i], gts[i], first_image_id=i)[0] for i in range(N)], 0)
+    pv = PipelinedValidation(m, args, imgs[0], slots=3, object_capacity=24)
+    for i in range(N):
+        pv.submit(imgs[i], gts[i], first_image_id=i)
+    rec = pv.collect()
+    assert rec.shape == (N, 10) and torch.equal(rec[:, 8:], ref[:, 8:])                 # counts and image ids exact
+    assert rel_dev(rec[:, :8], ref[:, :8]) < 1e-5                                        # (capacity 24 vs the pair's own Nmax: rounding)
+    assert pv.collect().shape[0] == 0
