@@ -135,6 +135,32 @@ class timed:
 
 
 # ---------------------------------------------------------------------------
+# a second stream for work that is independent of the main chain (object tokens beside image tokens)
+# ---------------------------------------------------------------------------
+_SIDE: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def token_overlap_enabled() -> bool:
+    """OCV_TOKEN_OVERLAP: '1' (default, round 4) = the object branch of the SA/CA stack (embedding, positional MLP, object
+    self-attention: ~20 launches of a few workgroups each) runs on a side stream beside the image branch (patch embedding + image
+    self-attention: equally latency-bound, small grids) and is joined in front of the cross-attention; '0' = one stream (A/B).
+    (Round 2 overlapped the object branch with the ENCODER, whose launches fill the chip: no gain.  Two small-grid chains do overlap.)"""
+    mode = os.environ.get("OCV_TOKEN_OVERLAP", "1")
+    if mode not in ("0", "1"):
+        raise ValueError(f"OCV_TOKEN_OVERLAP={mode!r}: expected '1' (default) or '0'")
+    return mode == "1"
+
+
+def side_stream(device: torch.device) -> "torch.cuda.Stream":
+    """The process's side stream of ``device`` (created on first use; its scratch is keyed by stream like everyone's)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _SIDE.get(idx)
+    if st is None:
+        st = _SIDE[idx] = torch.cuda.Stream(device=idx)
+    return st
+
+
+# ---------------------------------------------------------------------------
 # workspace: one growing byte buffer per (device, stream, tag), held in a STORE
 # ---------------------------------------------------------------------------
 class WorkspaceStore(dict):

@@ -246,12 +246,28 @@ class SelfAttnCrossAttn(nn.Module):
         return self._obj_stack(feats, mask), mask, counts                                 # :188 (padded rows -> 0)
 
     def forward(self, image_patch_embeddings, object_features, want_object_output: bool = True, pre_obj=None,
-                pad_objects_to: Optional[int] = None, counts: Optional[torch.Tensor] = None, group: Optional[int] = None):
+                pad_objects_to: Optional[int] = None, counts: Optional[torch.Tensor] = None, group: Optional[int] = None,
+                pre_join=None):
         """``counts`` / ``group``: see ``object_self_attention`` and hip_ops.object_front_pad -- ``group`` consecutive images
-        form one call of the reference (their longest list is the Nmax the key rows are front-padded to); None = the batch."""
+        form one call of the reference (their longest list is the Nmax the key rows are front-padded to); None = the batch.
+        ``pre_obj`` / ``pre_join``: the object half already issued by the caller, on the stream ``pre_join`` (joined here, behind
+        the image tokens' stack)."""
         x = image_patch_embeddings.contiguous()
         B, S, E = x.shape
+        main = torch.cuda.current_stream(x.device) if x.is_cuda else None
+        if pre_obj is None and x.is_cuda and self._obj_stack is not None and hip_ops.token_overlap_enabled():
+            # the object tokens' self-attention stack beside the image tokens': two independent chains of small launches
+            side = hip_ops.side_stream(x.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                pre_obj = self.object_self_attention(object_features, x.device, pad_objects_to, counts)
+            pre_join = side
         att_img = self._img_stack(x)                                                      # reference :169
+        if pre_join is not None:
+            main.wait_stream(pre_join)
+            for t in pre_obj:
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(main)
         att_obj, mask, counts = pre_obj if pre_obj is not None else \
             self.object_self_attention(object_features, x.device, pad_objects_to, counts)
         cap = att_obj.shape[1]
@@ -408,7 +424,20 @@ class ObjCAViT(nn.Module):
         dev = image_features.device
         B = image_features.shape[0]
         # 1. objects: Linear(512 -> E) + positional embedding, all images in one launch (reference :311-330)
-        if pre is None:
+        side = None
+        if pre is None and image_features.is_cuda and hip_ops.token_overlap_enabled():
+            # the whole object branch -- embedding, positional term, padding, object self-attention -- on the side stream, beside
+            # the patch embedding and the image tokens' stack (joined inside saca_1, in front of the cross-attention)
+            main = torch.cuda.current_stream(dev)
+            side = hip_ops.side_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                po = self._padded(object_features, object_xywh_list, dev, pad_objects_to)
+                emb = self._embed_objects(po, image_features)
+                pre_obj = self.saca_1.object_self_attention(emb, dev, None, po.counts)
+            for t in (po.features, po.xywh, po.counts, emb):
+                t.record_stream(main)
+        elif pre is None:
             po = self._padded(object_features, object_xywh_list, dev, pad_objects_to)
             emb = self._embed_objects(po, image_features)
             pre_obj = None
@@ -437,7 +466,7 @@ class ObjCAViT(nn.Module):
 
         # 3. self-attention / cross-attention stacks (reference :366-368)
         tok, obj = self.saca_1(tok, emb, want_object_output=self.use_2_saca, pre_obj=pre_obj, pad_objects_to=pad_objects_to,
-                               counts=po.counts, group=object_group)
+                               counts=po.counts, group=object_group, pre_join=side)
         if self.use_2_saca:
             tok, obj = self.saca_2(tok, obj, want_object_output=False)
 
