@@ -320,6 +320,15 @@ int ocv_pointwise_conv_nhwc_split_fwd(const float* x, const float* gate, int row
 int ocv_pointwise_conv_nhwc_split_hl_fwd(const float* x, const float* gate, int rows_per_image, const void* w_packed,
                                          const float* bias, const float* residual, float* y, void* y_hl, long M, int Cin,
                                          int Cout, int act, ocv_stream_t stream);
+/* The same with a caller-provided scratch of ocv_pointwise_split_workspace_bytes(M, Cin, Cout) bytes (0 for most shapes): where the
+ * launch would be a handful of 32-row tiles walking a long K on an otherwise idle chip (a batch of 1 - 2 in the late encoder stages:
+ * fewer than 128 tiles, K >= 1024) the K slabs of a tile are shared out over up to 8 workgroups that write raw partial tiles to the
+ * scratch, and a second launch adds them in ascending order + bias + activation + residual (bitwise reproducible).  Without scratch
+ * (or with y_hl) it is ocv_pointwise_conv_nhwc_split_hl_fwd. */
+size_t ocv_pointwise_split_workspace_bytes(long M, int Cin, int Cout);
+int ocv_pointwise_conv_nhwc_split_ws_fwd(const float* x, const float* gate, int rows_per_image, const void* w_packed,
+                                         const float* bias, const float* residual, float* y, void* y_hl, long M, int Cin, int Cout,
+                                         int act, void* workspace, size_t workspace_bytes, ocv_stream_t stream);
 /* The same contraction on a row operand that is ALREADY split, in the "hl32" layout (below: per pixel and 32-channel block,
  * 32 hi then 32 lo bf16 values, pad channels zero) -- what the depthwise / project epilogues of the late encoder stages
  * write -- read by LDS-DMA with no conversion work, and with the squeeze-excite gate folded into PER-IMAGE weights

@@ -73,6 +73,9 @@ PROTOTYPES = {
                                         C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_size_t, _stream]),
     "ocv_pointwise_conv_nhwc_split_hl_fwd": (C.c_int, [_f32p, _f32p, C.c_int, C.c_void_p, _f32p, _f32p, _f32p, C.c_void_p, C.c_long, C.c_int,
                                                        C.c_int, C.c_int, _stream]),
+    "ocv_pointwise_split_workspace_bytes": (C.c_size_t, [C.c_long, C.c_int, C.c_int]),
+    "ocv_pointwise_conv_nhwc_split_ws_fwd": (C.c_int, [_f32p, _f32p, C.c_int, C.c_void_p, _f32p, _f32p, _f32p, C.c_void_p, C.c_long, C.c_int,
+                                                       C.c_int, C.c_int, C.c_void_p, C.c_size_t, _stream]),
     "ocv_pointwise_hl_set_dispatch": (C.c_int, [C.c_int, C.c_int]),
     "ocv_pointwise_hl_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_int, _f32p, _f32p, _f32p, C.c_void_p, C.c_long,
                                        C.c_int, C.c_int, _stream]),

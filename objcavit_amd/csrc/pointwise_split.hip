@@ -44,6 +44,10 @@ struct PSArgs {
   __bf16* yhl;                      // nullable: hl32 split copy of the output (pad channels written as zero), for a consumer that
   int Cpo;                          // reads its rows by LDS-DMA (csrc/pointwise_hl.hip); Cpo = ceil32(N)
   int nbx, nby, col_major;          // tile kernel: row blocks, channel blocks, traversal order
+  int ksplit;                       // tile kernel: > 1 = the K slabs are shared out over that many workgroups per tile (round 4: the
+                                    // 1x1 layers of a batch of 1 - 2 are 10 - 40 tiles walking K = 1824 ... 3072 on an idle chip);
+                                    // slice z writes its RAW partial tile to y + z * M * N (bias / act / residual-free epilogue:
+                                    // pw_splitk_finish_kernel adds the slices in a fixed order)
 };
 
 __device__ __forceinline__ float act_fn(float v, int act) {
@@ -245,21 +249,28 @@ __global__ __launch_bounds__(64 * WN * WK) void pw_tile_kernel(PSArgs p) {
   // (each with its own 4 MB L2); give every XCD a CONTIGUOUS run of tiles in the order the host chose (channel-block
   // major when the whole weight matrix would not fit an L2, so an XCD keeps one weight slice resident and streams
   // rows; row-block major otherwise, so its rows are read once and all of W stays resident).
-  int bx, by;
+  int bx, by, kz = 0;
   {
     const int nwg = gridDim.x;
     int wg = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    if (p.ksplit > 1) {                                     // K slice fastest: the slices of a tile run side by side
+      kz = wg % p.ksplit;
+      wg /= p.ksplit;
+    }
     if (p.col_major) { by = wg / p.nbx; bx = wg % p.nbx; }
     else { bx = wg / p.nby; by = wg % p.nby; }
   }
+  if (p.ksplit > 1) p.y += (long)kz * p.M * p.N;
   const long m0 = (long)bx * ROWS;
   const int n = by * (32 * WN) + wn * 32 + l31;
   const int ntl_all = (p.N + 31) >> 5;
   const __bf16* wf = w_frag(p, min(by * WN + wn, ntl_all - 1), 4 * g, lane);      // + (it * KI / 16 + s) * 1024
   const int K = p.K, Kp = p.Kp;
-  const int nit = (Kp + KI - 1) / KI;
+  const int nit_all = (Kp + KI - 1) / KI;
+  const int it0 = p.ksplit > 1 ? nit_all * kz / p.ksplit : 0;           // this workgroup's K slabs [it0, nit)
+  const int nit = p.ksplit > 1 ? nit_all * (kz + 1) / p.ksplit : nit_all;
 
   // staging map: octet o -> (row, group, j): 8 floats at k = it * KI + 64 group + 8 j of row m0 + row
   const float* asrc[OCT];
@@ -337,11 +348,11 @@ __global__ __launch_bounds__(64 * WN * WK) void pw_tile_kernel(PSArgs p) {
       }
     }
   };
-  load_a(0);
-  load_w(0, wh, wl);
-  store_a(0);
+  load_a(it0);
+  load_w(it0, wh, wl);
+  store_a(it0 & 1);
   __syncthreads();
-  for (int it = 0; it + 1 < nit; ++it) {
+  for (int it = it0; it + 1 < nit; ++it) {
     load_a(it + 1);
     load_w(it + 1, whn, wln);
     multiply(it);
@@ -400,7 +411,8 @@ int launch_tile(const PSArgs& a, hipStream_t st) {
   b.nbx = (int)((a.M + ROWS - 1) / ROWS);
   b.nby = ocv_cdiv(a.N, 32 * WN);
   b.col_major = (long)a.N * a.Kp * 4 > (3L << 20);
-  hipLaunchKernelGGL((pw_tile_kernel<WN, WK, RT>), dim3((unsigned)((long)b.nbx * b.nby)), dim3(64 * WN * WK), LDS, st, b);
+  const int ks = a.ksplit > 1 ? a.ksplit : 1;
+  hipLaunchKernelGGL((pw_tile_kernel<WN, WK, RT>), dim3((unsigned)((long)b.nbx * b.nby * ks)), dim3(64 * WN * WK), LDS, st, b);
   OCV_CHECK_LAUNCH("ocv_pointwise_conv_nhwc_split_fwd");
   return 0;
 }
@@ -409,6 +421,47 @@ template <int WN>
 int launch_tile_wn(const PSArgs& a, int wk, hipStream_t st) {
   if (wk >= 4) return launch_tile<WN, 4, 1>(a, st);
   return wk >= 2 ? launch_tile<WN, 2, 1>(a, st) : launch_tile<WN, 1, 1>(a, st);
+}
+
+// Second pass of a split-K 1x1 layer: y = act(sum_z part[z] + bias) + residual, slices added in ascending order.
+struct PwFinArgs {
+  const float *part, *bias, *res;
+  float* y;
+  long M, items;         // items = M * N / 4
+  int N, act, ksplit;
+};
+
+__global__ __launch_bounds__(256) void pw_splitk_finish_kernel(PwFinArgs p) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.items) return;
+  const long o = 4 * i;
+  const int n = (int)(o % p.N);
+  float4 a = ld4(p.part + o);
+  for (int z = 1; z < p.ksplit; ++z) {
+    const float4 u = ld4(p.part + (long)z * p.M * p.N + o);
+    a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+  }
+  const float4 bv = p.bias != nullptr ? ld4(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  a.x = act_fn(a.x + bv.x, p.act); a.y = act_fn(a.y + bv.y, p.act); a.z = act_fn(a.z + bv.z, p.act); a.w = act_fn(a.w + bv.w, p.act);
+  if (p.res != nullptr) {
+    const float4 q = ld4(p.res + o);
+    a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+  }
+  *reinterpret_cast<float4*>(p.y + o) = a;
+}
+
+// K slices per tile for a tile-kernel launch of `tiles` workgroups over Kp inputs: only where the launch would leave most of the
+// chip idle (fewer than 128 tiles on 256 CUs) and the chain is long (a batch of 1 - 2 in B5's stages 5 - 7).  1 = no split.
+int pw_ksplit(long tiles, int Kp, int Cout) {
+  static const int forced = getenv("OCV_PW_KSPLIT") ? atoi(getenv("OCV_PW_KSPLIT")) : 0;
+  if ((Cout & 3) != 0) return 1;
+  const int slabs = Kp / 128;                                  // the split launch runs two K groups per workgroup: 128-wide slabs
+  if (forced >= 1) return forced > slabs ? (slabs > 1 ? slabs : 1) : forced;
+  if (tiles >= 128 || Kp < 1024) return 1;
+  int ks = (int)(256 / tiles);
+  if (ks > 8) ks = 8;
+  if (ks > slabs / 2) ks = slabs / 2;                          // at least two slabs per slice
+  return ks > 1 ? ks : 1;
 }
 
 // ---------------------------------------------------------------------------
@@ -529,6 +582,31 @@ extern "C" int ocv_pointwise_conv_nhwc_split_fwd(const float* x, const float* ga
 extern "C" int ocv_pointwise_conv_nhwc_split_hl_fwd(const float* x, const float* gate, int rows_per_image,
                                                     const void* w_packed, const float* bias, const float* residual,
                                                     float* y, void* y_hl, long M, int Cin, int Cout, int act, ocv_stream_t stream) {
+  return ocv_pointwise_conv_nhwc_split_ws_fwd(x, gate, rows_per_image, w_packed, bias, residual, y, y_hl, M, Cin, Cout, act, nullptr, 0,
+                                              stream);
+}
+
+// tiles of the 32-row kernel for (M, Cout) and the K slices the dispatcher would use
+static int pw_plan_ksplit(long M, int Cin, int Cout) {
+  const int Kp = (Cin + 15) / 16 * 16;
+  const int wn = Cout > 64 ? 4 : 2;
+  const long tiles = ((M + 31) / 32) * ocv_cdiv(Cout, 32 * wn);
+  return pw_ksplit(tiles, Kp, Cout);
+}
+
+extern "C" size_t ocv_pointwise_split_workspace_bytes(long M, int Cin, int Cout) {
+  if (M < 1 || Cin < 8 || Cout < 1) return 0;
+  const PwCfg& cfg = pw_cfg();
+  if (cfg.family != 0 && cfg.family != 3) return 0;
+  if ((Cout <= 32 && M >= 65536) || (Cin <= 128 && M >= 200000)) return 0;       // rows / stream kernels: no K split
+  const int ks = pw_plan_ksplit(M, Cin, Cout);
+  return ks > 1 ? (size_t)ks * M * Cout * sizeof(float) : 0;
+}
+
+extern "C" int ocv_pointwise_conv_nhwc_split_ws_fwd(const float* x, const float* gate, int rows_per_image,
+                                                    const void* w_packed, const float* bias, const float* residual,
+                                                    float* y, void* y_hl, long M, int Cin, int Cout, int act, void* workspace,
+                                                    size_t workspace_bytes, ocv_stream_t stream) {
   const int Kp = (Cin + 15) / 16 * 16;
   OCV_CHECK_ARG(y_hl == nullptr || (Cout % 8 == 0 && ocv_aligned16(y_hl)), "ocv_pointwise_conv_nhwc_split_hl_fwd: the split output needs Cout to be a multiple of 8 (got %d) and 16-byte alignment", Cout);
   OCV_CHECK_ARG(x && w_packed && y, "ocv_pointwise_conv_nhwc_split_fwd: null pointer");
@@ -574,6 +652,19 @@ extern "C" int ocv_pointwise_conv_nhwc_split_hl_fwd(const float* x, const float*
   int wn = Cout > 64 ? 4 : 2;
   if (cfg.wn == 2 || cfg.wn == 4) wn = cfg.wn;
   const long wgs = ((M + 31) / 32) * ocv_cdiv(Cout, 32 * wn);
+  // a batch of 1 - 2 in the late stages: a handful of tiles, each a long K chain on an idle chip -> the K slabs of a tile go to
+  // several workgroups (raw partial tiles into the caller's workspace) and a second launch adds them in a fixed order
+  const int ks = (cfg.wn == 0 && cfg.wk == 0 && y_hl == nullptr && workspace != nullptr) ? pw_plan_ksplit(M, Cin, Cout) : 1;
+  if (ks > 1 && workspace_bytes >= (size_t)ks * M * Cout * sizeof(float) && ocv_aligned16(workspace)) {
+    PSArgs h = a;
+    h.bias = nullptr; h.res = nullptr; h.act = OCV_ACT_NONE; h.yhl = nullptr; h.y = (float*)workspace; h.ksplit = ks;
+    const int rc = wn == 4 ? launch_tile_wn<4>(h, 2, st) : launch_tile_wn<2>(h, 2, st);
+    if (rc != 0) return rc;
+    PwFinArgs f{(const float*)workspace, bias, residual, y, M, M * Cout / 4, Cout, act, ks};
+    hipLaunchKernelGGL(pw_splitk_finish_kernel, dim3((unsigned)((f.items + 255) / 256)), dim3(256), 0, st, f);
+    OCV_CHECK_LAUNCH("ocv_pointwise_conv_nhwc_split_fwd(finish)");
+    return 0;
+  }
   // (round 4, the reference's own batch of 1 - 2: a stage 6 - 7 layer is then 10 - 40 workgroups walking K = 1824 ... 3072 in a
   // chain of 14 - 24 slabs, ~1 us each, on a chip that is otherwise idle: FOUR K groups per workgroup halve the chain)
   int wk = (wgs < 512 && Kp >= 512) ? ((wgs < 128 && Kp >= 1024) ? 4 : 2) : 1;

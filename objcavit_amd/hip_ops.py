@@ -1396,12 +1396,15 @@ def pointwise_nhwc(x: torch.Tensor, weight, bias: Optional[torch.Tensor], act: i
         if not (split and four and Cout % 8 == 0):
             raise ValueError("pointwise_nhwc: out_split needs a SplitWeight, a 4-D input and Cout % 8 == 0")
         ys = SplitAct.empty(B, Cout, H, Wd, x.device)
+    nws = int(lib.ocv_pointwise_split_workspace_bytes(M, Cin, Cout)) if (split and ys is None) else 0   # split-K slices (tiny batches only)
+    ws = workspace(nws, x.device, "pw_splitk") if nws else None
     with timed(f"pointwise|{M},{Cin},{Cout}"):
         if split:
-            check(lib.ocv_pointwise_conv_nhwc_split_hl_fwd(x.data_ptr(), _ptr(gate), rpi, weight.packed.data_ptr(),
+            check(lib.ocv_pointwise_conv_nhwc_split_ws_fwd(x.data_ptr(), _ptr(gate), rpi, weight.packed.data_ptr(),
                                                            _ptr(bias), _ptr(residual), y.data_ptr(),
-                                                           ys.hl.data_ptr() if ys is not None else None, M, Cin, Cout, act, _stream()),
-                  "ocv_pointwise_conv_nhwc_split_hl_fwd")
+                                                           ys.hl.data_ptr() if ys is not None else None, M, Cin, Cout, act,
+                                                           _ptr(ws), nws, _stream()),
+                  "ocv_pointwise_conv_nhwc_split_ws_fwd")
         else:
             check(lib.ocv_pointwise_conv_nhwc_fwd(x.data_ptr(), _ptr(gate), rpi, w2.data_ptr(), _ptr(bias), _ptr(residual),
                                                   y.data_ptr(), M, Cin, Cout, act, _stream()), "ocv_pointwise_conv_nhwc_fwd")
@@ -1449,6 +1452,10 @@ def pointwise_hl_project_pays(B: int, rows_per_image: int, cin: int, cout: int) 
     1056 -> 176 blocks.  End to end (bench.py --inflight 1, same box, two rounds): 919.7 / 918.0 img/s with this route
     against 915.7 / 914.2 without; with the stage 6 - 7 layers as well 889.5 / 888.5."""
     if pointwise_hl_mode() == "0" or cin % 32 != 0 or cout % 4 != 0:
+        return False
+    if B < int(os.environ.get("OCV_PW_HL_MIN_BATCH", "4")):
+        # a batch of 1 - 2 (round 4): the layer is ~40 tiles either way; the fp32-row kernel with its K slabs shared out over
+        # workgroups (ocv_pointwise_conv_nhwc_split_ws_fwd) and the plain gate launch beat folding the gate into per-image weights
         return False
     M = B * rows_per_image
     return (M <= int(os.environ.get("OCV_PW_HL_MAX_ROWS", "32768")) and cin >= int(os.environ.get("OCV_PW_HL_PROJECT_MIN_CIN", "1024"))

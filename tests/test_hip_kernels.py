@@ -825,6 +825,38 @@ def test_pointwise_nhwc_split_pinned_tile_shapes(ops, cfg, B, H, W, Cin, Cout, a
     assert lib.ocv_pointwise_split_set_dispatch(9, 0, 0) == -1
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,act,use_gate,use_res,split", [
+    (1, 15, 20, 3072, 512, 0, True, True, True),      # stage-7 project at the reference's batch: 10 x 4 tiles, K = 3072 -> 6 slices
+    (2, 15, 20, 1824, 304, 0, True, True, True),      # stage-6 project of an image + mirror pair: 19 x 3 tiles -> 4 slices
+    (1, 15, 20, 1824, 304, 3, False, False, True),    # SiLU in the finish pass
+    (1, 9, 11, 1040, 102, 0, True, True, False),      # N % 4 != 0: never split
+    (4, 15, 20, 1824, 304, 0, True, True, True),      # 114 tiles -> 2 slices
+    (8, 15, 20, 1824, 304, 0, True, True, False),     # 225 tiles: the chip is busy enough, no split
+])
+def test_pointwise_nhwc_split_k_across_workgroups(ops, B, H, W, Cin, Cout, act, use_gate, use_res, split):
+    """Round 4: a tiny batch's late 1x1 layers share the K slabs of a tile out over several workgroups (raw partial tiles in the
+    caller's scratch + a fixed-order finish pass with bias / activation / residual): against fp64, bitwise reproducible, and the
+    scratch query says where it applies."""
+    lib = ops._lib.load()
+    assert (lib.ocv_pointwise_split_workspace_bytes(B * H * W, Cin, Cout) > 0) == split
+    x, w, b = rnd("x", (B, Cin, H, W), 1), rnd("w", (Cout, Cin, 1, 1), 2, 1 / math.sqrt(Cin)), rnd("b", (Cout,), 3, 0.2)
+    gate = torch.sigmoid(rnd("g", (B, Cin), 4)) if use_gate else None
+    res = rnd("r", (B, Cout, H, W), 5) if use_res else None
+    xin = x if gate is None else x * gate[:, :, None, None]
+    ref = F.conv2d(xin.double(), w.double(), b.double())
+    ref = [ref, torch.relu(ref), F.leaky_relu(ref, 0.01), F.silu(ref), torch.sigmoid(ref)][act]
+    if res is not None:
+        ref = ref + res
+    cl = torch.channels_last
+    sw = ops.SplitWeight(dev(w))
+    xg = dev(x).contiguous(memory_format=cl)
+    kw = dict(gate=None if gate is None else dev(gate), residual=None if res is None else dev(res).contiguous(memory_format=cl))
+    poison = [torch.full((1 << 22,), float("nan"), device="cuda") for _ in range(4)]
+    del poison                                                  # the scratch comes out of NaN-filled memory
+    got = ops.pointwise_nhwc(xg, sw, dev(b), act, **kw)
+    assert rel_dev(got, ref) < SPLIT_TOL and torch.equal(got, ops.pointwise_nhwc(xg, sw, dev(b), act, **kw))
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,gate", [(16, 120, 160, 40, 240, False), (16, 240, 320, 48, 24, True), (16, 120, 160, 240, 40, True)])
 def test_pointwise_nhwc_split_many_rows(ops, B, H, W, Cin, Cout, gate):
     """Full-size stage-1/2 shapes: these take the rows (Cin <= 128) / stream (<= 32 channels) / tile kernels."""
@@ -948,8 +980,9 @@ def test_depthwise_hl_gate_weights_project(ops, monkeypatch, tail, cfg, k, s, B,
 
 
 def test_pointwise_nhwc_split_also_writes_the_split_copy(ops):
-    """ocv_pointwise_conv_nhwc_split_hl_fwd: the fp32-row kernel leaves the hl32 copy of its result for an LDS-DMA consumer."""
-    B, H, W, Cin, Cout = 2, 15, 20, 1824, 304
+    """ocv_pointwise_conv_nhwc_split_hl_fwd: the fp32-row kernel leaves the hl32 copy of its result for an LDS-DMA consumer.
+    (Eight images: 225 tiles -- a launch of fewer than 128 tiles without the split copy takes the split-K form, another summation order.)"""
+    B, H, W, Cin, Cout = 8, 15, 20, 1824, 304
     x, w, b = rnd("x", (B, Cin, H, W), 1), rnd("w", (Cout, Cin, 1, 1), 2, 1 / math.sqrt(Cin)), rnd("b", (Cout,), 3, 0.2)
     g = torch.sigmoid(rnd("g", (B, Cin), 4))
     res = dev(rnd("r", (B, Cout, H, W), 5)).contiguous(memory_format=torch.channels_last)
