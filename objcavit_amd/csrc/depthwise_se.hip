@@ -11,6 +11,8 @@
 //   work items of a quad are added through LDS in lane order and the workgroup writes ONE partial per channel:
 //   part[b][tile][c].  Fixed order everywhere -> bit-reproducible.
 // se_hidden_partials_kernel + se_gate_hid_kernel: pooling mean from the partials, hidden layer, gate (see there).
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "se_tail.hpp"
 #include "../../include/objcavit_hip.h"
@@ -321,6 +323,103 @@ __global__ __launch_bounds__(256) void se_gate_hid_kernel(const float* __restric
   gate[b * C + c] = fast_sigmoid((s0 + s1) + (s2 + s3));
 }
 
+// Both launches above as ONE, for the blocks whose squeeze-excite weights are small (round 4: B5's stages 1 - 5, 27 of 39 blocks):
+// grid (ceil(C / 256), B), 1024 threads; every workgroup of an image repeats the pooling and ALL hidden units (<= 64 of them: W1 is
+// <= 186 KB, L2-resident) and then forms the gate of its own 256 channels.  The arithmetic is the two kernels' own, statement for
+// statement (same thread -> element maps, same summation orders), so the gate is bit-identical to theirs; what goes away is one
+// launch floor (~4.5 us) and the hidden units' round trip through memory: 7.3 + 5.1 -> ~8.5 us at bs 1.
+__global__ __launch_bounds__(1024) void se_fused_small_kernel(const float* __restrict__ part, int tiles, float inv,
+                                                             const float* __restrict__ w1, const float* __restrict__ b1,
+                                                             const float* __restrict__ w2t, const float* __restrict__ b2,
+                                                             float* __restrict__ gate, int C, int R) {
+  extern __shared__ float sm[];            // mean[C] | red[TG][C] | hs[64]
+  float* mean = sm;
+  float* red = sm + C;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long b = blockIdx.y;
+  const float* pb = part + b * tiles * (long)C;
+  const int nq = C >> 2;
+  const int TG = nq >= 1024 ? 1 : min(tiles, 1024 / nq);
+  float* hs = red + (size_t)TG * C;
+  for (int idx = tid; idx < TG * nq; idx += 1024) {
+    const int q = idx % nq, tg = idx / nq;
+    float4 a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* src = pb + 4 * q;
+    for (int t0 = tg; t0 < tiles; t0 += 8 * TG) {
+      float4 u[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) u[j] = ld4(src + (long)min(t0 + j * TG, tiles - 1) * C);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool ok = t0 + j * TG < tiles;
+        a[j].x += ok ? u[j].x : 0.f; a[j].y += ok ? u[j].y : 0.f; a[j].z += ok ? u[j].z : 0.f; a[j].w += ok ? u[j].w : 0.f;
+      }
+    }
+    float4 r;
+    r.x = ((a[0].x + a[1].x) + (a[2].x + a[3].x)) + ((a[4].x + a[5].x) + (a[6].x + a[7].x));
+    r.y = ((a[0].y + a[1].y) + (a[2].y + a[3].y)) + ((a[4].y + a[5].y) + (a[6].y + a[7].y));
+    r.z = ((a[0].z + a[1].z) + (a[2].z + a[3].z)) + ((a[4].z + a[5].z) + (a[6].z + a[7].z));
+    r.w = ((a[0].w + a[1].w) + (a[2].w + a[3].w)) + ((a[4].w + a[5].w) + (a[6].w + a[7].w));
+    *reinterpret_cast<float4*>(red + tg * C + 4 * q) = r;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 1024) {
+    float s = red[c];
+    for (int tg = 1; tg < TG; ++tg) s += red[tg * C + c];
+    mean[c] = s * inv;
+  }
+  __syncthreads();
+  for (int r = wave; r < R; r += 16) {                 // every hidden unit, one wavefront each (se_hidden_partials_kernel's dot)
+    const float* wr = w1 + (long)r * C;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int q = lane;
+    for (; q + 192 < nq; q += 256) {
+      const float4 u0 = ld4(wr + 4 * q), u1 = ld4(wr + 4 * (q + 64)), u2 = ld4(wr + 4 * (q + 128)), u3 = ld4(wr + 4 * (q + 192));
+      const float4 m0 = *reinterpret_cast<const float4*>(mean + 4 * q), m1 = *reinterpret_cast<const float4*>(mean + 4 * (q + 64));
+      const float4 m2 = *reinterpret_cast<const float4*>(mean + 4 * (q + 128)), m3 = *reinterpret_cast<const float4*>(mean + 4 * (q + 192));
+      s0 = fmaf(u0.x, m0.x, fmaf(u0.y, m0.y, fmaf(u0.z, m0.z, fmaf(u0.w, m0.w, s0))));
+      s1 = fmaf(u1.x, m1.x, fmaf(u1.y, m1.y, fmaf(u1.z, m1.z, fmaf(u1.w, m1.w, s1))));
+      s2 = fmaf(u2.x, m2.x, fmaf(u2.y, m2.y, fmaf(u2.z, m2.z, fmaf(u2.w, m2.w, s2))));
+      s3 = fmaf(u3.x, m3.x, fmaf(u3.y, m3.y, fmaf(u3.z, m3.z, fmaf(u3.w, m3.w, s3))));
+    }
+    for (; q < nq; q += 64) {
+      const float4 u0 = ld4(wr + 4 * q);
+      const float4 m0 = *reinterpret_cast<const float4*>(mean + 4 * q);
+      s0 = fmaf(u0.x, m0.x, fmaf(u0.y, m0.y, fmaf(u0.z, m0.z, fmaf(u0.w, m0.w, s0))));
+    }
+    const float s = wave_sum((s0 + s1) + (s2 + s3));
+    if (lane == 0) hs[r] = fast_silu(s + b1[r]);
+  }
+  __syncthreads();
+  const int c = blockIdx.x * 256 + tid;
+  if (tid >= 256 || c >= C) return;
+  const float* w = w2t + c;
+  float s0 = b2[c], s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = 0;
+  for (; r + 15 < R; r += 16) {
+    float u[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) u[j] = w[(long)(r + j) * C];
+#pragma unroll
+    for (int j = 0; j < 16; j += 4) {
+      s0 = fmaf(u[j], hs[r + j], s0);
+      s1 = fmaf(u[j + 1], hs[r + j + 1], s1);
+      s2 = fmaf(u[j + 2], hs[r + j + 2], s2);
+      s3 = fmaf(u[j + 3], hs[r + j + 3], s3);
+    }
+  }
+  for (; r + 3 < R; r += 4) {
+    s0 = fmaf(w[(long)r * C], hs[r], s0);
+    s1 = fmaf(w[(long)(r + 1) * C], hs[r + 1], s1);
+    s2 = fmaf(w[(long)(r + 2) * C], hs[r + 2], s2);
+    s3 = fmaf(w[(long)(r + 3) * C], hs[r + 3], s3);
+  }
+  for (; r < R; ++r) s0 = fmaf(w[(long)r * C], hs[r], s0);
+  gate[b * C + c] = fast_sigmoid((s0 + s1) + (s2 + s3));
+}
+
 // The gate FOLDED INTO THE PROJECT WEIGHTS, per image: Wg[b][n][k] = W[n][k] * gate[b][k], split (hi = bf16, lo = bf16 of the
 // rest) and packed in the B-operand order of the pointwise kernels ([jt][s][part][lane][8], hip_ops.SplitWeight) -- so that
 // the project convolution's row operand is the depthwise output AS STORED (hl32, LDS-DMA) instead of rows re-gated and
@@ -497,6 +596,13 @@ extern "C" int ocv_se_gate_partials_fwd(const float* part, int tiles, long pixel
   OCV_CHECK_ARG(C <= 8192 && C % 4 == 0, "ocv_se_gate_partials_fwd: C must be a multiple of 4, at most 8192 (got %d)", C);
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = (size_t)(C + (C >= 4096 ? C : 4096)) * sizeof(float);      // mean[C] | red[TG][C], TG * C <= 4096
+  static const bool no_fuse = getenv("OCV_SE_FUSED") != nullptr && atoi(getenv("OCV_SE_FUSED")) == 0;
+  if (!no_fuse && C <= 1536 && R <= 64) {                                       // small squeeze-excite weights: ONE launch
+    hipLaunchKernelGGL(se_fused_small_kernel, dim3((C + 255) / 256, B), dim3(1024), lds + 64 * sizeof(float), st, part, tiles,
+                       1.0f / (float)pixels_per_image, w1, b1, w2t, b2, gate, C, R);
+    OCV_CHECK_LAUNCH("ocv_se_gate_partials_fwd(fused)");
+    return 0;
+  }
   hipLaunchKernelGGL(se_hidden_partials_kernel, dim3((R + 15) / 16, B), dim3(1024), lds, st, part, tiles,
                      1.0f / (float)pixels_per_image, w1, b1, hidden_ws, C, R);
   OCV_CHECK_LAUNCH("ocv_se_gate_partials_fwd(hidden)");
