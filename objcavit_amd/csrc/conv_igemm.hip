@@ -1421,14 +1421,14 @@ extern "C" int ocv_conv3x3_winograd43_split_fwd(const void* x_hl, int Cin, const
 namespace {
 __global__ __launch_bounds__(256) void patch_sum_kernel(const float* __restrict__ part, long M, int E, int S,
                                                         const float* __restrict__ bias, const float* __restrict__ pos,
-                                                        long pos_bs, float* __restrict__ out) {
+                                                        long pos_bs, float* __restrict__ out, int nslab) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;     // float4 index
   const int e4 = E / 4;
   if (idx >= M * e4) return;
   const long m = idx / e4;
   const int e = (int)(idx - m * e4) * 4;
   f32x4 a = {0.f, 0.f, 0.f, 0.f};
-  for (int ky = 0; ky < 16; ++ky) a += *reinterpret_cast<const f32x4*>(part + ((long)ky * M + m) * E + e);
+  for (int ky = 0; ky < nslab; ++ky) a += *reinterpret_cast<const f32x4*>(part + ((long)ky * M + m) * E + e);   // (ky, K part) ascending
   if (bias != nullptr) a += *reinterpret_cast<const f32x4*>(bias + e);
   if (pos != nullptr) {
     const long b = m / S, s = m - b * S;
@@ -1438,9 +1438,32 @@ __global__ __launch_bounds__(256) void patch_sum_kernel(const float* __restrict_
 }
 }  // namespace
 
+namespace {
+// K parts per patch row: the 16 GEMMs of the launch are 16 x (row tiles) x (channel tiles) workgroups, one per CU -- 304 at bs 16
+// (two rounds of the 256 CUs for 1.19 rounds of work), 32 at bs 1 (a 64-step chain on an eighth of the chip).  Every GEMM's
+// K = 16 C can be cut in 2 or 4 parts (raw partial slabs, summed in a fixed order by patch_sum_kernel like the 16 patch rows
+// themselves); the part count is the one with the least modelled time: rounds x (K steps of ~1.7 us + ~6 us of prologue and
+// stores) + the slabs written and read back at ~3 TB/s.  (bs 16: 256 -> 233 us modelled with 2 parts; bs 1: 117 -> 40 with 4.)
+int patch_ksplit(int B, int C, int h, int w, int E) {
+  const long M = (long)B * (h / 16) * (w / 16);
+  const long tiles = 16L * ocv_cdiv(M, CBM) * ocv_cdiv(E, CBN);
+  const int steps = 16 * C / CBK;
+  static const int forced = [] { const char* e = getenv("OCV_PATCH_KSPLIT"); return e ? atoi(e) : 0; }();   // A/B switch: 1, 2 or 4
+  if ((forced == 1 || forced == 2 || forced == 4) && steps / forced >= 16) return forced;
+  int best = 1;
+  double cost = 0.0;
+  for (int ks = 1; ks <= 4; ks *= 2) {
+    if (ks > 1 && steps / ks < 16) break;
+    const double c = (double)((tiles * ks + 255) / 256) * (1.7 * steps / ks + 6.0) + 16.0 * ks * (double)M * E * 8.0 / 3.0e6;
+    if (ks == 1 || c < 0.95 * cost) { cost = c; best = ks; }
+  }
+  return best;
+}
+}  // namespace
+
 extern "C" size_t ocv_patch_embed_split_workspace_bytes(int B, int C, int h, int w, int E) {
   if (B < 1 || C < 32 || C % 32 != 0 || h < 16 || w < 16 || E < 8 || E % 8 != 0) return 0;
-  return (size_t)16 * B * (h / 16) * (w / 16) * E * sizeof(float);
+  return (size_t)16 * patch_ksplit(B, C, h, w, E) * B * (h / 16) * (w / 16) * E * sizeof(float);
 }
 
 extern "C" int ocv_patch_embed_split_fwd(const void* x_hl, int C, const void* w_hi, const void* w_lo, const float* oscale, int f16,
@@ -1460,7 +1483,8 @@ extern "C" int ocv_patch_embed_split_fwd(const void* x_hl, int C, const void* w_
   const int gh = h / 16, gw = w / 16;
   ConvArgs a{};
   a.xhl = (const __bf16*)x_hl; a.whi = (const __bf16*)w_hi; a.wlo = (const __bf16*)w_lo; a.y = (float*)workspace;
-  a.C1 = 16 * C; a.Cin = 16 * C; a.Cout = E; a.H = B * gh; a.W = gw; a.ks = 1; a.act = OCV_ACT_NONE; a.ksplit = 1;
+  a.C1 = 16 * C; a.Cin = 16 * C; a.Cout = E; a.H = B * gh; a.W = gw; a.ks = 1; a.act = OCV_ACT_NONE;
+  a.ksplit = patch_ksplit(B, C, h, w, E);                                     // K parts per patch row (slab (ky, part) at index ky ksplit + part)
   a.Cpo = (E + 31) / 32 * 32;
   a.f16 = f16; a.oscale = oscale;                                             // (the 16 GEMMs share their output channels' scales)
   a.zbatch = 16;
@@ -1473,7 +1497,7 @@ extern "C" int ocv_patch_embed_split_fwd(const void* x_hl, int C, const void* w_
   if (rc != 0) return rc;
   const long M = (long)B * gh * gw;
   hipLaunchKernelGGL(patch_sum_kernel, dim3((unsigned)((M * (E / 4) + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)workspace, M, E, gh * gw, bias, pos, pos_bs, out);
+                     (const float*)workspace, M, E, gh * gw, bias, pos, pos_bs, out, 16 * a.ksplit);
   OCV_CHECK_LAUNCH("ocv_patch_embed_split_fwd(sum)");
   return 0;
 }

@@ -498,11 +498,12 @@ def test_patch_embed(ops, B, h, w, pos_mode):
 
 @pytest.mark.parametrize("B,C,h,w,E,pos_mode", [(2, 128, 64, 96, 128, "shared"), (16, 128, 240, 320, 128, "shared"),
                                                 (1, 64, 37, 53, 40, "none"), (3, 32, 48, 50, 128, "batched"),
-                                                (2, 128, 176, 608, 128, "shared")])
+                                                (2, 128, 176, 608, 128, "shared"), (1, 128, 240, 320, 128, "shared"),
+                                                (2, 128, 240, 320, 128, "batched")])
 def test_patch_embed_split(ops, B, C, h, w, E, pos_mode):
     """ocv_patch_embed_split_fwd (16 split-bf16 GEMMs over the hl32 map in one launch + fixed-order sum) against the
     convolution in fp64, at the split-bf16 convolutions' bar; ragged widths / heights (B = 1), KITTI's half-resolution map;
-    and bitwise repeatable."""
+    the validation loop's batches of 1 and 2 (K cut in 4 parts per patch row: 64 slabs); and bitwise repeatable."""
     x = rnd("x", (B, C, h, w), 1)
     wt, b = rnd("w", (E, C, 16, 16), 2, 1 / math.sqrt(C * 256)), rnd("b", (E,), 3, 0.1)
     S = (h // 16) * (w // 16)
