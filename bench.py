@@ -279,7 +279,8 @@ def kernel_report(timing, a, B, wl, split_f16=True):
     if os.path.exists(tpath):
         traffic_all = json.load(open(tpath))
     # the roofline launch is a FIXED one -- the eager islands of the graph replay, the direct 128 -> 128 convolution at
-    # half resolution (three launches per step, the longest single launches of the step since the first convolution of
+    # half resolution (three launches per step -- two of them islands: the heads' conv3x3 stays in the graph, beside the token
+    # chain (hip_ops.head_overlap_enabled) --, the longest single launches of the step since the first convolution of
     # every decoder stage runs at the low resolution; profiles/roofline_traffic.json holds the PMC traffic of this launch)
     island_shape = f"B{B} {wl.h}x{wl.w} 128->128 k3"
     direct = [c for c in convs if c["form"] == "direct" and " k3" in c["shape"]]
@@ -499,8 +500,9 @@ def main():
             from objcavit_amd.graph import GraphedGraphBins
             try:
                 # capture = part of warm-up; each slot clones img as its graph's static input.  The longest launches of the
-                # step (the three direct 128 -> 128 3x3 convolutions at half resolution: second convolution of the last
-                # decoder stage, the decoder's conv3, the head's conv3x3) stay outside the graph so that they are timed live.
+                # step (the direct 128 -> 128 3x3 convolutions at half resolution: second convolution of the last decoder
+                # stage and the decoder's conv3) stay outside the graph so that they are timed live; the third launch of
+                # that shape, the heads' conv3x3, is captured: it runs beside the token chain's side stream.
                 n = max(1, a.inflight)
                 slots = [GraphedGraphBins(model, img, eager_ops=(island,)) for _ in range(n)]
                 # a slot is replayed on the stream it was captured on: creating further streams can put two slots on
@@ -539,7 +541,7 @@ def main():
     # With several batches in flight the first ROOFLINE_STEPS steps of the timed region run ALONE on slot 0 (the other
     # slots wait for them): their event pairs are the live kernel timings of the JSON; the remaining steps are pipelined
     # and carry no events (a launch bracketed on one stream while another stream shares the chip would time the sharing).
-    ROOFLINE_STEPS = max(1, min(2, a.steps // 10))     # one step = three launches of the roofline convolution + one bin head
+    ROOFLINE_STEPS = max(1, min(2, a.steps // 10))     # one step = two event-timed launches of the roofline convolution + one bin head
     if not a.stub_cpu:
         hip_ops.enable_timing(True)
     records = []
@@ -605,9 +607,22 @@ def main():
                 sustained_s = time.perf_counter() - t1
                 sustained_ips = n_sus * B / sustained_s
                 log(f"sustained leg: {n_sus} steps in {sustained_s:.2f} s = {sustained_ips:.1f} img/s")
-                hip_ops.enable_timing(True)
-                for _ in range(3):
-                    model(img)
+                # per-kernel table: one stream (a launch bracketed while a side stream shares the chip would time the sharing)
+                saved = {k: os.environ.get(k) for k in ("OCV_HEAD_OVERLAP", "OCV_TOKEN_OVERLAP")}
+                os.environ.update(OCV_HEAD_OVERLAP="0", OCV_TOKEN_OVERLAP="0")
+                try:
+                    for _ in range(2):
+                        model(img)                       # (scratch of the one-stream order: allocated outside the timed pass)
+                    torch.cuda.synchronize()
+                    hip_ops.enable_timing(True)
+                    for _ in range(3):
+                        model(img)
+                finally:
+                    for k, v in saved.items():
+                        if v is None:
+                            os.environ.pop(k, None)
+                        else:
+                            os.environ[k] = v
                 extra = hip_ops.timing_results()
                 timing = {k: (v[0] / 3 * a.steps, v[1]) for k, v in extra.items()}
             else:

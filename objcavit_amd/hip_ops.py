@@ -82,6 +82,8 @@ class IslandHook:
 class _Tls(threading.local):
     def __init__(self):
         self.island_hook = None
+        self.islands_off = 0                 # > 0: inside islands_suspended()
+        self.single_chain = 0                # > 0: inside single_chain() -- no further forks
         self.ws_stack = None                 # workspace stores of this thread (bottom = the module-level store)
 
 
@@ -103,11 +105,24 @@ class island_scope:
         return False
 
 
+class islands_suspended:
+    """``with islands_suspended():`` launches issued inside stay IN the capture even when their name is an island's: for a launch
+    that runs beside a forked stream (a capture cannot end while a fork is open)."""
+
+    def __enter__(self):
+        _TLS.islands_off += 1
+        return self
+
+    def __exit__(self, *exc):
+        _TLS.islands_off -= 1
+        return False
+
+
 def launch(name: str, call) -> None:
     """Issue one C-ABI launch (``call`` enqueues it on the current stream) under the timing hook -- or hand it to the
     graph capturer of this thread as an eager island."""
     hook = _TLS.island_hook
-    if hook is not None and name in hook.names:
+    if hook is not None and name in hook.names and not _TLS.islands_off:
         hook.on_break(name, call)
         return
     with timed(name):
@@ -137,7 +152,7 @@ class timed:
 # ---------------------------------------------------------------------------
 # a second stream for work that is independent of the main chain (object tokens beside image tokens)
 # ---------------------------------------------------------------------------
-_SIDE: Dict[int, "torch.cuda.Stream"] = {}
+_SIDE: Dict[Tuple[int, int], "torch.cuda.Stream"] = {}
 
 
 def token_overlap_enabled() -> bool:
@@ -148,15 +163,58 @@ def token_overlap_enabled() -> bool:
     mode = os.environ.get("OCV_TOKEN_OVERLAP", "1")
     if mode not in ("0", "1"):
         raise ValueError(f"OCV_TOKEN_OVERLAP={mode!r}: expected '1' (default) or '0'")
+    return mode == "1" and not _TLS.single_chain
+
+
+class single_chain:
+    """``with single_chain():`` the code inside already runs beside another branch of the forward (the token chain beside the heads'
+    convolution): it forks no further side stream (``token_overlap_enabled`` is False inside).  Two parallel branches are all a
+    captured forward ever has -- a third one replays pathologically slowly or crashes hipStreamEndCapture on this ROCm
+    (``head_overlap_enabled``)."""
+
+    def __enter__(self):
+        _TLS.single_chain += 1
+        return self
+
+    def __exit__(self, *exc):
+        _TLS.single_chain -= 1
+        return False
+
+
+def object_prepass_enabled() -> bool:
+    """OCV_OBJ_OVERLAP: '1' (default since round 4) = where the object branch does not read the image features (the MLP positional
+    strategies) it is issued at the top of the forward, on a side stream beside the encoder (GraphBins.forward_until_head); '0' =
+    behind the decoder (beside the image tokens' stack with OCV_TOKEN_OVERLAP=1)."""
+    mode = os.environ.get("OCV_OBJ_OVERLAP", "1")
+    if mode not in ("0", "1"):
+        raise ValueError(f"OCV_OBJ_OVERLAP={mode!r}: expected '1' (default) or '0'")
     return mode == "1"
 
 
-def side_stream(device: torch.device) -> "torch.cuda.Stream":
-    """The process's side stream of ``device`` (created on first use; its scratch is keyed by stream like everyone's)."""
+def head_overlap_enabled() -> bool:
+    """OCV_HEAD_OVERLAP: '1' (default) = the heads' 3x3 convolution over the decoder's map (4800 workgroups, ~0.93 ms at bs 16)
+    is issued on the main stream while the image-token chain -- patch embedding, self-attention stack, cross-attention, bin
+    regressor: ~25 launches of 2 - 300 workgroups, ~0.6 ms of mostly idle chip -- runs on a second side stream; joined in front of
+    the bin head, the first consumer of both.  '0' = the tokens first, then the convolution (A/B).
+    Only with ONE side chain behind the decoder (the object branch already issued beside the encoder, or a model without one): a
+    captured forward with the object chain, the token chain and the convolution as three parallel branches replays 6 ms SLOWER
+    per step on this ROCm (23.2 vs 16.6 ms at bs 16, 8.7 vs 3.5 ms at bs 1: profiles/r04_head_overlap.txt), so that shape is
+    never built.  Measured gain, sequential bs 16: 17.41 -> 17.24 ms on one box (+1.0 %); bs 1 and three batches in flight:
+    unchanged.  The token kernels hold 52 KB of LDS per workgroup and cannot share a CU with the convolution's 144 KB: beside it
+    they run ~2x slower and the convolution 1.18 instead of 0.93 ms -- which is why the gain is a third of the chain's length."""
+    mode = os.environ.get("OCV_HEAD_OVERLAP", "1")
+    if mode not in ("0", "1"):
+        raise ValueError(f"OCV_HEAD_OVERLAP={mode!r}: expected '1' (default) or '0'")
+    return mode == "1"
+
+
+def side_stream(device: torch.device, which: int = 0) -> "torch.cuda.Stream":
+    """The process's side streams of ``device`` (created on first use; scratch is keyed by stream like everyone's): 0 = the object
+    branch, 1 = the token chain beside the heads' convolution."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    st = _SIDE.get(idx)
+    st = _SIDE.get((idx, which))
     if st is None:
-        st = _SIDE[idx] = torch.cuda.Stream(device=idx)
+        st = _SIDE[(idx, which)] = torch.cuda.Stream(device=idx)
     return st
 
 

@@ -134,17 +134,15 @@ class GraphBins(nn.Module):
         if not isinstance(object_features, PaddedObjects):
             object_features = [nf.float() for nf in object_features]
         pre = None
-        if image.is_cuda and self.objcavit.can_prepass() and os.environ.get("OCV_OBJ_OVERLAP", "0") == "1":
-            # Opt-in (OCV_OBJ_OVERLAP=1).  The object branch (embedding, positional MLP, first self-attention stack:
-            # ~30 launches of a few workgroups each, ~0.4 ms) does not depend on the image: here it runs on a second
-            # stream beside the encoder and is joined before the decoder starts (inside one hipGraph segment when the
-            # forward is captured).  Measured at bs = 16, same box, alternating runs: 21.71 / 21.76 ms per step with the
-            # overlap, 21.67 / 21.61 without -- the encoder's launches fill the chip and the extra branch only
-            # perturbs them -- so the default keeps the single stream.
+        if image.is_cuda and self.objcavit.can_prepass() and hip_ops.object_prepass_enabled():
+            # The object branch (embedding, positional MLP, first self-attention stack: ~20 launches of a few workgroups each,
+            # ~0.5 ms) does not depend on the image: it runs on a second stream beside the encoder and is joined before the decoder
+            # starts (inside one hipGraph segment when the forward is captured).  On its own that gains nothing (round 2, bs 16,
+            # alternating runs: 21.71 / 21.76 ms with it, 21.67 / 21.61 without -- the encoder's launches fill the chip); it is the
+            # default since round 4 because it leaves ONE side chain behind the decoder, the image tokens', which then runs beside
+            # the heads' 3x3 convolution (hip_ops.head_overlap_enabled; ObjCAViT.forward_parts).
             main = torch.cuda.current_stream(image.device)
-            side = self.__dict__.get("_side_stream")
-            if side is None or side.device != image.device:
-                side = self.__dict__["_side_stream"] = torch.cuda.Stream(device=image.device)
+            side = hip_ops.side_stream(image.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 pre = self.objcavit.object_prepass(object_features, object_xywh_list, image.device, pad_objects_to)

@@ -460,20 +460,38 @@ class ObjCAViT(nn.Module):
         gh, gw = image_features.shape[2] // 16, image_features.shape[3] // 16
         if gh * gw < self.n_query_channels + 1:
             raise ValueError(f"need at least {self.n_query_channels + 1} patches, got {gh * gw}")
-        tok = hip_ops.patch_embed_auto(image_features, self.image_embedding_convPxP.weight.detach(),
-                                       self.image_embedding_convPxP.bias.detach(), self._image_pos(image_features, gh, gw),
-                                       self._w_cl, self._w_pe)
-
-        # 3. self-attention / cross-attention stacks (reference :366-368)
-        tok, obj = self.saca_1(tok, emb, want_object_output=self.use_2_saca, pre_obj=pre_obj, pad_objects_to=pad_objects_to,
-                               counts=po.counts, group=object_group, pre_join=side)
-        if self.use_2_saca:
-            tok, obj = self.saca_2(tok, obj, want_object_output=False)
-
-        # 4. heads (reference :373-388)
-        feat = self._conv3x3_nhwc(image_features)
         ds = self.args[self.args.basic.dataset]
-        y = regress_bin_widths(self.regressor, tok[:, 0, :], self.norm, (ds.min_depth, ds.max_depth))
+
+        def tokens():
+            tok = hip_ops.patch_embed_auto(image_features, self.image_embedding_convPxP.weight.detach(),
+                                           self.image_embedding_convPxP.bias.detach(), self._image_pos(image_features, gh, gw),
+                                           self._w_cl, self._w_pe)
+            # 3. self-attention / cross-attention stacks (reference :366-368)
+            tok, obj = self.saca_1(tok, emb, want_object_output=self.use_2_saca, pre_obj=pre_obj, pad_objects_to=pad_objects_to,
+                                   counts=po.counts, group=object_group, pre_join=side)
+            if self.use_2_saca:
+                tok, obj = self.saca_2(tok, obj, want_object_output=False)
+            # 4. heads (reference :373-388): the bin regressor on token 0
+            return tok, regress_bin_widths(self.regressor, tok[:, 0, :], self.norm, (ds.min_depth, ds.max_depth))
+
+        if image_features.is_cuda and side is None and hip_ops.head_overlap_enabled():
+            # the heads' 3x3 convolution does not read the tokens: it fills the chip on this stream while the token chain's small
+            # launches run on a second side stream.  Never beside an object branch forked above (three parallel branches replay
+            # pathologically slowly from a hipGraph: hip_ops.head_overlap_enabled): only when that branch was issued by the caller
+            # (``pre``, beside the encoder) or runs in line
+            main = torch.cuda.current_stream(dev)
+            tst = hip_ops.side_stream(dev, 1)
+            tst.wait_stream(main)
+            with torch.cuda.stream(tst), hip_ops.single_chain():       # (a second SA/CA stack forks nothing in here)
+                tok, y = tokens()
+            with hip_ops.islands_suspended():                          # (a capture cannot be cut while the fork is open)
+                feat = self._conv3x3_nhwc(image_features)
+            main.wait_stream(tst)
+            for t in (tok, y):
+                t.record_stream(main)
+        else:
+            tok, y = tokens()
+            feat = self._conv3x3_nhwc(image_features)
         return y, feat, tok[:, 1:self.n_query_channels + 1, :]
 
     def _conv3x3_nhwc(self, x):

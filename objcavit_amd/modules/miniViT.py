@@ -55,11 +55,28 @@ class mViT(nn.Module):
     def forward_parts(self, x: torch.Tensor, depth_range=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """-> (bin_widths_normed B x dim_out, conv3x3 features B x E x h x w, queries B x n_query x E (view)).
         Used by AdaBins.forward so that the range-attention maps are never materialised (``depth_range``: regress_bin_widths)."""
-        tok = self.patch_transformer.forward_batch_first(x)           # B x S x E
-        if tok.shape[1] < self.n_query_channels + 1:
-            raise ValueError(f"need at least {self.n_query_channels + 1} patches, got {tok.shape[1]}")
-        feat = self._conv3x3_nhwc(x)
-        y = regress_bin_widths(self.regressor, tok[:, 0, :], self.norm, depth_range)
+        def tokens():
+            tok = self.patch_transformer.forward_batch_first(x)       # B x S x E
+            if tok.shape[1] < self.n_query_channels + 1:
+                raise ValueError(f"need at least {self.n_query_channels + 1} patches, got {tok.shape[1]}")
+            return tok, regress_bin_widths(self.regressor, tok[:, 0, :], self.norm, depth_range)
+
+        if x.is_cuda and hip_ops.head_overlap_enabled():
+            # the 3x3 convolution fills the chip on this stream while the token chain's small launches run beside it
+            # (hip_ops.head_overlap_enabled; joined in front of the bin head)
+            main = torch.cuda.current_stream(x.device)
+            tst = hip_ops.side_stream(x.device, 1)
+            tst.wait_stream(main)
+            with torch.cuda.stream(tst):
+                tok, y = tokens()
+            with hip_ops.islands_suspended():
+                feat = self._conv3x3_nhwc(x)
+            main.wait_stream(tst)
+            for t in (tok, y):
+                t.record_stream(main)
+        else:
+            tok, y = tokens()
+            feat = self._conv3x3_nhwc(x)
         return y, feat, tok[:, 1:self.n_query_channels + 1, :]
 
     def _conv3x3_nhwc(self, x):

@@ -183,9 +183,11 @@ def test_graphbins_with_table_object_provider():
     assert rel_dev(out.bin_edges, ref_edges) < 1e-4 and max_rel(out.depth_pred, ref_depth) < 1e-3
 
 
-def test_object_branch_on_second_stream_equals_single_stream(monkeypatch):
-    """OCV_OBJ_OVERLAP=1 issues the object embedding + first self-attention stack on a second stream beside the
-    encoder (eager and captured): same bits as the single-stream forward, ragged object counts included."""
+def test_side_streams_equal_the_single_stream(monkeypatch):
+    """The forward's side streams -- OCV_OBJ_OVERLAP (object branch beside the encoder), OCV_TOKEN_OVERLAP (object branch beside the
+    image tokens), OCV_HEAD_OVERLAP (token chain beside the heads' 3x3 convolution) -- in every combination, eager and captured: the
+    same kernels on the same operands, so the same bits as the single-stream forward, ragged object counts included."""
+    import itertools
     from objcavit_amd.graph import GraphedGraphBins
     from objcavit_amd.modules.GraphBins import GraphBins, SyntheticObjectProvider
     H, W = 352, 384
@@ -196,20 +198,31 @@ def test_object_branch_on_second_stream_equals_single_stream(monkeypatch):
     img = gen.randn("img", (2, 3, H, W), 57).cuda()
     feats = [gen.randn("f0", (5, 512), 1).cuda(), gen.randn("f1", (2, 512), 2).cuda()]
     boxes = [torch.rand(5, 4, device="cuda") * 100 + 10, torch.rand(2, 4, device="cuda") * 100 + 10]
-    monkeypatch.setenv("OCV_OBJ_OVERLAP", "0")
+
+    def switches(obj, tok, head):
+        monkeypatch.setenv("OCV_OBJ_OVERLAP", obj)
+        monkeypatch.setenv("OCV_TOKEN_OVERLAP", tok)
+        monkeypatch.setenv("OCV_HEAD_OVERLAP", head)
+
+    switches("0", "0", "0")
     ref = m(img).depth_pred.clone()
     ref_r = m(img, [f.clone() for f in feats], [b.clone() for b in boxes]).depth_pred.clone()
-    monkeypatch.setenv("OCV_OBJ_OVERLAP", "1")
-    for _ in range(2):
-        assert torch.equal(m(img).depth_pred, ref)
-        assert torch.equal(m(img, [f.clone() for f in feats], [b.clone() for b in boxes]).depth_pred, ref_r)
-    g = GraphedGraphBins(m, img)
-    assert torch.equal(g(img).depth_pred, ref) and torch.equal(g(img).depth_pred, ref)
+    for obj, tok, head in itertools.product("01", "01", "01"):
+        switches(obj, tok, head)
+        for _ in range(2):
+            assert torch.equal(m(img).depth_pred, ref), (obj, tok, head)
+            assert torch.equal(m(img, [f.clone() for f in feats], [b.clone() for b in boxes]).depth_pred, ref_r), (obj, tok, head)
+        g = GraphedGraphBins(m, img)
+        assert torch.equal(g(img).depth_pred, ref) and torch.equal(g(img).depth_pred, ref), (obj, tok, head)
 
 
-def test_graph_replay_with_eager_island_equals_eager_dispatch():
+@pytest.mark.parametrize("head_overlap", ["1", "0"])
+def test_graph_replay_with_eager_island_equals_eager_dispatch(monkeypatch, head_overlap):
     """GraphedGraphBins: graph segments + an eager island + the eager head give bit-identical depth to plain dispatch,
-    for the captured image and for new contents of the static input."""
+    for the captured image and for new contents of the static input.  With the token chain on a side stream beside the heads'
+    3x3 convolution (the default) that launch stays inside the capture -- a capture cannot be cut while a fork is open."""
+    monkeypatch.setenv("OCV_HEAD_OVERLAP", head_overlap)
+    n_isl = 2 if head_overlap == "1" else 3
     from objcavit_amd import hip_ops
     from objcavit_amd.graph import GraphedGraphBins
     from objcavit_amd.modules.GraphBins import GraphBins, SyntheticObjectProvider
@@ -222,9 +235,10 @@ def test_graph_replay_with_eager_island_equals_eager_dispatch():
     ref = m(img).depth_pred.clone()
     island = f"conv3x3|2,{H // 2},{W // 2},128,128"          # three launches per forward: decoder up4 / conv3, head conv3x3
     g = GraphedGraphBins(m, img, eager_ops=(island,))
-    # three islands + three graph segments: the EMPTY segment between up4's second convolution and conv3 (two adjacent
-    # islands) is dropped at capture instead of being replayed on every step
-    assert g.islands == [island] * 3 and len(g.segments) == 6 and g.empty_segments_dropped == 1
+    # the EMPTY segment between up4's second convolution and conv3 (two adjacent islands) is dropped at capture instead of being
+    # replayed on every step; so is the one behind the heads' convolution when that is an island (nothing is launched behind it)
+    n_graphs, n_empty = (2, 1) if head_overlap == "1" else (2, 2)
+    assert g.islands == [island] * n_isl and len(g.segments) == n_isl + n_graphs and g.empty_segments_dropped == n_empty
     assert torch.equal(g(img).depth_pred, ref)
     img2 = gen.randn("img2", (2, 3, H, W), 56).cuda()
     ref2 = m(img2).depth_pred.clone()
@@ -233,7 +247,7 @@ def test_graph_replay_with_eager_island_equals_eager_dispatch():
     t = hip_ops.timing_results()
     hip_ops.enable_timing(False)
     assert torch.equal(out2.depth_pred, ref2) and not torch.equal(ref2, ref)
-    assert island in t and "bin_head" in t and t[island][0] == 3          # the islands are event-timed on every replay
+    assert island in t and "bin_head" in t and t[island][0] == n_isl      # the islands are event-timed on every replay
     assert torch.equal(g(img).depth_pred, ref)
 
 
