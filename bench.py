@@ -504,6 +504,7 @@ def main():
                 # stage and the decoder's conv3) stay outside the graph so that they are timed live; the third launch of
                 # that shape, the heads' conv3x3, is captured: it runs beside the token chain's side stream.
                 n = max(1, a.inflight)
+                hip_ops.set_batches_in_flight(n)          # (the captures below read it: hip_ops.head_overlap_enabled)
                 slots = [GraphedGraphBins(model, img, eager_ops=(island,)) for _ in range(n)]
                 # a slot is replayed on the stream it was captured on: creating further streams can put two slots on
                 # the same hardware queue (ROCm maps streams round-robin onto GPU_MAX_HW_QUEUES = 4 queues), which

@@ -393,7 +393,176 @@ __device__ __forceinline__ void bh_split8_h2(const float4 u, const float4 v, bh_
   }
 }
 
+// Schedule (round 4).  A 32-bin tile is an MFMA phase (24 MFMAs of 32 cycles: the wavefront is held at the matrix pipe's door for
+// 768 cycles) and a VALU phase (its softmax arithmetic).  The round-3 kernel's two wavefronts per SIMD ran these phases IN STEP --
+// they leave the staging barrier together and do identical work -- so the SQ counters showed matrix pipe busy 40 % + VALU busy
+// 52 % = the SUM of the two, not their overlap.  Here (i) the wavefronts w + 4 start one MFMA phase late (one s_sleep): an offset
+// between two wavefronts that contend for the same pipes round-robin is preserved from tile to tile, so one's softmax runs under the
+// other's MFMAs; (ii) a wavefront alone in its MFMA phase must not wait on LDS, so the weight fragments are fetched
+// ahead through THREE rotating register sets (two steps ahead: a fourth set spills), the first two of the NEXT tile before the VALU phase starts, and the bias (the hi*hi
+// accumulator's initial value) as soon as the accumulators have been read; (iii) the VALU phase is shorter than the MFMA phase: the
+// logits carry a factor log2(e) (folded into the split weights and the bias when they are staged: the softmax is exp2 of
+// differences) and the arithmetic is two-wide packed fp32 -- per tile 8 v_pk_fma + 16 v_pk_add + 8 v_pk_fma, 16 v_exp_f32 and 8
+// v_max3 (~500 cycles) instead of 112 scalar operations + 16 v_exp_f32 (~700).  Measured on the way: the same two groups held half a
+// tile apart by raw s_barriers, weights one step ahead: 0.346 ms against round 3's 0.271 (LDS latency exposed in every K step).
+typedef float bh_f32x2 __attribute__((ext_vector_type(2)));
+
 __global__ __launch_bounds__(512, 2) void bin_head_h2_kernel(const float* __restrict__ feat, const float* __restrict__ Wf,
+                                                             const float* __restrict__ bout,
+                                                             const float* __restrict__ centers, float* __restrict__ depth,
+                                                             long P, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  _Float16* wfrag = reinterpret_cast<_Float16*>(lds);       // [8 bin tiles][8 K steps][hi, lo'][64 lanes][8]
+  float* bl = lds + (NB * CH * 2 * 2) / 4;                   // [256]  bias * log2(e)
+  float* cl = bl + NB;                                       // [256]  bin centres
+  constexpr float LOG2E = 1.44269504088896340736f;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.y;
+  const float* fb = feat + (long)b * CH * P;
+  const float* wb = Wf + (long)b * NB * CH;
+
+  for (int idx = tid; idx < NB * CH / 8; idx += 512) {
+    const int k = idx >> 4, o = idx & 15;                    // bin, K octet
+    bh_h16x8 hi, lo;
+    float4 u = ld4(wb + (long)k * CH + 8 * o), v = ld4(wb + (long)k * CH + 8 * o + 4);
+    u.x *= LOG2E; u.y *= LOG2E; u.z *= LOG2E; u.w *= LOG2E;
+    v.x *= LOG2E; v.y *= LOG2E; v.z *= LOG2E; v.w *= LOG2E;
+    bh_split8_h2(u, v, hi, lo);
+    _Float16* d = wfrag + ((((k >> 5) * 8 + (o >> 1)) * 2) * 64 + (o & 1) * 32 + (k & 31)) * 8;
+    *reinterpret_cast<bh_h16x8*>(d) = hi;
+    *reinterpret_cast<bh_h16x8*>(d + 512) = lo;
+  }
+  if (tid < NB) {
+    bl[tid] = bout[tid] * LOG2E;
+    cl[tid] = centers[(long)b * NB + tid];
+  }
+  __syncthreads();
+
+  float4 cur[16], nxt[16];
+  auto load_px = [&](float4 (&dst)[16], long pix) {
+    const float* src = fb + (pix < P ? pix : 0) * CH + 8 * hh;   // (a pixel beyond the map computes pixel 0 again and stores nothing)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      dst[2 * s] = ld4(src + 16 * s);
+      dst[2 * s + 1] = ld4(src + 16 * s + 4);
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) load_px(cur, (long)tile * TP3 + wave * 32 + l31);
+  for (; tile < ntiles; tile += gridDim.x) {
+    const long pix = (long)tile * TP3 + wave * 32 + l31;
+    const int tn = tile + gridDim.x;
+    bh_h16x8 ph[8], pl[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) bh_split8_h2(cur[2 * s], cur[2 * s + 1], ph[s], pl[s]);
+    __builtin_amdgcn_sched_barrier(0);                       // (the raw values are dead before the next tile's are asked for)
+    if (tn < ntiles) load_px(nxt, (long)tn * TP3 + wave * 32 + l31);
+
+    // weight fragments of (bin tile t, K step s): hi at wfrag + ((t 8 + s) 2) 512 + lane 8, lo' 512 halves further
+    bh_h16x8 wh[3], wl[3];                                   // three rotating sets: K step s lives in set s % 3
+    auto fetch_w = [&](int t, int s_) {
+      const _Float16* wf = wfrag + ((t * 8 + s_) * 2) * 512 + lane * 8;
+      wh[s_ % 3] = *reinterpret_cast<const bh_h16x8*>(wf);
+      wl[s_ % 3] = *reinterpret_cast<const bh_h16x8*>(wf + 512);
+    };
+    auto fetch_bias = [&](int t, f32x16& a1) {               // accumulator register r = bin acc_row(r, hh): four runs of four
+      const float* bp = bl + t * 32 + 4 * hh;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bp + 8 * g);
+        a1[4 * g] = b4[0]; a1[4 * g + 1] = b4[1]; a1[4 * g + 2] = b4[2]; a1[4 * g + 3] = b4[3];
+      }
+    };
+    // the 24 MFMAs of bin tile t: a1 (preloaded with the bias) += hi hi, a2 = 2^11 (lo hi + hi lo); weights two K steps ahead
+    // (the first two steps' fetch is this tile's own: the softmax instructions interleaved with it cover their latency)
+    auto mma_tile = [&](int t, f32x16& a1, f32x16& a2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a2[r] = 0.f;
+      fetch_w(t, 0); fetch_w(t, 1);
+#pragma unroll
+      for (int s_ = 0; s_ < 8; ++s_) {
+        if (s_ + 2 < 8) fetch_w(t, s_ + 2);
+        a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[s_ % 3], ph[s_], a2, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s_ % 3], ph[s_], a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s_ % 3], pl[s_], a2, 0, 0, 0);
+      }
+    };
+    float m_run = -__builtin_inff();                         // online softmax over this lane's 16 bins per tile, in base 2
+    bh_f32x2 l2 = {0.f, 0.f}, d2 = {0.f, 0.f};               // (its pixel's other 16 bins sit in lane ^ 32)
+    // softmax arithmetic of bin tile t; afterwards a1 holds the bias of tile tb (the accumulator's next initial value)
+    auto softmax_tile = [&](int t, f32x16& a1, const f32x16& a2, int tb) {
+      bh_f32x2 lg[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        lg[i] = bh_f32x2{a2[2 * i], a2[2 * i + 1]} * (1.0f / 2048.0f) + bh_f32x2{a1[2 * i], a1[2 * i + 1]};
+      fetch_bias(tb, a1);
+      float tmax = fmaxf(lg[0].x, lg[0].y);
+#pragma unroll
+      for (int i = 1; i < 8; ++i) tmax = fmaxf(fmaxf(tmax, lg[i].x), lg[i].y);
+      tmax = xor32_max(tmax);
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      const float* cp = cl + t * 32 + 4 * hh;
+      bh_f32x2 ps = {0.f, 0.f}, ds = {0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 c4 = *reinterpret_cast<const f32x4*>(cp + 8 * g);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const bh_f32x2 e = lg[2 * g + j] - bh_f32x2{m_new, m_new};
+          const bh_f32x2 pr = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+          ps += pr;
+          ds += pr * bh_f32x2{c4[2 * j], c4[2 * j + 1]};
+        }
+      }
+      l2 = l2 * alpha + ps;
+      d2 = d2 * alpha + ds;
+      m_run = m_new;
+    };
+    // one MFMA, one LDS read, four VALU slots -- 24 times: the program order of a fused half step
+#define BH_INTERLEAVE()                                                   \
+  _Pragma("unroll") for (int q_ = 0; q_ < 24; ++q_) {                     \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                    \
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                    \
+  }
+    f32x16 A1, A2, B1, B2;
+    fetch_bias(0, A1);
+    fetch_bias(1, B1);
+    mma_tile(0, A1, A2);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (int t = 0; t < NB / 32 - 2; t += 2) {
+      mma_tile(t + 1, B1, B2);
+      softmax_tile(t, A1, A2, t + 2);
+      BH_INTERLEAVE();
+      __builtin_amdgcn_sched_barrier(0);
+      mma_tile(t + 2, A1, A2);
+      softmax_tile(t + 1, B1, B2, t + 3);
+      BH_INTERLEAVE();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mma_tile(NB / 32 - 1, B1, B2);
+    softmax_tile(NB / 32 - 2, A1, A2, 0);
+    BH_INTERLEAVE();
+    __builtin_amdgcn_sched_barrier(0);
+    softmax_tile(NB / 32 - 1, B1, B2, 1);
+    __builtin_amdgcn_sched_barrier(0);
+#undef BH_INTERLEAVE
+    const float l = xor32_sum(l2.x + l2.y), d = xor32_sum(d2.x + d2.y);
+    if (hh == 0 && pix < P) depth[(long)b * P + pix] = d / l;
+
+    if (tn < ntiles) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) cur[s] = nxt[s];
+    }
+  }
+}
+
+// (A/B only, OCV_BH_VARIANT=r3: the round-3 schedule)
+__global__ __launch_bounds__(512, 2) void bin_head_h2_r3_kernel(const float* __restrict__ feat, const float* __restrict__ Wf,
                                                              const float* __restrict__ bout,
                                                              const float* __restrict__ centers, float* __restrict__ depth,
                                                              long P, int ntiles) {
@@ -617,6 +786,16 @@ extern "C" int ocv_bin_head_folded_fwd(const float* feat, int channels_last, con
     if (perh > nt) perh = nt;
     if (perh < 1) perh = 1;
     const size_t ldsh = (size_t)NB * CH * 2 * 2 + 2 * NB * sizeof(float);
+    static const bool r3 = getenv("OCV_BH_VARIANT") != nullptr && strcmp(getenv("OCV_BH_VARIANT"), "r3") == 0;
+    if (r3) {
+      static bool attr4 = false;
+      if (!attr4) {
+        (void)hipFuncSetAttribute((const void*)bin_head_h2_r3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr4 = true;
+      }
+      hipLaunchKernelGGL(bin_head_h2_r3_kernel, dim3(perh, B), dim3(512), ldsh, (hipStream_t)stream, feat, Wf, bout, centers, depth,
+                         (long)P, nt);
+    } else
     hipLaunchKernelGGL(bin_head_h2_kernel, dim3(perh, B), dim3(512), ldsh, (hipStream_t)stream, feat, Wf, bout, centers, depth,
                        (long)P, nt);
     OCV_CHECK_LAUNCH("ocv_bin_head_folded_fwd(h2)");

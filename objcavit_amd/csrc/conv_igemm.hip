@@ -70,6 +70,9 @@ struct ConvArgs {
   int zbatch;                           // conv_split_dma_kernel: > 1 = that many independent GEMMs in one launch (the 16
   long xz_bytes, wz_bytes;              // Winograd positions): operand z at xhl + z xz_bytes / whi, wlo + z wz_bytes, raw fp32
                                         // result at y + (z ksplit + khalf) * M * Cout
+  int zflat;                            // conv_split_dma_kernel, 1 x 1 only: > 0 = the zbatch GEMMs are the consecutive pieces of ONE
+                                        // K axis (the patch embedding's 16 patch rows): its zbatch * Cp / 32 steps are cut in zflat
+                                        // equal parts, one workgroup per (tile, part), raw fp32 result of part k at y + k * M * Cout
   int f16;                              // conv_split_dma_kernel: != 0 = the operands are fp16 (hi, lo) pairs (conv_split_dma_kernel<true>)
                                         // and so is the split copy of the output (yhl)
   const float* oscale;                  // nullable [Cout]: raw accumulators are multiplied by it before bias / activation (the
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
 
-  const int ntile = p.mtiles * p.ntiles, nwg = ntile * p.ksplit * p.zbatch;
+  const int ntile = p.mtiles * p.ntiles, nwg = ntile * (p.zflat > 0 ? p.zflat : p.ksplit * p.zbatch);
   int wg = blockIdx.x;
   {
     const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
@@ -486,17 +489,27 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
   }
   const int kz = wg / ntile;                                     // (GEMM of the batch, K part) of this workgroup
   wg -= kz * ntile;
-  const int zb = kz / p.ksplit, kh = kz - zb * p.ksplit;         // kh: 0 unless ksplit == 2; zb: 0 unless zbatch > 1
-  const char* const xz = (const char*)p.xhl + (long)zb * p.xz_bytes;
-  const char* const whz = (const char*)p.whi + (long)zb * p.wz_bytes;
-  const char* const wlz = (const char*)p.wlo + (long)zb * p.wz_bytes;
+  const int taps = p.ks * p.ks, pad = p.ks >> 1;
+  const int nchunk = p.Cp / CBK;
+  int zb, ch0, nsteps;
+  if (p.zflat > 0) {                                             // steps [s0, s1) of the zbatch GEMMs' chunks laid end to end
+    const int S = p.zbatch * nchunk;
+    const int s0 = (int)((long)S * kz / p.zflat), s1 = (int)((long)S * (kz + 1) / p.zflat);
+    zb = s0 / nchunk;
+    ch0 = s0 - zb * nchunk;
+    nsteps = s1 - s0;
+  } else {
+    zb = kz / p.ksplit;                                          // zb: 0 unless zbatch > 1
+    const int kh = kz - zb * p.ksplit;                           // kh: 0 unless ksplit == 2
+    ch0 = nchunk * kh / p.ksplit;                                // channel chunks [ch0, ch1)
+    nsteps = taps * (nchunk * (kh + 1) / p.ksplit - ch0);
+  }
+  const char* xz = (const char*)p.xhl + (long)zb * p.xz_bytes;   // (advanced by the producers in zflat mode)
+  const char* whz = (const char*)p.whi + (long)zb * p.wz_bytes;
+  const char* wlz = (const char*)p.wlo + (long)zb * p.wz_bytes;
   const int mt = wg / p.ntiles, nt = wg - mt * p.ntiles;
   const long m0 = (long)mt * CBM;
   const int n0 = nt * CBN;
-  const int taps = p.ks * p.ks, pad = p.ks >> 1;
-  const int nchunk = p.Cp / CBK;
-  const int ch0 = nchunk * kh / p.ksplit, ch1 = nchunk * (kh + 1) / p.ksplit;      // channel chunks [ch0, ch1)
-  const int nsteps = taps * (ch1 - ch0);
   const long yoff = (long)kz * p.M * p.Cout;
 
   if (wave < 4) {
@@ -645,16 +658,23 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
   int nx_tap = 0, nx_c0 = ch0 * CBK, nx_ky = 0, nx_kx = 0;
   auto issue_dma = [&](int buf) {
     const int tap = nx_tap, c0 = nx_c0, ky = nx_ky, kx = nx_kx;
+    const char* const xz_ = xz;
+    const char* const whz_ = whz;
+    const char* const wlz_ = wlz;
     if (++nx_kx == p.ks) { nx_kx = 0; ++nx_ky; }
     if (++nx_tap == taps) { nx_tap = 0; nx_ky = 0; nx_c0 += CBK; }
+    if (p.zflat > 0 && nx_c0 == p.Cp) {                          // next step: first chunk of the next GEMM of the batch
+      nx_c0 = 0;
+      xz += p.xz_bytes; whz += p.wz_bytes; wlz += p.wz_bytes;
+    }
     const int soff = (((ky - pad) * p.W + (kx - pad)) * 2 * p.Cp + 2 * c0) * 2;       // hl32: chunk c0 starts at 2 c0
     unsigned char* base = lds + buf * DBUF;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const bool ok = ((tapmask[i] >> tap) & 1u);               // pad channels are zeros in memory: no channel check
       const unsigned off = rbA[i] + (unsigned)soff;
-      const void* sh = ok ? (const void*)(xz + off) : (const void*)ocv_zero_page;
-      const void* sl = ok ? (const void*)(xz + off + 64) : (const void*)ocv_zero_page;   // same 128-B line
+      const void* sh = ok ? (const void*)(xz_ + off) : (const void*)ocv_zero_page;
+      const void* sl = ok ? (const void*)(xz_ + off + 64) : (const void*)ocv_zero_page;   // same 128-B line
       unsigned char* dst = base + (64 * pw + 16 * i) * DROW;
       __builtin_amdgcn_global_load_lds((gptr_t)sh, (lptr_t)dst, 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)sl, (lptr_t)(dst + DA), 16, 0, 0);
@@ -663,8 +683,8 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       unsigned char* dst = base + 2 * DA + (32 * pw + 16 * i) * DROW;
-      __builtin_amdgcn_global_load_lds((gptr_t)(whz + woff + rbB[i]), (lptr_t)dst, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(wlz + woff + rbB[i]), (lptr_t)(dst + DB), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(whz_ + woff + rbB[i]), (lptr_t)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(wlz_ + woff + rbB[i]), (lptr_t)(dst + DB), 16, 0, 0);
     }
   };
 
@@ -781,10 +801,11 @@ int launch_conv(ConvArgs& a, int B, bool in_split, hipStream_t st) {
     }
     if (a.ksplit < 1) a.ksplit = 1;
     if (a.zbatch < 1) a.zbatch = 1;
+    const unsigned parts = a.zflat > 0 ? a.zflat : a.ksplit * a.zbatch;
     if (a.f16)
-      hipLaunchKernelGGL(conv_split_dma_kernel<true>, dim3(a.mtiles * a.ntiles * a.ksplit * a.zbatch), dim3(512), DNBUF * DBUF, st, a);
+      hipLaunchKernelGGL(conv_split_dma_kernel<true>, dim3(a.mtiles * a.ntiles * parts), dim3(512), DNBUF * DBUF, st, a);
     else
-      hipLaunchKernelGGL(conv_split_dma_kernel<false>, dim3(a.mtiles * a.ntiles * a.ksplit * a.zbatch), dim3(512), DNBUF * DBUF, st, a);
+      hipLaunchKernelGGL(conv_split_dma_kernel<false>, dim3(a.mtiles * a.ntiles * parts), dim3(512), DNBUF * DBUF, st, a);
   } else if (in_split) hipLaunchKernelGGL(conv_igemm_kernel<true>, dim3(a.mtiles * a.ntiles), dim3(512), 2 * BUF_BYTES, st, a);
   else hipLaunchKernelGGL(conv_igemm_kernel<false>, dim3(a.mtiles * a.ntiles), dim3(512), 2 * BUF_BYTES, st, a);
   OCV_CHECK_LAUNCH("ocv_conv_nhwc");
@@ -1427,8 +1448,23 @@ __global__ __launch_bounds__(256) void patch_sum_kernel(const float* __restrict_
   if (idx >= M * e4) return;
   const long m = idx / e4;
   const int e = (int)(idx - m * e4) * 4;
-  f32x4 a = {0.f, 0.f, 0.f, 0.f};
-  for (int ky = 0; ky < nslab; ++ky) a += *reinterpret_cast<const f32x4*>(part + ((long)ky * M + m) * E + e);   // (ky, K part) ascending
+  // K pieces in a FIXED order: four interleaved chains (pieces k = j mod 4), eight loads in flight, then (a0 + a1) + (a2 + a3)
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  const float* src = part + m * E + e;
+  const long slab = M * E;
+  int k = 0;
+  for (; k + 8 <= nslab; k += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(src + (k + j) * slab);
+    a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+    a0 += v[4]; a1 += v[5]; a2 += v[6]; a3 += v[7];
+  }
+  for (; k < nslab; ++k) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + k * slab);
+    if ((k & 3) == 0) a0 += v; else if ((k & 3) == 1) a1 += v; else if ((k & 3) == 2) a2 += v; else a3 += v;
+  }
+  f32x4 a = (a0 + a1) + (a2 + a3);
   if (bias != nullptr) a += *reinterpret_cast<const f32x4*>(bias + e);
   if (pos != nullptr) {
     const long b = m / S, s = m - b * S;
@@ -1439,23 +1475,23 @@ __global__ __launch_bounds__(256) void patch_sum_kernel(const float* __restrict_
 }  // namespace
 
 namespace {
-// K parts per patch row: the 16 GEMMs of the launch are 16 x (row tiles) x (channel tiles) workgroups, one per CU -- 304 at bs 16
-// (two rounds of the 256 CUs for 1.19 rounds of work), 32 at bs 1 (a 64-step chain on an eighth of the chip).  Every GEMM's
-// K = 16 C can be cut in 2 or 4 parts (raw partial slabs, summed in a fixed order by patch_sum_kernel like the 16 patch rows
-// themselves); the part count is the one with the least modelled time: rounds x (K steps of ~1.7 us + ~6 us of prologue and
-// stores) + the slabs written and read back at ~3 TB/s.  (bs 16: 256 -> 233 us modelled with 2 parts; bs 1: 117 -> 40 with 4.)
-int patch_ksplit(int B, int C, int h, int w, int E) {
+// K parts of the patch embedding.  Per patch the contraction is over (ky, kx, c): 16 C / 32 K steps for each of the 16 patch rows,
+// 1024 steps at C = 128, which the kernel walks as ONE axis (ConvArgs::zflat) cut in `parts` equal pieces -- one workgroup per (row
+// tile, piece), raw partial slabs summed in a fixed order by patch_sum_kernel.  With the pieces = the 16 patch rows (rounds 2 - 4) bs
+// 16 was 19 x 16 = 304 workgroups: two rounds of the 256 CUs for 1.19 rounds of work (203 us); 13 pieces are 247 workgroups, ONE round
+// of 79 steps.  The part count is the one with the least modelled time: rounds x (steps x ~1.4 us + ~6 us of prologue and stores) + the
+// slabs written and read back at ~3 TB/s; at least 16 steps per piece.
+int patch_parts(int B, int C, int h, int w, int E) {
   const long M = (long)B * (h / 16) * (w / 16);
-  const long tiles = 16L * ocv_cdiv(M, CBM) * ocv_cdiv(E, CBN);
-  const int steps = 16 * C / CBK;
-  static const int forced = [] { const char* e = getenv("OCV_PATCH_KSPLIT"); return e ? atoi(e) : 0; }();   // A/B switch: 1, 2 or 4
-  if ((forced == 1 || forced == 2 || forced == 4) && steps / forced >= 16) return forced;
+  const long tiles = (long)ocv_cdiv(M, CBM) * ocv_cdiv(E, CBN);
+  const int S = 16 * (16 * C / CBK);
+  static const int forced = [] { const char* e = getenv("OCV_PATCH_PARTS"); return e ? atoi(e) : 0; }();   // A/B switch
+  if (forced >= 1 && forced <= 256 && S / forced >= 8) return forced;                                      // (A/B: down to 8 steps)
   int best = 1;
   double cost = 0.0;
-  for (int ks = 1; ks <= 4; ks *= 2) {
-    if (ks > 1 && steps / ks < 16) break;
-    const double c = (double)((tiles * ks + 255) / 256) * (1.7 * steps / ks + 6.0) + 16.0 * ks * (double)M * E * 8.0 / 3.0e6;
-    if (ks == 1 || c < 0.95 * cost) { cost = c; best = ks; }
+  for (int n = 1; n <= 256 && S / n >= 16; ++n) {
+    const double c = (double)((tiles * n + 255) / 256) * (1.4 * ((S + n - 1) / n) + 6.0) + (double)n * (double)M * E * 8.0 / 3.0e6;
+    if (n == 1 || c < cost) { cost = c; best = n; }
   }
   return best;
 }
@@ -1463,7 +1499,7 @@ int patch_ksplit(int B, int C, int h, int w, int E) {
 
 extern "C" size_t ocv_patch_embed_split_workspace_bytes(int B, int C, int h, int w, int E) {
   if (B < 1 || C < 32 || C % 32 != 0 || h < 16 || w < 16 || E < 8 || E % 8 != 0) return 0;
-  return (size_t)16 * patch_ksplit(B, C, h, w, E) * B * (h / 16) * (w / 16) * E * sizeof(float);
+  return (size_t)patch_parts(B, C, h, w, E) * B * (h / 16) * (w / 16) * E * sizeof(float);
 }
 
 extern "C" int ocv_patch_embed_split_fwd(const void* x_hl, int C, const void* w_hi, const void* w_lo, const float* oscale, int f16,
@@ -1484,7 +1520,8 @@ extern "C" int ocv_patch_embed_split_fwd(const void* x_hl, int C, const void* w_
   ConvArgs a{};
   a.xhl = (const __bf16*)x_hl; a.whi = (const __bf16*)w_hi; a.wlo = (const __bf16*)w_lo; a.y = (float*)workspace;
   a.C1 = 16 * C; a.Cin = 16 * C; a.Cout = E; a.H = B * gh; a.W = gw; a.ks = 1; a.act = OCV_ACT_NONE;
-  a.ksplit = patch_ksplit(B, C, h, w, E);                                     // K parts per patch row (slab (ky, part) at index ky ksplit + part)
+  a.ksplit = 1;
+  a.zflat = patch_parts(B, C, h, w, E);                                       // pieces of the (ky, kx, c) axis: slab k at workspace + k M E
   a.Cpo = (E + 31) / 32 * 32;
   a.f16 = f16; a.oscale = oscale;                                             // (the 16 GEMMs share their output channels' scales)
   a.zbatch = 16;
@@ -1497,7 +1534,7 @@ extern "C" int ocv_patch_embed_split_fwd(const void* x_hl, int C, const void* w_
   if (rc != 0) return rc;
   const long M = (long)B * gh * gw;
   hipLaunchKernelGGL(patch_sum_kernel, dim3((unsigned)((M * (E / 4) + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)workspace, M, E, gh * gw, bias, pos, pos_bs, out, 16 * a.ksplit);
+                     (const float*)workspace, M, E, gh * gw, bias, pos, pos_bs, out, a.zflat);
   OCV_CHECK_LAUNCH("ocv_patch_embed_split_fwd(sum)");
   return 0;
 }

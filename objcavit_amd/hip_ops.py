@@ -184,28 +184,44 @@ class single_chain:
 def object_prepass_enabled() -> bool:
     """OCV_OBJ_OVERLAP: '1' (default since round 4) = where the object branch does not read the image features (the MLP positional
     strategies) it is issued at the top of the forward, on a side stream beside the encoder (GraphBins.forward_until_head); '0' =
-    behind the decoder (beside the image tokens' stack with OCV_TOKEN_OVERLAP=1)."""
+    behind the decoder (beside the image tokens' stack with OCV_TOKEN_OVERLAP=1).  Alone it gains nothing for one batch at a time
+    (978 vs 974 img/s); with three batches in flight it is +4.7 % (975 -> 1021 img/s, same box, alternating runs): the ~20 tiny
+    launches leave the stretch behind the decoder, where every slot's chain is latency-bound."""
     mode = os.environ.get("OCV_OBJ_OVERLAP", "1")
     if mode not in ("0", "1"):
         raise ValueError(f"OCV_OBJ_OVERLAP={mode!r}: expected '1' (default) or '0'")
     return mode == "1"
 
 
+_IN_FLIGHT = 1
+
+
+def set_batches_in_flight(n: int) -> int:
+    """A hint from whoever drives the model (bench.py's slots, PipelinedValidation): how many batches it keeps in flight on this
+    GPU.  Read when a forward is issued or captured (``head_overlap_enabled``); returns the previous value."""
+    global _IN_FLIGHT
+    prev, _IN_FLIGHT = _IN_FLIGHT, max(1, int(n))
+    return prev
+
+
 def head_overlap_enabled() -> bool:
-    """OCV_HEAD_OVERLAP: '1' (default) = the heads' 3x3 convolution over the decoder's map (4800 workgroups, ~0.93 ms at bs 16)
-    is issued on the main stream while the image-token chain -- patch embedding, self-attention stack, cross-attention, bin
-    regressor: ~25 launches of 2 - 300 workgroups, ~0.6 ms of mostly idle chip -- runs on a second side stream; joined in front of
-    the bin head, the first consumer of both.  '0' = the tokens first, then the convolution (A/B).
+    """OCV_HEAD_OVERLAP: '1' = the heads' 3x3 convolution over the decoder's map (4800 workgroups, ~0.93 ms at bs 16) is issued on the
+    main stream while the image-token chain -- patch embedding, self-attention stack, cross-attention, bin regressor: ~25 launches
+    of 2 - 300 workgroups, ~0.6 ms of mostly idle chip -- runs on a second side stream; joined in front of the bin head, the first
+    consumer of both.  '0' = the tokens first, then the convolution.  'auto' (default) = '1' for a lone batch, '0' when the driver
+    keeps several batches in flight (``set_batches_in_flight``): their launches already fill the token chain's idle CUs, and the
+    extra branch only takes CUs from the convolution -- measured on one box, alternating runs (profiles/r04_head_overlap.txt):
+    one batch at a time 978 -> 983 img/s with it, three in flight 1021 -> 984.
     Only with ONE side chain behind the decoder (the object branch already issued beside the encoder, or a model without one): a
     captured forward with the object chain, the token chain and the convolution as three parallel branches replays 6 ms SLOWER
-    per step on this ROCm (23.2 vs 16.6 ms at bs 16, 8.7 vs 3.5 ms at bs 1: profiles/r04_head_overlap.txt), so that shape is
-    never built.  Measured gain, sequential bs 16: 17.41 -> 17.24 ms on one box (+1.0 %); bs 1 and three batches in flight:
-    unchanged.  The token kernels hold 52 KB of LDS per workgroup and cannot share a CU with the convolution's 144 KB: beside it
-    they run ~2x slower and the convolution 1.18 instead of 0.93 ms -- which is why the gain is a third of the chain's length."""
-    mode = os.environ.get("OCV_HEAD_OVERLAP", "1")
-    if mode not in ("0", "1"):
-        raise ValueError(f"OCV_HEAD_OVERLAP={mode!r}: expected '1' (default) or '0'")
-    return mode == "1"
+    per step on this ROCm (23.2 vs 16.6 ms at bs 16, 8.7 vs 3.5 ms at bs 1), and a nested third branch crashed
+    hipStreamEndCapture, so that shape is never built.  The token kernels hold 52 KB of LDS per workgroup and cannot share a CU
+    with the convolution's 144 KB: beside it they run ~2x slower and the convolution 1.18 instead of 0.93 ms -- which is why the
+    gain is a third of the chain's length."""
+    mode = os.environ.get("OCV_HEAD_OVERLAP", "auto")
+    if mode not in ("0", "1", "auto"):
+        raise ValueError(f"OCV_HEAD_OVERLAP={mode!r}: expected 'auto' (default), '1' or '0'")
+    return _IN_FLIGHT <= 1 if mode == "auto" else mode == "1"
 
 
 def side_stream(device: torch.device, which: int = 0) -> "torch.cuda.Stream":

@@ -104,8 +104,12 @@ class PipelinedValidation:
         self.min_depth, self.max_depth = float(ds.min_depth), float(ds.max_depth)
         self.B = int(example_image.shape[0])
         both = torch.cat([example_image, example_image.flip(dims=[3])], 0) if flip_tta else example_image
-        self.graphs = [GraphedGraphBins(model, both, object_capacity=object_capacity, object_group=self.B if flip_tta else None)
-                       for _ in range(slots)]
+        prev = hip_ops.set_batches_in_flight(slots)        # read by the captures (hip_ops.head_overlap_enabled)
+        try:
+            self.graphs = [GraphedGraphBins(model, both, object_capacity=object_capacity, object_group=self.B if flip_tta else None)
+                           for _ in range(slots)]
+        finally:
+            hip_ops.set_batches_in_flight(prev)
         self._next = 0
         self._pending = []
 

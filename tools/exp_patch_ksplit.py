@@ -1,5 +1,5 @@
-"""A/B of the patch embedding's K parts (OCV_PATCH_KSPLIT=1|2|4 vs the modelled choice) at the validation loop's batch sizes.
-python tools/exp_patch_ksplit.py   (GPU box)"""
+"""A/B of the patch embedding's K pieces (OCV_PATCH_PARTS=n vs the modelled choice; 16 = one piece per patch row, the form of rounds
+2 - 4) at the validation loop's batch sizes.  python tools/exp_patch_ksplit.py   (GPU box)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1:
@@ -25,10 +25,10 @@ if len(sys.argv) > 1:
         torch.cuda.synchronize()
         print(f"  bs {B:2d}: {e0.elapsed_time(e1) / 50 * 1e3:7.1f} us", flush=True)
     sys.exit(0)
-for ks in ("1", "2", "4", ""):
+for ks in ("16", "8", "13", "26", "32", "64", "128", ""):
     env = dict(os.environ)
-    env.pop("OCV_PATCH_KSPLIT", None)
+    env.pop("OCV_PATCH_PARTS", None)
     if ks:
-        env["OCV_PATCH_KSPLIT"] = ks
-    print(f"OCV_PATCH_KSPLIT={ks or '(modelled)'}", flush=True)
+        env["OCV_PATCH_PARTS"] = ks
+    print(f"OCV_PATCH_PARTS={ks or '(modelled)'}", flush=True)
     subprocess.run([sys.executable, __file__, "child"], env=env, check=True)
