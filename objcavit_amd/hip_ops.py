@@ -155,15 +155,26 @@ class timed:
 _SIDE: Dict[Tuple[int, int], "torch.cuda.Stream"] = {}
 
 
+def _side_switch(name: str) -> bool:
+    """The side-stream switches OCV_OBJ_OVERLAP / OCV_TOKEN_OVERLAP / OCV_HEAD_OVERLAP: '1', '0' or 'auto' (default) = on for a lone
+    batch, off when the driver keeps several batches in flight on this GPU (``set_batches_in_flight``: bench.py's slots,
+    PipelinedValidation).  A fork inside a captured forward makes the replay use further streams; with three slots replaying at once
+    those collide with the other slots' streams on the GPU's hardware queues and the slots serialise each other.  One box, alternating
+    runs, bs 16 (profiles/r04_head_overlap.txt, block 5), three in flight / one at a time:  no fork 1037 / 953 img/s;  object branch
+    beside the encoder 1015 / 961;  that + the token chain beside the heads' convolution 976 / 972;  object branch beside the image
+    tokens (this round's first default) 968 / 964."""
+    mode = os.environ.get(name, "auto")
+    if mode not in ("0", "1", "auto"):
+        raise ValueError(f"{name}={mode!r}: expected 'auto' (default), '1' or '0'")
+    return _IN_FLIGHT <= 1 if mode == "auto" else mode == "1"
+
+
 def token_overlap_enabled() -> bool:
-    """OCV_TOKEN_OVERLAP: '1' (default, round 4) = the object branch of the SA/CA stack (embedding, positional MLP, object
-    self-attention: ~20 launches of a few workgroups each) runs on a side stream beside the image branch (patch embedding + image
-    self-attention: equally latency-bound, small grids) and is joined in front of the cross-attention; '0' = one stream (A/B).
-    (Round 2 overlapped the object branch with the ENCODER, whose launches fill the chip: no gain.  Two small-grid chains do overlap.)"""
-    mode = os.environ.get("OCV_TOKEN_OVERLAP", "1")
-    if mode not in ("0", "1"):
-        raise ValueError(f"OCV_TOKEN_OVERLAP={mode!r}: expected '1' (default) or '0'")
-    return mode == "1" and not _TLS.single_chain
+    """OCV_TOKEN_OVERLAP (``_side_switch``): the object branch of the SA/CA stack (embedding, positional MLP, object self-attention:
+    ~20 launches of a few workgroups each) on a side stream beside the image branch (patch embedding + image self-attention: equally
+    latency-bound, small grids), joined in front of the cross-attention -- where the branch could not already be issued beside the
+    encoder (``object_prepass_enabled``).  Lone batch: +3 % at bs 1 - 2, +0.9 % at bs 16."""
+    return _side_switch("OCV_TOKEN_OVERLAP") and not _TLS.single_chain
 
 
 class single_chain:
@@ -182,15 +193,11 @@ class single_chain:
 
 
 def object_prepass_enabled() -> bool:
-    """OCV_OBJ_OVERLAP: '1' (default since round 4) = where the object branch does not read the image features (the MLP positional
-    strategies) it is issued at the top of the forward, on a side stream beside the encoder (GraphBins.forward_until_head); '0' =
-    behind the decoder (beside the image tokens' stack with OCV_TOKEN_OVERLAP=1).  Alone it gains nothing for one batch at a time
-    (978 vs 974 img/s); with three batches in flight it is +4.7 % (975 -> 1021 img/s, same box, alternating runs): the ~20 tiny
-    launches leave the stretch behind the decoder, where every slot's chain is latency-bound."""
-    mode = os.environ.get("OCV_OBJ_OVERLAP", "1")
-    if mode not in ("0", "1"):
-        raise ValueError(f"OCV_OBJ_OVERLAP={mode!r}: expected '1' (default) or '0'")
-    return mode == "1"
+    """OCV_OBJ_OVERLAP (``_side_switch``): where the object branch does not read the image features (the MLP positional strategies) it
+    is issued at the top of the forward, on a side stream beside the encoder (GraphBins.forward_until_head), instead of behind the
+    decoder.  On its own worth little (lone batch 953 -> 961 img/s); it leaves ONE side chain behind the decoder, which is what
+    ``head_overlap_enabled`` needs."""
+    return _side_switch("OCV_OBJ_OVERLAP")
 
 
 _IN_FLIGHT = 1
@@ -205,23 +212,17 @@ def set_batches_in_flight(n: int) -> int:
 
 
 def head_overlap_enabled() -> bool:
-    """OCV_HEAD_OVERLAP: '1' = the heads' 3x3 convolution over the decoder's map (4800 workgroups, ~0.93 ms at bs 16) is issued on the
-    main stream while the image-token chain -- patch embedding, self-attention stack, cross-attention, bin regressor: ~25 launches
-    of 2 - 300 workgroups, ~0.6 ms of mostly idle chip -- runs on a second side stream; joined in front of the bin head, the first
-    consumer of both.  '0' = the tokens first, then the convolution.  'auto' (default) = '1' for a lone batch, '0' when the driver
-    keeps several batches in flight (``set_batches_in_flight``): their launches already fill the token chain's idle CUs, and the
-    extra branch only takes CUs from the convolution -- measured on one box, alternating runs (profiles/r04_head_overlap.txt):
-    one batch at a time 978 -> 983 img/s with it, three in flight 1021 -> 984.
+    """OCV_HEAD_OVERLAP (``_side_switch``): the heads' 3x3 convolution over the decoder's map (4800 workgroups, ~0.93 ms at bs 16) is
+    issued on the main stream while the image-token chain -- patch embedding, self-attention stack, cross-attention, bin regressor:
+    ~25 launches of 2 - 300 workgroups, ~0.6 ms of mostly idle chip -- runs on a second side stream; joined in front of the bin head,
+    the first consumer of both.  Lone batch at bs 16: 961 -> 972 img/s.
     Only with ONE side chain behind the decoder (the object branch already issued beside the encoder, or a model without one): a
     captured forward with the object chain, the token chain and the convolution as three parallel branches replays 6 ms SLOWER
     per step on this ROCm (23.2 vs 16.6 ms at bs 16, 8.7 vs 3.5 ms at bs 1), and a nested third branch crashed
     hipStreamEndCapture, so that shape is never built.  The token kernels hold 52 KB of LDS per workgroup and cannot share a CU
     with the convolution's 144 KB: beside it they run ~2x slower and the convolution 1.18 instead of 0.93 ms -- which is why the
     gain is a third of the chain's length."""
-    mode = os.environ.get("OCV_HEAD_OVERLAP", "auto")
-    if mode not in ("0", "1", "auto"):
-        raise ValueError(f"OCV_HEAD_OVERLAP={mode!r}: expected 'auto' (default), '1' or '0'")
-    return _IN_FLIGHT <= 1 if mode == "auto" else mode == "1"
+    return _side_switch("OCV_HEAD_OVERLAP")
 
 
 def side_stream(device: torch.device, which: int = 0) -> "torch.cuda.Stream":
