@@ -375,3 +375,40 @@ def test_validation_step_joint_forward_on_a_stand_in_model():
     two = ValidationStep(Toy(), make_args(), joint=False)
     o2, m2 = two._forward_pair(img)
     assert torch.equal(out.depth_pred, o2.depth_pred) and torch.equal(mirror, m2)
+
+
+def test_side_stream_switches_follow_the_batches_in_flight(monkeypatch):
+    """OCV_OBJ_OVERLAP / OCV_TOKEN_OVERLAP / OCV_HEAD_OVERLAP: 'auto' (default) = on for a lone batch, off once the driver announces
+    several batches in flight (hip_ops.set_batches_in_flight); '0' / '1' override; anything else is an error, not a silent default;
+    inside hip_ops.single_chain() no further fork is offered; launches inside islands_suspended() stay in the capture."""
+    from objcavit_amd import hip_ops
+    switches = {"OCV_OBJ_OVERLAP": hip_ops.object_prepass_enabled, "OCV_TOKEN_OVERLAP": hip_ops.token_overlap_enabled,
+                "OCV_HEAD_OVERLAP": hip_ops.head_overlap_enabled}
+    for k in switches:
+        monkeypatch.delenv(k, raising=False)
+    prev = hip_ops.set_batches_in_flight(1)
+    try:
+        assert all(f() for f in switches.values())
+        assert hip_ops.set_batches_in_flight(3) == 1
+        assert not any(f() for f in switches.values())
+        for k, f in switches.items():
+            monkeypatch.setenv(k, "1")
+            assert f()
+            monkeypatch.setenv(k, "0")
+            assert not f()
+            monkeypatch.setenv(k, "yes")
+            with pytest.raises(ValueError):
+                f()
+            monkeypatch.delenv(k)
+        assert hip_ops.set_batches_in_flight(0) == 3 and all(f() for f in switches.values())      # (clamped to 1)
+        with hip_ops.single_chain():
+            assert not hip_ops.token_overlap_enabled() and hip_ops.head_overlap_enabled()
+        assert hip_ops.token_overlap_enabled()
+        broke = []
+        with hip_ops.island_scope(hip_ops.IslandHook(("x",), lambda name, call: broke.append(name))):
+            with hip_ops.islands_suspended():
+                hip_ops.launch("x", lambda: broke.append("ran"))
+            hip_ops.launch("x", lambda: broke.append("never"))
+        assert broke == ["ran", "x"]
+    finally:
+        hip_ops.set_batches_in_flight(prev)
