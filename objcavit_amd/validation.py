@@ -85,16 +85,17 @@ class PipelinedValidation:
     [batch | mirrored batch] forward captured on a stream of its own (objcavit_amd/graph.py; live objects with
     ``object_capacity``), the steps go to the slots round-robin, the per-image records are collected at the end (or whenever the
     caller asks).  At bs 1 every launch is latency, so consecutive images overlap almost freely: measured on MI355X
-    (bench.py --batch 1: the same slot mechanism) 261 img/s one after the other, **575 img/s with three in flight**; bs 2
-    (= image + mirror) 433 -> 796.  Results are those of ``ValidationStep(joint=True)``: same kernels, same order per step.
+    (bench.py --batch 1: the same slot mechanism) 288 img/s one after the other, 609 with three in flight, **685 - 692 with
+    four** (the default; five and more collapse to 420 - 530 whatever GPU_MAX_HW_QUEUES says: the slots then share hardware queues);
+    bs 2 (= image + mirror) 461 -> 817 -> 872.  Results are those of ``ValidationStep(joint=True)``: same kernels, same order per step.
 
-        pv = PipelinedValidation(model, args, example_image, slots=3)
+        pv = PipelinedValidation(model, args, example_image)
         for i, (image, depth_gt) in enumerate(loader):      # bs 1, as the reference
             pv.submit(image.cuda(non_blocking=True), depth_gt.cuda(non_blocking=True), first_image_id=i)
         records = pv.collect()                                # [N, 10] per-image records, submission order
     """
 
-    def __init__(self, model, args, example_image: torch.Tensor, slots: int = 3, object_capacity: Optional[int] = None,
+    def __init__(self, model, args, example_image: torch.Tensor, slots: int = 4, object_capacity: Optional[int] = None,
                  flip_tta: bool = True):
         from .graph import GraphedGraphBins
         if slots < 1:

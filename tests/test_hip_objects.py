@@ -204,11 +204,11 @@ def test_baseline_config_at_the_reference_validation_batch(B):
 
 
 def test_pipelined_validation_equals_the_sequential_step():
-    """PipelinedValidation: the reference's bs-1 validation loop with three steps in flight (one captured joint image + mirror graph
-    per slot, own stream each) gives the records of ValidationStep(joint=True) issued one after the other -- seven images, more
-    than two rounds of the three slots, live objects from the model's provider (different per image and for the mirror)."""
+    """PipelinedValidation: the reference's bs-1 validation loop with four steps in flight (the default: one captured joint image +
+    mirror graph per slot, own stream each) gives the records of ValidationStep(joint=True) issued one after the other -- nine images,
+    more than two rounds of the four slots, live objects from the model's provider (different per image and for the mirror)."""
     from objcavit_amd.validation import PipelinedValidation, ValidationStep
-    H, W, B, N = 352, 384, 1, 7
+    H, W, B, N = 352, 384, 1, 9
 
     class Prov:                                             # a "detector": objects follow from the image content
         def __call__(self, image):
@@ -226,7 +226,8 @@ def test_pipelined_validation_equals_the_sequential_step():
     gts = [(torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(i)) * 9.0 + 0.5).cuda() for i in range(N)]
     seq = ValidationStep(m, args, joint=True)
     ref = torch.cat([seq(imgs[i], gts[i], first_image_id=i)[0] for i in range(N)], 0)
-    pv = PipelinedValidation(m, args, imgs[0], slots=3, object_capacity=24)
+    pv = PipelinedValidation(m, args, imgs[0], object_capacity=24)
+    assert len(pv.graphs) == 4
     for i in range(N):
         pv.submit(imgs[i], gts[i], first_image_id=i)
     rec = pv.collect()
