@@ -98,6 +98,133 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Round 4: the kernel above, re-done for the shapes the encoder has (Cout a multiple of 8).
+// Index arithmetic is 32-bit throughout (the launcher checks that the image and the output have fewer than 2^31 elements): the first
+// version did three 64-bit divisions per lane and tile plus a 64-bit multiply per load and store -- 1629 vector instructions per
+// 32-pixel tile (SQ counters, profiles/r04g_sq.json: VALU busy 121 us of the launch's 174), i.e. it was bound by its own address
+// arithmetic, not by the 295 MB it moves.  The activation is a template parameter; only the last tile checks its rows.
+template <int KS, int NT, int ACT, int KT>        // KT = K steps of two taps: 14 for the encoder's 3 channels x 9 taps, 16 in general
+__global__ __launch_bounds__(256, 2) void stem_conv_wide_kernel(StemArgs p) {
+  const int lane = threadIdx.x & 63, l31 = lane & 31, hh = lane >> 5;
+  const int K = p.Cin * KS * KS;
+  float wreg[NT][KT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = 32 * j + l31;
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      const int k = 2 * t + hh;
+      wreg[j][t] = (n < p.Cout && k < K) ? p.w[n * K + k] : 0.f;          // (taps beyond K multiply by zero: no branch in the loop)
+    }
+  }
+  // The MFMA's A operand is the WEIGHT pair of channel l31, its B operand the tap pair of pixel l31: the accumulator's rows are
+  // channels (register r = channel acc_row(r, hh): four runs of four consecutive channels), its column is this lane's pixel -- a lane
+  // stores its pixel's channels as 16-byte pieces (6 wide stores per tile at 48 channels, where the pixel-major accumulator took 48
+  // four-byte ones).  For Cout % 8 == 0 (the launcher keeps the kernel above for other widths).
+  float bv[NT][16];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = 32 * j + acc_row(r, hh);
+      bv[j][r] = (p.bias != nullptr && n < p.Cout) ? p.bias[n] : 0.f;
+    }
+
+  // taps k = 2 t (lanes 0 - 31) and 2 t + 1 (lanes 32 - 63): plane / row / column offsets are wave-uniform per parity (scalar registers),
+  // a lane selects its own with one v_cndmask -- held per lane they cost 48 VGPRs and a wavefront of occupancy
+  const unsigned plane = (unsigned)(p.H * p.W);
+  auto tap_ky = [&](int t) { const int k0 = (2 * t) % (KS * KS), k1 = (2 * t + 1) % (KS * KS); return hh ? k1 / KS : k0 / KS; };
+  auto tap_kx = [&](int t) { const int k0 = (2 * t) % (KS * KS), k1 = (2 * t + 1) % (KS * KS); return hh ? k1 % KS : k0 % KS; };
+  auto tap_off = [&](int t) {
+    const int k0 = 2 * t, k1 = 2 * t + 1;
+    const int o0 = k0 < K ? (int)((k0 / (KS * KS)) * plane) + ((k0 % (KS * KS)) / KS) * p.W + (k0 % KS) : -1;
+    const int o1 = k1 < K ? (int)((k1 / (KS * KS)) * plane) + ((k1 % (KS * KS)) / KS) * p.W + (k1 % KS) : -1;
+    return hh ? o1 : o0;
+  };
+  const unsigned M = (unsigned)p.M, Wo = (unsigned)p.Wo, Ho = (unsigned)p.Ho;
+  const unsigned img_elems = (unsigned)p.Cin * plane;
+  const unsigned lane_off = (unsigned)(l31 * p.Cout + 4 * hh);               // output offset of pixel l31, channel 4 hh
+  const unsigned wave0 = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  // the taps of a tile: KT gathers per lane, issued one tile AHEAD (their ~2 us of latency was a third of a wavefront's time per tile)
+  // (the loads are UNCONDITIONAL, from a clamped index; which taps lie outside the image is a bit mask applied when the values are
+  //  used, one tile later -- a select right behind the load would make the wavefront wait for it there)
+  auto gather = [&](unsigned tile, float (&a)[KT]) -> unsigned {
+    const unsigned m = tile * 32 + l31;
+    const bool ok = m < M;
+    const unsigned mm = ok ? m : 0u;
+    const unsigned row = mm / Wo, ox = mm - row * Wo;
+    const unsigned b = row / Ho, oy = row - b * Ho;
+    const int iy0 = (int)oy * p.stride - p.pad_t, ix0 = (int)ox * p.stride - p.pad_l;
+    const int base = (int)(b * img_elems) + iy0 * p.W + ix0;                 // 32-bit element index from p.x (scalar base + lane offset)
+    const bool inner = ok && iy0 >= 0 && ix0 >= 0 && iy0 + KS <= p.H && ix0 + KS <= p.W;
+    unsigned mask = 0;
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      const int iy = iy0 + tap_ky(t), ix = ix0 + tap_kx(t), off = tap_off(t);
+      const bool in = off >= 0 && (inner || (ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W));
+      mask |= in ? 1u << t : 0u;
+      a[t] = p.x[in ? (unsigned)(base + off) : 0u];
+    }
+    return mask;
+  };
+  float a[KT], an[KT];
+  unsigned amask = 0, anmask = 0;
+  if (wave0 < (unsigned)p.tiles) amask = gather(wave0, a);
+  for (unsigned tile = wave0; tile < (unsigned)p.tiles; tile += nwaves) {    // (scalar: the tile is the wavefront's)
+    if (tile + nwaves < (unsigned)p.tiles) anmask = gather(tile + nwaves, an);
+#pragma unroll
+    for (int t = 0; t < KT; ++t) a[t] = (amask >> t) & 1u ? a[t] : 0.f;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = bv[j][r];
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = mfma_32x32x2(wreg[j][t], a[t], acc[j]);
+    const unsigned yt = tile * 32 * (unsigned)p.Cout + lane_off;             // 32-bit element index from p.y
+    const bool pix_ok = tile * 32 + l31 < M;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (32 * j + 8 * g < p.Cout) {                                        // wave-uniform (Cout % 8 == 0: both halves of the run are channels)
+          float4 v;
+          float* vv = reinterpret_cast<float*>(&v);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x = acc[j][4 * g + e];
+            if (ACT == OCV_ACT_SILU) x = fast_silu(x);
+            else if (ACT == OCV_ACT_RELU) x = fmaxf(x, 0.f);
+            else if (ACT == OCV_ACT_LEAKY_RELU) x = x > 0.f ? x : 0.01f * x;
+            vv[e] = x;
+          }
+          if (pix_ok) *reinterpret_cast<float4*>(p.y + (yt + 32 * j + 8 * g)) = v;
+        }
+      }
+#pragma unroll
+    for (int t = 0; t < KT; ++t) a[t] = an[t];
+    amask = anmask;
+  }
+}
+
+template <int NT, int KT>
+void stem_wide_launch_kt(const StemArgs& a, unsigned blocks, hipStream_t st) {
+  switch (a.act) {
+    case OCV_ACT_SILU: hipLaunchKernelGGL((stem_conv_wide_kernel<3, NT, OCV_ACT_SILU, KT>), dim3(blocks), dim3(256), 0, st, a); break;
+    case OCV_ACT_RELU: hipLaunchKernelGGL((stem_conv_wide_kernel<3, NT, OCV_ACT_RELU, KT>), dim3(blocks), dim3(256), 0, st, a); break;
+    case OCV_ACT_LEAKY_RELU: hipLaunchKernelGGL((stem_conv_wide_kernel<3, NT, OCV_ACT_LEAKY_RELU, KT>), dim3(blocks), dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((stem_conv_wide_kernel<3, NT, OCV_ACT_NONE, KT>), dim3(blocks), dim3(256), 0, st, a); break;
+  }
+}
+template <int NT>
+void stem_wide_launch(const StemArgs& a, unsigned blocks, hipStream_t st) {
+  if (a.Cin * 9 <= 28) stem_wide_launch_kt<NT, 14>(a, blocks, st);
+  else stem_wide_launch_kt<NT, STEM_KT>(a, blocks, st);
+}
+
 }  // namespace
 
 extern "C" int ocv_stem_conv_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W,
@@ -115,7 +242,10 @@ extern "C" int ocv_stem_conv_fwd(const float* x, const float* w, const float* bi
   long blocks = (a.tiles + 3) / 4;
   if (blocks > 256L * 8) blocks = 256L * 8;
   hipStream_t st = (hipStream_t)stream;
-  if (Cout <= 32) hipLaunchKernelGGL((stem_conv_kernel<3, 1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  if (Cout % 8 == 0 && ocv_aligned16(y) && (long)B * Cin * H * W < (1L << 31) && (long)B * Ho * Wo * Cout < (1L << 31)) {
+    if (Cout <= 32) stem_wide_launch<1>(a, (unsigned)blocks, st);           // 32-bit index arithmetic, 16-byte stores
+    else stem_wide_launch<2>(a, (unsigned)blocks, st);
+  } else if (Cout <= 32) hipLaunchKernelGGL((stem_conv_kernel<3, 1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((stem_conv_kernel<3, 2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
   OCV_CHECK_LAUNCH("ocv_stem_conv_fwd");
   return 0;

@@ -62,7 +62,7 @@ def shape_key(r):
 SQ_KERNELS = ("tap_interp_kernel", "layer_tail3_kernel", "lin3_kernel", "conv_split_dma_kernel", "wino_input_kernel", "wino_output_kernel", "bin_head_split3_kernel", "bin_head_combine_kernel", "pw_tile_kernel", "pw_big_kernel", "pw_rows_kernel", "patch_embed_partial_kernel", "bin_head_kernel",
               "bin_head_split_kernel", "attention_kernel", "cross_attn_fused_kernel", "ffn_fused_kernel", "linear_stream_kernel",
               "dw_slide_kernel", "mbconv_expand_dw_kernel", "upsample_concat_split_lds_kernel", "encoder_stack_kernel", "pw_hl_kernel",
-              "xattn_main3_kernel", "xattn_kv3_kernel", "se_gate_weights_kernel", "xattn_main_h2_kernel", "xattn_kv_h2_kernel", "bin_head_h2_kernel", "attention_h2_kernel", "layer_tail_h2_kernel")
+              "xattn_main3_kernel", "xattn_kv3_kernel", "se_gate_weights_kernel", "stem_conv_kernel", "se_fused_small_kernel", "pw_stream_kernel", "xattn_main_h2_kernel", "xattn_kv_h2_kernel", "bin_head_h2_kernel", "attention_h2_kernel", "layer_tail_h2_kernel")
 N_SIMD = 1024            # 256 CUs x 4 SIMDs
 
 
