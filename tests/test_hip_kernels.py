@@ -3,6 +3,7 @@ ctypes -> libobjcavit_hip.so), against the CPU oracle on the same seeded
 inputs.  All arithmetic is fp32; tolerances are stated per test (relative to
 the largest reference magnitude unless noted)."""
 import math
+import random
 
 import numpy as np
 import pytest
@@ -520,6 +521,28 @@ def test_patch_embed_split(ops, B, C, h, w, E, pos_mode):
     if (C, E) == (128, 128):                                  # the exact-fp32 kernel is built for the model's 128 -> 128
         exact = ops.patch_embed(dev(x), dev(wt), dev(b), None if pos is None else dev(pos))
         assert rel_dev(got, exact) < SPLIT_TOL
+
+
+def test_patch_embed_split_seeded_shape_sweep(ops):
+    """The patch embedding's K axis is cut in a modelled number of pieces that depends on the batch and the map (1 ... 64 pieces, each
+    piece crossing patch-row boundaries wherever the cut falls): a seeded sweep over batches and map sizes, fp16 and bf16 pairs,
+    against the convolution in fp64; every call bitwise repeatable."""
+    rng = random.Random(1234)
+    for _ in range(14):
+        B = rng.choice((1, 1, 2, 3, 5, 8, 12))
+        h, w = 16 * rng.randint(1, 9), 16 * rng.randint(1, 12)
+        C, E = rng.choice(((128, 128), (64, 128), (32, 40), (96, 64)))
+        f16 = rng.random() < 0.6
+        x = rnd("x", (B, C, h, w), rng.randint(0, 999))
+        wt, b = rnd("w", (E, C, 16, 16), rng.randint(0, 999), 1 / math.sqrt(C * 256)), rnd("b", (E,), 3, 0.1)
+        pos = rnd("p", ((h // 16) * (w // 16), E), 4)
+        ref = F.conv2d(x.double(), wt.double(), b.double(), stride=16).flatten(2).permute(0, 2, 1) + pos.double()
+        xs = ops.split_act(dev(x).contiguous(memory_format=torch.channels_last), f16)
+        prep = ops.prep_patch_embed_weight(dev(wt), f16)
+        call = lambda: ops.patch_embed_split(xs, prep[0], prep[1], dev(b), dev(pos), oscale=prep[2] if f16 else None)
+        got = call()
+        assert rel_dev(got, ref) < SPLIT_TOL, (B, C, h, w, E, f16)
+        assert torch.equal(got, call()), (B, C, h, w, E, f16)
 
 
 def test_patch_embed_split_rejects_what_it_cannot_address(ops):
