@@ -393,18 +393,23 @@ __device__ __forceinline__ void bh_split8_h2(const float4 u, const float4 v, bh_
   }
 }
 
-// Schedule (round 4).  A 32-bin tile is an MFMA phase (24 MFMAs of 32 cycles: the wavefront is held at the matrix pipe's door for
-// 768 cycles) and a VALU phase (its softmax arithmetic).  The round-3 kernel's two wavefronts per SIMD ran these phases IN STEP --
-// they leave the staging barrier together and do identical work -- so the SQ counters showed matrix pipe busy 40 % + VALU busy
-// 52 % = the SUM of the two, not their overlap.  Here (i) the wavefronts w + 4 start one MFMA phase late (one s_sleep): an offset
-// between two wavefronts that contend for the same pipes round-robin is preserved from tile to tile, so one's softmax runs under the
-// other's MFMAs; (ii) a wavefront alone in its MFMA phase must not wait on LDS, so the weight fragments are fetched
-// ahead through THREE rotating register sets (two steps ahead: a fourth set spills), the first two of the NEXT tile before the VALU phase starts, and the bias (the hi*hi
-// accumulator's initial value) as soon as the accumulators have been read; (iii) the VALU phase is shorter than the MFMA phase: the
-// logits carry a factor log2(e) (folded into the split weights and the bias when they are staged: the softmax is exp2 of
-// differences) and the arithmetic is two-wide packed fp32 -- per tile 8 v_pk_fma + 16 v_pk_add + 8 v_pk_fma, 16 v_exp_f32 and 8
-// v_max3 (~500 cycles) instead of 112 scalar operations + 16 v_exp_f32 (~700).  Measured on the way: the same two groups held half a
-// tile apart by raw s_barriers, weights one step ahead: 0.346 ms against round 3's 0.271 (LDS latency exposed in every K step).
+// Schedule (round 4).  A 32-bin tile is 24 MFMAs of 32 cycles (the wavefront is held at the matrix pipe's door for 768 cycles) and
+// its softmax arithmetic.  The round-3 kernel ran the two one after the other, and its two wavefronts per SIMD IN STEP -- they leave
+// the staging barrier together and do identical work -- so the SQ counters showed matrix pipe busy 46 % + VALU busy 53 % = the SUM
+// of the two, not their overlap.  A wavefront issues in order: its vector work runs under its own MFMAs only when it sits BETWEEN
+// them in program order.  So the loop over the eight tiles is software-pipelined with two accumulator sets: the 24 MFMAs of tile
+// t + 1 are interleaved one by one with the softmax instructions of tile t (__builtin_amdgcn_sched_group_barrier pins 1 MFMA :
+// 1 LDS read : 4 VALU per slot), the weight fragments are fetched two K steps ahead through three rotating register sets (a
+// fourth set spills; the first two fetches of a tile are its own, covered by the interleaved softmax), and the VALU side is made
+// to fit the slots: the logits carry a factor log2(e) (folded into the split weights and the bias when they are staged: the
+// softmax is exp2 of differences), the bias is the hi*hi accumulator's INITIAL value (fetched into the accumulator as soon as the
+// previous tile's values have been read), and the arithmetic is two-wide packed fp32 -- per tile 8 v_pk_fma + 16 v_pk_add + 8
+// v_pk_fma, 16 v_exp_f32 and 8 v_max3 instead of 112 scalar operations + 16 v_exp_f32.  Result (profiles/r04_binhead_sq.txt):
+// vector instructions 63 M -> 45 M, wave cycles -29 %, matrix pipe busy 46 -> 65 %, 0.287 -> 0.244 ms in the step (the launch is
+// power-bound: the clock sinks as the pipes fill).  Measured on the way and dropped: two wavefront groups held half a tile apart
+// by raw s_barriers, weights one step ahead (0.346 ms: with ONE wavefront per SIMD in its MFMA phase the LDS latency is exposed
+// in every K step); the same stagger by one s_sleep with the weights two steps ahead (0.255 ms; MFMA / VALU co-execution 7 M
+// cycles against 71 M before: the groups fall back in step).
 typedef float bh_f32x2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(512, 2) void bin_head_h2_kernel(const float* __restrict__ feat, const float* __restrict__ Wf,
