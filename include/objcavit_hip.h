@@ -218,13 +218,14 @@ int ocv_patch_embed_fwd(const float* fmap, int channels_last, const float* W, co
                         size_t workspace_bytes, ocv_stream_t stream);
 
 /* The same patch embedding on a feature map that is already stored in the "hl32" split-bf16 layout (below: what the
- * decoder's last convolution leaves beside its fp32 result), as 16 split-bf16 GEMMs -- one per patch row ky -- in ONE launch
- * of the LDS-DMA convolution kernel, summed in a fixed order with bias and positional embedding.  In that layout the 16 x C
+ * decoder's last convolution leaves beside its fp32 result), as 16 two-term-split GEMMs -- one per patch row ky -- in ONE launch
+ * of the LDS-DMA convolution kernel (since round 4 their K steps are one axis cut in a batch-dependent number of pieces: the raw
+ * partial results, 1 ... 64 of them, go to the workspace), summed in a fixed order with bias and positional embedding.  In that layout the 16 x C
  * values of one patch row are contiguous and the patches of an image row follow each other, so the map is read in place.
  * Products hi*hi + hi*lo + lo*hi (error <= 2^-17 per product, as in every convolution of the path), fp32 accumulation.
  *   x_hl  [B][h][w][2 C] bf16 (C a multiple of 32);   w_hi / w_lo [16 (ky)][E][16 C] bf16, column kx*C + c =
  *   bf16 split of W[e][c][ky][kx];   pos / pos_bs / out as above;   E a multiple of 8;   h a multiple of 16 when B > 1.
- *   workspace: ocv_patch_embed_split_workspace_bytes (the 16 raw results).
+ *   workspace: ocv_patch_embed_split_workspace_bytes (the raw partial results).
  *   f16 / oscale: the element type of x_hl, w_hi, w_lo (0 = bf16 pairs, 1 = fp16 pairs) and the nullable per-output-channel
  *   factor [E] on the raw sums, as ocv_conv_nhwc_split_x_fwd (ABI 3). */
 size_t ocv_patch_embed_split_workspace_bytes(int B, int C, int h, int w, int E);
