@@ -73,11 +73,14 @@ __device__ __forceinline__ float4 fx_fma4(const float4 w, const float4 v, float4
   return a;
 }
 
-template <int K, int S, int KS>
-__global__ __launch_bounds__(256, K == 3 ? 2 : 1) void mbconv_expand_dw_kernel(FXArgs p) {
+// TAIL: the image's last workgroup computes the squeeze-excite gate (se_tail.hpp; opt-in).  A template parameter because the tail's
+// 32 loads in flight set the register count of the WHOLE kernel: compiled in, the default launches paid for it in occupancy.
+template <int K, int S, int KS, bool TAIL>
+__global__ __launch_bounds__(256, K == 3 ? ((TAIL || S == 2) ? 2 : 3) : 1) void mbconv_expand_dw_kernel(FXArgs p) {
   using G = FXGeom<K, S>;
   extern __shared__ __attribute__((aligned(16))) float e[];        // [MT * 32 pixels][32 channels]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: what depends on it branches on the scalar unit
 
   int wg = blockIdx.x;
   {
@@ -95,11 +98,7 @@ __global__ __launch_bounds__(256, K == 3 ? 2 : 1) void mbconv_expand_dw_kernel(F
   const int q = tid & 7, col = (tid >> 3) % G::TW, rg = (tid >> 3) / G::TW;
   const int cq = n0 + 4 * q;
   const bool cok = cq < p.mid;
-  float4 wdw[K * K];
-  if (K == 3) {
-#pragma unroll
-    for (int t = 0; t < K * K; ++t) wdw[t] = cok ? ld4(p.wd + (long)t * p.mid + cq) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
+  float4 wdw[K * K];                              // (fetched behind phase A: held through it they cost a wavefront of occupancy)
   const float4 bdw = (cok && p.bd != nullptr) ? ld4(p.bd + cq) : make_float4(0.f, 0.f, 0.f, 0.f);
 
   // ---------------- phase A: expand GEMM of the halo pixels into LDS
@@ -116,7 +115,9 @@ __global__ __launch_bounds__(256, K == 3 ? 2 : 1) void mbconv_expand_dw_kernel(F
   const float* xb = p.x + (long)b * p.H * p.W * p.Cin;
   const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + G::IH <= p.H && ix0 + G::IW <= p.W;      // wave-uniform
   constexpr int NMT = (G::MT + 3) / 4;          // M tiles (32 halo pixels) per wavefront
-  constexpr int GRP = 3;                        // M tiles whose loads are in flight together
+  constexpr int GRP = S == 1 ? 2 : 3;           // M tiles whose loads are in flight together.  Stride 1 (stage 2's four blocks): two, at
+                                                // three wavefronts per SIMD (194 -> 179 us); stride 2: three at two per SIMD (the other way
+                                                // round they lose 7 - 14 %: tools/exp_mbconv.py)
 #pragma unroll
   for (int g0 = 0; g0 < NMT; g0 += GRP) {
     float4 raw[GRP][KS][2];
@@ -124,18 +125,20 @@ __global__ __launch_bounds__(256, K == 3 ? 2 : 1) void mbconv_expand_dw_kernel(F
     for (int i = 0; i < GRP; ++i) {
       const int mt = wave + 4 * (g0 + i);
       if (g0 + i < NMT && mt < G::MT) {
-        const int pp = mt * 32 + l31;
+        // UNCONDITIONAL loads from a clamped address: rows beyond the halo (the last M tile) and pixels outside the image read a
+        // real pixel instead -- the former land in LDS slots nobody reads, the latter are forced to zero at the store below --
+        // and the K padding (Cin = 40: octet 40 .. 47) re-reads the pixel's last octet against zero weights (hip_ops.SplitWeight
+        // pads K with zeros).  A predicated load is a branch around every load here: ~200 in this kernel before.
+        const int pp = min(mt * 32 + l31, G::P - 1);
         const int py = pp / G::IW, j = pp - py * G::IW;
         const int px = S == 1 ? j : (j < G::HALF ? 2 * j : 2 * (j - G::HALF) + 1);
-        const int iy = iy0 + py, ix = ix0 + px;
-        const bool v = pp < G::P && (interior || ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W));
-        const float* row = xb + ((long)(v ? iy : 0) * p.W + (v ? ix : 0)) * p.Cin;
+        const int iy = min(max(iy0 + py, 0), p.H - 1), ix = min(max(ix0 + px, 0), p.W - 1);
+        const float* row = xb + (unsigned)((iy * p.W + ix) * p.Cin);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-          const int k = 16 * s + 8 * hh;
-          const bool ld = v && k < p.Cin;
-          raw[i][s][0] = ld ? ld4(row + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-          raw[i][s][1] = ld ? ld4(row + k + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const int k = min(16 * s + 8 * hh, p.Cin - 8);
+          raw[i][s][0] = ld4(row + k);
+          raw[i][s][1] = ld4(row + k + 4);
         }
       }
     }
@@ -178,9 +181,10 @@ __global__ __launch_bounds__(256, K == 3 ? 2 : 1) void mbconv_expand_dw_kernel(F
       }
     }
   }
-  if (K != 3) {
+  {
+    const int cqs = cok ? cq : 0;                 // (channels beyond mid: any quad -- their outputs are never stored)
 #pragma unroll
-    for (int t = 0; t < K * K; ++t) wdw[t] = cok ? ld4(p.wd + (long)t * p.mid + cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < K * K; ++t) wdw[t] = ld4(p.wd + (unsigned)(t * p.mid + cqs));
   }
   __syncthreads();
 
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(256, K == 3 ? 2 : 1) void mbconv_expand_dw_kernel(F
 #pragma unroll 8
     for (int j = 0; j < 32; ++j) s += e[j * 32 + tid];
     float* dst = p.part + ((long)b * p.tiles_per_image + t2) * p.mid + n0 + tid;
-    if (p.se.cnt != nullptr) {
+    if constexpr (TAIL) {
       se_store_sc1(dst, s);                                     // write-through: read by the image's last workgroup, on any XCD
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
@@ -234,8 +238,10 @@ __global__ __launch_bounds__(256, K == 3 ? 2 : 1) void mbconv_expand_dw_kernel(F
     }
   }
   // (the staging array is free again behind se_arrive's first barrier: it needs SE_TAIL_LDS_FLOATS floats of it)
-  if (p.se.cnt != nullptr && se_arrive(p.se, b, e))
-    se_gate_from_partials(p.se, p.part + (long)b * p.tiles_per_image * p.mid, p.tiles_per_image, p.mid, b, e);
+  if constexpr (TAIL) {
+    if (se_arrive(p.se, b, e))
+      se_gate_from_partials(p.se, p.part + (long)b * p.tiles_per_image * p.mid, p.tiles_per_image, p.mid, b, e);
+  }
 }
 
 template <int K, int S, int KS>
@@ -243,11 +249,15 @@ int fx_launch(const FXArgs& a, int B, hipStream_t st) {
   using G = FXGeom<K, S>;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)mbconv_expand_dw_kernel<K, S, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)mbconv_expand_dw_kernel<K, S, KS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)mbconv_expand_dw_kernel<K, S, KS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     attr = true;
   }
   const long grid = (long)B * a.tiles_per_image * a.nchunks;
-  hipLaunchKernelGGL((mbconv_expand_dw_kernel<K, S, KS>), dim3((unsigned)grid), dim3(256), G::LDS_BYTES, st, a);
+  if (a.se.cnt != nullptr)
+    hipLaunchKernelGGL((mbconv_expand_dw_kernel<K, S, KS, true>), dim3((unsigned)grid), dim3(256), G::LDS_BYTES, st, a);
+  else
+    hipLaunchKernelGGL((mbconv_expand_dw_kernel<K, S, KS, false>), dim3((unsigned)grid), dim3(256), G::LDS_BYTES, st, a);
   OCV_CHECK_LAUNCH("ocv_mbconv_expand_dw_fwd");
   return 0;
 }
