@@ -39,7 +39,9 @@ struct DWSArgs {
 // 3x instead of 15x at k = 5 (PX = 2).  The L1 <- L2 path, not HBM, is what bounded the plain kernel (its 18 / 40
 // loads per x-block moved 6.5 TB/s out of L2 for 2.9 TB/s of useful traffic).
 // Weights: K = 3 in VGPRs (36); K = 5 in LDS (the 100 registers go to the window instead).
-template <int K, int S, int PX>
+// TAIL: the image's last workgroup forms the squeeze-excite gate (se_tail.hpp; opt-in, OCV_SE_TAIL=1).  A template parameter: compiled
+// into the one kernel, the tail's 32 loads in flight set the register count of every launch (k = 5: 9 spilled registers).
+template <int K, int S, int PX, bool TAIL>
 __global__ __launch_bounds__(256, 2) void dw_slide_kernel(DWSArgs p) {
   constexpr int NIN = (PX - 1) * S + K;
   constexpr bool WLDS = K > 3;
@@ -181,15 +183,17 @@ __global__ __launch_bounds__(256, 2) void dw_slide_kernel(DWSArgs p) {
       t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
     }
     float* dst = p.part + ((b * p.tiles + tile) * (long)p.C) + c;
-    if (p.se.cnt != nullptr) {
+    if constexpr (TAIL) {
       se_store_sc1(dst, t);                                     // write-through: read by the image's last workgroup, on any XCD
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drained before this workgroup's ticket is drawn
     } else {
       *reinterpret_cast<float4*>(dst) = t;
     }
   }
-  if (p.se.cnt != nullptr && se_arrive(p.se, b, se_sm))
-    se_gate_from_partials(p.se, p.part + b * p.tiles * (long)p.C, p.tiles, p.C, b, se_sm);
+  if constexpr (TAIL) {
+    if (se_arrive(p.se, b, se_sm))
+      se_gate_from_partials(p.se, p.part + b * p.tiles * (long)p.C, p.tiles, p.C, b, se_sm);
+  }
 }
 
 // workgroup geometry shared by the size query and the launch
@@ -508,7 +512,10 @@ __global__ __launch_bounds__(256) void se_gate_weights_kernel(const float* __res
 
 template <int K, int S, int PX>
 int launch_dws(const DWSArgs& a, const DWSGeom& g, int B, hipStream_t st) {
-  hipLaunchKernelGGL((dw_slide_kernel<K, S, PX>), dim3((unsigned)((long)g.tiles * g.chunks * B)), dim3(256), 0, st, a);
+  if (a.se.cnt != nullptr)
+    hipLaunchKernelGGL((dw_slide_kernel<K, S, PX, true>), dim3((unsigned)((long)g.tiles * g.chunks * B)), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((dw_slide_kernel<K, S, PX, false>), dim3((unsigned)((long)g.tiles * g.chunks * B)), dim3(256), 0, st, a);
   OCV_CHECK_LAUNCH("ocv_depthwise_conv_nhwc_sum_fwd");
   return 0;
 }
