@@ -537,6 +537,12 @@ def main():
             step(0, k)                                 # also warms the metric kernel (lazy code loading)
         barrier() if world == 1 else (None if a.stub_cpu else torch.cuda.synchronize())
         log(f"warm-up step {i} done")
+    if world > 1:
+        # warm-up of the job's ONE collective, same shape as the timed one: the first all-gather of a communicator sets up its
+        # own channels (the barrier's all-reduce does not), which must not land inside a timed region of a few hundred ms
+        warm = torch.zeros(a.steps * B, len(dp.RECORD_FIELDS), dtype=torch.float32, device=device if not a.stub_cpu else "cpu")
+        warm[:, dp.RECORD_FIELDS.index("image_id")] = torch.arange(a.steps * B, dtype=torch.float32, device=warm.device) + rank * a.steps * B
+        dp.gather_records(warm, world, n_total=world * a.steps * B)
     barrier()
 
     # With several batches in flight the first ROOFLINE_STEPS steps of the timed region run ALONE on slot 0 (the other
