@@ -778,7 +778,7 @@ def patch_embed_auto(fmap: torch.Tensor, weight: torch.Tensor, bias: Optional[to
         if prep is not None:
             return patch_embed_split(pre, prep[0], prep[1], bias, pos, oscale=prep[2])
         ROUTE_REPORT["patch_embed"] = "weights do not fit fp16 pairs (column spread > 2^17): exact-fp32 kernel on the fp32 map"
-    return patch_embed(fmap, weight, bias, pos, cl_cache=cl_cache)
+    return patch_embed(fp32_map(fmap), weight, bias, pos, cl_cache=cl_cache)
 
 
 def prep_patch_embed_weight(weight: torch.Tensor, f16: bool = False):
@@ -1181,6 +1181,39 @@ def tap_interp_combine(z: torch.Tensor, s: Optional[torch.Tensor], bias: Optiona
     if out_fp32 and out_split:
         return y, ys
     return y if out_fp32 else ys
+
+
+def split_only_enabled() -> bool:
+    """Whether the decoder may hand the heads its output in split form ONLY (``map_placeholder``): the default; off with
+    OCV_PATCH_EMBED=exact (that A/B route reads the fp32 map) or OCV_DECODER_FP32=1."""
+    return os.environ.get("OCV_PATCH_EMBED", "split") == "split" and os.environ.get("OCV_DECODER_FP32", "0") != "1"
+
+
+def map_placeholder(split: "SplitAct") -> torch.Tensor:
+    """The decoder's output when both heads' consumers -- the 16x16 patch embedding and the 3x3 convolution -- take its split copy
+    (``_ocv_split``): a [B, C, H, W] tensor of the right shape and device WITHOUT storage of its own (one NaN, stride 0), so the
+    convolution that produces the map writes 4 bytes per value instead of 8 (629 MB less per step at bs 16).  Anything that does read
+    the fp32 values (the reported fallbacks: weights that do not fit fp16 pairs) goes through ``fp32_map`` first; a read that
+    forgets to is NaN, not silently wrong."""
+    B, Cc, H, W = split.shape
+    t = torch.full((1,), float("nan"), dtype=torch.float32, device=split.hl.device).expand(B, Cc, H, W)
+    t._ocv_split = split
+    t._ocv_fp32_missing = True
+    return t
+
+
+def fp32_map(fmap: torch.Tensor) -> torch.Tensor:
+    """``fmap`` itself, or -- for a ``map_placeholder`` -- the fp32 map rebuilt from its split copy (hi + lo: 22 bits from fp16
+    pairs, 16 from bf16 pairs), channels_last, carrying the same split copy."""
+    if not getattr(fmap, "_ocv_fp32_missing", False):
+        return fmap
+    sp = fmap._ocv_split
+    B, Cc, H, W = sp.shape
+    v = sp.hl.view(B, H, W, -1, 2, 32).float()
+    out = (v[..., 0, :] + v[..., 1, :]).reshape(B, H, W, -1)[..., :Cc].permute(0, 3, 1, 2)      # NHWC storage = channels_last
+    out = out.contiguous(memory_format=torch.channels_last)
+    out._ocv_split = sp
+    return out
 
 
 def split_act(x: torch.Tensor, f16: bool = False) -> "SplitAct":

@@ -74,7 +74,7 @@ class AdaBins(nn.Module):
             yield from m.parameters()
 
     def forward(self, image):
-        unet_out = self.dense_feature_extractor(image)
+        unet_out = self.dense_feature_extractor(image, _split_only=True)        # (the heads read the split copy: hip_ops.map_placeholder)
         ds = self.args[self.args.basic.dataset]
         bin_widths_normed, feat, queries = self.adaptive_bins_layer.forward_parts(unet_out, (ds.min_depth, ds.max_depth))
         bin_edges, centers = bin_edges_and_centers(bin_widths_normed, ds.min_depth, ds.max_depth)

@@ -509,7 +509,9 @@ class Decoder(nn.Module):
 
         return shape, (x0, key, fn, (h + 2, w + 2))
 
-    def forward(self, features):
+    def forward(self, features, _split_only: bool = False):
+        """``_split_only`` (GraphBins / AdaBins inference calls): the heads read the split copy of the result, so the last convolution
+        writes only that and the returned tensor is a ``hip_ops.map_placeholder``."""
         b0, b1, b2, b3, b4 = (features[i] for i in self.feature_select)
         if b4.device.type == "cuda" and not self.training and not torch.is_grad_enabled():
             # inference on the GPU: the decoder runs in channels_last (NHWC), the layout of every kernel of the path
@@ -554,6 +556,9 @@ class Decoder(nn.Module):
                     # do_final_upscale (reference :99-101,116-117): a fifth stage against the IMAGE, in the same low-resolution form
                     # (tap GEMM at half resolution, a 3 x 3 convolution over the image's three channels, tap interpolation)
                     xs = fin.forward_split(xs, features[0], out_fp32=False, out_split=True, f16=f16)
+                if _split_only and hip_ops.split_only_enabled():
+                    sp = self._split3.run_split(xs, hip_ops.ACT_NONE, out_fp32=False, out_split=True)
+                    return hip_ops.map_placeholder(sp), sp
                 return self._split3.run_split(xs, hip_ops.ACT_NONE, out_fp32=True, out_split=True)
 
             calibrate = mode[1] and len(mode) == 2 and not torch.cuda.is_current_stream_capturing()
@@ -627,6 +632,6 @@ class DenseFeatureExtractor(nn.Module):
         self._encoder_params_module_list.append(self.encoder)
         self._non_encoder_params_module_list.append(self.decoder)
 
-    def forward(self, image):
+    def forward(self, image, _split_only: bool = False):
         fast = image.device.type == "cuda" and not self.training and not torch.is_grad_enabled()
-        return self.decoder(self.encoder(image, _defer_head=True) if fast else self.encoder(image))
+        return self.decoder(self.encoder(image, _defer_head=True) if fast else self.encoder(image), _split_only=_split_only and fast)

@@ -148,9 +148,9 @@ class GraphBins(nn.Module):
                 pre = self.objcavit.object_prepass(object_features, object_xywh_list, image.device, pad_objects_to)
             encoded = self.dense_feature_extractor.encoder(image, _defer_head=not torch.is_grad_enabled() and not self.training)
             main.wait_stream(side)
-            dense_features = self.dense_feature_extractor.decoder(encoded)
+            dense_features = self.dense_feature_extractor.decoder(encoded, _split_only=True)
         else:
-            dense_features = self.dense_feature_extractor(image)
+            dense_features = self.dense_feature_extractor(image, _split_only=True)   # (the heads read the split copy: hip_ops.map_placeholder)
         bin_widths_normed, feat, queries = self.objcavit.forward_parts(dense_features, object_features, object_xywh_list, pre=pre,
                                                                      pad_objects_to=pad_objects_to, object_group=object_group)
         ds = self.args[self.args.basic.dataset]

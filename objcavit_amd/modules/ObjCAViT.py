@@ -509,8 +509,8 @@ class ObjCAViT(nn.Module):
                     if torch.cuda.is_current_stream_capturing():
                         raise
                     hip_ops.ROUTE_REPORT["heads.conv3x3"] = f"bf16 pairs on the fp32 map: {e}"
-            return plan(x)                                            # split-bf16 implicit GEMM, NHWC in / out
-        return plan.exact(x)                                          # OCV_CONV=exact, or channels not a multiple of 4
+            return plan(hip_ops.fp32_map(x))                          # split-bf16 implicit GEMM, NHWC in / out
+        return plan.exact(hip_ops.fp32_map(x))                        # OCV_CONV=exact, or channels not a multiple of 4
 
     def forward(self, image_features, object_features, object_xywh_list, pad_objects_to: Optional[int] = None):
         y, feat, queries = self.forward_parts(image_features, object_features, object_xywh_list, pad_objects_to=pad_objects_to)

@@ -216,6 +216,40 @@ def test_side_streams_equal_the_single_stream(monkeypatch):
         assert torch.equal(g(img).depth_pred, ref) and torch.equal(g(img).depth_pred, ref), (obj, tok, head)
 
 
+def test_decoder_output_in_split_form_only(monkeypatch):
+    """GraphBins / AdaBins ask the decoder for its output in split form only (hip_ops.map_placeholder: the last convolution writes 4
+    bytes per value instead of 8): same kernels on the same split copy as with the fp32 map written too (OCV_DECODER_FP32=1), so the
+    same bits; the placeholder has no storage (NaN, stride 0), ``fp32_map`` rebuilds the map to the pairs' 22 bits, and a patch-embedding
+    weight that does NOT fit fp16 pairs takes the rebuilt map through the exact kernel -- reported, finite, at the oracle's bar."""
+    from objcavit_amd import hip_ops
+    from objcavit_amd.modules.GraphBins import GraphBins, SyntheticObjectProvider
+    H, W = 352, 384
+    args = make_args(dimensions_train=[H, W], dimensions_test=[H, W], language="clip")
+    m = GraphBins(args, object_provider=SyntheticObjectProvider(8, "clip", seed=3)).eval()
+    gen.load_into(m, 61, gen.PEAKY)
+    m = m.cuda()
+    img = gen.randn("img", (2, 3, H, W), 61).cuda()
+    monkeypatch.setenv("OCV_DECODER_FP32", "1")
+    ref = m(img)
+    full = m.dense_feature_extractor(img, _split_only=True)                  # (switch off: the fp32 map is written)
+    assert not getattr(full, "_ocv_fp32_missing", False) and bool(torch.isfinite(full).all())
+    monkeypatch.delenv("OCV_DECODER_FP32")
+    out = m(img)
+    assert torch.equal(out.depth_pred, ref.depth_pred) and torch.equal(out.bin_edges, ref.bin_edges)
+    ph = m.dense_feature_extractor(img, _split_only=True)
+    assert ph._ocv_fp32_missing and ph.stride() == (0, 0, 0, 0) and tuple(ph.shape) == tuple(full.shape) and bool(torch.isnan(ph).all())
+    rebuilt = hip_ops.fp32_map(ph)
+    assert rebuilt.is_contiguous(memory_format=torch.channels_last) and rel_dev(rebuilt, full) < 2.0 ** -21
+    assert m.dense_feature_extractor(img) is not None and not getattr(m.dense_feature_extractor(img), "_ocv_fp32_missing", False)   # the public call
+    # the reported fallback: one input column of the patch embedding 2^-30 below the rest in every row -> no fp16 pairs for that weight
+    hip_ops.ROUTE_REPORT.clear()
+    m.objcavit.image_embedding_convPxP.weight[:, 0, 0, 0] *= 2.0 ** -30      # (in place on the parameter: its version moves)
+    out2 = m(img)
+    assert "patch_embed" in hip_ops.ROUTE_REPORT, hip_ops.ROUTE_REPORT
+    assert bool(torch.isfinite(out2.depth_pred).all())
+    hip_ops.ROUTE_REPORT.clear()
+
+
 @pytest.mark.parametrize("head_overlap", ["1", "0"])
 def test_graph_replay_with_eager_island_equals_eager_dispatch(monkeypatch, head_overlap):
     """GraphedGraphBins: graph segments + an eager island + the eager head give bit-identical depth to plain dispatch,
