@@ -1183,6 +1183,9 @@ def tap_interp_combine(z: torch.Tensor, s: Optional[torch.Tensor], bias: Optiona
     return y if out_fp32 else ys
 
 
+_NAN: Dict["torch.device", torch.Tensor] = {}
+
+
 def split_only_enabled() -> bool:
     """Whether the decoder may hand the heads its output in split form ONLY (``map_placeholder``): the default; off with
     OCV_PATCH_EMBED=exact (that A/B route reads the fp32 map) or OCV_DECODER_FP32=1."""
@@ -1196,7 +1199,13 @@ def map_placeholder(split: "SplitAct") -> torch.Tensor:
     the fp32 values (the reported fallbacks: weights that do not fit fp16 pairs) goes through ``fp32_map`` first; a read that
     forgets to is NaN, not silently wrong."""
     B, Cc, H, W = split.shape
-    t = torch.full((1,), float("nan"), dtype=torch.float32, device=split.hl.device).expand(B, Cc, H, W)
+    dev = split.hl.device
+    nan = _NAN.get(dev)
+    if nan is None:                                        # (one scalar per device, made once: no fill launch per forward / replay)
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("map_placeholder: run one eager warm-up call before capture")
+        nan = _NAN[dev] = torch.full((1,), float("nan"), dtype=torch.float32, device=dev)
+    t = nan.expand(B, Cc, H, W)
     t._ocv_split = split
     t._ocv_fp32_missing = True
     return t
