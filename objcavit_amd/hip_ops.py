@@ -1202,7 +1202,7 @@ def map_placeholder(split: "SplitAct") -> torch.Tensor:
     dev = split.hl.device
     nan = _NAN.get(dev)
     if nan is None:                                        # (one scalar per device, made once: no fill launch per forward / replay)
-        if torch.cuda.is_current_stream_capturing():
+        if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
             raise RuntimeError("map_placeholder: run one eager warm-up call before capture")
         nan = _NAN[dev] = torch.full((1,), float("nan"), dtype=torch.float32, device=dev)
     t = nan.expand(B, Cc, H, W)

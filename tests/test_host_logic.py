@@ -412,3 +412,28 @@ def test_side_stream_switches_follow_the_batches_in_flight(monkeypatch):
         assert broke == ["ran", "x"]
     finally:
         hip_ops.set_batches_in_flight(prev)
+
+
+def test_map_placeholder_and_fp32_map_on_the_host():
+    """hip_ops.map_placeholder / fp32_map (the decoder's output in split form only): the placeholder has the map's shape, no storage
+    and NaN contents; fp32_map rebuilds hi + lo from the hl32 layout (hi | lo per 32 channels, pad channels dropped), returns real
+    tensors unchanged, and keeps the split copy attached."""
+    from objcavit_amd import hip_ops
+    B, C, H, W = 2, 40, 3, 5                                   # 40 channels: two 32-blocks, the second one padded
+    x = torch.randn(B, C, H, W)
+    Cp = 64
+    xp = torch.zeros(B, H, W, Cp)
+    xp[..., :C] = x.permute(0, 2, 3, 1)
+    for dt, tol in ((torch.float16, 2.0 ** -21), (torch.bfloat16, 2.0 ** -15)):
+        hi = xp.to(dt)
+        lo = (xp - hi.float()).to(dt)
+        hl = torch.stack([hi.view(B, H, W, Cp // 32, 32), lo.view(B, H, W, Cp // 32, 32)], dim=4).reshape(B, H, W, 2 * Cp)
+        sp = hip_ops.SplitAct(hl.contiguous(), C)
+        ph = hip_ops.map_placeholder(sp)
+        assert tuple(ph.shape) == (B, C, H, W) and ph.stride() == (0, 0, 0, 0) and bool(torch.isnan(ph).all())
+        assert ph._ocv_fp32_missing and ph._ocv_split is sp
+        full = hip_ops.fp32_map(ph)
+        assert tuple(full.shape) == (B, C, H, W) and full.is_contiguous(memory_format=torch.channels_last) and full._ocv_split is sp
+        assert float((full - x).abs().max() / x.abs().max()) < tol
+    real = torch.randn(1, 8, 2, 2)
+    assert hip_ops.fp32_map(real) is real
