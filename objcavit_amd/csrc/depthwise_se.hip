@@ -336,7 +336,7 @@ __global__ __launch_bounds__(1024) void se_fused_small_kernel(const float* __res
                                                              const float* __restrict__ w1, const float* __restrict__ b1,
                                                              const float* __restrict__ w2t, const float* __restrict__ b2,
                                                              float* __restrict__ gate, int C, int R) {
-  extern __shared__ float sm[];            // mean[C] | red[TG][C] | hs[64]
+  extern __shared__ float sm[];            // mean[C] | red[TG][C] | hs[128]
   float* mean = sm;
   float* red = sm + C;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -604,8 +604,10 @@ extern "C" int ocv_se_gate_partials_fwd(const float* part, int tiles, long pixel
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = (size_t)(C + (C >= 4096 ? C : 4096)) * sizeof(float);      // mean[C] | red[TG][C], TG * C <= 4096
   static const bool no_fuse = getenv("OCV_SE_FUSED") != nullptr && atoi(getenv("OCV_SE_FUSED")) == 0;
-  if (!no_fuse && C <= 1536 && R <= 64) {                                       // small squeeze-excite weights: ONE launch
-    hipLaunchKernelGGL(se_fused_small_kernel, dim3((C + 255) / 256, B), dim3(1024), lds + 64 * sizeof(float), st, part, tiles,
+  static const int max_c = getenv("OCV_SE_FUSED_MAXC") ? atoi(getenv("OCV_SE_FUSED_MAXC")) : 1536;      // (A/B: 1824 / 3072 take stages 6 / 7 in)
+  static const int max_r = getenv("OCV_SE_FUSED_MAXR") ? atoi(getenv("OCV_SE_FUSED_MAXR")) : 64;
+  if (!no_fuse && C <= max_c && R <= max_r && R <= 128) {                       // small squeeze-excite weights: ONE launch
+    hipLaunchKernelGGL(se_fused_small_kernel, dim3((C + 255) / 256, B), dim3(1024), lds + 128 * sizeof(float), st, part, tiles,
                        1.0f / (float)pixels_per_image, w1, b1, w2t, b2, gate, C, R);
     OCV_CHECK_LAUNCH("ocv_se_gate_partials_fwd(fused)");
     return 0;
