@@ -193,6 +193,18 @@ int ocv_layer_tail_split3_fwd(const float* ctx, const float* x, const ocv_encode
 int ocv_layer_tail_h2_fwd(const float* ctx, const float* x, const ocv_encoder_layer_params* p, const void* next_in_proj_h2,
                               const float* next_in_proj_b, float eps, const uint8_t* zero_row_mask, float* out,
                               float* qkv_next, int M, int E, int FF, ocv_stream_t stream);
+/* The same with the feed-forward chunks of every 32-token row block shared out over G workgroups where the launch would leave
+ * most of the chip idle (few tokens: the reference's own batch of 1 - 2 images); the row block's last workgroup to arrive adds the
+ * partial sums in a fixed order and finishes the layer (one launch, nobody waits).  ocv_layer_tail_h2_groups: G for (M, FF) -- 8 up
+ * to 24 row blocks, 4 up to 56, else 1.  workspace: ocv_layer_tail_h2_workspace_bytes (0 when G = 1) = the partial sums
+ * followed by one arrival ticket per row block; THE TICKETS MUST BE ZERO WHEN THE CALL STARTS and are zero again when it has
+ * finished (ocv_encoder_stack_fwd clears them itself).  workspace NULL / too small: one workgroup per row block, as above.
+ * Results are bit-reproducible for a given (M, FF); they differ from the G = 1 form in the last bits (summation order). */
+int ocv_layer_tail_h2_groups(int M, int FF);
+size_t ocv_layer_tail_h2_workspace_bytes(int M, int FF);
+int ocv_layer_tail_h2_ws_fwd(const float* ctx, const float* x, const ocv_encoder_layer_params* p, const void* next_in_proj_h2,
+                             const float* next_in_proj_b, float eps, const uint8_t* zero_row_mask, float* out,
+                             float* qkv_next, int M, int E, int FF, void* workspace, size_t workspace_bytes, ocv_stream_t stream);
 /* nn.TransformerEncoder(layer, n_layers) forward (eval, post-norm, batch-first [B,S,E]) in 1 + 2 n_layers launches: the
  * packed projection of layer 0, then per layer ocv_attention_fwd and ocv_layer_tail_split3_fwd.  Every layer needs its
  * packed split3 weights.  Semantics of key_padding_mask / zero_padded_rows as in ocv_encoder_layer_fwd (the zeros are

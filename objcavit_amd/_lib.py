@@ -65,6 +65,10 @@ PROTOTYPES = {
                                             C.c_int, C.c_int, C.c_int, _stream]),
     "ocv_layer_tail_h2_fwd": (C.c_int, [_f32p, _f32p, C.POINTER(EncoderLayerParams), C.c_void_p, _f32p, C.c_float, _u8p, _f32p, _f32p,
                                             C.c_int, C.c_int, C.c_int, _stream]),
+    "ocv_layer_tail_h2_groups": (C.c_int, [C.c_int, C.c_int]),
+    "ocv_layer_tail_h2_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "ocv_layer_tail_h2_ws_fwd": (C.c_int, [_f32p, _f32p, C.POINTER(EncoderLayerParams), C.c_void_p, _f32p, C.c_float, _u8p, _f32p, _f32p,
+                                           C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, _stream]),
     "ocv_encoder_stack_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "ocv_encoder_stack_fwd": (C.c_int, [_f32p, C.POINTER(EncoderLayerParams), C.c_int, _u8p, C.c_int, _f32p, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_size_t, _stream]),

@@ -203,7 +203,8 @@ extern "C" int ocv_encoder_layer_fwd(const float* x, const ocv_encoder_layer_par
 extern "C" size_t ocv_encoder_stack_workspace_bytes(int B, int S, int E) {
   if (B < 1 || S < 1 || E < 1) return 0;
   const size_t M = (size_t)B * S;
-  return align_up(M * 3 * E * sizeof(float)) + 3 * align_up(M * E * sizeof(float));
+  // + the feed-forward partial sums and arrival tickets of the tails' few-token form (ocv_layer_tail_h2_ws_fwd; 0 for large M)
+  return align_up(M * 3 * E * sizeof(float)) + 3 * align_up(M * E * sizeof(float)) + align_up(ocv_layer_tail_h2_workspace_bytes((int)M, 1024));
 }
 
 extern "C" int ocv_encoder_stack_fwd(const float* x, const ocv_encoder_layer_params* layers_caller, int n_layers,
@@ -232,6 +233,20 @@ extern "C" int ocv_encoder_stack_fwd(const float* x, const ocv_encoder_layer_par
   float* xa = (float*)ws;
   ws += align_up((size_t)M * E * sizeof(float));
   float* xb = (float*)ws;
+  ws += align_up((size_t)M * E * sizeof(float));
+  // few tokens: the tails share their feed-forward chunks out over workgroups; their arrival tickets are cleared ONCE per call
+  // (every tail leaves them zero); FF other than the 1024 the workspace was sized for: one workgroup per row block
+  void* tail_ws = nullptr;
+  const size_t tail_bytes = FF == 1024 ? ocv_layer_tail_h2_workspace_bytes(M, FF) : 0;
+  if (tails_h2 && tail_bytes != 0) {
+    tail_ws = ws;
+    const size_t nblk = (size_t)((M + 31) / 32), G = (size_t)ocv_layer_tail_h2_groups(M, FF);
+    const hipError_t e = hipMemsetAsync((char*)tail_ws + nblk * G * 32 * 128 * sizeof(float), 0, nblk * sizeof(unsigned), (hipStream_t)stream);
+    if (e != hipSuccess) {
+      ocv_set_error("ocv_encoder_stack_fwd: clearing the tails' arrival tickets failed: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+  }
   int rc;
   if ((rc = ocv_linear_split3_fwd(x, E, layers[0].in_proj_p3, layers[0].in_proj_b, qkv, 3 * E, M, 3 * E, E, OCV_ACT_NONE, stream))) return rc;
   const float* cur = x;
@@ -244,8 +259,8 @@ extern "C" int ocv_encoder_stack_fwd(const float* x, const ocv_encoder_layer_par
     // the tail of layer l writes the next layer's q | k | v into the buffer this layer's attention has just consumed:
     // launches on one stream run in order, so the attention above has finished reading it
     if (tails_h2)
-      rc = ocv_layer_tail_h2_fwd(ctx, cur, &layers[l], last ? nullptr : layers[l + 1].in_proj_h2, last ? nullptr : layers[l + 1].in_proj_b,
-                                 eps, zmask, dst, last ? nullptr : qkv, M, E, FF, stream);
+      rc = ocv_layer_tail_h2_ws_fwd(ctx, cur, &layers[l], last ? nullptr : layers[l + 1].in_proj_h2, last ? nullptr : layers[l + 1].in_proj_b,
+                                    eps, zmask, dst, last ? nullptr : qkv, M, E, FF, tail_ws, tail_bytes, stream);
     else
       rc = ocv_layer_tail_split3_fwd(ctx, cur, &layers[l], last ? nullptr : layers[l + 1].in_proj_p3,
                                      last ? nullptr : layers[l + 1].in_proj_b, eps, zmask, dst, last ? nullptr : qkv, M, E, FF, stream);

@@ -12,8 +12,10 @@
 // fp16's range applies to the tokens, the hidden activations and the weights (packer saturates); OCV_TOKENS=split3 keeps
 // the three-term bf16 kernels, OCV_TOKENS=fp32 the exact ones.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "common.hpp"
+#include "se_tail.hpp"             // sc1 stores / typed atomics of the in-launch hand-off
 #include "../../include/objcavit_hip.h"
 
 namespace {
@@ -131,22 +133,35 @@ struct TailArgs {
   float* out;                           // [M][128]
   float* qkv;                           // [M][384] (nullable with wqkv_p)
   int M, FF;
+  float* part;                          // G > 1: [row blocks][G][32][128] raw feed-forward partial sums
+  unsigned* cnt;                        // G > 1: [row blocks] arrival tickets, zero at launch, zero again afterwards
 };
 
 // Three fragment sets rotate (64 registers each): while a phase multiplies from one, the next TWO phases' fragments are
 // in flight -- the three-term kernel, with 96-register sets, could hold two and waited 2 - 3 us per phase for fragments
 // requested one 0.75 us phase earlier.
+//
+// G > 1 (round 4, few tokens -- the reference's own batch of 1 - 2 images, 10 - 19 row blocks on 256 CUs): the launch is bound by
+// the 20-phase fragment stream of ONE workgroup (~50 us whatever the batch), so the eight feed-forward chunks of a row block go to
+// G workgroups (each repeats the output projection and LN1, walks nchunk / G chunks and leaves its raw partial sums write-through),
+// and the row block's LAST workgroup to arrive -- an agent-scope ticket, nobody waits (se_tail.hpp) -- adds the partials in the
+// fixed order 0 .. G - 1, does LN2 and the next layer's projection: 3 + 4 phases instead of 20.  G = 1 is the kernel of round 3,
+// instruction for instruction.
+template <int G>
 __global__ __launch_bounds__(256, 1) void layer_tail_h2_kernel(TailArgs p) {
   __shared__ __attribute__((aligned(16))) _Float16 xp[2 * PLANE];   // ctx, then x1, then x2 (two planes)
   __shared__ __attribute__((aligned(16))) _Float16 hp[2 * PLANE];   // hidden chunk
   __shared__ float Cs[TM][E128 + 1];                                 // fp32: sums, x1, x2
+  __shared__ unsigned last_flag;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
-  const int m0 = blockIdx.x * TM;
+  const int blk = G == 1 ? (int)blockIdx.x : (int)blockIdx.x / G, g = G == 1 ? 0 : (int)blockIdx.x % G;
+  const int m0 = blk * TM;
   const int col = wave * 32 + l31;
-  const int ksteps2 = p.FF >> 4, nchunk = p.FF / KC;
-  auto w1_at = [&](int c) { return p.w1_p + ((long)(c * 4 + wave) * NS * 2) * 512 + lane * 8; };
-  auto w2_at = [&](int c) { return p.w2_p + (((long)wave * ksteps2 + c * (KC / 16)) * 2) * 512 + lane * 8; };
+  const int ksteps2 = p.FF >> 4, nchunk_all = p.FF / KC;
+  const int c0 = nchunk_all * g / G, nchunk = nchunk_all * (g + 1) / G - c0;        // this workgroup's chunks [c0, c0 + nchunk)
+  auto w1_at = [&](int c) { return p.w1_p + ((long)((c0 + c) * 4 + wave) * NS * 2) * 512 + lane * 8; };
+  auto w2_at = [&](int c) { return p.w2_p + (((long)wave * ksteps2 + (c0 + c) * (KC / 16)) * 2) * 512 + lane * 8; };
 
   // ---- x1 = LN1(x + ctx Wo^T + bo)
   WFragH fa, fb, fc;                    // roles rotate: see the feed-forward loop
@@ -177,7 +192,7 @@ __global__ __launch_bounds__(256, 1) void layer_tail_h2_kernel(TailArgs p) {
   // freed set takes W2(c + 1), after phase 2 the next freed one takes W1(c + 2): every fragment is requested two phases ahead.
   f32x16 acc1 = {0}, acc2 = {0};
   auto ffn_chunk = [&](int c, WFragH& s1, WFragH& s2, WFragH& s3) {
-    const float b1 = p.b1[c * KC + col];
+    const float b1 = p.b1[(c0 + c) * KC + col];
     f32x16 h1 = {0}, h2 = {0};
     chunk_h2(h1, h2, xp, s1, l31, hh);
     if (c + 1 < nchunk) load_wh(s1, w2_at(c + 1));
@@ -205,6 +220,40 @@ __global__ __launch_bounds__(256, 1) void layer_tail_h2_kernel(TailArgs p) {
   if (c < nchunk) {
     ffn_chunk(c, fb, fc, fa);
     if (c + 1 < nchunk) ffn_chunk(c + 1, fa, fb, fc);
+  }
+  if constexpr (G > 1) {
+    // raw partial sums of this workgroup's chunks, write-through; then the ticket
+    float* mine = p.part + ((long)(blk * G + g) * TM) * E128 + col;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) se_store_sc1(mine + acc_row(r, hh) * E128, acc1[r] + acc2[r] * LO_DOWN);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned old = __hip_atomic_fetch_add((se_gu32*)(p.cnt + blk), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool last = old == (unsigned)(G - 1);
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store((se_gu32*)(p.cnt + blk), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // nobody else touches it any more
+      }
+      last_flag = last ? 1u : 0u;
+    }
+    __syncthreads();
+    if (last_flag == 0u) return;
+    // the row block's last workgroup: partials of all G workgroups, fixed order (its own comes back from memory like the others)
+    const float* all = p.part + ((long)blk * G * TM) * E128 + col;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = acc_row(r, hh);
+      float v[G];
+#pragma unroll
+      for (int gg = 0; gg < G; ++gg) v[gg] = all[((long)gg * TM + row) * E128];
+      float sacc = v[0];
+#pragma unroll
+      for (int gg = 1; gg < G; ++gg) sacc += v[gg];
+      acc1[r] = sacc;
+      acc2[r] = 0.f;
+    }
   }
   const bool next = p.wqkv_p != nullptr;
   WFragH& q0 = fa;
@@ -261,6 +310,34 @@ extern "C" int ocv_layer_tail_h2_fwd(const float* ctx, const float* x, const ocv
                                      const void* next_in_proj_h2, const float* next_in_proj_b, float eps,
                                      const uint8_t* zero_row_mask, float* out, float* qkv_next, int M, int E, int FF,
                                      ocv_stream_t stream) {
+  return ocv_layer_tail_h2_ws_fwd(ctx, x, p_caller, next_in_proj_h2, next_in_proj_b, eps, zero_row_mask, out, qkv_next, M, E, FF, nullptr, 0,
+                                  stream);
+}
+
+// Feed-forward chunks per row block over G workgroups: only where the launch leaves most of the chip idle (see the kernel)
+extern "C" int ocv_layer_tail_h2_groups(int M, int FF) {
+  static const int forced = [] { const char* e = getenv("OCV_TAIL_GROUPS"); return e ? atoi(e) : 0; }();      // A/B: 1, 2, 4 or 8
+  const int nblk = ocv_cdiv(M, TM), nchunk = FF / KC;
+  int G = nblk <= 24 ? 8 : nblk <= 56 ? 4 : 1;          // (2 groups at 75 - 105 row blocks measured neutral: 870 vs 870, 641 vs 640 img/s)
+  if (forced == 1 || forced == 2 || forced == 4 || forced == 8) G = forced;
+  while (G > 1 && nchunk % G != 0) G >>= 1;
+  return G;
+}
+
+extern "C" size_t ocv_layer_tail_h2_workspace_bytes(int M, int FF) {
+  if (M < 1 || FF < KC) return 0;
+  const int G = ocv_layer_tail_h2_groups(M, FF);
+  if (G == 1) return 0;
+  const size_t nblk = (size_t)ocv_cdiv(M, TM);
+  return nblk * G * TM * E128 * sizeof(float) + ((nblk * sizeof(unsigned) + 255) / 256) * 256;
+}
+
+// workspace (ocv_layer_tail_h2_workspace_bytes; may be null / 0 = one workgroup per row block): partial sums, then the row blocks'
+// arrival tickets, which must be ZERO when the call starts and are zero again when it has finished.
+extern "C" int ocv_layer_tail_h2_ws_fwd(const float* ctx, const float* x, const ocv_encoder_layer_params* p_caller,
+                                        const void* next_in_proj_h2, const float* next_in_proj_b, float eps,
+                                        const uint8_t* zero_row_mask, float* out, float* qkv_next, int M, int E, int FF,
+                                        void* workspace, size_t workspace_bytes, ocv_stream_t stream) {
   OCV_CHECK_ARG(ctx && x && p_caller && out, "ocv_layer_tail_h2_fwd: null pointer");
   ocv_encoder_layer_params pv;
   OCV_CHECK_ARG(ocv_layer_params_view(p_caller, 0, &pv), "ocv_layer_tail_h2_fwd: params->struct_size (%zu) is not a valid ocv_encoder_layer_params size", p_caller->struct_size);
@@ -275,8 +352,20 @@ extern "C" int ocv_layer_tail_h2_fwd(const float* ctx, const float* x, const ocv
   if (M == 0) return 0;
   TailArgs a{ctx, x, (const _Float16*)p->out_proj_h2, (const _Float16*)p->linear1_h2, (const _Float16*)p->linear2_h2,
              (const _Float16*)next_in_proj_h2, p->out_proj_b, p->norm1_w, p->norm1_b, p->linear1_b, p->linear2_b, p->norm2_w,
-             p->norm2_b, next_in_proj_b, eps, zero_row_mask, out, qkv_next, M, FF};
-  hipLaunchKernelGGL(layer_tail_h2_kernel, dim3(ocv_cdiv(M, TM)), dim3(256), 0, (hipStream_t)stream, a);
+             p->norm2_b, next_in_proj_b, eps, zero_row_mask, out, qkv_next, M, FF, nullptr, nullptr};
+  const int nblk = ocv_cdiv(M, TM);
+  const size_t need = ocv_layer_tail_h2_workspace_bytes(M, FF);
+  const int G = (workspace != nullptr && need != 0 && workspace_bytes >= need && ocv_aligned16(workspace)) ? ocv_layer_tail_h2_groups(M, FF) : 1;
+  if (G > 1) {
+    a.part = (float*)workspace;
+    a.cnt = (unsigned*)((char*)workspace + (size_t)nblk * G * TM * E128 * sizeof(float));
+  }
+  switch (G) {
+    case 8: hipLaunchKernelGGL(layer_tail_h2_kernel<8>, dim3(nblk * 8), dim3(256), 0, (hipStream_t)stream, a); break;
+    case 4: hipLaunchKernelGGL(layer_tail_h2_kernel<4>, dim3(nblk * 4), dim3(256), 0, (hipStream_t)stream, a); break;
+    case 2: hipLaunchKernelGGL(layer_tail_h2_kernel<2>, dim3(nblk * 2), dim3(256), 0, (hipStream_t)stream, a); break;
+    default: hipLaunchKernelGGL(layer_tail_h2_kernel<1>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a); break;
+  }
   OCV_CHECK_LAUNCH("ocv_layer_tail_h2_fwd");
   return 0;
 }

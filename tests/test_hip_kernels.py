@@ -434,7 +434,7 @@ def _encoder_sd(seed, prefix="layers."):
 
 
 @pytest.mark.parametrize("mode", ["h2", "split3"])
-@pytest.mark.parametrize("B,S,counts", [(2, 132, None), (1, 300, None), (3, 40, [40, 7, 1]), (16, 32, [32] * 16), (2, 1200, None)])
+@pytest.mark.parametrize("B,S,counts", [(2, 132, None), (1, 300, None), (3, 40, [40, 7, 1]), (16, 32, [32] * 16), (2, 1200, None), (4, 418, None)])
 def test_transformer_encoder_stack(ops, monkeypatch, B, S, counts, mode):
     """nn.TransformerEncoder (4 post-norm layers) in 1 + 2 L launches: the layer tails as two-term fp16 splits (OCV_TOKENS=h2, the
     default: csrc/token_h2.hip) or as three-term bf16 splits (split3), against the oracle and against the exact-fp32 route."""
@@ -458,6 +458,27 @@ def test_transformer_encoder_stack(ops, monkeypatch, B, S, counts, mode):
     assert rel_dev(exact, ref) < 5e-5
     ok = ~dev(mask) if mask is not None else torch.ones(B, S, dtype=torch.bool, device="cuda")
     assert rel_dev(got[ok], exact[ok]) < 2e-5
+
+
+def test_layer_tails_share_their_feed_forward_out_over_workgroups_repeatably(ops):
+    """Few tokens: a row block's eight feed-forward chunks go to 8 (up to 24 row blocks) or 4 (up to 56) workgroups and the LAST one to
+    arrive finishes the layer (csrc/token_h2.hip; agent-scope ticket, tickets cleared once per stack call and left zero by every tail).
+    Thirty back-to-back stacks per shape -- 192 / 188 workgroups per tail launch, every ticket used 4 x 30 times -- give the same bits
+    every time, and the oracle's values."""
+    from objcavit_amd.modules.layers import HipEncoderStack
+    enc, sd = _encoder_sd(21)
+    stack = HipEncoderStack(enc.cuda())
+    lib = ops._lib.load()
+    for B, S, G in ((6, 128, 8), (4, 370, 4), (1, 32, 8), (5, 418, 1)):
+        assert lib.ocv_layer_tail_h2_groups(B * S, 1024) == G
+        assert (lib.ocv_layer_tail_h2_workspace_bytes(B * S, 1024) > 0) == (G > 1)
+        x = rnd("x", (B, S, 128), 30 + B)
+        ref = restate.transformer_encoder(x, sd, "", None)
+        xd = dev(x)
+        first = stack(xd).clone()
+        assert rel_dev(first, ref) < 5e-5, (B, S)
+        for _ in range(30):
+            assert torch.equal(stack(xd), first), (B, S)
 
 
 def test_encoder_layer_params_truncated_struct_reads_missing_fields_as_null(ops):
