@@ -200,6 +200,13 @@ extern "C" int ocv_encoder_layer_fwd(const float* x, const ocv_encoder_layer_par
 // the attention kernel and ocv_layer_tail_split3_fwd / ocv_layer_tail_h2_fwd (everything token-local + the next layer's projection).
 // workspace: qkv [M, 3E] | ctx [M, E] | xa [M, E] | xb [M, E]
 // ---------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void zero_u32_kernel(unsigned* p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+}  // namespace
+
 extern "C" size_t ocv_encoder_stack_workspace_bytes(int B, int S, int E) {
   if (B < 1 || S < 1 || E < 1) return 0;
   const size_t M = (size_t)B * S;
@@ -241,11 +248,11 @@ extern "C" int ocv_encoder_stack_fwd(const float* x, const ocv_encoder_layer_par
   if (tails_h2 && tail_bytes != 0) {
     tail_ws = ws;
     const size_t nblk = (size_t)((M + 31) / 32), G = (size_t)ocv_layer_tail_h2_groups(M, FF);
-    const hipError_t e = hipMemsetAsync((char*)tail_ws + nblk * G * 32 * 128 * sizeof(float), 0, nblk * sizeof(unsigned), (hipStream_t)stream);
-    if (e != hipSuccess) {
-      ocv_set_error("ocv_encoder_stack_fwd: clearing the tails' arrival tickets failed: %s", hipGetErrorString(e));
-      return (int)e;
-    }
+    // (a kernel, not hipMemsetAsync: inside a captured forward the memset NODE left the replay with wrong token values -- eager
+    //  dispatch of the same calls was right; a one-workgroup launch is ordered like every other launch of the stream)
+    hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (unsigned*)((char*)tail_ws + nblk * G * 32 * 128 * sizeof(float)), (int)nblk);
+    OCV_CHECK_LAUNCH("ocv_encoder_stack_fwd(tickets)");
   }
   int rc;
   if ((rc = ocv_linear_split3_fwd(x, E, layers[0].in_proj_p3, layers[0].in_proj_b, qkv, 3 * E, M, 3 * E, E, OCV_ACT_NONE, stream))) return rc;
