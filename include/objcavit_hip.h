@@ -198,7 +198,7 @@ int ocv_layer_tail_h2_fwd(const float* ctx, const float* x, const ocv_encoder_la
  * partial sums in a fixed order and finishes the layer (one launch, nobody waits).  ocv_layer_tail_h2_groups: G for (M, FF) -- 8 up
  * to 24 row blocks, 4 up to 56, else 1.  workspace: ocv_layer_tail_h2_workspace_bytes (0 when G = 1) = the partial sums
  * followed by one arrival ticket per row block; THE TICKETS MUST BE ZERO WHEN THE CALL STARTS and are zero again when it has
- * finished (ocv_encoder_stack_fwd clears them itself).  workspace NULL / too small: one workgroup per row block, as above.
+ * finished (ocv_encoder_stack_fwd, which uses this form for batches of up to 4 sequences, clears them itself).  workspace NULL / too small: one workgroup per row block, as above.
  * Results are bit-reproducible for a given (M, FF); they differ from the G = 1 form in the last bits (summation order). */
 int ocv_layer_tail_h2_groups(int M, int FF);
 size_t ocv_layer_tail_h2_workspace_bytes(int M, int FF);

@@ -211,7 +211,8 @@ extern "C" size_t ocv_encoder_stack_workspace_bytes(int B, int S, int E) {
   if (B < 1 || S < 1 || E < 1) return 0;
   const size_t M = (size_t)B * S;
   // + the feed-forward partial sums and arrival tickets of the tails' few-token form (ocv_layer_tail_h2_ws_fwd; 0 for large M)
-  return align_up(M * 3 * E * sizeof(float)) + 3 * align_up(M * E * sizeof(float)) + align_up(ocv_layer_tail_h2_workspace_bytes((int)M, 1024));
+  return align_up(M * 3 * E * sizeof(float)) + 3 * align_up(M * E * sizeof(float)) +
+         align_up(B <= 4 ? ocv_layer_tail_h2_workspace_bytes((int)M, 1024) : 0);
 }
 
 extern "C" int ocv_encoder_stack_fwd(const float* x, const ocv_encoder_layer_params* layers_caller, int n_layers,
@@ -244,7 +245,10 @@ extern "C" int ocv_encoder_stack_fwd(const float* x, const ocv_encoder_layer_par
   // few tokens: the tails share their feed-forward chunks out over workgroups; their arrival tickets are cleared ONCE per call
   // (every tail leaves them zero); FF other than the 1024 the workspace was sized for: one workgroup per row block
   void* tail_ws = nullptr;
-  const size_t tail_bytes = FF == 1024 ? ocv_layer_tail_h2_workspace_bytes(M, FF) : 0;
+  // (only for batches of up to 4 images: at bs 16 the OBJECT tokens' stack is few tokens too -- 16 row blocks -- but the chip has the
+  //  other launches of the forward / the other batches in flight to run beside it, and the groups' repeated output projection is
+  //  then pure extra work: 1073 -> 1067 img/s with three batches in flight, 997 -> 995 one at a time)
+  const size_t tail_bytes = (FF == 1024 && B <= 4) ? ocv_layer_tail_h2_workspace_bytes(M, FF) : 0;
   if (tails_h2 && tail_bytes != 0) {
     tail_ws = ws;
     const size_t nblk = (size_t)((M + 31) / 32), G = (size_t)ocv_layer_tail_h2_groups(M, FF);
