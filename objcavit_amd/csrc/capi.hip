@@ -201,11 +201,24 @@ extern "C" int ocv_encoder_layer_fwd(const float* x, const ocv_encoder_layer_par
 // workspace: qkv [M, 3E] | ctx [M, E] | xa [M, E] | xb [M, E]
 // ---------------------------------------------------------------------------
 namespace {
-__global__ __launch_bounds__(256) void zero_u32_kernel(unsigned* p, int n) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) p[i] = 0u;
+__global__ __launch_bounds__(256) void zero_u32_kernel(unsigned* p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
 }
 }  // namespace
+
+int ocv_zero_async(void* p, size_t nbytes, hipStream_t stream) {
+  if (nbytes == 0) return 0;
+  if (p == nullptr || (reinterpret_cast<uintptr_t>(p) & 3) != 0 || (nbytes & 3) != 0) {
+    ocv_set_error("ocv_zero_async: needs a 4-byte aligned buffer of a multiple of 4 bytes");
+    return -1;
+  }
+  const size_t n = nbytes / 4;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (unsigned*)p, n);
+  OCV_CHECK_LAUNCH("ocv_zero_async");
+  return 0;
+}
 
 extern "C" size_t ocv_encoder_stack_workspace_bytes(int B, int S, int E) {
   if (B < 1 || S < 1 || E < 1) return 0;
@@ -252,11 +265,9 @@ extern "C" int ocv_encoder_stack_fwd(const float* x, const ocv_encoder_layer_par
   if (tails_h2 && tail_bytes != 0) {
     tail_ws = ws;
     const size_t nblk = (size_t)((M + 31) / 32), G = (size_t)ocv_layer_tail_h2_groups(M, FF);
-    // (a kernel, not hipMemsetAsync: inside a captured forward the memset NODE left the replay with wrong token values -- eager
-    //  dispatch of the same calls was right; a one-workgroup launch is ordered like every other launch of the stream)
-    hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (unsigned*)((char*)tail_ws + nblk * G * 32 * 128 * sizeof(float)), (int)nblk);
-    OCV_CHECK_LAUNCH("ocv_encoder_stack_fwd(tickets)");
+    // (ocv_zero_async: a launch, not a memset node -- see common.hpp)
+    const int zrc = ocv_zero_async((char*)tail_ws + nblk * G * 32 * 128 * sizeof(float), nblk * sizeof(unsigned), (hipStream_t)stream);
+    if (zrc != 0) return zrc;
   }
   int rc;
   if ((rc = ocv_linear_split3_fwd(x, E, layers[0].in_proj_p3, layers[0].in_proj_b, qkv, 3 * E, M, 3 * E, E, OCV_ACT_NONE, stream))) return rc;

@@ -81,6 +81,11 @@ void ocv_set_error(const char* fmt, ...);
     }                                                                       \
   } while (0)
 
+// zero-fill of a device buffer (4-byte aligned, a multiple of 4 bytes) by a LAUNCH: a hipMemsetAsync issued inside a stream capture
+// becomes a memset node, and a forward replayed with such a node came back with wrong values (csrc/capi.hip, round 4) while eager
+// dispatch of the same calls was right.  0 / hipError_t.
+int ocv_zero_async(void* p, size_t nbytes, hipStream_t stream);
+
 // attention launch with an explicit row stride for the key-padding mask (mask[b * mask_ld + key])
 int ocv_attention_launch(const float* q, long q_bs, int q_ss, const float* k, long k_bs, int k_ss, const float* v,
                          long v_bs, int v_ss, const uint8_t* key_padding_mask, int mask_ld, float* ctx, long o_bs,

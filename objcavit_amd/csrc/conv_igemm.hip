@@ -843,8 +843,8 @@ extern "C" int ocv_conv_nhwc_split_x_fwd(const void* x_hl, int Cin, const void* 
   a.C1 = Cin; a.C2 = 0; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.ks = ksize; a.act = act; a.ksplit = 1;
   a.f16 = f16; a.oscale = oscale;
   if (y_hl != nullptr && Cout % 32 != 0) {       // the kernels write channels < Cout only: pad channels must read as zero
-    const hipError_t e = hipMemsetAsync(y_hl, 0, ocv_split_act_elems(B, H, W, Cout) * sizeof(__bf16), (hipStream_t)stream);
-    OCV_CHECK_ARG(e == hipSuccess, "ocv_conv_nhwc_split_fwd: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    const int zrc = ocv_zero_async(y_hl, ocv_split_act_elems(B, H, W, Cout) * sizeof(__bf16), (hipStream_t)stream);          // (a launch, not a memset node: common.hpp)
+    if (zrc != 0) return zrc;
   }
   const long M = (long)B * H * W;
   const int ks = conv_ksplit(M, Cout, Cin, ksize);
@@ -1082,8 +1082,8 @@ extern "C" int ocv_conv3x3_winograd_split_fwd(const void* x_hl, int Cin, const v
   __bf16* v = (__bf16*)workspace;
   float* m = (float*)((char*)workspace + wino_align((size_t)16 * T * 2 * Cp * sizeof(__bf16)));
   if (y_hl != nullptr && Cout % 32 != 0) {
-    const hipError_t e = hipMemsetAsync(y_hl, 0, ocv_split_act_elems(B, H, W, Cout) * sizeof(__bf16), st);
-    OCV_CHECK_ARG(e == hipSuccess, "ocv_conv3x3_winograd_split_fwd: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    const int zrc = ocv_zero_async(y_hl, ocv_split_act_elems(B, H, W, Cout) * sizeof(__bf16), st);          // (a launch, not a memset node: common.hpp)
+    if (zrc != 0) return zrc;
   }
   WinoInArgs wi{(const __bf16*)x_hl, v, B, H, W, Cp, th, tw, T, T * (Cp / 8)};
   hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((wi.items + 255) / 256)), dim3(256), 0, st, wi);
@@ -1403,8 +1403,8 @@ extern "C" int ocv_conv3x3_winograd43_split_fwd(const void* x_hl, int Cin, const
   float* m = (float*)((char*)workspace + v_bytes);
   float* tinv = (float*)((char*)workspace + v_bytes + m_bytes);
   if (y_hl != nullptr && Cout % 32 != 0) {
-    const hipError_t e = hipMemsetAsync(y_hl, 0, ocv_split_act_elems(B, H, W, Cout) * sizeof(__bf16), st);
-    OCV_CHECK_ARG(e == hipSuccess, "ocv_conv3x3_winograd43_split_fwd: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    const int zrc = ocv_zero_async(y_hl, ocv_split_act_elems(B, H, W, Cout) * sizeof(__bf16), st);          // (a launch, not a memset node: common.hpp)
+    if (zrc != 0) return zrc;
   }
   Wino43InArgs wi{(const __bf16*)x_hl, v, cscale, tinv, B, H, W, Cp, th, tw, T, hl_f16};
   const int nq = Cp / 4;

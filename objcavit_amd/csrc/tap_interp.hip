@@ -313,8 +313,8 @@ extern "C" int ocv_tap_interp_combine_x_fwd(const float* z, int h, int w, int zp
   const long nwg = (long)a.tiles_x * a.tiles_y * B;
   OCV_CHECK_ARG(nwg < (1L << 31) && ocv_cdiv(Cout, CB) <= 65535, "ocv_tap_interp_combine_fwd: grid too large");
   if (y_hl != nullptr && Cout % 32 != 0) {
-    const hipError_t e = hipMemsetAsync(y_hl, 0, ocv_split_act_elems(B, H, W, Cout) * sizeof(__bf16), (hipStream_t)stream);
-    OCV_CHECK_ARG(e == hipSuccess, "ocv_tap_interp_combine_fwd: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    const int zrc = ocv_zero_async(y_hl, ocv_split_act_elems(B, H, W, Cout) * sizeof(__bf16), (hipStream_t)stream);          // (a launch, not a memset node: common.hpp)
+    if (zrc != 0) return zrc;
   }
   const dim3 grid((unsigned)nwg, ocv_cdiv(Cout, CB));
   const size_t lds = (size_t)NBUF * a.fq_cap * CB * sizeof(float);

@@ -1225,6 +1225,23 @@ def test_conv_nhwc_split_in_and_out(ops, B, H, W, Cin, Cout, k, act):
     assert rel_dev(ys.float(), y) < 1e-5
     y2 = ops.conv_nhwc_split(xs, hi, lo, dev(b), k, act, out_fp32=True, out_split=False)
     assert torch.equal(y, y2)
+    if Cout % 32:
+        # pad channels of the last 32-block read as zero (ocv_zero_async: a launch, so that the same holds in a graph replay)
+        Cp = (Cout + 31) // 32 * 32
+        pads = lambda t: t.hl.view(B, H, W, Cp // 32, 2, 32).permute(0, 1, 2, 4, 3, 5).reshape(B, H, W, 2, Cp)[..., Cout:]
+        assert not bool(pads(ys).any())
+        torch.cuda.synchronize()
+        g, st, bg = torch.cuda.CUDAGraph(), torch.cuda.Stream(), dev(b)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(st):
+            poison = torch.full_like(ys.hl, 7.0)                 # the replay's output lands where this was: pads start dirty
+            del poison
+            with torch.cuda.graph(g, stream=st):
+                _, ys_g = ops.conv_nhwc_split(xs, hi, lo, bg, k, act, out_fp32=True, out_split=True)
+        ys_g.hl.fill_(7.0)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(ys_g.hl, ys.hl)
     # and it agrees with the fp32-input kernel to rounding
     y3 = ops.conv_nhwc(dev(x), None, hi, lo, dev(b), k, act)
     assert rel_dev(y, y3) < 1e-5
