@@ -156,7 +156,7 @@ _SIDE: Dict[Tuple[int, int], "torch.cuda.Stream"] = {}
 
 
 def _side_switch(name: str) -> bool:
-    """The side-stream switches OCV_OBJ_OVERLAP / OCV_TOKEN_OVERLAP / OCV_HEAD_OVERLAP: '1', '0' or 'auto' (default) = on for a lone
+    """The side-stream switches OCV_OBJ_OVERLAP / OCV_TOKEN_OVERLAP / OCV_HEAD_OVERLAP / OCV_SKIP_OVERLAP: '1', '0' or 'auto' (default) = on for a lone
     batch, off when the driver keeps several batches in flight on this GPU (``set_batches_in_flight``: bench.py's slots,
     PipelinedValidation).  A fork inside a captured forward makes the replay use further streams; with three slots replaying at once
     those collide with the other slots' streams on the GPU's hardware queues and the slots serialise each other.  One box, alternating
@@ -198,6 +198,14 @@ def object_prepass_enabled() -> bool:
     decoder.  On its own worth little (lone batch 953 -> 961 img/s); it leaves ONE side chain behind the decoder, which is what
     ``head_overlap_enabled`` needs."""
     return _side_switch("OCV_OBJ_OVERLAP")
+
+
+def skip_overlap_enabled() -> bool:
+    """OCV_SKIP_OVERLAP (``_side_switch``): the skip-part convolutions of the decoder's last three stages (short-K GEMMs over encoder
+    activations of stages 2 - 4, ~0.9 ms at bs 16) are issued on side stream 0 behind the encoder's fourth stage, beside its late
+    stages, together with the object branch -- one fork, one join (modules/DenseFeatureExtractor.py ``SkipPrepass``).  Lone batch:
+    +1.6 % at bs 16, +4.4 % at bs 1."""
+    return _side_switch("OCV_SKIP_OVERLAP")
 
 
 _IN_FLIGHT = 1

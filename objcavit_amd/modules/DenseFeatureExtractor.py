@@ -204,9 +204,11 @@ class Encoder(nn.Module):
         self.original_model = backend
         self.keep = keep
 
-    def forward(self, x: torch.Tensor, _defer_head: bool = False) -> List[Optional[torch.Tensor]]:
+    def forward(self, x: torch.Tensor, _defer_head: bool = False, _on_feature=None) -> List[Optional[torch.Tensor]]:
         """``_defer_head`` (DenseFeatureExtractor's GPU inference call only): the bias-free 1x1 ``conv_head``, when nothing
-        but Identity modules follow it, is handed on un-applied (DeferredConv1x1) for the decoder to compose."""
+        but Identity modules follow it, is handed on un-applied (DeferredConv1x1) for the decoder to compose.
+        ``_on_feature(idx, tensor)``: called the moment a KEPT activation exists (SkipPrepass: the decoder's skip-part convolutions
+        start beside the rest of the encoder)."""
         feats: List[Optional[torch.Tensor]] = [x]
         cur = x
 
@@ -214,7 +216,10 @@ class Encoder(nn.Module):
             nonlocal cur
             cur = t
             idx = len(feats)
-            feats.append(t if t is not None and (self.keep is None or idx in self.keep) else None)
+            kept = t is not None and (self.keep is None or idx in self.keep)
+            feats.append(t if kept else None)
+            if kept and _on_feature is not None and isinstance(t, torch.Tensor):
+                _on_feature(idx, t)
 
         skip = self._fused_stem(x, push)
         names = list(self.original_model._modules)
@@ -333,7 +338,7 @@ class UpSampleWithSkip(nn.Module):
         return (c1 % 32 == 0 and cout % 8 == 0 and x.shape[2] < skip_features.shape[2] and x.shape[3] < skip_features.shape[3]
                 and hip_ops.tap_interp_supported(x.shape[2], x.shape[3], skip_features.shape[2], skip_features.shape[3], cout))
 
-    def forward_split(self, x, skip_features, out_fp32=True, out_split=False, affine_of=None, f16=False):
+    def forward_split(self, x, skip_features, out_fp32=True, out_split=False, affine_of=None, f16=False, sk_pre=None):
         """GPU inference plan.  ``x``: the stage input, fp32 channels_last or already split (hip_ops.SplitAct).
         ``affine_of`` = (x0, key, fn, (h, w)): the stage input is NOT materialised -- it is the h x w grid whose interior is
         P x0 + pb (per pixel, (P, pb) = fn() in float64) and whose one-pixel border ring is pb (Decoder.conv2's padded
@@ -344,7 +349,9 @@ class UpSampleWithSkip(nn.Module):
         bilinear interpolation of (W_tap x) -- formed once per LOW-resolution pixel by one 1x1 GEMM with 9 Cout columns,
         ~4x fewer matrix-core operations for the up-sampled channels -- + conv3x3 over the skip channels, combined,
         biased, activated and split by ocv_tap_interp_combine_fwd.  Otherwise: resize + concat + fp32->split in ONE
-        pass, then the direct 3x3 convolution.  The second convolution hands the next stage fp32 and / or the split pair."""
+        pass, then the direct 3x3 convolution.  The second convolution hands the next stage fp32 and / or the split pair.
+        ``sk_pre``: the skip part of the first convolution, already formed beside the encoder (``SkipPrepass``; ``skip_part`` below
+        is the one statement of that launch)."""
         H, W = skip_features.shape[-2:]
 
         def as_split(t):
@@ -371,8 +378,10 @@ class UpSampleWithSkip(nn.Module):
                 c2 = skip_features.shape[1]
                 if c2 % 4 and getattr(skip_features, "_ocv_hl", None) is None:      # 3-channel image: one zero channel more (the weight's pad columns are zero too)
                     skip_features = F.pad(skip_features, (0, 0, 0, 0, 0, 4 - c2 % 4))
-                sk = hip_ops.conv_nhwc_split(as_split(skip_features), wt["s_hi"], wt["s_lo"], None, 3, hip_ops.ACT_NONE, out_fp32=True,
-                                             oscale=wt["s_osc"])
+                else:
+                    # what a later forward may issue beside the encoder (SkipPrepass): this skip shape with this weight arrangement
+                    self.__dict__["_skip_plan"] = (tuple(skip_features.shape), self._split1._w_up[0])
+                sk = sk_pre if sk_pre is not None else self.skip_part(skip_features, wt, f16)
             f = hip_ops.tap_interp_combine(z, sk, wt["bias"], (H, W), hip_ops.ACT_LEAKY_RELU, out_fp32=False, out_split=True,
                                            border=wt["border"], split_f16=f16)
         else:
@@ -381,6 +390,17 @@ class UpSampleWithSkip(nn.Module):
             cat = hip_ops.upsample_concat_split(x, skip_features, (H, W), f16=f16)
             f = self._split1.run_split(cat, hip_ops.ACT_LEAKY_RELU, out_fp32=False, out_split=True)
         return self._split2.run_split(f, hip_ops.ACT_LEAKY_RELU, out_fp32=out_fp32, out_split=out_split)
+
+    def skip_part(self, skip_features, wt, f16):
+        """conv3x3 over the skip channels with the first convolution's weight columns of those channels: fp32, no bias, no
+        activation (the tap interpolation adds it to the up-sampled channels' part)."""
+        if isinstance(skip_features, hip_ops.SplitAct):
+            xs = skip_features if skip_features.f16 == f16 else \
+                hip_ops.split_act(skip_features.float().contiguous(memory_format=torch.channels_last), f16=f16)
+        else:
+            ride = getattr(skip_features, "_ocv_hl", None)      # (an encoder block of the late stages may leave its split copy beside it)
+            xs = ride if ride is not None and ride.f16 == f16 else hip_ops.split_act(skip_features, f16=f16)
+        return hip_ops.conv_nhwc_split(xs, wt["s_hi"], wt["s_lo"], None, 3, hip_ops.ACT_NONE, out_fp32=True, oscale=wt["s_osc"])
 
     def split_ready(self, x, skip_features) -> bool:
         c1, c2 = x.shape[1], skip_features.shape[1]
@@ -422,6 +442,77 @@ class UpSampleWithSkip(nn.Module):
         w1, b1, w2, b2 = self._folded
         f = F.leaky_relu(F.conv2d(f, w1, b1, padding=1), 0.01)
         return F.leaky_relu(F.conv2d(f, w2, b2, padding=1), 0.01)
+
+
+class SkipPrepass:
+    """The skip-part convolutions of the decoder's first convolutions (conv3x3 over 64 / 40 / 24 encoder channels at 60x80 ...
+    240x320: short-K GEMMs, ~0.9 ms of a bs-16 step at a fifth of the matrix pipe) depend on the ENCODER's activations only: the three
+    are issued on the side stream the moment the last of their activations exists (``Encoder.forward(_on_feature=...)``: behind
+    stage 4 of 7), beside the encoder's late stages, whose launches leave most of the chip idle, and joined behind the encoder.
+    Same launches on the same operands as in ``UpSampleWithSkip.forward_split`` (``skip_part``): bitwise the same result.  Only for
+    stages whose previous forward took that route with the same shapes and weight arrangement (``_skip_plan``), and only once the
+    decoder's element type is settled (never during the calibrating first call).
+    ONE fork and ONE join, on the object branch's side stream (hip_ops.side_stream 0), shared with that branch (``extra``:
+    GraphBins hands its object pre-pass over instead of forking it at the top of the forward).  Measured shapes
+    (tools/ab_skip_overlap.sh, one batch at a time, captured forward, alternating runs on one box):
+      * each convolution issued when its own activation appeared and joined where it was read (four forks, four joins between two
+        streams): every replay 3.5 ms SLOWER at every batch size (bs 16: 20.6 vs 16.9 ms; bs 1: 6.9 vs 3.4), one replay crashed
+        (hipGraphLaunch);
+      * one fork behind stage 4 for the three, the object branch still forked at the top (= a side branch with TWO incoming edges
+        from the main chain): 21.1 vs 16.6 ms, 8.2 vs 3.4 ms -- on this ROCm a graph branch may depend on the main chain ONCE;
+      * this shape: **bs 16 984.6 -> 1000.0 img/s (+1.6 %), bs 1 296.4 -> 309.6 (+4.4 %)**; with two / one of the three
+        convolutions (forks behind stage 3 / 2: OCV_SKIP_STAGES) 992 / 988 and 304 / 303 (tools/ab_skip_stages.sh)."""
+
+    def __init__(self, decoder: "Decoder", device: torch.device, extra=None):
+        self.extra, self.extra_result = extra, None      # further image-independent work for the same fork (GraphBins: the object branch)
+        self.main = torch.cuda.current_stream(device)
+        self.side = hip_ops.side_stream(device, 0)
+        self.f16 = decoder.settled_f16()
+        sel = decoder.feature_select
+        import os
+        n = min(3, max(1, int(os.environ.get("OCV_SKIP_STAGES", "3"))))       # (A/B switch: tools/ab_skip_stages.sh)
+        stages = [(sel[0], decoder.up4), (sel[1], decoder.up3), (sel[2], decoder.up2)][:n]
+        self.stage_of = {} if self.f16 is None else dict(stages)
+        self.trigger = stages[-1][0]                     # the last of the activations to appear
+        self.pending = []                                # (stage, activation, weight dict)
+        self.ready = {}                                  # id(stage) -> skip part
+        self.forked = self.joined = False
+
+    def on_feature(self, idx: int, t: torch.Tensor) -> None:
+        up = self.stage_of.get(idx)
+        if up is not None and t.dim() == 4:
+            plan = up.__dict__.get("_skip_plan")
+            up._split1._ensure_prepared()
+            cache = up._split1._w_up
+            t = t.contiguous(memory_format=torch.channels_last)
+            if plan is not None and cache is not None and plan == (tuple(t.shape), cache[0]) and cache[0][2] == self.f16 \
+                    and cache[1]["s_lo"] is not None:
+                self.pending.append((up, t, cache[1]))
+        if idx == self.trigger and (self.pending or self.extra is not None):
+            self.side.wait_stream(self.main)
+            self.forked = True
+            with torch.cuda.stream(self.side), hip_ops.islands_suspended():
+                for up, t, wt in self.pending:
+                    t.record_stream(self.side)
+                    self.ready[id(up)] = up.skip_part(t, wt, self.f16)
+                if self.extra is not None:
+                    self.extra_result = self.extra()
+            self.pending = []
+
+    def join(self) -> None:
+        """The main stream waits for the side stream (once; GraphBins' own join of the object branch counts: ``joined``)."""
+        if self.forked and not self.joined:
+            self.main.wait_stream(self.side)
+        self.joined = True
+
+    def take(self, up, f16: bool):
+        """The stage's skip part -- or None (the stage forms it itself)."""
+        sk = self.ready.pop(id(up), None)
+        if sk is None or f16 != self.f16:
+            return None
+        self.join()
+        sk.record_stream(self.main)
+        return sk
 
 
 class Decoder(nn.Module):
@@ -509,9 +600,25 @@ class Decoder(nn.Module):
 
         return shape, (x0, key, fn, (h + 2, w + 2))
 
-    def forward(self, features, _split_only: bool = False):
+    def settled_f16(self):
+        """The element type of the split pipeline once it is decided for the current weights (True: fp16 pairs, False: bf16 pairs);
+        None before the calibrating first call / after a weight update."""
+        mode = self.__dict__.get("_f16_mode")
+        if mode is None or (mode[1] and len(mode) == 2):
+            return None
+        wkey = (hip_ops.conv_split_f16(),) + tuple((p.data_ptr(), p._version) for p in self.parameters()) + \
+            tuple((b.data_ptr(), b._version) for b in self.buffers())
+        return bool(mode[1]) if mode[0] == wkey else None
+
+    def forward(self, features, _split_only: bool = False, _skip_pre: Optional[SkipPrepass] = None):
         """``_split_only`` (GraphBins / AdaBins inference calls): the heads read the split copy of the result, so the last convolution
-        writes only that and the returned tensor is a ``hip_ops.map_placeholder``."""
+        writes only that and the returned tensor is a ``hip_ops.map_placeholder``.  ``_skip_pre``: skip-part convolutions already
+        issued beside the encoder (``SkipPrepass``)."""
+        if _skip_pre is not None:
+            _skip_pre.join()                       # (before anything of the decoder: one fork, one join -- SkipPrepass)
+        return self._forward(features, _split_only, _skip_pre)
+
+    def _forward(self, features, _split_only, _skip_pre):
         b0, b1, b2, b3, b4 = (features[i] for i in self.feature_select)
         if b4.device.type == "cuda" and not self.training and not torch.is_grad_enabled():
             # inference on the GPU: the decoder runs in channels_last (NHWC), the layout of every kernel of the path
@@ -543,6 +650,9 @@ class Decoder(nn.Module):
             if mode is None or mode[0] != wkey:
                 mode = self.__dict__["_f16_mode"] = (wkey, hip_ops.conv_split_f16())
 
+            def pre_of(up, f16):
+                return None if _skip_pre is None else _skip_pre.take(up, f16)
+
             def pipeline(f16):
                 x_ = x
                 for i, (up, skip) in enumerate(stages[:-1]):
@@ -550,8 +660,8 @@ class Decoder(nn.Module):
                     nxt, nskip = stages[i + 1]
                     want_split = nxt.lowres_ready(_ShapeOnly(x_.shape[0], up._net[3].out_channels, skip.shape[2], skip.shape[3]), nskip)
                     x_ = up.forward_split(x_, skip, out_fp32=not want_split, out_split=want_split,
-                                          affine_of=affine[1] if i == 0 and affine is not None else None, f16=f16)
-                xs = self.up4.forward_split(x_, b0, out_fp32=False, out_split=True, f16=f16)
+                                          affine_of=affine[1] if i == 0 and affine is not None else None, f16=f16, sk_pre=pre_of(up, f16))
+                xs = self.up4.forward_split(x_, b0, out_fp32=False, out_split=True, f16=f16, sk_pre=pre_of(self.up4, f16))
                 if fin is not None:
                     # do_final_upscale (reference :99-101,116-117): a fifth stage against the IMAGE, in the same low-resolution form
                     # (tap GEMM at half resolution, a 3 x 3 convolution over the image's three channels, tap interpolation)
@@ -632,6 +742,24 @@ class DenseFeatureExtractor(nn.Module):
         self._encoder_params_module_list.append(self.encoder)
         self._non_encoder_params_module_list.append(self.decoder)
 
+    def skip_prepass(self, image, extra=None) -> Optional[SkipPrepass]:
+        """The fork of this forward's encoder call (``SkipPrepass``; ``extra``: a callable issued on the same side stream behind the
+        skip-part convolutions), or None: switched off (hip_ops.skip_overlap_enabled), not a GPU inference call, or the decoder's
+        element type not settled yet."""
+        fast = image.device.type == "cuda" and not self.training and not torch.is_grad_enabled()
+        if not (fast and hip_ops.skip_overlap_enabled() and split_bf16_convs_enabled()):
+            return None
+        pre = SkipPrepass(self.decoder, image.device, extra)
+        return pre if pre.stage_of else None
+
+    def encode(self, image, pre: Optional[SkipPrepass] = None):
+        """The encoder call of ``forward`` (``pre``: see ``skip_prepass``; whoever passes it joins it or hands it to the decoder)."""
+        fast = image.device.type == "cuda" and not self.training and not torch.is_grad_enabled()
+        if not fast:
+            return self.encoder(image)
+        return self.encoder(image, _defer_head=True, _on_feature=None if pre is None else pre.on_feature)
+
     def forward(self, image, _split_only: bool = False):
         fast = image.device.type == "cuda" and not self.training and not torch.is_grad_enabled()
-        return self.decoder(self.encoder(image, _defer_head=True) if fast else self.encoder(image), _split_only=_split_only and fast)
+        pre = self.skip_prepass(image)
+        return self.decoder(self.encode(image, pre), _split_only=_split_only and fast, _skip_pre=pre)

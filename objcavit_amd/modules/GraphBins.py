@@ -141,14 +141,26 @@ class GraphBins(nn.Module):
             # alternating runs: 21.71 / 21.76 ms with it, 21.67 / 21.61 without -- the encoder's launches fill the chip); it is the
             # default since round 4 because it leaves ONE side chain behind the decoder, the image tokens', which then runs beside
             # the heads' 3x3 convolution (hip_ops.head_overlap_enabled; ObjCAViT.forward_parts).
+            # With the decoder's skip-part convolutions on the same side stream (SkipPrepass) the two share ONE fork, behind the
+            # encoder's fourth stage: a side branch with two incoming edges from the main chain replays pathologically slowly.
             main = torch.cuda.current_stream(image.device)
             side = hip_ops.side_stream(image.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                pre = self.objcavit.object_prepass(object_features, object_xywh_list, image.device, pad_objects_to)
-            encoded = self.dense_feature_extractor.encoder(image, _defer_head=not torch.is_grad_enabled() and not self.training)
+            dfe = self.dense_feature_extractor
+
+            def object_branch():
+                return self.objcavit.object_prepass(object_features, object_xywh_list, image.device, pad_objects_to)
+
+            skip_pre = dfe.skip_prepass(image, extra=object_branch)
+            if skip_pre is None:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    pre = object_branch()
+            encoded = dfe.encode(image, skip_pre)
             main.wait_stream(side)
-            dense_features = self.dense_feature_extractor.decoder(encoded, _split_only=True)
+            if skip_pre is not None:
+                skip_pre.joined = True             # (same side stream: the wait above is its join too)
+                pre = skip_pre.extra_result
+            dense_features = dfe.decoder(encoded, _split_only=not torch.is_grad_enabled() and not self.training, _skip_pre=skip_pre)
         else:
             dense_features = self.dense_feature_extractor(image, _split_only=True)   # (the heads read the split copy: hip_ops.map_placeholder)
         bin_widths_normed, feat, queries = self.objcavit.forward_parts(dense_features, object_features, object_xywh_list, pre=pre,

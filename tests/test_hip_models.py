@@ -185,8 +185,10 @@ def test_graphbins_with_table_object_provider():
 
 def test_side_streams_equal_the_single_stream(monkeypatch):
     """The forward's side streams -- OCV_OBJ_OVERLAP (object branch beside the encoder), OCV_TOKEN_OVERLAP (object branch beside the
-    image tokens), OCV_HEAD_OVERLAP (token chain beside the heads' 3x3 convolution) -- in every combination, eager and captured: the
-    same kernels on the same operands, so the same bits as the single-stream forward, ragged object counts included."""
+    image tokens), OCV_HEAD_OVERLAP (token chain beside the heads' 3x3 convolution), OCV_SKIP_OVERLAP (the decoder's skip-part
+    convolutions beside the encoder) -- in every combination, eager and captured: the same kernels on the same operands, so the same
+    bits as the single-stream forward, ragged object counts included.  The skip-part convolutions really are issued on the side
+    stream (counted), and an AdaBins forward (no object branch) takes the same route."""
     import itertools
     from objcavit_amd.graph import GraphedGraphBins
     from objcavit_amd.modules.GraphBins import GraphBins, SyntheticObjectProvider
@@ -199,21 +201,45 @@ def test_side_streams_equal_the_single_stream(monkeypatch):
     feats = [gen.randn("f0", (5, 512), 1).cuda(), gen.randn("f1", (2, 512), 2).cuda()]
     boxes = [torch.rand(5, 4, device="cuda") * 100 + 10, torch.rand(2, 4, device="cuda") * 100 + 10]
 
-    def switches(obj, tok, head):
+    def switches(obj, tok, head, skip):
         monkeypatch.setenv("OCV_OBJ_OVERLAP", obj)
         monkeypatch.setenv("OCV_TOKEN_OVERLAP", tok)
         monkeypatch.setenv("OCV_HEAD_OVERLAP", head)
+        monkeypatch.setenv("OCV_SKIP_OVERLAP", skip)
 
-    switches("0", "0", "0")
+    from objcavit_amd.modules import DenseFeatureExtractor as dfe
+    issued = []
+    real_on_feature = dfe.SkipPrepass.on_feature
+
+    def counting(self, idx, t):
+        real_on_feature(self, idx, t)
+        issued.append(len(self.ready))
+    monkeypatch.setattr(dfe.SkipPrepass, "on_feature", counting)
+
+    switches("0", "0", "0", "0")
     ref = m(img).depth_pred.clone()
     ref_r = m(img, [f.clone() for f in feats], [b.clone() for b in boxes]).depth_pred.clone()
-    for obj, tok, head in itertools.product("01", "01", "01"):
-        switches(obj, tok, head)
+    assert not issued
+    for obj, tok, head, skip in itertools.product("01", "01", "01", "01"):
+        switches(obj, tok, head, skip)
+        del issued[:]
         for _ in range(2):
-            assert torch.equal(m(img).depth_pred, ref), (obj, tok, head)
-            assert torch.equal(m(img, [f.clone() for f in feats], [b.clone() for b in boxes]).depth_pred, ref_r), (obj, tok, head)
+            assert torch.equal(m(img).depth_pred, ref), (obj, tok, head, skip)
+            assert torch.equal(m(img, [f.clone() for f in feats], [b.clone() for b in boxes]).depth_pred, ref_r), (obj, tok, head, skip)
+        assert (max(issued) == 3) if skip == "1" else not issued, (skip, issued)      # three stages' skip parts rode the side stream
         g = GraphedGraphBins(m, img)
-        assert torch.equal(g(img).depth_pred, ref) and torch.equal(g(img).depth_pred, ref), (obj, tok, head)
+        assert torch.equal(g(img).depth_pred, ref) and torch.equal(g(img).depth_pred, ref), (obj, tok, head, skip)
+    # a forward without an object branch (AdaBins) on the same route
+    from objcavit_amd.modules.AdaBins import AdaBins
+    a = AdaBins(make_args(model="adabins", dimensions_train=[H, W], dimensions_test=[H, W])).eval()
+    gen.load_into(a, 58, gen.PEAKY)
+    a = a.cuda()
+    switches("0", "0", "0", "0")
+    ref_a = a(img).depth_pred.clone()
+    ref_a = a(img).depth_pred.clone()
+    switches("1", "1", "1", "1")
+    del issued[:]
+    assert torch.equal(a(img).depth_pred, ref_a) and max(issued) == 3
 
 
 def test_decoder_output_in_split_form_only(monkeypatch):

@@ -378,12 +378,12 @@ def test_validation_step_joint_forward_on_a_stand_in_model():
 
 
 def test_side_stream_switches_follow_the_batches_in_flight(monkeypatch):
-    """OCV_OBJ_OVERLAP / OCV_TOKEN_OVERLAP / OCV_HEAD_OVERLAP: 'auto' (default) = on for a lone batch, off once the driver announces
+    """OCV_OBJ_OVERLAP / OCV_TOKEN_OVERLAP / OCV_HEAD_OVERLAP / OCV_SKIP_OVERLAP: 'auto' (default) = on for a lone batch, off once the driver announces
     several batches in flight (hip_ops.set_batches_in_flight); '0' / '1' override; anything else is an error, not a silent default;
     inside hip_ops.single_chain() no further fork is offered; launches inside islands_suspended() stay in the capture."""
     from objcavit_amd import hip_ops
     switches = {"OCV_OBJ_OVERLAP": hip_ops.object_prepass_enabled, "OCV_TOKEN_OVERLAP": hip_ops.token_overlap_enabled,
-                "OCV_HEAD_OVERLAP": hip_ops.head_overlap_enabled}
+                "OCV_HEAD_OVERLAP": hip_ops.head_overlap_enabled, "OCV_SKIP_OVERLAP": hip_ops.skip_overlap_enabled}
     for k in switches:
         monkeypatch.delenv(k, raising=False)
     prev = hip_ops.set_batches_in_flight(1)
