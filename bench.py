@@ -612,7 +612,7 @@ def main():
             seq_step()
             torch.cuda.synchronize()
             step_latency_ms = (time.perf_counter() - t1) * 1e3          # one batch alone, submit -> metrics record
-            nseq = max(2, a.steps // 2)                                  # reference: the same steps strictly one after the other
+            nseq = max(4, a.steps)                                       # reference: the same steps strictly one after the other
             t1 = time.perf_counter()
             for _ in range(nseq):
                 seq_step()
