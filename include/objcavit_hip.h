@@ -559,6 +559,17 @@ int ocv_tap_interp_combine_fwd(const float* z, int h, int w, int zpad, const flo
 /* the same with the element type of y_hl as a parameter (0 = bf16 pairs, 1 = fp16 pairs: ocv_conv_nhwc_split_x_fwd) */
 int ocv_tap_interp_combine_x_fwd(const float* z, int h, int w, int zpad, const float* zborder, const float* s, const float* bias,
                                  float* y, void* y_hl, int hl_f16, int B, int H, int W, int Cout, int act, ocv_stream_t stream);
+/* the same with the skip part s formed INSIDE the launch, on the matrix cores, instead of read as a tensor: skip_hl = the skip
+ * tensor [B,H,W,Cs] in the hl32 split layout (ocv_split_act_elems(B,H,W,Cs) 2-byte elements, pad channels zero), ws_hi / ws_lo
+ * the split halves [9][Cout][Cs rounded up to 32] of the convolution weight's skip columns (tap-major, as for
+ * ocv_conv_nhwc_split_fwd with ksize 3), s_oscale [Cout] (nullable) the per-channel scale of the raw sums (fp16 pairs with scaled
+ * weights).  hl_f16 names the element type of skip_hl, of the weight halves AND of y_hl.  Three products per K step (hi hi +
+ * hi lo + lo hi, fp32 accumulate): the arithmetic of ocv_conv_nhwc_split_x_fwd on the same operands, in another summation order;
+ * zero padding of the 3 x 3 convolution applied per tap.  Saves the skip-part launch and one fp32 [B,H,W,Cout] tensor written
+ * and read (modules/DenseFeatureExtractor.py:37-39,44-47: the skip half of UpSampleWithSkip's first convolution). */
+int ocv_tap_interp_skip_fwd(const float* z, int h, int w, int zpad, const float* zborder, const void* skip_hl, int Cs,
+                            const void* ws_hi, const void* ws_lo, const float* s_oscale, const float* bias, float* y, void* y_hl,
+                            int hl_f16, int B, int H, int W, int Cout, int act, ocv_stream_t stream);
 
 /* Bilinear resize of x [B,h,w,C1] (NHWC fp32) to H x W with align_corners = True, concatenated along channels with
  * skip [B,H,W,C2] (nullable, then C2 = 0), written in the hl32 split layout for C1+C2 channels (out_hl,

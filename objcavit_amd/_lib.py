@@ -154,6 +154,8 @@ PROTOTYPES = {
     "ocv_conv3x3_winograd43_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
     "ocv_conv3x3_winograd43_split_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p, _f32p, C.c_void_p] + [C.c_int] * 6 +
                                          [C.c_void_p, C.c_size_t, _stream]),
+    "ocv_tap_interp_skip_fwd": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p,
+                                          C.c_void_p] + [C.c_int] * 6 + [_stream]),
     "ocv_tap_interp_supported": (C.c_int, [C.c_int] * 5),
     "ocv_tap_interp_combine_fwd": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_void_p] + [C.c_int] * 5 + [_stream]),
     "ocv_upsample_concat_split_fwd": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_void_p,

@@ -1147,13 +1147,31 @@ def tap_interp_supported(h: int, w: int, H: int, W: int, Cout: int) -> bool:
     return bool(_lib.load().ocv_tap_interp_supported(int(h), int(w), int(H), int(W), int(Cout)))
 
 
+def tap_skip_fused_pays(Cs: int, Cout: int, H: int, W: int) -> bool:
+    """Whether the skip part of a low-resolution first convolution is formed inside the tap-interpolation launch
+    (``tap_interp_combine(..., skip=...)``) instead of by a convolution launch of its own.  **Opt-in** (OCV_TAP_SKIP=1, then for up to
+    OCV_TAP_SKIP_MAX_CP = 64 padded skip channels): built, correct (``test_tap_interp_with_the_skip_part_inside``) and SLOWER -- bs 16,
+    one box, alternating: 1050 -> 963 img/s three in flight, 991 -> 889 one at a time, bs 1 308 -> 292; the last stage alone 1057 -> 1030,
+    its fused launch 1.53 ms against 0.735 + 0.42 for the pair (profiles/r04_tap_skip.txt).
+    It saves the skip-part launches (0.42 + 0.30 + 0.16 ms) and 1.1 GB of fp32 written and read, but a 32-pixel x 32-channel
+    wavefront tile re-reads its operands from L1 for every tap: ~300 KB per workgroup through a texture path that the kernel's own
+    staging already uses (3 workgroups per CU, 160 KB of LDS: no room to stage the skip halo and the weights), and the launches take
+    1.3 ms longer per step than the two-launch form's GEMM with its 256 x 128 LDS tiles."""
+    mode = os.environ.get("OCV_TAP_SKIP", "0")
+    if mode not in ("0", "1"):
+        raise ValueError(f"OCV_TAP_SKIP={mode!r}: expected '0' (default) or '1'")
+    return mode == "1" and (Cs + 31) // 32 * 32 <= int(os.environ.get("OCV_TAP_SKIP_MAX_CP", "64"))
+
+
 def tap_interp_combine(z: torch.Tensor, s: Optional[torch.Tensor], bias: Optional[torch.Tensor], size: Tuple[int, int],
                        act: int = ACT_NONE, out_fp32: bool = True, out_split: bool = False,
-                       border: Optional[torch.Tensor] = None, split_f16: bool = False):
+                       border: Optional[torch.Tensor] = None, split_f16: bool = False, skip=None):
     """act(bias + s + sum over the 9 taps of the bilinear (align_corners) interpolation of z's tap products at the tap
     position): ocv_tap_interp_combine_fwd.  z [B, 9 Cout, h, w] channels_last (tap-major columns), s [B, Cout, H, W]
     channels_last or None.  ``border`` [9 Cout]: z is the interior of an (h+2) x (w+2) grid whose border ring holds this
-    vector (Decoder.conv2's padding).  Returns fp32 tensor, SplitAct, or (fp32, SplitAct)."""
+    vector (Decoder.conv2's padding).  ``skip`` = (SplitAct of the skip tensor, w_hi, w_lo, oscale or None) instead of ``s``: the
+    skip part is formed inside the launch (ocv_tap_interp_skip_fwd; the pairs' element type must be ``split_f16``'s).
+    Returns fp32 tensor, SplitAct, or (fp32, SplitAct)."""
     lib = _lib.load()
     if not (out_fp32 or out_split):
         raise ValueError("tap_interp_combine: nothing to output")
@@ -1181,10 +1199,31 @@ def tap_interp_combine(z: torch.Tensor, s: Optional[torch.Tensor], bias: Optiona
         raise ValueError(f"tap_interp_combine: unsupported resize {h}x{w} -> {H}x{W} / channel count {Cout}")
     y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=z.device, memory_format=torch.channels_last) if out_fp32 else None
     ys = SplitAct.empty(B, Cout, H, W, z.device, f16=split_f16) if out_split else None
-    with timed(f"tap_interp|{B},{H},{W},{Cout}"):
-        check(lib.ocv_tap_interp_combine_x_fwd(z.data_ptr(), h, w, zpad, _ptr(border), _ptr(s), _ptr(bias), _ptr(y),
-                                               ys.hl.data_ptr() if out_split else None, int(bool(split_f16)), B, H, W, Cout, act,
-                                               _stream()), "ocv_tap_interp_combine_fwd")
+    if skip is not None:
+        xs, w_hi, w_lo, osc = skip
+        if s is not None:
+            raise ValueError("tap_interp_combine: either the skip part (s) or the skip tensor and its weight (skip), not both")
+        Cs = xs.C
+        Cps = (Cs + 31) // 32 * 32
+        if tuple(xs.shape) != (B, Cs, H, W) or xs.f16 != bool(split_f16) or not xs.hl.is_contiguous():
+            raise ValueError(f"tap_interp_combine: skip must be a contiguous {(B, Cs, H, W)} SplitAct of the output's element type")
+        want = torch.float16 if split_f16 else torch.bfloat16
+        for t in (w_hi, w_lo):
+            if t.dtype != want or tuple(t.shape) != (9, Cout, Cps) or not t.is_contiguous() or t.device != z.device:
+                raise ValueError(f"tap_interp_combine: skip weight halves must be contiguous {(9, Cout, Cps)} {want}")
+        if osc is not None:
+            _req(osc, "oscale")
+            if osc.numel() != Cout:
+                raise ValueError("tap_interp_combine: oscale size mismatch")
+        with timed(f"tap_interp|{B},{H},{W},{Cout}"):
+            check(lib.ocv_tap_interp_skip_fwd(z.data_ptr(), h, w, zpad, _ptr(border), xs.hl.data_ptr(), Cs, w_hi.data_ptr(), w_lo.data_ptr(),
+                                              _ptr(osc), _ptr(bias), _ptr(y), ys.hl.data_ptr() if out_split else None,
+                                              int(bool(split_f16)), B, H, W, Cout, act, _stream()), "ocv_tap_interp_skip_fwd")
+    else:
+        with timed(f"tap_interp|{B},{H},{W},{Cout}"):
+            check(lib.ocv_tap_interp_combine_x_fwd(z.data_ptr(), h, w, zpad, _ptr(border), _ptr(s), _ptr(bias), _ptr(y),
+                                                   ys.hl.data_ptr() if out_split else None, int(bool(split_f16)), B, H, W, Cout, act,
+                                                   _stream()), "ocv_tap_interp_combine_fwd")
     _note_range(f"tap_interp|{B},{H},{W},{Cout}", ys)
     if out_fp32 and out_split:
         return y, ys

@@ -1452,6 +1452,48 @@ def test_tap_interp_combine(ops, B, h, w, H, W, Cout, act):
     assert not ops.tap_interp_supported(64, 64, 32, 32, Cout)          # a down-scaling: the footprint does not fit
 
 
+@pytest.mark.parametrize("B,h,w,H,W,Cs,Cout,act,f16", [
+    (2, 15, 20, 30, 40, 24, 128, 2, True),       # the last decoder stage's shape class: 24 skip channels (one padded block)
+    (1, 15, 20, 30, 40, 40, 64, 2, False),       # two channel blocks, bf16 pairs
+    (1, 17, 22, 30, 40, 64, 72, 0, True),        # ragged resize, Cout % 32 != 0 (channel tail: clamped weight rows, pad channels zero)
+    (1, 5, 7, 11, 13, 8, 8, 3, True),            # tiles past the image on both axes, a quarter-filled channel block
+    (3, 30, 40, 60, 80, 100, 32, 2, False),      # four blocks deep
+    (1, 2, 3, 9, 23, 4, 40, 1, True),            # > 3x up-sampling (other staging round counts)
+    (1, 11, 38, 22, 76, 48, 32, 2, True)])       # KITTI's aspect
+def test_tap_interp_with_the_skip_part_inside(ops, B, h, w, H, W, Cs, Cout, act, f16):
+    """ocv_tap_interp_skip_fwd: the skip half of the stage's first convolution (conv3x3 over the skip tensor's split pairs, three
+    products per K step on the matrix cores) formed INSIDE the tap-interpolation launch -- against the definition in fp64 at the
+    split convolutions' bar, against the two-launch form (skip-part convolution + ocv_tap_interp_combine_fwd: the same products in
+    another order), and bitwise repeatable; zero padding per tap, ragged tiles, channel tails."""
+    z = rnd("z", (B, 9 * Cout, h, w), 1)
+    xs_, b = rnd("xs", (B, Cs, H, W), 2), rnd("b", (Cout,), 3, 0.3)
+    ws = rnd("ws", (Cout, Cs, 3, 3), 4, 1 / math.sqrt(9 * Cs))
+    if f16:
+        ws = ws * torch.logspace(-3, 2, Cout).view(-1, 1, 1, 1)              # per-channel scales: oscale is exercised
+    ref = F.conv2d(xs_.double(), ws.double(), padding=1) + b.double().view(1, -1, 1, 1)
+    for t in range(9):
+        up = F.interpolate(z[:, t * Cout:(t + 1) * Cout].double(), size=(H, W), mode="bilinear", align_corners=True)
+        dy, dx = t // 3 - 1, t % 3 - 1
+        ref = ref + F.pad(up, (1, 1, 1, 1))[:, :, 1 + dy:1 + dy + H, 1 + dx:1 + dx + W]
+    ref = [ref, torch.relu(ref), F.leaky_relu(ref, 0.01), F.silu(ref)][act]
+    cl = torch.channels_last
+    zg = dev(z).contiguous(memory_format=cl)
+    prep = ops.prep_conv_weight(dev(ws), f16=f16)
+    hi, lo, osc = prep if f16 else (prep[0], prep[1], None)
+    skip = ops.split_act(dev(xs_).contiguous(memory_format=cl), f16=f16)
+    y, ys = ops.tap_interp_combine(zg, None, dev(b), (H, W), act, out_fp32=True, out_split=True, split_f16=f16, skip=(skip, hi, lo, osc))
+    scale = ref.abs().max().item()
+    assert y.is_contiguous(memory_format=cl) and (y.cpu().double() - ref).abs().max().item() < SPLIT_TOL * scale
+    assert rel_dev(ys.float(), y) < 1e-5
+    sk = ops.conv_nhwc_split(skip, hi, lo, None, 3, 0, out_fp32=True, oscale=osc)
+    two = ops.tap_interp_combine(zg, sk, dev(b), (H, W), act, out_fp32=True, split_f16=f16)
+    assert (y - two).abs().max().item() < 4e-6 * scale                          # same products, another summation order
+    y_again = ops.tap_interp_combine(zg, None, dev(b), (H, W), act, out_fp32=True, split_f16=f16, skip=(skip, hi, lo, osc))
+    assert torch.equal(y, y_again)
+    with pytest.raises(ValueError):
+        ops.tap_interp_combine(zg, sk, dev(b), (H, W), act, skip=(skip, hi, lo, osc))
+
+
 @pytest.mark.parametrize("B,h,w,H,W,Cout,act", [(2, 15, 20, 30, 40, 64, 2), (1, 3, 4, 11, 13, 8, 0), (1, 1, 1, 7, 9, 40, 2),
                                                 (2, 6, 9, 17, 23, 96, 1)])
 def test_tap_interp_combine_bordered_grid(ops, B, h, w, H, W, Cout, act):
