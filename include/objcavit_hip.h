@@ -614,7 +614,9 @@ int ocv_bin_edges_fwd(const float* raw, int mode, float min_depth, float max_dep
  *   ocv_object_front_pad_fwd: objects [B][capacity][E] -> out [B][S][E] = [ pad_value x (S - Nmax) | rows 0 .. Nmax-1 ] (rows
  *     padded at the FRONT), key_padding_mask [B][S] = (j >= counts[b]) (mask padded at the BACK).  Nmax = nmax
  *     when nmax > 0 (the global batch's longest list, data-parallel shards), else the largest count within the image's group
- *     of `group` consecutive images (one group = one call of the reference: its Nmax is that call's longest list, Q3). */
+ *     of `group` consecutive images (one group = one call of the reference: its Nmax is that call's longest list, Q3).
+ * counts[b] is read as min(max(counts[b], 1), capacity): the reference never has an image without a row (an image without
+ * detections carries ONE <UNK> row, :311-315), and a count of 0 would mask every key (softmax over nothing = NaN). */
 int ocv_object_tokens_pad_fwd(const float* tokens, const int* counts, float pad_value, float* out, uint8_t* mask, int B,
                               int capacity, int E, ocv_stream_t stream);
 int ocv_object_front_pad_fwd(const float* objects, const int* counts, int group, int nmax, float pad_value, float* out,

@@ -24,7 +24,8 @@ __global__ __launch_bounds__(256) void object_tokens_pad_kernel(const float* __r
   if (i >= (long)B * cap * E4) return;
   const long row = i / E4;
   const int b = (int)(row / cap), j = (int)(row - (long)b * cap);
-  const bool live = j < counts[b];
+  const bool live = j < min(max(counts[b], 1), cap);            // counts are device data nobody has checked: [1, cap] by force, so an
+                                                               // image always keeps one live key (a count of 0 = fully masked softmax = NaN)
   const float4 v = live ? ld4(tok + 4 * i) : make_float4(pad, pad, pad, pad);
   *reinterpret_cast<float4*>(out + 4 * i) = v;
   if (i - row * E4 == 0) mask[row] = live ? 0 : 1;
@@ -42,11 +43,11 @@ __global__ __launch_bounds__(256) void object_front_pad_kernel(const float* __re
     const int g0 = (b / group) * group, g1 = min(B, g0 + group);
     for (int g = g0; g < g1; ++g) nmax = max(nmax, counts[g]);
   }
-  nmax = min(nmax, cap);
+  nmax = min(max(nmax, 1), cap);
   const int src = j - (S - nmax);                              // rows are padded at the FRONT (reference :194)
   const float4 v = src >= 0 ? ld4(obj + (((long)b * cap + src) * E4 + (i - row * E4)) * 4) : make_float4(pad, pad, pad, pad);
   *reinterpret_cast<float4*>(out + 4 * i) = v;
-  if (i - row * E4 == 0) kpm[row] = j >= counts[b] ? 1 : 0;    // the mask at the BACK (reference :193)
+  if (i - row * E4 == 0) kpm[row] = j >= min(max(counts[b], 1), cap) ? 1 : 0;    // the mask at the BACK (reference :193); count in [1, cap] by force
 }
 
 }  // namespace

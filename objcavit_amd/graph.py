@@ -28,7 +28,7 @@ from typing import Callable, List, Optional, Sequence, Tuple, Union
 
 import torch
 
-from . import hip_ops
+from . import graph_topology, hip_ops
 from .modules.ObjCAViT import PaddedObjects
 
 # Stream capture is a process-wide affair on ROCm 7.2: two threads capturing at the same time abort inside capture_end
@@ -61,7 +61,10 @@ class GraphedGraphBins:
     images_are_independent = True      # an image's result does not depend on its batch mates (per object group: SURVEY.md Q3)
 
     def __init__(self, model, example_image: torch.Tensor, warmup: int = 2, eager_ops: Sequence[str] = (),
-                 object_capacity: Optional[int] = None, object_group: Optional[int] = None):
+                 object_capacity: Optional[int] = None, object_group: Optional[int] = None, check_topology: bool = True):
+        """``check_topology``: every captured segment is read back from the runtime and must be a chain of single fork / single join
+        diamonds (objcavit_amd/graph_topology.py): a forward whose side streams were forked any other way -- the shapes that
+        replayed 3.5 - 6 ms slower per step or crashed hipGraphLaunch in round 4 -- raises HERE, before anything is replayed."""
         if example_image.device.type != "cuda":
             raise RuntimeError("graph capture needs a GPU tensor")
         self.model = model
@@ -117,6 +120,15 @@ class GraphedGraphBins:
             if empty:
                 self.empty_segments_dropped += 1
             else:
+                topo = graph_topology.read(g.raw_cuda_graph(), kernel_names=False) if check_topology else None
+                if topo is not None:
+                    bad = graph_topology.check(topo)
+                    self.segment_topology.append(topo.summary())
+                    if bad:
+                        state["g"] = None
+                        raise RuntimeError("captured forward is not a chain of single fork / single join branches (" + "; ".join(bad) +
+                                           "): on ROCm 7.2 such a graph replays milliseconds slower per step or crashes hipGraphLaunch "
+                                           "(profiles/r05_graph_shapes.txt) -- fork a side stream off the main chain once and join it once")
                 g.instantiate()
                 self.segments.append(g)
             self.segment_nodes.append(n)
@@ -130,6 +142,7 @@ class GraphedGraphBins:
             begin()
 
         self.empty_segments_dropped = 0
+        self.segment_topology: List[dict] = []            # graph_topology.Topology.summary() per kept segment (check_topology)
         self.segment_nodes: List[Optional[int]] = []      # nodes per captured segment (dropped ones included), None = not readable
         # the hook is an object handed to hip_ops for the duration of THIS capture on THIS thread (thread-local scope)
         with _CAPTURE_LOCK, hip_ops.island_scope(hip_ops.IslandHook(eager_ops, on_break)), hip_ops.workspace_scope(self.scratch), \
@@ -147,7 +160,9 @@ class GraphedGraphBins:
     @torch.no_grad()
     def load_objects(self, object_features, object_xywh_list=None, image: Optional[torch.Tensor] = None) -> None:
         """Copy one batch's objects into the graph's static buffers (current stream): a ``PaddedObjects`` of at most the graph's
-        capacity, the reference's two lists, or None = ask the model's provider (for ``image``, default the static image)."""
+        capacity, the reference's two lists (``object_xywh_list`` None = no boxes: every image carries the <UNK> box), or None = ask
+        the model's provider (for ``image``, default the static image).  Device counts are not read back here: the kernels take
+        them as min(max(count, 1), capacity) (csrc/objects_pad.hip), so a stray 0 cannot mask every key of an image."""
         if self.objects is None:
             raise RuntimeError("this graph was captured with its objects baked in (no object_capacity): it takes only the image")
         st = self.objects

@@ -63,6 +63,10 @@ class _PerDevice:
             self._vals.move_to_end(k)
         if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
             self._pinned[k] = v                         # a hipGraph now reads this address on every replay: never freed
+        elif isinstance(v, torch.Tensor) and v.is_cuda:
+            # built on whichever stream was current at first use, read on any (side streams, slot streams): the caching allocator
+            # must not hand an evicted entry's block out again while a launch of another stream still reads it
+            v.record_stream(torch.cuda.current_stream(v.device))
         return v
 
     def __len__(self):
@@ -99,6 +103,8 @@ class PaddedObjects:
         """The reference's two lists (N_i x F features, N_i x 4 boxes or None) -> padded tensors + device counts.  The counts
         tensor comes from a small LRU keyed on the tuple of counts (a host -> device copy: not inside a graph capture)."""
         B = len(object_features)
+        if object_xywh_list is None:
+            object_xywh_list = [None] * B          # no boxes at all: every image carries the <UNK> box (reference :313)
         if len(object_xywh_list) != B:
             raise ValueError("object_features / object_xywh_list must have one entry per image")
         boxes = [_NO_BOX.get(device) if b is None else b.to(device, torch.float32) for b in object_xywh_list]    # :313

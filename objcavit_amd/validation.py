@@ -46,8 +46,12 @@ class ValidationStep:
         """(output of the un-mirrored forward, depth of the mirrored forward -- still mirrored, as the metric kernel wants it)."""
         B = image.shape[0]
         mirrored = image.flip(dims=[3])
-        if not (self.joint and getattr(self.model, "images_are_independent", False)):
-            return self.model(image), self.model(mirrored).depth_pred
+        if not (self.joint and getattr(self.model, "images_are_independent", False) and _joint_fits(self.model, B)):
+            first = self.model(image)
+            if getattr(self.model, "static_image", None) is not None:
+                # a captured graph hands out its STATIC result tensors (bin_edges): the mirror's replay would overwrite them
+                first = type(first)(**{k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in first._asdict().items()})
+            return first, self.model(mirrored).depth_pred
         both = torch.cat([image, mirrored], dim=0)
         # the provider sees the mirrored images as images of their own, exactly as the reference's detector does (:173); the two
         # halves keep their own Nmax (object_group = B): bit for bit what two calls compute, up to batch-size-dependent kernel
@@ -72,11 +76,43 @@ class ValidationStep:
 
 
 def _takes_group(model) -> bool:
+    """Whether ``model.forward`` has the ``object_group`` argument.  A captured graph (``GraphedGraphBins``: ``__call__`` only,
+    no ``forward``) does not -- its group was fixed when it was captured."""
     import inspect
+    fwd = getattr(model, "forward", None)
+    if fwd is None:
+        return False
     try:
-        return "object_group" in inspect.signature(model.forward).parameters
+        return "object_group" in inspect.signature(fwd).parameters
     except (TypeError, ValueError):
         return False
+
+
+def _joint_fits(model, B: int) -> bool:
+    """A model of free shape takes any 2B-image batch.  A captured graph takes the joint [batch | mirrored batch] forward only
+    if it was captured for exactly that: 2B images with ``object_group = B`` (each half keeps its own Nmax, SURVEY.md Q3);
+    a graph captured for B images serves the pair as two replays instead."""
+    static = getattr(model, "static_image", None)
+    if static is None:
+        return True
+    return int(static.shape[0]) == 2 * B and getattr(model, "object_group", None) == B
+
+
+def hw_queue_note(slots: int) -> Optional[str]:
+    """None when the environment gives ``slots`` concurrent streams hardware queues of their own, else what is wrong."""
+    import os
+    if slots <= 1:
+        return None
+    raw = os.environ.get("GPU_MAX_HW_QUEUES")
+    try:
+        have = int(raw) if raw is not None else None
+    except ValueError:
+        have = None
+    if have is not None and have >= slots:
+        return None
+    return (f"{slots} steps in flight want GPU_MAX_HW_QUEUES >= {slots} set before the HIP runtime starts (found "
+            f"{'unset: the runtime default of 4 shares queues between later streams' if raw is None else repr(raw)}); slots that "
+            "share a hardware queue serialise (measured 781 vs 840 img/s)")
 
 
 class PipelinedValidation:
@@ -88,6 +124,10 @@ class PipelinedValidation:
     (bench.py --batch 1: the same slot mechanism) 288 img/s one after the other, 609 with three in flight, **685 - 692 with
     four** (the default; five and more collapse to 420 - 530 whatever GPU_MAX_HW_QUEUES says: the slots then share hardware queues);
     bs 2 (= image + mirror) 461 -> 817 -> 872.  Results are those of ``ValidationStep(joint=True)``: same kernels, same order per step.
+    REQUIRES ``GPU_MAX_HW_QUEUES >= slots`` in the environment BEFORE the HIP runtime initialises (the runtime's default is 4 and
+    gives only the first streams queues of their own: slots that share a hardware queue run one after the other, measured 781
+    instead of 840 img/s; ``OCV_SET_HW_QUEUES=8`` before ``import objcavit_amd`` sets it).  A smaller or unset value is accepted
+    but WARNED about and recorded in ``hip_ops.ROUTE_REPORT["PipelinedValidation"]``.
 
         pv = PipelinedValidation(model, args, example_image)
         for i, (image, depth_gt) in enumerate(loader):      # bs 1, as the reference
@@ -100,6 +140,11 @@ class PipelinedValidation:
         from .graph import GraphedGraphBins
         if slots < 1:
             raise ValueError("PipelinedValidation: slots must be >= 1")
+        note = hw_queue_note(slots)
+        if note:
+            import warnings
+            warnings.warn(f"PipelinedValidation: {note}", RuntimeWarning, stacklevel=2)
+            hip_ops.ROUTE_REPORT["PipelinedValidation"] = note
         self.args, self.flip_tta = args, flip_tta
         ds = args[args.basic.dataset]
         self.min_depth, self.max_depth = float(ds.min_depth), float(ds.max_depth)

@@ -184,6 +184,29 @@ def test_validation_step_as_one_2b_forward(kw):
     assert torch.equal(rec_j[:, 8:], rec_t[:, 8:]) and rel_dev(rec_j[:, :8], rec_t[:, :8]) < 1e-4
 
 
+@pytest.mark.parametrize("joint_capture", [False, True])
+def test_validation_step_on_a_captured_graph(joint_capture):
+    """ValidationStep(GraphedGraphBins(...)) -- a graph captured for B images serves image and mirror as two replays, one
+    captured for 2B images with object_group = B as the joint forward; both give the eager model's records."""
+    from objcavit_amd.graph import GraphedGraphBins
+    from objcavit_amd.modules.GraphBins import SyntheticObjectProvider
+    from objcavit_amd.validation import ValidationStep
+    H, W, B = 352, 384, 2
+    m, _, args = _model(dict(strategy="learned_bbox_wh", use_2_saca=True), H, W, 37, provider=SyntheticObjectProvider(12, "clip", seed=5))
+    img = gen.randn("img", (B, 3, H, W), 37).cuda()
+    gt = (torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(5)) * 9.0 + 0.5).cuda()
+    rec_e, out_e = ValidationStep(m, args, joint=joint_capture)(img, gt, first_image_id=2)
+    d_e, e_e = out_e.depth_pred.clone(), out_e.bin_edges.clone()
+    if joint_capture:
+        g = GraphedGraphBins(m, torch.cat([img, img.flip(dims=[3])], 0), object_group=B)
+    else:
+        g = GraphedGraphBins(m, img)
+    rec_g, out_g = ValidationStep(g, args, joint=True)(img, gt, first_image_id=2)
+    assert tuple(out_g.depth_pred.shape) == (B, 1, H // 2, W // 2)
+    assert max_rel(out_g.depth_pred, d_e) < 1e-5 and rel_dev(out_g.bin_edges, e_e) < 1e-6
+    assert torch.equal(rec_g[:, 8:], rec_e[:, 8:]) and rel_dev(rec_g[:, :8], rec_e[:, :8]) < 1e-5
+
+
 @pytest.mark.parametrize("B", [1, 2])
 def test_baseline_config_at_the_reference_validation_batch(B):
     """BASELINE configs[2] (NYU 480x640, learned positional MLP, 32 objects with text features) at the batch the reference's own

@@ -377,6 +377,45 @@ def test_validation_step_joint_forward_on_a_stand_in_model():
     assert torch.equal(out.depth_pred, o2.depth_pred) and torch.equal(mirror, m2)
 
 
+def test_validation_step_on_a_captured_graph_stand_in():
+    """a captured graph has ``__call__`` and ``static_image`` but no ``forward``.  Captured for B images it serves the
+    image / mirror pair as two replays (and the first replay's STATIC result tensors are copied before the second overwrites them);
+    captured for 2B images with ``object_group = B`` it takes the joint forward."""
+    import collections
+    from objcavit_amd.config import make_args
+    from objcavit_amd.validation import ValidationStep, _takes_group
+    Out = collections.namedtuple("Out", ["depth_pred", "bin_edges", "detections"])
+
+    class Graphish:
+        images_are_independent = True
+
+        def __init__(self, n, group=None):
+            self.static_image = torch.zeros(n, 3, 8, 12)
+            self.object_group = group
+            self.calls = []
+            self.edges = torch.zeros(n, 1)                      # static, overwritten by every "replay"
+
+        def __call__(self, image, object_features=None, object_xywh_list=None):
+            assert image.shape == self.static_image.shape
+            self.calls.append(tuple(image.shape))
+            self.edges.copy_(image.mean(dim=(1, 2, 3))[:, None])
+            return Out(image[:, :1, ::2, ::2].abs() + 0.5, self.edges, None)
+
+    img = torch.randn(3, 3, 8, 12)
+    g = Graphish(3)
+    assert not _takes_group(g)
+    out, mirror = ValidationStep(g, make_args(), joint=True)._forward_pair(img)
+    assert g.calls == [(3, 3, 8, 12)] * 2
+    assert torch.equal(out.bin_edges, img.mean(dim=(1, 2, 3))[:, None])          # not the mirror's replay
+    assert torch.equal(mirror, img.flip(dims=[3])[:, :1, ::2, ::2].abs() + 0.5)
+    g2 = Graphish(6, group=3)
+    out2, mirror2 = ValidationStep(g2, make_args(), joint=True)._forward_pair(img)
+    assert g2.calls == [(6, 3, 8, 12)] and torch.equal(out2.depth_pred, out.depth_pred) and torch.equal(mirror2, mirror)
+    g3 = Graphish(6, group=None)                                                  # 2B images but not grouped: not a joint capture of B
+    with pytest.raises(AssertionError):
+        ValidationStep(g3, make_args(), joint=True)._forward_pair(img)
+
+
 def test_side_stream_switches_follow_the_batches_in_flight(monkeypatch):
     """OCV_OBJ_OVERLAP / OCV_TOKEN_OVERLAP / OCV_HEAD_OVERLAP / OCV_SKIP_OVERLAP: 'auto' (default) = on for a lone batch, off once the driver announces
     several batches in flight (hip_ops.set_batches_in_flight); '0' / '1' override; anything else is an error, not a silent default;
