@@ -729,7 +729,8 @@ def main():
                                  "an fp32 FMA chain); depthwise and squeeze-excite on exact fp32 FMA.  exact_fp32_* = the same workload with "
                                  "every contraction on exact-fp32 arithmetic (" + " ".join(f"{k}={v}" for k, v in EXACT_ENV.items()) + ")")
             from objcavit_amd import hip_ops as _ops
-            fmode = model.dense_feature_extractor.decoder.__dict__.get("_f16_mode")
+            dec = model.dense_feature_extractor.decoder
+            fmode = dec.__dict__.get("_f16_modes", {}).get(dec._wkey())
             split_f16 = bool(fmode[1]) if fmode else _ops.conv_split_f16()
             res["conv_split"] = {"pairs": "fp16" if split_f16 else "bf16",
                                  # the decoder measured its activations' range on its first eager batch (host syncs, that call only)

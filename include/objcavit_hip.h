@@ -38,6 +38,17 @@ typedef void* ocv_stream_t;
 int ocv_abi_version(void);
 const char* ocv_last_error(void);
 
+/* Range guard of the fp16 pairs (round 5).  The reference's convolutions are nn.Conv2d in fp32 for ANY input
+ * (modules/DenseFeatureExtractor.py:37-47,104-118); the two-term fp16 split of the decoder's activations ends at +-65504.  Every
+ * launcher that writes fp16 "hl32" pairs (ocv_conv_nhwc_split_x_fwd, ocv_conv3x3_winograd43_split_fwd,
+ * ocv_upsample_concat_split_x_fwd, ocv_tap_interp_*_fwd) ORs 1 into the word the CALLING THREAD armed with ocv_range_flag_set when
+ * a value it converts exceeds 32752 in magnitude (an atomic on that rare branch only; NULL = not armed, the default).  The word is
+ * device memory owned by the caller, sticky until the caller clears it; ocv_range_flag_take_fwd copies it to `out` and zeroes it
+ * on the stream (one tiny launch: capturable).  The host reads `out` where it reads results and re-runs the batch on bf16 pairs
+ * (objcavit_amd/hip_ops.py RangeGuard).  Both return 0 / -1. */
+int ocv_range_flag_set(unsigned* flag);
+int ocv_range_flag_take_fwd(unsigned* flag, unsigned* out, ocv_stream_t stream);
+
 /* activation codes for ocv_linear_fwd */
 #define OCV_ACT_NONE 0
 #define OCV_ACT_RELU 1

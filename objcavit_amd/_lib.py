@@ -35,6 +35,8 @@ class EncoderLayerParams(C.Structure):
 PROTOTYPES = {
     "ocv_abi_version": (C.c_int, []),
     "ocv_last_error": (C.c_char_p, []),
+    "ocv_range_flag_set": (C.c_int, [C.c_void_p]),
+    "ocv_range_flag_take_fwd": (C.c_int, [C.c_void_p, C.c_void_p, _stream]),
     "ocv_linear_fwd": (C.c_int, [_f32p, C.c_int, C.c_long, _f32p, C.c_int, C.c_long, C.c_int, _f32p, _f32p, C.c_int,
                                  C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
     "ocv_linear_residual_layernorm_fwd": (C.c_int, [_f32p, C.c_int, _f32p, C.c_int, _f32p, _f32p, C.c_int, _f32p, _f32p,

@@ -36,6 +36,36 @@ bool ocv_layer_params_view(const void* caller_params, int index, void* lib_param
   return true;
 }
 
+// ---------------------------------------------------------------------------
+// range guard of the fp16 pairs (common.hpp: ocv_range_note)
+// ---------------------------------------------------------------------------
+namespace {
+thread_local unsigned* g_range_flag = nullptr;
+
+__global__ void range_flag_take_kernel(unsigned* __restrict__ flag, unsigned* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    *out = *flag;
+    *flag = 0u;
+  }
+}
+}  // namespace
+
+unsigned* ocv_range_flag_current() { return g_range_flag; }
+
+extern "C" int ocv_range_flag_set(unsigned* flag) {
+  OCV_CHECK_ARG((reinterpret_cast<uintptr_t>(flag) & 3) == 0, "ocv_range_flag_set: the word must be 4-byte aligned");
+  g_range_flag = flag;
+  return 0;
+}
+
+extern "C" int ocv_range_flag_take_fwd(unsigned* flag, unsigned* out, ocv_stream_t stream) {
+  OCV_CHECK_ARG(flag && out && flag != out, "ocv_range_flag_take_fwd: null pointer (or out == flag)");
+  OCV_CHECK_ARG(((reinterpret_cast<uintptr_t>(flag) | reinterpret_cast<uintptr_t>(out)) & 3) == 0, "ocv_range_flag_take_fwd: 4-byte alignment");
+  hipLaunchKernelGGL(range_flag_take_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, out);
+  OCV_CHECK_LAUNCH("ocv_range_flag_take_fwd");
+  return 0;
+}
+
 extern "C" int ocv_abi_version(void) { return OCV_ABI_VERSION; }
 extern "C" const char* ocv_last_error(void) { return g_err; }
 

@@ -59,10 +59,28 @@ __device__ __forceinline__ void ocv_split1(float v, unsigned short& hi, unsigned
   }
 }
 
+// Range guard of the fp16 pairs (round 5).  The reference's convolutions are fp32 for any input (modules/DenseFeatureExtractor.py:
+// 37-47,104-118); fp16 pairs end at +-65504.  Whether a model's activations fit is calibrated on its first batch -- and a LATER batch,
+// or a replay of a captured graph, can exceed it.  So every kernel that writes fp16 pairs keeps the largest magnitude it converts
+// (one v_max per element pair) and, on the rare true branch only, ORs 1 into ONE device word (the guard the host armed for this
+// thread: ocv_range_flag_set; nullptr = not armed).  The word is sticky; the host reads it where it reads results and re-runs the
+// batch on bf16 pairs (objcavit_amd/hip_ops.py RangeGuard).  Half of fp16's largest value: a tripped batch is never wrong yet
+// un-tripped, and NaN inputs stay NaN (loud) without tripping -- bf16 pairs would not cure them.
+constexpr float OCV_F16_GUARD = 32752.f;
+__device__ __forceinline__ void ocv_range_note(unsigned* flag, float amax) {
+  if (flag != nullptr && amax > OCV_F16_GUARD) atomicOr(flag, 1u);
+}
+__device__ __forceinline__ float ocv_amax4(float m, const f32x4 v) {
+  return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 void ocv_set_error(const char* fmt, ...);
+
+// the calling thread's armed range-guard word (device memory), or nullptr (csrc/capi.hip)
+unsigned* ocv_range_flag_current();
 
 #define OCV_CHECK_ARG(cond, ...)        \
   do {                                  \

@@ -77,6 +77,7 @@ struct ConvArgs {
                                         // and so is the split copy of the output (yhl)
   const float* oscale;                  // nullable [Cout]: raw accumulators are multiplied by it before bias / activation (the
                                         // per-output-channel power of two the fp16 weights were scaled by, inverted)
+  unsigned* range_flag;                 // nullable: the armed range-guard word (common.hpp ocv_range_note); read only where yhl holds fp16 pairs
   unsigned rowpitch;                    // conv_split_dma_kernel: bytes between consecutive rows of the (B H) x W pixel grid of the
                                         // split input when they are not dense (0 = dense, W * 4 Cp); the patch embedding reads
                                         // every 16th image row of the feature map as one GEMM row grid this way
@@ -440,6 +441,7 @@ __device__ __forceinline__ void conv_store_rows(const ConvArgs& p, const unsigne
     bv[e] = p.bias != nullptr ? p.bias[ncol + e] : 0.f;
     sv[e] = p.oscale != nullptr ? p.oscale[ncol + e] : 1.f;
   }
+  float amax = 0.f;                               // largest magnitude written as an fp16 pair (range guard, common.hpp)
 #pragma unroll 4
   for (int it = 0; it < 8; ++it) {
     const int row = half * 64 + it * 8 + rsub;
@@ -465,11 +467,13 @@ __device__ __forceinline__ void conv_store_rows(const ConvArgs& p, const unsigne
       __attribute__((aligned(16))) unsigned short hi[8], lo[8];
       split4_bits<F16>(a, hi, lo);
       split4_bits<F16>(c, hi + 4, lo + 4);
+      if constexpr (F16) amax = ocv_amax4(ocv_amax4(amax, a), c);
       const long oh = hl_index(m, ncol, p.Cpo);          // ncol % 8 == 0: the octet stays inside one 32-block
       *reinterpret_cast<bf16x8*>(p.yhl + oh) = *reinterpret_cast<bf16x8*>(hi);
       *reinterpret_cast<bf16x8*>(p.yhl + oh + 32) = *reinterpret_cast<bf16x8*>(lo);
     }
   }
+  if constexpr (F16) ocv_range_note(p.range_flag, amax);
 }
 
 // F16: the operands are fp16 (hi, lo) pairs instead of bf16 ones -- the same bytes through the same LDS-DMA pipeline, the
@@ -601,6 +605,7 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
             if (p.y != nullptr) p.y[yoff + m * p.Cout + n] = v;
             if (p.yhl != nullptr) {
               if constexpr (F16) {
+                ocv_range_note(p.range_flag, fabsf(v));
                 _Float16* yh = reinterpret_cast<_Float16*>(p.yhl);
                 const _Float16 hb = (_Float16)v;
                 yh[hl_index(m, n, p.Cpo)] = hb;
@@ -730,6 +735,7 @@ struct FinArgs {
   int Cout, Cpo, act, ksplit;
   const float* oscale;   // nullable [Cout] (ConvArgs::oscale)
   int f16;               // element type of yhl
+  unsigned* range_flag;  // nullable (ConvArgs::range_flag)
 };
 
 __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(FinArgs p) {
@@ -761,6 +767,7 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(FinArgs p) {
     __attribute__((aligned(16))) unsigned short hi[8], lo[8];
     split4_bits(a, hi, lo, p.f16 != 0);
     split4_bits(c, hi + 4, lo + 4, p.f16 != 0);
+    if (p.f16 != 0) ocv_range_note(p.range_flag, ocv_amax4(ocv_amax4(0.f, a), c));
     const long oh = hl_index(m, n, p.Cpo);
     *reinterpret_cast<bf16x8*>(p.yhl + oh) = *reinterpret_cast<bf16x8*>(hi);
     *reinterpret_cast<bf16x8*>(p.yhl + oh + 32) = *reinterpret_cast<bf16x8*>(lo);
@@ -842,6 +849,7 @@ extern "C" int ocv_conv_nhwc_split_x_fwd(const void* x_hl, int Cin, const void* 
   a.whi = (const __bf16*)w_hi; a.wlo = (const __bf16*)w_lo; a.bias = bias; a.res = residual; a.y = y;
   a.C1 = Cin; a.C2 = 0; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.ks = ksize; a.act = act; a.ksplit = 1;
   a.f16 = f16; a.oscale = oscale;
+  a.range_flag = (f16 && y_hl != nullptr) ? ocv_range_flag_current() : nullptr;
   if (y_hl != nullptr && Cout % 32 != 0) {       // the kernels write channels < Cout only: pad channels must read as zero
     const int zrc = ocv_zero_async(y_hl, ocv_split_act_elems(B, H, W, Cout) * sizeof(__bf16), (hipStream_t)stream);          // (a launch, not a memset node: common.hpp)
     if (zrc != 0) return zrc;
@@ -856,7 +864,7 @@ extern "C" int ocv_conv_nhwc_split_x_fwd(const void* x_hl, int Cin, const void* 
     h.bias = nullptr; h.res = nullptr; h.yhl = nullptr; h.act = OCV_ACT_NONE; h.y = (float*)workspace; h.ksplit = ks; h.oscale = nullptr;
     const int rc = launch_conv(h, B, true, (hipStream_t)stream);
     if (rc != 0) return rc;
-    FinArgs f{(const float*)workspace, bias, residual, y, (__bf16*)y_hl, M, M * Cout / 8, Cout, a.Cpo, act, ks, oscale, f16};
+    FinArgs f{(const float*)workspace, bias, residual, y, (__bf16*)y_hl, M, M * Cout / 8, Cout, a.Cpo, act, ks, oscale, f16, a.range_flag};
     hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)((f.items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, f);
     OCV_CHECK_LAUNCH("ocv_conv_nhwc_split_fwd(finish)");
     return 0;
@@ -1311,6 +1319,7 @@ struct Wino43OutArgs {
   int B, H, W, Cout, Cpo, th, tw, act;
   long T, items;          // items = T * Cout / 4
   int out_f16;
+  unsigned* range_flag;   // nullable (ConvArgs::range_flag)
 };
 
 // one thread = (tile, 4 channels): Y = A^T M A (A^T = [1 1 1 1 1 0; 0 1 -1 2 -1/2 0; 0 1 1 4 1/4 0; 0 1 -1 8 -1/8 1]), bias,
@@ -1338,6 +1347,7 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(Wino43OutArgs p) {
     s[3][jj] = m[1] - m[2] + 8.f * m[3] - 0.125f * m[4] + m[5];
   }
   const f32x4 bv = p.bias != nullptr ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+  float amax = 0.f;
 #pragma unroll
   for (int dy = 0; dy < 4; ++dy) {
     const int y = 4 * ty + dy;
@@ -1359,12 +1369,14 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(Wino43OutArgs p) {
       if (p.yhl != nullptr) {
         __attribute__((aligned(8))) unsigned short hi[4], lo[4];
         split4_bits(v, hi, lo, p.out_f16 != 0);
+        amax = ocv_amax4(amax, v);
         const long oh = hl_index(px, n, p.Cpo);
         *reinterpret_cast<uint2*>(p.yhl + oh) = *reinterpret_cast<uint2*>(hi);
         *reinterpret_cast<uint2*>(p.yhl + oh + 32) = *reinterpret_cast<uint2*>(lo);
       }
     }
   }
+  if (p.out_f16 != 0 && p.yhl != nullptr) ocv_range_note(p.range_flag, amax);
 }
 
 }  // namespace
@@ -1422,7 +1434,8 @@ extern "C" int ocv_conv3x3_winograd43_split_fwd(const void* x_hl, int Cin, const
   a.f16 = 1;
   const int rc = launch_conv(a, 1, true, st);
   if (rc != 0) return rc;
-  Wino43OutArgs wo{m, fscale, tinv, bias, y, (__bf16*)y_hl, B, H, W, Cout, a.Cpo, th, tw, act, T, T * (Cout / 4), hl_f16};
+  Wino43OutArgs wo{m, fscale, tinv, bias, y, (__bf16*)y_hl, B, H, W, Cout, a.Cpo, th, tw, act, T, T * (Cout / 4), hl_f16,
+                   (hl_f16 && y_hl != nullptr) ? ocv_range_flag_current() : nullptr};
   hipLaunchKernelGGL(wino43_output_kernel, dim3((unsigned)((wo.items + 255) / 256)), dim3(256), 0, st, wo);
   OCV_CHECK_LAUNCH("ocv_conv3x3_winograd43_split_fwd(output transform)");
   return 0;

@@ -60,6 +60,7 @@ struct TIArgs {
   const void* swlo;
   const float* sosc;     // [Cout] scale of the raw skip sums (fp16 pairs with per-channel weight scales), nullable
   int Cps;               // skip channels rounded up to 32
+  unsigned* range_flag;  // nullable: armed range-guard word, noted only where yhl holds fp16 pairs (common.hpp ocv_range_note)
 };
 
 template <int ACT>
@@ -312,6 +313,7 @@ __device__ __forceinline__ void ti_store(const TIArgs& p, const float4 (&acc)[4]
       ti_bf16x4 hi, lo;
       unsigned short hb_[4], lb_[4];
       if (p.f16) {                                                 // (uniform: one scalar branch per store)
+        ocv_range_note(p.range_flag, fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))));
 #pragma unroll
         for (int e = 0; e < 4; ++e) ocv_split1<true>(f[e], hb_[e], lb_[e]);
       } else {
@@ -392,7 +394,8 @@ int ti_launch(const char* who, const float* z, int h, int w, int zpad, const flo
   const int nj = ocv_cdiv(ti_footprint(h, w, H, W) + 1, 32);       // 1..6 staging rounds per tap (footprint + one spare slot)
   TIArgs a{z, zborder, s, bias, y, (__bf16*)y_hl, h, w, H, W, Cout, (Cout + 31) / 32 * 32, act, zpad,
            H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f,
-           ocv_cdiv(W, TX), ocv_cdiv(H, TY), nj * 32, hl_f16, skip_hl, ws_hi, ws_lo, s_oscale, Cps};
+           ocv_cdiv(W, TX), ocv_cdiv(H, TY), nj * 32, hl_f16, skip_hl, ws_hi, ws_lo, s_oscale, Cps,
+           (hl_f16 && y_hl != nullptr) ? ocv_range_flag_current() : nullptr};
   const long nwg = (long)a.tiles_x * a.tiles_y * B;
   OCV_CHECK_ARG(nwg < (1L << 31) && ocv_cdiv(Cout, CB) <= 65535, "%s: grid too large", who);
   if (y_hl != nullptr && Cout % 32 != 0) {

@@ -40,11 +40,13 @@ struct UpArgs {
   int h, w, H, W, C1, C2;
   float sh, sw;
   long total;                   // B * H * W * Cp / 4
+  unsigned* range_flag;         // nullable: armed range-guard word, fp16 pairs only (common.hpp ocv_range_note)
 };
 
 // 4 consecutive channels c .. c + 3 (c % 4 == 0: inside one 32-block) of pixel pix
 template <bool F16>
-__device__ __forceinline__ void store_split4(unsigned short* hl, long pix, int c, int Cp, float4 v) {
+__device__ __forceinline__ void store_split4(unsigned short* hl, long pix, int c, int Cp, float4 v, unsigned* range_flag) {
+  if constexpr (F16) ocv_range_note(range_flag, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
   unsigned short* hi = hl + pix * 2 * Cp + (c >> 5) * 64 + (c & 31);
   unsigned short* lo = hi + 32;
   const float f[4] = {v.x, v.y, v.z, v.w};
@@ -53,6 +55,11 @@ __device__ __forceinline__ void store_split4(unsigned short* hl, long pix, int c
   for (int i = 0; i < 4; ++i) ocv_split1<F16>(f[i], h[i], l[i]);
   *reinterpret_cast<uint2*>(hi) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
   *reinterpret_cast<uint2*>(lo) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+}
+
+__device__ __forceinline__ float up_amax8(const float (&f)[8]) {
+  return fmaxf(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))),
+               fmaxf(fmaxf(fabsf(f[4]), fabsf(f[5])), fmaxf(fabsf(f[6]), fabsf(f[7]))));
 }
 
 constexpr int UP_ITEMS = 8;
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(256) void upsample_concat_split_kernel(UpArgs p) {
     } else {
       v = ld4(p.skip + ((b * p.H + Y) * (long)p.W + X) * p.C2 + (c - p.C1));
     }
-    store_split4<F16>(p.hl, (b * p.H + Y) * (long)p.W + X, c, p.Cp, v);
+    store_split4<F16>(p.hl, (b * p.H + Y) * (long)p.W + X, c, p.Cp, v, p.range_flag);
   }
 }
 
@@ -117,6 +124,7 @@ struct Up8Args {
   float sh, sw, inv_noct;
   int noct, PB;                  // octets per pixel (Cp / 8), pixels per workgroup
   long npix;                     // B * H * W
+  unsigned* range_flag;          // nullable (UpArgs::range_flag)
 };
 
 __device__ __forceinline__ float4 up_lerp(const float4 a, const float4 b, const float4 c, const float4 d, float h0, float h1,
@@ -176,6 +184,7 @@ __global__ __launch_bounds__(256) void upsample_concat_split8_kernel(Up8Args p) 
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 va = is_up ? la : (is_skip ? a0 : z), vb = is_up ? lb : (is_skip ? a1 : z);
     const float f[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+    if constexpr (F16) ocv_range_note(p.range_flag, up_amax8(f));
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       unsigned short hb_, lb_;
@@ -206,6 +215,7 @@ struct UpBArgs {
   int noct, PB;                  // octets per pixel, blocks per workgroup
   int BW, BH;                    // blocks per row / column of one image
   long nblk;                     // B * BH * BW
+  unsigned* range_flag;          // nullable (UpArgs::range_flag)
 };
 
 __device__ __forceinline__ float4 up_sel(bool second, const float4 a, const float4 b) {
@@ -295,6 +305,7 @@ __global__ __launch_bounds__(256) void upsample_concat_split_2x2_kernel(UpBArgs 
         vb = n1[j][i];
       }
       const float f[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+    if constexpr (F16) ocv_range_note(p.range_flag, up_amax8(f));
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         unsigned short hb_, lb_;
@@ -338,6 +349,7 @@ struct UpLArgs {
   int Cp, h, w, H, W, C1, C2;
   float sh, sw;
   int tiles_x, tiles_per_image, nup;     // nup = C1 / 64 resize chunks; further chunks: 64 skip / pad channels each
+  unsigned* range_flag;                  // nullable (UpArgs::range_flag)
 };
 
 template <bool F16>
@@ -376,6 +388,7 @@ __global__ __launch_bounds__(256) void upsample_concat_split_lds_kernel(UpLArgs 
       const float4 va = up_lerp(src[r0 + c0][2 * oct], src[r0 + c1][2 * oct], src[r1 + c0][2 * oct], src[r1 + c1][2 * oct], h0, h1, w0, w1);
       const float4 vb = up_lerp(src[r0 + c0][2 * oct + 1], src[r0 + c1][2 * oct + 1], src[r1 + c0][2 * oct + 1], src[r1 + c1][2 * oct + 1], h0, h1, w0, w1);
       const float f[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+    if constexpr (F16) ocv_range_note(p.range_flag, up_amax8(f));
       up_bf16x8 hi, lo;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -407,6 +420,7 @@ __global__ __launch_bounds__(256) void upsample_concat_split_lds_kernel(UpLArgs 
       vb = ld4(sp + 4);
     }
     const float f[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+    if constexpr (F16) ocv_range_note(p.range_flag, up_amax8(f));
     up_bf16x8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -433,11 +447,11 @@ extern "C" int ocv_upsample_concat_split_x_fwd(const float* x, int h, int w, int
   const int Cp = (C1 + C2 + 31) / 32 * 32;
   UpArgs a{x, skip, (unsigned short*)out_hl, Cp, h, w, H, W, C1, C2,
            H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f,
-           (long)B * H * W * (Cp / 4)};
+           (long)B * H * W * (Cp / 4), f16 ? ocv_range_flag_current() : nullptr};
   static const bool quad_only = getenv("OCV_UPSAMPLE_QUAD") != nullptr;
   static const bool no_lds = getenv("OCV_UPSAMPLE_NOLDS") != nullptr;
   if (C1 % ULC == 0 && C2 % 8 == 0 && a.sh <= 0.5f && a.sw <= 0.5f && !no_lds && getenv("OCV_UPSAMPLE_QUAD") == nullptr) {
-    UpLArgs g{x, skip, (__bf16*)out_hl, Cp, h, w, H, W, C1, C2, a.sh, a.sw, (W + ULT_W - 1) / ULT_W, 0, C1 / ULC};
+    UpLArgs g{x, skip, (__bf16*)out_hl, Cp, h, w, H, W, C1, C2, a.sh, a.sw, (W + ULT_W - 1) / ULT_W, 0, C1 / ULC, a.range_flag};
     g.tiles_per_image = ((H + ULT_H - 1) / ULT_H) * g.tiles_x;
     const long nb = (long)B * g.tiles_per_image;
     const int nchunk = g.nup + (Cp - C1 + ULC - 1) / ULC;
@@ -449,7 +463,7 @@ extern "C" int ocv_upsample_concat_split_x_fwd(const float* x, int h, int w, int
   }
   static const bool no_2x2 = getenv("OCV_UPSAMPLE_NO2X2") != nullptr;
   if (C1 % 8 == 0 && C2 % 8 == 0 && Cp / 8 <= 256 && a.sh <= 1.0f && a.sw <= 1.0f && !quad_only && !no_2x2) {
-    UpBArgs g{x, skip, (__bf16*)out_hl, Cp, h, w, H, W, C1, C2, a.sh, a.sw, 0.f, Cp / 8, 1, (W + 1) / 2, (H + 1) / 2, 0};
+    UpBArgs g{x, skip, (__bf16*)out_hl, Cp, h, w, H, W, C1, C2, a.sh, a.sw, 0.f, Cp / 8, 1, (W + 1) / 2, (H + 1) / 2, 0, a.range_flag};
     g.inv_noct = 1.0f / (float)g.noct;
     g.nblk = (long)B * g.BH * g.BW;
     int threads = 256;                                            // workgroup size with the fewest idle lanes
@@ -464,7 +478,7 @@ extern "C" int ocv_upsample_concat_split_x_fwd(const float* x, int h, int w, int
     return 0;
   }
   if (C1 % 8 == 0 && C2 % 8 == 0 && Cp / 8 <= 256 * UP8_ITEMS && !quad_only) {
-    Up8Args g{x, skip, (__bf16*)out_hl, Cp, h, w, H, W, C1, C2, a.sh, a.sw, 0.f, Cp / 8, 1, (long)B * H * W};
+    Up8Args g{x, skip, (__bf16*)out_hl, Cp, h, w, H, W, C1, C2, a.sh, a.sw, 0.f, Cp / 8, 1, (long)B * H * W, a.range_flag};
     g.inv_noct = 1.0f / (float)g.noct;
     g.PB = (256 * UP8_ITEMS) / g.noct;                           // a workgroup's items fit one pass of its threads
     const long nb = (g.npix + g.PB - 1) / g.PB;

@@ -21,6 +21,7 @@ read back on ROCm 7.2).
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import threading
 import warnings
@@ -61,13 +62,26 @@ class GraphedGraphBins:
     images_are_independent = True      # an image's result does not depend on its batch mates (per object group: SURVEY.md Q3)
 
     def __init__(self, model, example_image: torch.Tensor, warmup: int = 2, eager_ops: Sequence[str] = (),
-                 object_capacity: Optional[int] = None, object_group: Optional[int] = None, check_topology: bool = True):
-        """``check_topology``: every captured segment is read back from the runtime and must be a chain of single fork / single join
+                 object_capacity: Optional[int] = None, object_group: Optional[int] = None, check_topology: bool = True,
+                 pairs: Optional[str] = None):
+        """``pairs``: None = the element type the model's decoder settled on (fp16 pairs unless its weights / first batch said
+        otherwise); "bf16" = warm up and capture under ``hip_ops.bf16_pairs()`` (fp32's range: what ``rerun_on_bf16`` replays).
+        ``check_topology``: every captured segment is read back from the runtime and must be a chain of single fork / single join
         diamonds (objcavit_amd/graph_topology.py): a forward whose side streams were forked any other way -- the shapes that
         replayed 3.5 - 6 ms slower per step or crashed hipGraphLaunch in round 4 -- raises HERE, before anything is replayed."""
         if example_image.device.type != "cuda":
             raise RuntimeError("graph capture needs a GPU tensor")
+        if pairs not in (None, "bf16"):
+            raise ValueError("pairs must be None (the model's own decision) or 'bf16'")
         self.model = model
+        self.pairs = pairs
+        self._ctor = dict(warmup=warmup, object_capacity=object_capacity, object_group=object_group, check_topology=check_topology)
+        self._fallback: Optional["GraphedGraphBins"] = None
+        # fp16 range guard (hip_ops.RangeGuard): the word every fp16-pair producer of THIS graph's launches ORs into; taken behind
+        # every replay into ``last_flag`` (device), read by ``tripped`` / ``checked`` where the caller reads results
+        self.range_guard = hip_ops.RangeGuard(example_image.device)
+        self.last_flag: Optional[torch.Tensor] = None
+        self.trips = 0
         self.static_image = example_image.clone()
         self.object_group = object_group
         self.objects: Optional[PaddedObjects] = None
@@ -84,7 +98,7 @@ class GraphedGraphBins:
         # the graph OWNS its scratch: every workspace requested during warm-up, capture and replay comes from this
         # store, so no eager call or later capture at other shapes can free a buffer whose address is baked in here
         self.scratch = hip_ops.WorkspaceStore()
-        with hip_ops.workspace_scope(self.scratch), torch.cuda.stream(self.stream), torch.no_grad():
+        with self._route(), hip_ops.workspace_scope(self.scratch), torch.cuda.stream(self.stream), torch.no_grad():
             for _ in range(warmup):                      # sizes every workspace / weight cache before capture
                 model(self.static_image, self.objects, None, None, self.object_group)
         torch.cuda.current_stream().wait_stream(self.stream)
@@ -145,13 +159,14 @@ class GraphedGraphBins:
         self.segment_topology: List[dict] = []            # graph_topology.Topology.summary() per kept segment (check_topology)
         self.segment_nodes: List[Optional[int]] = []      # nodes per captured segment (dropped ones included), None = not readable
         # the hook is an object handed to hip_ops for the duration of THIS capture on THIS thread (thread-local scope)
-        with _CAPTURE_LOCK, hip_ops.island_scope(hip_ops.IslandHook(eager_ops, on_break)), hip_ops.workspace_scope(self.scratch), \
-                torch.cuda.stream(self.stream), torch.no_grad():
+        with _CAPTURE_LOCK, self._route(), self.range_guard.armed(), hip_ops.island_scope(hip_ops.IslandHook(eager_ops, on_break)), \
+                hip_ops.workspace_scope(self.scratch), torch.cuda.stream(self.stream), torch.no_grad():
             begin()
             parts = model.forward_until_head(self.static_image, self.objects, None, None, self.object_group)
             end()
         torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
+        self.range_guard.flag.zero_()                    # (the capture run's islands executed once: start clean)
         self.scratch.freeze()
         self.feat, self.queries, self.centers, self.bin_edges, self.detections = parts
         self.ReturnType = model.ReturnType
@@ -197,7 +212,7 @@ class GraphedGraphBins:
             self.static_image.copy_(image)
         if self.objects is not None:
             self.load_objects(object_features, object_xywh_list, image)
-        with hip_ops.workspace_scope(self.scratch):
+        with self._route(), hip_ops.workspace_scope(self.scratch), self.range_guard.armed():
             for seg in self.segments:
                 if isinstance(seg, tuple):
                     with hip_ops.timed(seg[0]):
@@ -205,4 +220,37 @@ class GraphedGraphBins:
                 else:
                     seg.replay()
             depth = self.model.head(self.feat, self.queries, self.centers)
+        if self.pairs is None:
+            self.last_flag = self.range_guard.take()     # one-thread launch: flag -> last_flag, flag = 0 (nobody waits for it here)
         return self.ReturnType(depth_pred=depth, bin_edges=self.bin_edges, detections=self.detections)
+
+    def _route(self):
+        return hip_ops.bf16_pairs() if self.pairs == "bf16" else contextlib.nullcontext()
+
+    def tripped(self, taken: Optional[torch.Tensor] = None) -> bool:
+        """Whether the last replay (or the replay whose ``last_flag`` the caller kept) converted a value beyond the fp16 pairs'
+        guarded range.  A host read: call it where the result is read anyway."""
+        taken = self.last_flag if taken is None else taken
+        return taken is not None and hip_ops.RangeGuard.tripped(taken)
+
+    @torch.no_grad()
+    def rerun_on_bf16(self, image: torch.Tensor, object_features=None, object_xywh_list=None):
+        """The same batch through the bf16-pair capture of the same forward (fp32's range, 2^-17 products instead of 2^-22: rounds
+        1 - 3's arithmetic, parity-tested on its own) -- captured lazily, once, on the first trip; recorded in ROUTE_REPORT."""
+        if self._fallback is None:
+            cur = torch.cuda.current_stream(image.device)
+            cur.synchronize()                            # nothing of this graph is in flight while its sibling is captured
+            self._fallback = GraphedGraphBins(self.model, self.static_image, pairs="bf16", **self._ctor)
+        self.trips += 1
+        hip_ops.ROUTE_REPORT["range_guard"] = (f"{self.trips} batch(es) exceeded the fp16 pairs' guarded range (|x| > 32752 in a decoder "
+                                               "/ heads activation) under a captured graph and were re-run on the bf16-pair capture")
+        return self._fallback(image, object_features, object_xywh_list)
+
+    @torch.no_grad()
+    def checked(self, image: torch.Tensor, object_features=None, object_xywh_list=None):
+        """``__call__`` + the range guard's verdict (a host synchronisation) + the handled fallback: what a caller that reads the
+        result next should use (ValidationStep does); pipelined callers keep ``last_flag`` per step and decide when they collect."""
+        out = self(image, object_features, object_xywh_list)
+        if self.tripped():
+            out = self.rerun_on_bf16(image, object_features, object_xywh_list)
+        return out

@@ -84,6 +84,8 @@ class _Tls(threading.local):
         self.island_hook = None
         self.islands_off = 0                 # > 0: inside islands_suspended()
         self.single_chain = 0                # > 0: inside single_chain() -- no further forks
+        self.bf16_pairs = 0                  # > 0: inside bf16_pairs() -- the split pipeline on bf16 pairs
+        self.range_flag = None               # the armed RangeGuard word of this thread (a tensor), or None
         self.ws_stack = None                 # workspace stores of this thread (bottom = the module-level store)
 
 
@@ -755,17 +757,21 @@ class PatchEmbedSplitWeight:
 
     def __init__(self):
         self._key = None
-        self._val = None
+        self._vals = {}                     # f16 -> prepared weight: BOTH element types stay alive side by side (a captured graph
+                                            # of the fp16 route and its bf16 fallback graph hold their addresses)
 
     def get(self, w: torch.Tensor, f16: bool = False):
-        key = (w.data_ptr(), w._version, tuple(w.shape), bool(f16))
+        key = (w.data_ptr(), w._version, tuple(w.shape))
         if key != self._key:
+            self._vals = {}
+            self._key = key
+        f16 = bool(f16)
+        if f16 not in self._vals:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("weight preparation during graph capture: run one eager warm-up call first")
             # (None: the weight does not fit fp16 pairs -- judged once per weight version, a host synchronisation)
-            self._val = prep_patch_embed_weight(w, f16) if not f16 or fp16_weight_safe(w.detach().flatten(1)) else None
-            self._key = key
-        return self._val
+            self._vals[f16] = prep_patch_embed_weight(w, f16) if not f16 or fp16_weight_safe(w.detach().flatten(1)) else None
+        return self._vals[f16]
 
 
 def patch_embed_auto(fmap: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], pos: Optional[torch.Tensor],
@@ -1065,7 +1071,89 @@ def conv_split_f16() -> bool:
     mode = os.environ.get("OCV_CONV_SPLIT", "f16")
     if mode not in ("f16", "bf16"):
         raise ValueError(f"OCV_CONV_SPLIT={mode!r}: expected 'f16' (default) or 'bf16'")
-    return mode == "f16"
+    return mode == "f16" and not _TLS.bf16_pairs
+
+
+class bf16_pairs:
+    """``with bf16_pairs():`` forwards issued (or captured) inside run the decoder's / heads' split pipeline on bf16 pairs
+    whatever OCV_CONV_SPLIT says (thread-local): the handled fallback of a batch that tripped the fp16 range guard
+    (``RangeGuard``), and how its hipGraph is captured."""
+
+    def __enter__(self):
+        _TLS.bf16_pairs += 1
+        return self
+
+    def __exit__(self, *exc):
+        _TLS.bf16_pairs -= 1
+        return False
+
+
+class RangeGuard:
+    """One device word that every launch writing fp16 pairs ORs 1 into when a value it converts exceeds 32752 in magnitude
+    (include/objcavit_hip.h ``ocv_range_flag_set``; csrc/common.hpp ``ocv_range_note``).  The reference computes these layers in
+    fp32 for any input (modules/DenseFeatureExtractor.py:37-47,104-118); the fp16-pair pipeline is calibrated on a model's FIRST
+    batch only, and a captured graph cannot change its mind -- so the owner of a forward (GraphBins / AdaBins eagerly,
+    GraphedGraphBins per replay) arms this word around its launches, takes it behind them (``take``: a one-thread launch on the
+    stream, capturable) and reads the taken copy where it reads results (``tripped``: a host read); a tripped batch is re-run on
+    bf16 pairs and recorded in ``ROUTE_REPORT``.  Arming is per thread, like a capture."""
+
+    def __init__(self, device: torch.device):
+        self.flag = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def armed(self) -> "_Armed":
+        return _Armed(self.flag)
+
+    def take(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Enqueue ``out = flag; flag = 0`` on the current stream; -> ``out`` (int32 [1] on the device, a new tensor by default)."""
+        if out is None:
+            out = torch.empty(1, dtype=torch.int32, device=self.flag.device)
+        check(_lib.load().ocv_range_flag_take_fwd(self.flag.data_ptr(), out.data_ptr(), _stream()), "ocv_range_flag_take_fwd")
+        return out
+
+    @staticmethod
+    def tripped(taken: torch.Tensor) -> bool:
+        """Host read of a taken word (synchronises with the stream that took it)."""
+        return bool(int(taken.item()) != 0)
+
+
+def guarded_forward(owner, decoder, device: torch.device, run):
+    """The eager inference forward of a model under its range guard: ``run()`` issues the forward; when the decoder runs on fp16
+    pairs and a launch tripped the guard, the SAME batch is issued again on bf16 pairs (``bf16_pairs``) and the route is reported.
+    Costs one one-thread launch and one 4-byte host read per forward (a synchronisation: the eager path is the slow path anyway --
+    a captured forward keeps the word on the device, objcavit_amd/graph.py); ``owner.range_guard_sync = False`` switches it off.
+    Inside a graph capture (warm-up of another owner's graph excepted: that is eager) nothing is read: the capturing owner arms
+    its own word."""
+    if (device.type != "cuda" or torch.is_grad_enabled() or owner.training or torch.cuda.is_current_stream_capturing()
+            or not getattr(owner, "range_guard_sync", True) or _TLS.bf16_pairs or decoder.settled_f16() is False):
+        return run()
+    guard = owner.__dict__.get("_range_guard")
+    if guard is None or guard.flag.device != device:
+        guard = owner.__dict__["_range_guard"] = RangeGuard(device)
+    with guard.armed():
+        out = run()
+    if RangeGuard.tripped(guard.take()):
+        n = owner.__dict__["_range_trips"] = owner.__dict__.get("_range_trips", 0) + 1
+        ROUTE_REPORT["range_guard"] = (f"{n} batch(es) exceeded the fp16 pairs' guarded range (|x| > 32752 in a decoder / heads "
+                                       "activation) and were re-run on bf16 pairs")
+        with bf16_pairs():
+            out = run()
+    return out
+
+
+class _Armed:
+    def __init__(self, flag: torch.Tensor):
+        self.flag = flag
+
+    def __enter__(self):
+        self.prev = _TLS.range_flag
+        _TLS.range_flag = self.flag
+        check(_lib.load().ocv_range_flag_set(self.flag.data_ptr()), "ocv_range_flag_set")
+        return self
+
+    def __exit__(self, *exc):
+        _TLS.range_flag = self.prev
+        check(_lib.load().ocv_range_flag_set(None if self.prev is None else self.prev.data_ptr()), "ocv_range_flag_set")
+        return False
 
 
 ROUTE_REPORT: Dict[str, str] = {}        # layer / model name -> why it left the default route (never silent: bench.py prints it)

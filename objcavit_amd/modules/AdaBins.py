@@ -74,6 +74,10 @@ class AdaBins(nn.Module):
             yield from m.parameters()
 
     def forward(self, image):
+        """reference :73-89; on the GPU in eval / no_grad under the fp16 range guard (hip_ops.guarded_forward)."""
+        return hip_ops.guarded_forward(self, self.dense_feature_extractor.decoder, image.device, lambda: self._forward(image))
+
+    def _forward(self, image):
         unet_out = self.dense_feature_extractor(image, _split_only=True)        # (the heads read the split copy: hip_ops.map_placeholder)
         ds = self.args[self.args.basic.dataset]
         bin_widths_normed, feat, queries = self.adaptive_bins_layer.forward_parts(unet_out, (ds.min_depth, ds.max_depth))

@@ -57,7 +57,8 @@ class SplitConv3x3:
         self._w_folded = None
         self._w_exact = None
         self._w_up = None
-        self._prep16 = None
+        self._w_up_all = {}              # every arrangement built for this weight version: the fp16-pair one and its bf16 fallback
+        self._prep16 = None              # stay alive side by side (two captured graphs may hold their addresses)
 
     def prep_for(self, f16: bool):
         """(w_hi, w_lo, bias, oscale) in the element type of the input: bf16 pairs (oscale None) or fp16 pairs."""
@@ -119,6 +120,7 @@ class SplitConv3x3:
                 self._wino = None                                      # transformed / tap-major weights: built on first use
                 self._w_exact = None
                 self._w_up = None
+                self._w_up_all = {}
                 self._prep16 = None
                 self._w_folded = w.detach()
             self._key = key
@@ -134,6 +136,8 @@ class SplitConv3x3:
         instead of bf16 pairs.  -> dict(a_hi, a_lo, a_osc, s_hi, s_lo, s_osc, bias, border)."""
         self._ensure_prepared()
         ckey = None if compose is None else compose[0]
+        if (self._w_up is None or self._w_up[0] != (c1, ckey, bool(f16))) and (c1, ckey, bool(f16)) in self._w_up_all:
+            self._w_up = self._w_up_all[(c1, ckey, bool(f16))]
         if self._w_up is None or self._w_up[0] != (c1, ckey, bool(f16)):
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("weight preparation during graph capture: run one eager warm-up call first")
@@ -160,7 +164,7 @@ class SplitConv3x3:
                     raise Fp16Unsafe(f"{self.conv} (skip part): column spread beyond 2^17")
                 ps = hip_ops.prep_conv_weight(ws, f16=f16)
                 d.update(s_hi=ps[0], s_lo=ps[1], s_osc=ps[2] if f16 else None)
-            self._w_up = ((c1, ckey, bool(f16)), d)
+            self._w_up = self._w_up_all[(c1, ckey, bool(f16))] = ((c1, ckey, bool(f16)), d)
         return dict(self._w_up[1], bias=self._prep[2])
 
     def run_split(self, x: "hip_ops.SplitAct", act=hip_ops.ACT_NONE, out_fp32=True, out_split=False):
@@ -608,12 +612,24 @@ class Decoder(nn.Module):
     def settled_f16(self):
         """The element type of the split pipeline once it is decided for the current weights (True: fp16 pairs, False: bf16 pairs);
         None before the calibrating first call / after a weight update."""
-        mode = self.__dict__.get("_f16_mode")
+        wkey = self._wkey()
+        mode = self.__dict__.get("_f16_modes", {}).get(wkey)
         if mode is None or (mode[1] and len(mode) == 2):
             return None
-        wkey = (hip_ops.conv_split_f16(),) + tuple((p.data_ptr(), p._version) for p in self.parameters()) + \
+        return bool(mode[1])
+
+    def _wkey(self):
+        """(requested element type, identity + version of every parameter / buffer): what a decision about the split pipeline's
+        element type is valid for.  The fp16 route and the bf16 route (hip_ops.bf16_pairs: the range guard's fallback) of ONE weight
+        version keep their own entries side by side."""
+        return (hip_ops.conv_split_f16(),) + tuple((p.data_ptr(), p._version) for p in self.parameters()) + \
             tuple((b.data_ptr(), b._version) for b in self.buffers())
-        return bool(mode[1]) if mode[0] == wkey else None
+
+    def _set_mode(self, wkey, mode):
+        modes = {k: v for k, v in self.__dict__.get("_f16_modes", {}).items() if k[1:] == wkey[1:]}      # (stale weight versions dropped)
+        modes[wkey] = mode
+        self.__dict__["_f16_modes"] = modes
+        return mode
 
     def forward(self, features, _split_only: bool = False, _skip_pre: Optional[SkipPrepass] = None):
         """``_split_only`` (GraphBins / AdaBins inference calls): the heads read the split copy of the result, so the last convolution
@@ -649,11 +665,10 @@ class Decoder(nn.Module):
             # (patch embedding reads it) AND its split copy, which rides along for the heads' 3x3 convolution.  Element type of
             # every split tensor: fp16 pairs (round 4) unless a weight of the pipeline does not fit them -- then bf16 pairs for
             # the whole pipeline, decided once per weight version and REPORTED (hip_ops.ROUTE_REPORT), never silent.
-            wkey = (hip_ops.conv_split_f16(),) + tuple((p.data_ptr(), p._version) for p in self.parameters()) + \
-                tuple((b.data_ptr(), b._version) for b in self.buffers())
-            mode = self.__dict__.get("_f16_mode")
-            if mode is None or mode[0] != wkey:
-                mode = self.__dict__["_f16_mode"] = (wkey, hip_ops.conv_split_f16())
+            wkey = self._wkey()
+            mode = self.__dict__.get("_f16_modes", {}).get(wkey)
+            if mode is None:
+                mode = self._set_mode(wkey, (wkey, hip_ops.conv_split_f16()))
 
             def pre_of(up, f16):
                 return None if _skip_pre is None else _skip_pre.take(up, f16)
@@ -690,7 +705,7 @@ class Decoder(nn.Module):
                     if calibrate:
                         hip_ops.range_check(False)          # whatever happened: never leave the synchronising recorder on
                 if calibrate:
-                    mode = self.__dict__["_f16_mode"] = (wkey, rep["ok"], rep)
+                    mode = self._set_mode(wkey, (wkey, rep["ok"], rep))
                     if not rep["ok"]:
                         hip_ops.ROUTE_REPORT["Decoder"] = ("split pipeline on bf16 pairs instead of fp16 pairs: activation range "
                                                            f"{rep['out_of_range']} outside [2^-6, 65504 / 16] on the first batch")
@@ -699,7 +714,7 @@ class Decoder(nn.Module):
                 if torch.cuda.is_current_stream_capturing():
                     raise
                 hip_ops.ROUTE_REPORT["Decoder"] = f"split pipeline on bf16 pairs instead of fp16 pairs: {e}"
-                self.__dict__["_f16_mode"] = (wkey, False, None)
+                self._set_mode(wkey, (wkey, False, None))
                 out, out_split = pipeline(False)
             out._ocv_split = out_split
             return out

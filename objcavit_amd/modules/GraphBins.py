@@ -178,7 +178,11 @@ class GraphBins(nn.Module):
         """``pad_objects_to``: the longest object list of the GLOBAL batch when ``image`` is one rank's shard of it
         (objcavit_amd/dp.py ``sharded_forward``); None = this batch's own maximum, as the reference pads.
         ``object_group``: see ``forward_until_head``."""
-        feat, queries, centers, bin_edges, detections = self.forward_until_head(image, object_features, object_xywh_list, pad_objects_to,
-                                                                                object_group)
-        depth_pred = self.head(feat, queries, centers)
-        return self.ReturnType(depth_pred=depth_pred, bin_edges=bin_edges, detections=detections)
+        def run():
+            feat, queries, centers, bin_edges, detections = self.forward_until_head(image, object_features, object_xywh_list,
+                                                                                    pad_objects_to, object_group)
+            depth_pred = self.head(feat, queries, centers)
+            return self.ReturnType(depth_pred=depth_pred, bin_edges=bin_edges, detections=detections)
+
+        # (GPU, eval, no_grad: under the fp16 range guard -- a batch beyond the fp16 pairs' range is re-run on bf16 pairs and reported)
+        return hip_ops.guarded_forward(self, self.dense_feature_extractor.decoder, image.device, run)

@@ -42,21 +42,27 @@ class ValidationStep:
         ds = args[args.basic.dataset]
         self.min_depth, self.max_depth = float(ds.min_depth), float(ds.max_depth)
 
+    def _call(self, *a):
+        """One forward.  A captured graph is called through ``checked``: its fp16 range guard is read here (this sequential step
+        reads its result next anyway) and a tripped batch re-run on the bf16-pair capture; an eager model guards itself."""
+        fn = getattr(self.model, "checked", None)
+        return fn(*a) if fn is not None else self.model(*a)
+
     def _forward_pair(self, image: torch.Tensor):
         """(output of the un-mirrored forward, depth of the mirrored forward -- still mirrored, as the metric kernel wants it)."""
         B = image.shape[0]
         mirrored = image.flip(dims=[3])
         if not (self.joint and getattr(self.model, "images_are_independent", False) and _joint_fits(self.model, B)):
-            first = self.model(image)
+            first = self._call(image)
             if getattr(self.model, "static_image", None) is not None:
                 # a captured graph hands out its STATIC result tensors (bin_edges): the mirror's replay would overwrite them
                 first = type(first)(**{k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in first._asdict().items()})
-            return first, self.model(mirrored).depth_pred
+            return first, self._call(mirrored).depth_pred
         both = torch.cat([image, mirrored], dim=0)
         # the provider sees the mirrored images as images of their own, exactly as the reference's detector does (:173); the two
         # halves keep their own Nmax (object_group = B): bit for bit what two calls compute, up to batch-size-dependent kernel
         # dispatch (split-K, tile shapes)
-        out = self.model(both, None, None, None, B) if _takes_group(self.model) else self.model(both)
+        out = self.model(both, None, None, None, B) if _takes_group(self.model) else self._call(both)
         first = type(out)(**{k: (None if v is None else v[:B]) for k, v in out._asdict().items()})
         return first, out.depth_pred[B:]
 
@@ -66,7 +72,7 @@ class ValidationStep:
         if self.flip_tta:
             out, mirror = self._forward_pair(image)
         else:
-            out, mirror = self.model(image), None
+            out, mirror = self._call(image), None
         H, W = depth_gt.shape[2:]
         rec = hip_ops.depth_metrics(out.depth_pred.contiguous(), depth_gt.contiguous(), self.min_depth, self.max_depth,
                                     crop=crop_box(self.args, H, W),
@@ -158,6 +164,7 @@ class PipelinedValidation:
             hip_ops.set_batches_in_flight(prev)
         self._next = 0
         self._pending = []
+        self.rerun_steps = 0                                 # steps re-run on bf16 pairs by collect() (fp16 range guard)
 
     @torch.no_grad()
     def submit(self, image: torch.Tensor, depth_gt: torch.Tensor, first_image_id: int = 0, object_features=None, object_xywh_list=None) -> None:
@@ -173,26 +180,41 @@ class PipelinedValidation:
         with torch.cuda.stream(g.stream):
             both = torch.cat([image, image.flip(dims=[3])], 0) if self.flip_tta else image
             out = g(both, object_features, object_xywh_list) if g.objects is not None else g(both)
-            H, W = depth_gt.shape[2:]
-            B = self.B
-            rec = hip_ops.depth_metrics(out.depth_pred[:B].contiguous(), depth_gt.contiguous(), self.min_depth, self.max_depth,
-                                        crop=crop_box(self.args, H, W),
-                                        pred_mirror=out.depth_pred[B:].contiguous() if self.flip_tta else None,
-                                        first_image_id=first_image_id)
+            rec = self._records(out, depth_gt, first_image_id)
         for t in (image, depth_gt):
             t.record_stream(g.stream)                        # the caching allocator must not recycle them under the slot's launches
-        self._pending.append((rec, g.stream))
+        # the step's inputs stay referenced until collect(): a step whose fp16 range guard tripped (``g.last_flag``, read there in ONE
+        # host copy for all pending steps) is re-run from them on the bf16-pair capture
+        self._pending.append((rec, g.stream, g.last_flag, g, (both, depth_gt, first_image_id, object_features, object_xywh_list)))
+
+    def _records(self, out, depth_gt: torch.Tensor, first_image_id: int) -> torch.Tensor:
+        H, W = depth_gt.shape[2:]
+        B = self.B
+        return hip_ops.depth_metrics(out.depth_pred[:B].contiguous(), depth_gt.contiguous(), self.min_depth, self.max_depth,
+                                     crop=crop_box(self.args, H, W),
+                                     pred_mirror=out.depth_pred[B:].contiguous() if self.flip_tta else None,
+                                     first_image_id=first_image_id)
 
     def collect(self) -> torch.Tensor:
-        """Wait for every submitted step; -> records [N * B, 10] in submission order (and forget them)."""
-        cur = None
-        for _, st in self._pending:
-            st.synchronize()
-            cur = st
+        """Wait for every submitted step; -> records [N * B, 10] in submission order (and forget them).  The steps' inputs are held
+        until here (fp16 range guard: a tripped step is re-run on bf16 pairs): call it every few hundred steps on a long run."""
         if not self._pending:
             return torch.empty(0, 10)
-        out = torch.cat([r for r, _ in self._pending], 0)
-        del cur
+        for p in self._pending:
+            p[1].synchronize()
+        recs = [p[0] for p in self._pending]
+        flags = [p[2] for p in self._pending]
+        if any(f is not None for f in flags):
+            # fp16 range guard: one host read for all pending steps; a tripped step is re-run on its slot's bf16-pair capture
+            # (captured once, on the first trip) from the inputs kept since submit()
+            hit = torch.cat([f if f is not None else torch.zeros(1, dtype=torch.int32, device=recs[0].device) for f in flags]).cpu()
+            for i in hit.nonzero().flatten().tolist():
+                _, _, _, g, (both, depth_gt, first_id, of, ox) = self._pending[i]
+                out = g.rerun_on_bf16(both, of, ox) if g.objects is not None else g.rerun_on_bf16(both)
+                recs[i] = self._records(out, depth_gt, first_id)
+                self.rerun_steps += 1
+            torch.cuda.current_stream(recs[0].device).synchronize()
+        out = torch.cat(recs, 0)
         self._pending = []
         return out
 

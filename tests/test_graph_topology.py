@@ -27,6 +27,17 @@ def test_one_fork_one_chain_one_join_passes_also_three_in_sequence():
     assert check(Topology(9, chain([0, 1, 2, 3, 4, 5]) + [(1, 6), (1, 6)] + chain([6, 7, 8]) + [(8, 4)])) == []
 
 
+def test_redundant_stream_order_edges_are_ignored():
+    """What the runtime really records for two forks in sequence on ONE side stream (tools/graph_shapes.py 'three_diamonds',
+    profiles/r05_graph_shapes.txt): the side stream's own order adds an edge from the last launch of the first side chain to
+    the first launch of the second, which already waits for the main chain behind the first join."""
+    main = list(range(10))
+    e = chain(main) + [(1, 10), (10, 11), (11, 3)] + [(5, 12), (12, 13), (13, 7)] + [(11, 12)]
+    assert check(Topology(14, e)) == []
+    # but a second REAL dependency of the side chain (nothing implies it) stays a violation
+    assert check(Topology(14, chain(main) + [(1, 10), (10, 11), (11, 12), (12, 13), (13, 7)] + [(4, 12)]))
+
+
 def test_a_side_stream_from_the_very_top_and_an_unjoined_tail_are_a_virtual_fork_and_join():
     # side chain 5-6 has no predecessor (forked before the main stream issued anything), joined into main node 3
     assert check(Topology(7, chain([0, 1, 2, 3, 4]) + [(5, 6), (6, 3)])) == []
@@ -55,8 +66,8 @@ def test_three_parallel_branches_and_a_nested_fork_fail():
     v = check(Topology(7, e))
     assert v and "more than two" in v[0], v
     # a fork inside an open fork: side node 5 forks again
-    e = chain([0, 1, 2, 3, 4]) + [(1, 5), (5, 6), (6, 3), (5, 7), (7, 6)]
-    v = check(Topology(8, e))
+    e = chain([0, 1, 2, 3, 4]) + [(1, 5), (5, 6), (6, 3), (5, 7), (7, 8), (8, 3)]
+    v = check(Topology(9, e))
     assert v and "nested" in v[0], v
 
 

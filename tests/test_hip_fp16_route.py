@@ -209,7 +209,7 @@ def test_stress_margin_on_fp16_pairs_and_reported_fallback(ops, monkeypatch):
     # ... and an ACTIVATION range the pairs cannot hold: a fresh model fed images 1e-7 times the usual scale calibrates itself onto
     # bf16 pairs on its first batch (every tensor's largest entry far below 2^-6) and says so
     _, m2, _ = _stress({"OCV_CONV_SPLIT": "f16"}, monkeypatch)
-    m2.dense_feature_extractor.decoder.__dict__.pop("_f16_mode", None)
+    m2.dense_feature_extractor.decoder.__dict__.pop("_f16_modes", None)
     enc = m2.dense_feature_extractor.encoder.original_model
     enc.blocks[6][2].bn3.weight *= 1e-6                                    # the decoder's deepest input shrinks by 1e6
     enc.blocks[6][2].bn3.bias *= 1e-6
@@ -219,3 +219,129 @@ def test_stress_margin_on_fp16_pairs_and_reported_fallback(ops, monkeypatch):
     m2(img[:1].cuda())
     assert "range" in ops.ROUTE_REPORT.get("Decoder", ""), ops.ROUTE_REPORT
     ops.ROUTE_REPORT.clear()
+
+
+# ---------------------------------------------------------------------------
+# round 5: the sticky on-device range guard of the fp16 pairs and its handled bf16 fallback
+# ---------------------------------------------------------------------------
+def test_range_guard_word_is_set_by_every_fp16_pair_producer_and_only_by_them(ops):
+    """Every launcher that writes fp16 pairs ORs 1 into the armed word when it converts |v| > 32752 (the reference computes these
+    layers in fp32 for any input: modules/DenseFeatureExtractor.py:37-47,104-118): the resize + concat + split kernels (all four),
+    the convolution's coalesced, element-wise and split-K finish epilogues, the Winograd output transform and the tap interpolation.
+    Tame values, bf16 pairs, and an un-armed thread leave the word alone; ``take`` reads and clears it on the stream."""
+    guard = ops.RangeGuard(torch.device("cuda"))
+
+    def tripped(fn):
+        with guard.armed():
+            fn()
+        return ops.RangeGuard.tripped(guard.take())
+
+    big = 40000.0
+    for (B, h, w, H, W, C1, C2) in [(2, 15, 20, 30, 40, 64, 24), (1, 8, 9, 8, 9, 40, 0), (2, 7, 5, 20, 17, 36, 12), (1, 30, 40, 60, 80, 128, 64)]:
+        x = rnd("x", (B, C1, h, w), 1).contiguous(memory_format=CL)
+        skip = rnd("s", (B, C2, H, W), 2).contiguous(memory_format=CL) if C2 else None
+        xb = x.clone()
+        xb[0, 3, 2, 1] = big
+        sk = None if skip is None else dev(skip)
+        assert not tripped(lambda: ops.upsample_concat_split(dev(x), sk, (H, W), f16=True))
+        assert tripped(lambda: ops.upsample_concat_split(dev(xb), sk, (H, W), f16=True)), (h, w, H, W, C1, C2)
+        assert not tripped(lambda: ops.upsample_concat_split(dev(xb), sk, (H, W), f16=False))        # bf16 pairs hold fp32's range
+        if skip is not None:
+            sb = skip.clone()
+            sb[-1, C2 - 1, H - 1, W - 1] = -big
+            assert tripped(lambda: ops.upsample_concat_split(dev(x), dev(sb), (H, W), f16=True))
+    ops.upsample_concat_split(dev(xb), sk, (H, W), f16=True)                                       # not armed: nobody is told
+    assert not ops.RangeGuard.tripped(guard.take())
+    # convolution epilogues: coalesced (Cout % 8 == 0), element-wise (Cout = 36), split-K finish (16 x 30 x 40, 1024 -> 128)
+    for (B, H, W, Cin, Cout, k) in [(2, 30, 40, 88, 128, 3), (1, 5, 7, 40, 36, 3), (16, 30, 40, 1024, 128, 3)]:
+        x = rnd("x", (B, Cin, H, W), 1)
+        wt, b = rnd("w", (Cout, Cin, k, k), 3, 1 / math.sqrt(Cin * k * k)), rnd("b", (Cout,), 4, 0.2)
+        hi, lo, osc = ops.prep_conv_weight(dev(wt), f16=True)
+        xs = ops.split_act(dev(x).contiguous(memory_format=CL), f16=True)
+        bb = b.clone()
+        bb[5] = big                                                         # one output channel far out of range
+        split_ok = Cout % 8 == 0
+        if split_ok:
+            assert not tripped(lambda: ops.conv_nhwc_split(xs, hi, lo, dev(b), k, 0, out_fp32=True, out_split=True, oscale=osc))
+            assert tripped(lambda: ops.conv_nhwc_split(xs, hi, lo, dev(bb), k, 0, out_fp32=True, out_split=True, oscale=osc)), (B, Cout)
+            assert not tripped(lambda: ops.conv_nhwc_split(xs, hi, lo, dev(bb), k, 0, out_fp32=True, out_split=False, oscale=osc))   # no pairs written
+    # Winograd F(4x4, 3x3) output transform
+    x = rnd("x", (1, 512, 30, 40), 1)
+    wt, b = rnd("w", (512, 512, 3, 3), 3, 1 / math.sqrt(512 * 9)), rnd("b", (512,), 4, 0.2)
+    u_hi, u_lo, fs, cs = ops.prep_winograd43_weight(dev(wt))
+    xs = ops.split_act(dev(x).contiguous(memory_format=CL), f16=True)
+    bb = b.clone()
+    bb[17] = -big
+    assert not tripped(lambda: ops.conv3x3_winograd43_split(xs, u_hi, u_lo, fs, dev(b), 0, out_fp32=False, out_split=True, cscale=cs))
+    assert tripped(lambda: ops.conv3x3_winograd43_split(xs, u_hi, u_lo, fs, dev(bb), 0, out_fp32=False, out_split=True, cscale=cs))
+
+
+def _guard_model(H=352, W=384, seed=41):
+    from objcavit_amd.modules.GraphBins import GraphBins, SyntheticObjectProvider
+    args = make_args(strategy="learned", language="clip", dimensions_train=[H, W], dimensions_test=[H, W])
+    m = GraphBins(args, object_provider=SyntheticObjectProvider(12, "clip", seed=3)).eval()
+    sd = gen.load_into(m, seed, gen.PEAKY)
+    return m.cuda(), sd, args
+
+
+GUARD_SCALE = 1e4        # VERDICT r4 item 2: "replay a batch scaled x1e4 through the same captured graph"
+
+
+def test_range_guard_reruns_a_batch_beyond_fp16_range_on_bf16_pairs(ops):
+    """Calibrate on a tame batch, capture, replay a batch scaled x1e4 through the SAME captured graph: the guard trips, the batch is
+    re-run on the bf16-pair capture (captured lazily, once), the depth is finite and within 1e-3 of the CPU oracle, the route is
+    reported; the same graph then serves tame batches on fp16 pairs again, bit for bit.  The eager model guards itself the same way."""
+    from objcavit_amd.graph import GraphedGraphBins
+    H, W, B = 352, 384, 2
+    m, sd, args = _guard_model(H, W)
+    img = gen.randn("img", (B, 3, H, W), 41)
+    ops.ROUTE_REPORT.clear()
+    tame = m(img.cuda()).depth_pred.clone()
+    assert m.dense_feature_extractor.decoder.settled_f16() is True and "range_guard" not in ops.ROUTE_REPORT
+    g = GraphedGraphBins(m, img.cuda())
+    out = g.checked(img.cuda())
+    assert g.trips == 0 and torch.equal(out.depth_pred, tame)
+    big = img * GUARD_SCALE
+    raw = g(big.cuda())                                                    # what the fp16-pair capture alone makes of it: flagged
+    assert g.tripped()
+    out_big = g.checked(big.cuda())
+    d_big, e_big = out_big.depth_pred.clone(), out_big.bin_edges.clone()
+    assert g.trips == 1 and g._fallback is not None and g._fallback.pairs == "bf16"
+    assert "bf16" in ops.ROUTE_REPORT.get("range_guard", ""), ops.ROUTE_REPORT
+    assert bool(torch.isfinite(d_big).all())
+    feats, boxes, _ = m.object_provider(big.cuda())
+    ref_d, ref_e = restate.graphbins_forward(big, [f.cpu() for f in feats], [b.cpu() for b in boxes], sd, 0.001, 10.0, strategy="learned")
+    assert rel_dev(e_big, ref_e) < 1e-4 and max_rel(d_big, ref_d) < 1e-3, (rel_dev(e_big, ref_e), max_rel(d_big, ref_d))
+    again = g.checked(img.cuda())                                          # the word was cleared by the take: fp16 pairs again
+    assert g.trips == 1 and torch.equal(again.depth_pred, tame)
+    g.checked(big.cuda())
+    assert g.trips == 2                                                    # (the fallback graph is reused, not re-captured)
+    # eager: GraphBins.forward arms its own word, reads it and re-runs on bf16 pairs
+    ops.ROUTE_REPORT.clear()
+    e = m(big.cuda())
+    assert "range_guard" in ops.ROUTE_REPORT and max_rel(e.depth_pred, ref_d) < 1e-3
+    assert torch.equal(m(img.cuda()).depth_pred, tame)
+    m.range_guard_sync = False                                             # switched off: the fp16 pairs' inf / NaN come through, loudly
+    assert not bool(torch.isfinite(m(big.cuda()).depth_pred).all()) or max_rel(m(big.cuda()).depth_pred, ref_d) > 1e-3
+    m.range_guard_sync = True
+
+
+def test_pipelined_validation_reruns_tripped_steps_at_collect(ops):
+    """PipelinedValidation keeps each step's guard word on the device and reads all of them in one copy at collect(): the step whose
+    batch exceeded the fp16 pairs' range is re-run on bf16 pairs there, its neighbours are untouched."""
+    from objcavit_amd.validation import PipelinedValidation, ValidationStep
+    H, W = 352, 384
+    m, sd, args = _guard_model(H, W, seed=43)
+    imgs = [gen.randn(f"im{i}", (1, 3, H, W), 400 + i).cuda() for i in range(5)]
+    imgs[2] = imgs[2] * GUARD_SCALE
+    gts = [(torch.rand(1, 1, H, W, generator=torch.Generator().manual_seed(i)) * 9.0 + 0.5).cuda() for i in range(5)]
+    m(imgs[0])
+    seq = ValidationStep(m, args, joint=True)                               # eager: every step guarded by the model itself
+    ref = torch.cat([seq(imgs[i], gts[i], first_image_id=i)[0] for i in range(5)], 0)
+    assert bool(torch.isfinite(ref).all())
+    pv = PipelinedValidation(m, args, imgs[0], slots=2)
+    for i in range(5):
+        pv.submit(imgs[i], gts[i], first_image_id=i)
+    rec = pv.collect()
+    assert pv.rerun_steps == 1 and rec.shape == (5, 10) and bool(torch.isfinite(rec).all())
+    assert torch.equal(rec[:, 8:], ref[:, 8:]) and rel_dev(rec[:, :8], ref[:, :8]) < 1e-4

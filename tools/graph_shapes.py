@@ -147,6 +147,65 @@ def run_one(shape):
                       "value_check": float(expect[0])}), flush=True)
 
 
+def _shape2_forward_until_head(self, image, object_features=None, object_xywh_list=None, pad_objects_to=None, object_group=None):
+    """GraphBins.forward_until_head as round 4's REJECTED shape 2: the object branch forked at the top of the forward AND the
+    skip-part convolutions forked behind encoder stage 4 onto the same side stream (its first launch depends on the object
+    branch's last launch and on a main-chain launch), one join behind the encoder."""
+    import torch
+    from objcavit_amd import hip_ops
+    from objcavit_amd.modules.AdaBins import bin_edges_and_centers
+    object_features = self.object_provider.padded(image)
+    main = torch.cuda.current_stream(image.device)
+    side = hip_ops.side_stream(image.device)
+    dfe = self.dense_feature_extractor
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        pre = self.objcavit.object_prepass(object_features, object_xywh_list, image.device, pad_objects_to)
+    skip_pre = dfe.skip_prepass(image, extra=None)
+    encoded = dfe.encode(image, skip_pre)
+    main.wait_stream(side)
+    if skip_pre is not None:
+        skip_pre.joined = True
+    dense = dfe.decoder(encoded, _split_only=True, _skip_pre=skip_pre)
+    bw, feat, queries = self.objcavit.forward_parts(dense, object_features, object_xywh_list, pre=pre, pad_objects_to=pad_objects_to,
+                                                    object_group=object_group)
+    ds = self.args[self.args.basic.dataset]
+    bin_edges, centers = bin_edges_and_centers(bw, ds.min_depth, ds.max_depth)
+    return feat, queries, centers, bin_edges, None
+
+
+def run_model_timed(shape):
+    """The real forward at bs 1 (352x384) captured in the product's shape or in shape 2: topology, checker verdict, ms per replay."""
+    import torch
+    from objcavit_amd import graph_topology as gt
+    from objcavit_amd import synth as gen
+    from objcavit_amd.config import make_args
+    from objcavit_amd.graph import GraphedGraphBins
+    from objcavit_amd.modules.GraphBins import GraphBins, SyntheticObjectProvider
+    torch.set_grad_enabled(False)
+    H, W = 352, 384
+    args = make_args(strategy="learned", language="clip", dimensions_train=[H, W], dimensions_test=[H, W])
+    m = GraphBins(args, object_provider=SyntheticObjectProvider(16, "clip")).eval()
+    gen.load_into(m, 1, gen.PEAKY)
+    m = m.cuda()
+    img = gen.randn("img", (1, 3, H, W), 1).cuda()
+    m(img)
+    m(img)
+    if shape == "shape2":
+        GraphBins.forward_until_head = _shape2_forward_until_head
+    g = GraphedGraphBins(m, img, check_topology=False)
+    topo = gt.read(g.segments[0].raw_cuda_graph())
+    print(json.dumps({"model_shape": shape, "topology": topo.summary(), "violations": gt.check(topo)}), flush=True)
+    for _ in range(3):
+        g(img)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(30):
+        g(img)
+    torch.cuda.synchronize()
+    print(json.dumps({"model_shape": shape, "replay_ms": round((time.perf_counter() - t0) / 30 * 1e3, 3)}), flush=True)
+
+
 def run_model():
     import torch
     from objcavit_amd import graph_topology as gt
@@ -178,6 +237,8 @@ if __name__ == "__main__":
         run_one(sys.argv[2])
     elif len(sys.argv) >= 2 and sys.argv[1] == "model":
         run_model()
+    elif len(sys.argv) >= 3 and sys.argv[1] == "model_timed":
+        run_model_timed(sys.argv[2])
     else:
         for s in SHAPES:                                   # the parent never touches the GPU
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "one", s], capture_output=True, text=True, timeout=150)
