@@ -424,6 +424,75 @@ def exact_fp32_pass(device, wl, img, gt, box, B, default_depth, steps=10):
     return steps * B / dt, depth, rel
 
 
+def cpu_share() -> int:
+    """CPUs this job may really use: the affinity mask, capped by the cgroup CPU quota (v2 cpu.max / v1 cfs quota) when there is one."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def side_leg(device, wl, model, nslot, seconds, seed=42):
+    """One more workload behind the timed region, on the driver's clock too: ``wl`` captured as ``nslot``
+    hipGraph slots (1 = a lone-batch capture with its side streams, one step strictly after the other), run for ~``seconds``.
+    Every step = forward + the fused metric kernel, as in the timed region.  -> dict for the JSON line."""
+    import torch
+    from objcavit_amd import hip_ops
+    from objcavit_amd.graph import GraphedGraphBins
+    from objcavit_amd.validation import crop_box
+    B = wl.batch
+    img = synthetic_images(B, seed, wl.H, wl.W).to(device)
+    gt = (torch.rand(B, 1, wl.H, wl.W, generator=torch.Generator().manual_seed(7)) * (0.9 * wl.max_depth) + 0.05 * wl.max_depth).to(device)
+    box = crop_box(model.args, wl.H, wl.W)
+    t_build = time.perf_counter()
+    model(img)                                               # calibrating first call of this model / shape
+    prev = hip_ops.set_batches_in_flight(nslot)
+    try:
+        slots = [GraphedGraphBins(model, img) for _ in range(nslot)]
+    finally:
+        hip_ops.set_batches_in_flight(prev)
+    t_build = time.perf_counter() - t_build
+
+    def step(k):
+        g = slots[k % nslot]
+        with torch.cuda.stream(g.stream):
+            out = g(img)
+            hip_ops.depth_metrics(out.depth_pred, gt, wl.min_depth, wl.max_depth, crop=box, first_image_id=0)
+
+    for k in range(2 * nslot):
+        step(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(nslot):
+        step(k)
+    torch.cuda.synchronize()
+    per_round = max(nslot, int(0.2 / max((time.perf_counter() - t0) / nslot, 1e-4)) // nslot * nslot)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for k in range(per_round):
+            step(k)
+        torch.cuda.synchronize()
+        n += per_round
+    dt = time.perf_counter() - t0
+    tripped = sum(int(g.tripped()) for g in slots)
+    nodes = [sum(x for x in g.segment_nodes if x) for g in slots][0]
+    del slots
+    torch.cuda.empty_cache()
+    return {"images_per_s": round(n * B / dt, 1), "ms_per_step": round(dt / n * 1e3, 3), "batch": B, "inflight": nslot, "steps": n,
+            "seconds": round(dt, 2), "graph_nodes": nodes, "capture_s": round(t_build, 2), "fp16_range_guard_tripped": tripped,
+            "workload": f"BASELINE configs[{wl.idx}] {wl.H}x{wl.W}, {wl.n_obj} objs/img, {wl.kw}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -445,6 +514,8 @@ def main():
                          "replayed on its own stream, slots taking the steps round-robin, so that the latency-bound launches "
                          "of one batch (token path, squeeze-excite, late 1x1 layers) run under the compute-bound ones of "
                          "another.  1 = strictly one step after the other")
+    ap.add_argument("--leg-seconds", type=float, default=1.0,
+                    help="length of each leg of configs_all / small_batch behind the timed region (N = 1, skipped by --no-extras)")
     ap.add_argument("--stub-cpu", action="store_true", help=argparse.SUPPRESS)   # plumbing test only (gloo, no model)
     a = ap.parse_args()
 
@@ -460,6 +531,10 @@ def main():
     rank, local, world = dp.init_from_env(dev_type)
     device = torch.device("cpu") if a.stub_cpu else torch.device("cuda", local)
     torch.set_grad_enabled(False)
+    if world > 1:
+        # N ranks share the host: the seeded weight generator and torch's CPU copies (model build, before the first GPU call) would
+        # otherwise run N x (all logical CPUs) threads on the job's CPU share -- 8 x 128 threads on a 16-CPU quota
+        torch.set_num_threads(max(1, cpu_share() // world))
     launcher = "none (single process)" if world == 1 else \
         ("bench.py spawned the ranks itself" if os.environ.get("OCV_BENCH_LAUNCHER") == "self" else "external (torch.distributed.run)")
 
@@ -500,9 +575,10 @@ def main():
             from objcavit_amd.graph import GraphedGraphBins
             try:
                 # capture = part of warm-up; each slot clones img as its graph's static input.  The longest launches of the
-                # step (the direct 128 -> 128 3x3 convolutions at half resolution: second convolution of the last decoder
-                # stage and the decoder's conv3) stay outside the graph so that they are timed live; the third launch of
-                # that shape, the heads' conv3x3, is captured: it runs beside the token chain's side stream.
+                # step -- the three direct 128 -> 128 3x3 convolutions at half resolution (second convolution of the last
+                # decoder stage, the decoder's conv3, the heads' conv3x3) -- stay outside the graph as eager islands so that
+                # they are timed live (with several batches in flight no side stream is forked, so the heads' convolution
+                # can be an island too: the log line below lists all three).
                 n = max(1, a.inflight)
                 hip_ops.set_batches_in_flight(n)          # (the captures below read it: hip_ops.head_overlap_enabled)
                 slots = [GraphedGraphBins(model, img, eager_ops=(island,)) for _ in range(n)]
@@ -544,6 +620,7 @@ def main():
         warm[:, dp.RECORD_FIELDS.index("image_id")] = torch.arange(a.steps * B, dtype=torch.float32, device=warm.device) + rank * a.steps * B
         dp.gather_records(warm, world, n_total=world * a.steps * B)
     barrier()
+    startup_s = time.perf_counter() - _T0              # process start -> model built, captured, warmed (per rank; min / max in the JSON)
 
     # With several batches in flight the first ROOFLINE_STEPS steps of the timed region run ALONE on slot 0 (the other
     # slots wait for them): their event pairs are the live kernel timings of the JSON; the remaining steps are pipelined
@@ -582,6 +659,9 @@ def main():
     exact = None
     if not a.stub_cpu:
         timing = hip_ops.timing_results()          # graph mode: only the eager islands + bin head carry events here
+        # fp16 range guard: every replay took its word into the slot's last_flag on the device (one one-thread launch per step inside
+        # the timed region); read here, behind it.  A tripped synthetic batch would mean the timed steps need the bf16 re-run.
+        guard_tripped = sum(int(g.tripped()) for g in slots if hasattr(g, "tripped"))
         log(f"timed region done: {dt / a.steps * 1e3:.1f} ms/step")
         default_depth = depth.clone()              # slot outputs are overwritten by the legs below
         if not a.eager:
@@ -661,11 +741,40 @@ def main():
             ips, exact_depth, rel = exact_fp32_pass(device, wl, img, gt, box, B, default_depth)
             exact = dict(images_per_s=round(ips, 1), depth=exact_depth, max_rel_vs_default_route=rel)
             log(f"exact-fp32 route: {ips:.1f} img/s, max rel vs default route {rel:.2e}")
+        legs = None
+        if world == 1 and not a.no_extras and not a.eager and a.config == 2 and a.batch is None:
+            # Every other BASELINE configuration and the reference's own batch sizes, on the driver's clock:
+            # configs[1] / [3] / [4] with this run's --inflight, configs[2] at bs 1 and bs 2 (= image + mirror) one step at a time
+            # and at bs 16 one step at a time.  ~leg-seconds each + a capture; slots of the timed region are released first.
+            del slots, run
+            torch.cuda.empty_cache()
+            legs = {"configs_all": {}, "small_batch": {}}
+            for c in (1, 3, 4):
+                wl_c = Workload(c)
+                if c == 1:                                    # same network as configs[2]: other objects only
+                    from objcavit_amd.modules.GraphBins import SyntheticObjectProvider
+                    m_c, keep = model, model.object_provider
+                    model.object_provider = SyntheticObjectProvider(wl_c.n_obj, wl_c.language, seed=42)
+                else:
+                    m_c, keep = build_model(device, wl_c)[0], None
+                legs["configs_all"][f"configs[{c}]"] = side_leg(device, wl_c, m_c, max(1, a.inflight), a.leg_seconds)
+                if keep is not None:
+                    model.object_provider = keep
+                else:
+                    del m_c
+                    torch.cuda.empty_cache()
+                log(f"configs[{c}]: {legs['configs_all'][f'configs[{c}]']['images_per_s']} img/s")
+            for b in (1, 2, 16):
+                legs["small_batch"][f"bs{b}_one_at_a_time"] = side_leg(device, Workload(2, b), model, 1, a.leg_seconds)
+                log(f"configs[2] bs {b} one at a time: {legs['small_batch'][f'bs{b}_one_at_a_time']['images_per_s']} img/s")
         depth = default_depth
 
     # max over ranks of the job time; ranks RCCL / gloo actually saw; per-rank rates
-    ranks_seen, rank_rates = 1, [a.steps * B / t_local]
+    ranks_seen, rank_rates, rank_startup = 1, [a.steps * B / t_local], [startup_s]
     if world > 1:
+        st = torch.zeros(world, dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(st, torch.tensor([startup_s], dtype=torch.float64, device=device))
+        rank_startup = st.tolist()
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -705,6 +814,8 @@ def main():
             "step_latency_ms": None if step_latency_ms is None else round(step_latency_ms, 3),
             "sequential_images_per_s_this_rank": None if sequential_ips is None else round(sequential_ips, 1),
             "per_rank_images_per_s": {"min": round(min(rank_rates), 2), "max": round(max(rank_rates), 2)},
+            # process start -> ready for the timed region (imports, rendezvous, seeded weights, capture, warm-up), per rank
+            "per_rank_startup_s": {"min": round(min(rank_startup), 2), "max": round(max(rank_startup), 2)},
             "config": {"workload": f"BASELINE configs[{wl.idx}]: {wl.desc}, bs={B} per GPU; seeded random weights with the "
                                    f"parity tests' gains on attention / bin-head layers (gen.{'PEAKY' if wl.gains_name == 'PEAKY' else 'KITTI_GAINS'}: "
                                    "a non-degenerate bin softmax, SURVEY Q12) -- no trained checkpoint exists offline",
@@ -735,8 +846,12 @@ def main():
             res["conv_split"] = {"pairs": "fp16" if split_f16 else "bf16",
                                  # the decoder measured its activations' range on its first eager batch (host syncs, that call only)
                                  "fp16_range_first_batch": (fmode[2] if fmode and len(fmode) > 2 else None),
-                                 "route_report": dict(_ops.ROUTE_REPORT)}
+                                 "route_report": dict(_ops.ROUTE_REPORT),
+                                 # sticky device word ORed by every fp16-pair producer, taken per replay (hip_ops.RangeGuard)
+                                 "fp16_range_guard_tripped_slots": guard_tripped}
             res.update(kernel_report(timing, a, B, wl, split_f16))
+            if legs is not None:
+                res.update(legs)
             if exact is not None:
                 res["exact_fp32_images_per_s"] = exact["images_per_s"]
                 res["exact_fp32_max_rel_vs_default_route"] = exact["max_rel_vs_default_route"]

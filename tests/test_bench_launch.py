@@ -51,6 +51,32 @@ def test_bench_gpus_2_with_three_slots_in_flight_per_rank():
 
 
 @pytest.mark.timeout(300)
+def test_bench_gpus_8_on_a_sixteen_cpu_share_starts_and_finishes_quickly():
+    """what an 8-GPU driver run meets first -- eight ranks starting at once on the job's CPU share (16 CPUs on
+    the driver's box; at most that many here).  Each rank caps torch's intra-op pool at its share (not 8 x all logical CPUs), the
+    eight ranks rendezvous, three slots each, every record arrives, start-up seconds are reported per rank, the whole job < 60 s."""
+    import time
+    cpus = sorted(os.sched_getaffinity(0))[:16]
+
+    def restrict():
+        os.sched_setaffinity(0, cpus)
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "12", "--warmup", "1", "--batch", "2",
+                        "--inflight", "3", "--stub-cpu"], env=env, capture_output=True, text=True, timeout=240, preexec_fn=restrict)
+    wall = time.perf_counter() - t0
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["n_gpus"] == 8 and j["ranks_seen"] == 8 and j["inflight"] == 3
+    assert j["metrics_gathered"]["images"] == 8 * 12 * 2
+    assert j["host_threads"]["torch_intra_op"] <= max(1, len(cpus) // 8), j["host_threads"]
+    assert 0 < j["per_rank_startup_s"]["min"] <= j["per_rank_startup_s"]["max"] < 60
+    assert j["per_rank_images_per_s"]["min"] > 0
+    assert wall < 60, wall
+
+
+@pytest.mark.timeout(300)
 def test_bench_rank_failure_is_a_nonzero_exit():
     # --gpus 2 inside a 3-rank launcher environment: every rank refuses, the job fails loudly
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2", "--stub-cpu"],
