@@ -477,6 +477,17 @@ int ocv_mbconv_expand_dw_fwd(const float* x, const void* w_packed, const float* 
                              const float* bias_dw, float* y, float* part, int B, int H, int W, int Cin, int mid, int k,
                              int stride, int pad_t, int pad_l, int Ho, int Wo, ocv_stream_t stream);
 
+/* The same pair of layers for the LATE stages (round 5): stride 1, small maps, wide layers -- a workgroup owns (image, band of
+ * rows, 32 expanded channels), the band's pixels are one GEMM with no halo recompute across columns, the expanded values live
+ * in LDS only.  Built for 15 x 20 (one band) and 30 x 40 maps (4 bands of 8 rows): ocv_mbconv_image_tiles returns the
+ * bands per image (= `tiles` of part [B][tiles][mid] for ocv_se_gate_partials_fwd) or 0 for a shape it does not cover.
+ * x [B,H,W,Cin] NHWC fp32, Cin a multiple of 16; mid a multiple of 32; TF "SAME" padding of a stride-1 odd kernel ((k - 1) / 2 on
+ * every side); operands and numerics otherwise as ocv_mbconv_expand_dw_fwd.  Replaces the same reference lines. */
+int ocv_mbconv_image_tiles(int H, int W, int k);
+int ocv_mbconv_image_fwd(const float* x, const void* w_packed, const float* bias_expand, const float* w_dw,
+                         const float* bias_dw, float* y, float* part, int B, int H, int W, int Cin, int mid, int k,
+                         ocv_stream_t stream);
+
 /* Split-bf16 activation layout "hl32" shared by ocv_upsample_concat_split_fwd and ocv_conv_nhwc_split_fwd: for a
  * logical NHWC activation [B,H,W,C] one bf16 buffer [B*H*W][2*Cp], Cp = C rounded up to 32, holding per pixel and per
  * block of 32 channels the 32 hi values (hi = bf16(v)) followed by the 32 lo values (lo = bf16(v - hi)); element

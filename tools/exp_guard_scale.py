@@ -1,9 +1,13 @@
-"""How far can a batch be scaled before the fp32 function itself is too ill-conditioned for a 1e-3 comparison?  For the range-guard
-test (tests/test_hip_fp16_route.py GUARD_SCALE): deviation of the bf16-pair route and of the exact-fp32 route from the CPU oracle
-at input scales 1 ... 1e4, and whether the fp16 pairs' guard trips."""
+"""Which batch trips the fp16 range guard while the FUNCTION stays well enough conditioned for a 1e-3 comparison with the CPU oracle?
+(tests/test_hip_fp16_route.py::test_range_guard_*.)  Scaling the whole image does not do: every layer up to the bin softmax is
+positively homogeneous, so the logits scale with the input and the depth of ANY fp32-accurate implementation moves by O(1) long before
+an activation reaches 32752 (first table: the fp16-pair, the bf16-pair and the exact-fp32 route against the oracle).  What does: a
+network whose DECODER carries a large intermediate -- the third stage's output scaled by alpha in its BatchNorm, the fourth stage's
+first convolution by 1 / alpha on those input channels: the same function, an activation alpha times larger between them -- fed a
+batch a few times the calibration batch (second table)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import torch
 from objcavit_amd import hip_ops as ops, synth as gen
 from objcavit_amd.config import make_args
@@ -11,22 +15,76 @@ from objcavit_amd.modules.GraphBins import GraphBins, SyntheticObjectProvider
 from oracle import restate
 torch.set_grad_enabled(False)
 H, W, B = 352, 384, 2
-args = make_args(strategy="learned", language="clip", dimensions_train=[H, W], dimensions_test=[H, W])
-m = GraphBins(args, object_provider=SyntheticObjectProvider(12, "clip", seed=3)).eval()
-sd = gen.load_into(m, 41, gen.PEAKY)
-m = m.cuda()
+MILD = (("in_proj_weight", 2.0), ("conv_out", 2.0), ("conv3x3", 1.0), ("regressor.4", 2.0))
+
+
+def build(gains, alpha=None):
+    args = make_args(strategy="learned", language="clip", dimensions_train=[H, W], dimensions_test=[H, W])
+    m = GraphBins(args, object_provider=SyntheticObjectProvider(12, "clip", seed=3)).eval()
+    sd = gen.load_into(m, 41, gains)
+    if alpha is not None:
+        sd = dict(sd)
+        pre = "dense_feature_extractor.decoder."
+        for k in (pre + "up3._net.4.weight", pre + "up3._net.4.bias"):
+            sd[k] = sd[k] * alpha
+        k = pre + "up4._net.0.weight"
+        w = sd[k].clone()
+        w[:, :256] = w[:, :256] / alpha                      # the up-sampled half of cat([up(x), skip]) (decoder widths 2048 .. 128)
+        sd[k] = w
+        m.load_state_dict(sd, strict=True)
+    return m.cuda(), sd
+
+
+def oracle(sd, img, m):
+    feats, boxes, _ = m.object_provider(img.cuda())
+    return restate.graphbins_forward(img, [f.cpu() for f in feats], [b.cpu() for b in boxes], sd, 0.001, 10.0, strategy="learned")[0]
+
+
+rel = lambda a, r: float(((a - r).abs() / r).max())
 img = gen.randn("img", (B, 3, H, W), 41)
-m(img.cuda())
-dec = m.dense_feature_extractor.decoder
-print("first batch:", dec.__dict__["_f16_modes"][dec._wkey()][2])
-for s in (1.0, 30.0, 300.0, 3000.0, 1e4, 1e5):
-    big = img * s
-    feats, boxes, _ = m.object_provider(big.cuda())
-    ref_d, _ = restate.graphbins_forward(big, [f.cpu() for f in feats], [b.cpu() for b in boxes], sd, 0.001, 10.0, strategy="learned")
+for name, gains in (("PEAKY", gen.PEAKY), ("MILD", MILD)):
+    m, sd = build(gains)
+    m(img.cuda())
+    saved = {k: os.environ.get(k) for k in ("OCV_CONV", "OCV_PW", "OCV_TOKENS", "OCV_BINHEAD", "OCV_PATCH_EMBED", "OCV_ATTN_FORM")}
+    os.environ.update(OCV_CONV="exact", OCV_PW="fp32", OCV_TOKENS="fp32", OCV_BINHEAD="exact", OCV_PATCH_EMBED="exact", OCV_ATTN_FORM="fp32")
+    mx, _ = build(gains)
+    mx(img.cuda())
+    for k, v in saved.items():
+        os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    print(f"== whole image scaled, gains {name}")
+    for s in (1.0, 4.0, 12.0, 30.0, 300.0):
+        big = img * s
+        ref = oracle(sd, big, m)
+        m.range_guard_sync = False
+        d16 = m(big.cuda()).depth_pred.cpu()
+        with ops.bf16_pairs():
+            db = m(big.cuda()).depth_pred.cpu()
+        os.environ.update(OCV_CONV="exact", OCV_PW="fp32", OCV_TOKENS="fp32", OCV_BINHEAD="exact", OCV_PATCH_EMBED="exact", OCV_ATTN_FORM="fp32")
+        dx = mx(big.cuda()).depth_pred.cpu()
+        for k, v in saved.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        print(f"  x{s:6.0f}: fp16 pairs {rel(d16, ref):.2e}  bf16 pairs {rel(db, ref):.2e}  exact fp32 {rel(dx, ref):.2e}", flush=True)
+
+print("== decoder intermediate scaled by alpha (same function), gains MILD")
+m0, _ = build(MILD)
+ops.range_check(True)
+m0.range_guard_sync = False
+m0(img.cuda())
+rep = ops.fp16_range_report()
+ops.range_check(False)
+seen = dict(ops._Range.seen)
+for k, v in seen.items():
+    print("   ", k, round(v[0], 3))
+for alpha in (256.0, 1024.0):
+    m, sd = build(MILD, alpha)
     ops.ROUTE_REPORT.clear()
-    d = m(big.cuda()).depth_pred.cpu()
-    tripped = "range_guard" in ops.ROUTE_REPORT
-    with ops.bf16_pairs():
-        db = m(big.cuda()).depth_pred.cpu()
-    rel = lambda a: float(((a - ref_d).abs() / ref_d).max())
-    print(f"scale {s:8.0f}: guard tripped {tripped}; guarded route max-rel {rel(d):.2e}; bf16 pairs max-rel {rel(db):.2e}; depth range {float(ref_d.min()):.3f}..{float(ref_d.max()):.3f}", flush=True)
+    d0 = m(img.cuda()).depth_pred.cpu()
+    dec = m.dense_feature_extractor.decoder
+    mode = dec.__dict__["_f16_modes"][dec._wkey()]
+    print(f"  alpha {alpha}: calibration ok={mode[1]} max_amax={mode[2]['max_amax'] if len(mode) > 2 and mode[2] else None}; tame batch vs oracle {rel(d0, oracle(sd, img, m)):.2e}; report {dict(ops.ROUTE_REPORT)}")
+    for s in (2.0, 4.0, 8.0, 12.0, 16.0):
+        big = img * s
+        ref = oracle(sd, big, m)
+        ops.ROUTE_REPORT.clear()
+        d = m(big.cuda()).depth_pred.cpu()
+        print(f"    x{s:4.0f}: guard tripped {'range_guard' in ops.ROUTE_REPORT}; guarded forward vs oracle {rel(d, ref):.2e}", flush=True)

@@ -193,9 +193,12 @@ def run_model_timed(shape):
     m(img)
     if shape == "shape2":
         GraphBins.forward_until_head = _shape2_forward_until_head
-    g = GraphedGraphBins(m, img, check_topology=False)
-    topo = gt.read(g.segments[0].raw_cuda_graph())
-    print(json.dumps({"model_shape": shape, "topology": topo.summary(), "violations": gt.check(topo)}), flush=True)
+    islands = (f"conv3x3|1,{H // 2},{W // 2},128,128",) if os.environ.get("SHAPES_ISLANDS") else ()     # as bench.py captures
+    g = GraphedGraphBins(m, img, check_topology=False, eager_ops=islands)
+    graphs = [sg for sg in g.segments if not isinstance(sg, tuple)]
+    topo = gt.read(graphs[0].raw_cuda_graph())
+    print(json.dumps({"model_shape": shape, "segments": len(graphs), "islands": g.islands, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                      "topology": topo.summary(), "violations": gt.check(topo)}), flush=True)
     for _ in range(3):
         g(img)
     torch.cuda.synchronize()
