@@ -43,7 +43,10 @@ import time
 # ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4: the first two streams a process creates get
 # queues of their own, later ones share the last) and streams that share a queue run one after the other; the pipelined
 # mode below needs its slot streams on queues of their own.  Must be set before the HIP runtime loads.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Round 5: FOUR, not eight -- three slots + the default stream fit four queues (same pipelined rate: 1052 vs 1056 img/s), and only
+# on <= 4 hardware queues may a lone batch's capture fork side streams (hip_ops.hw_queues_allow_forks: a forked graph replays 3x
+# slower on 6+ queues; lone-batch rate 1010 vs 977 img/s at bs 16, 310 vs 294 at bs 1: profiles/r05_graph_shapes.txt).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -456,11 +459,7 @@ def side_leg(device, wl, model, nslot, seconds, seed=42):
     box = crop_box(model.args, wl.H, wl.W)
     t_build = time.perf_counter()
     model(img)                                               # calibrating first call of this model / shape
-    prev = hip_ops.set_batches_in_flight(nslot)
-    try:
-        slots = [GraphedGraphBins(model, img) for _ in range(nslot)]
-    finally:
-        hip_ops.set_batches_in_flight(prev)
+    slots = [GraphedGraphBins(model, img, in_flight=nslot) for _ in range(nslot)]
     t_build = time.perf_counter() - t_build
 
     def step(k):
@@ -580,8 +579,7 @@ def main():
                 # they are timed live (with several batches in flight no side stream is forked, so the heads' convolution
                 # can be an island too: the log line below lists all three).
                 n = max(1, a.inflight)
-                hip_ops.set_batches_in_flight(n)          # (the captures below read it: hip_ops.head_overlap_enabled)
-                slots = [GraphedGraphBins(model, img, eager_ops=(island,)) for _ in range(n)]
+                slots = [GraphedGraphBins(model, img, eager_ops=(island,), in_flight=n) for _ in range(n)]
                 # a slot is replayed on the stream it was captured on: creating further streams can put two slots on
                 # the same hardware queue (ROCm maps streams round-robin onto GPU_MAX_HW_QUEUES = 4 queues), which
                 # serialises them -- measured: 781 instead of 840 img/s with the same code, depending on creation order
@@ -671,15 +669,11 @@ def main():
             live = {k: (v[0] / timed_steps * a.steps, v[1]) for k, v in timing.items()}
             hip_ops.enable_timing(False)
             # one batch at a time: what a caller with a single forward in flight gets -- a capture of its own, made the way
-            # such a caller makes it (hip_ops.set_batches_in_flight(1): the lone-batch side streams on), on slot 0's stream
+            # such a caller makes it (in_flight = 1: the lone-batch side streams on where the hardware-queue count allows), on slot 0's stream
             seq_step = lambda: step(0, 0)
             if nslot > 1:
                 from objcavit_amd.graph import GraphedGraphBins
-                hip_ops.set_batches_in_flight(1)
-                try:
-                    lone = GraphedGraphBins(model, img, eager_ops=(island,))
-                finally:
-                    hip_ops.set_batches_in_flight(nslot)
+                lone = GraphedGraphBins(model, img, eager_ops=(island,), in_flight=1)
 
                 def seq_step():
                     with torch.cuda.stream(lone.stream):

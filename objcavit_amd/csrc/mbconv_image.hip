@@ -11,10 +11,10 @@
 //   phase A  [pixels of the band + halo rows] x [Cin] x [Cin x 32] on v_mfma_f32_32x32x16_bf16 with the numerics of
 //            csrc/pointwise_split.hip (activation rows split hi / lo on the fly, packed two-term weights, hi*hi + hi*lo + lo*hi,
 //            fp32 accumulate from the bias).  The band's pixels are CONTIGUOUS rows of the NHWC map (full-width bands), so the A
-//            operand is a plain [M x Cin] matrix read straight into A-operand order (lane = row, 8 consecutive channels); wavefront w
-//            takes M tiles w, w + 5, ...; the chunk's weight fragments come from L1 / L2 (8 KB per 64-wide K slab, the same bytes
-//            for all five wavefronts); no LDS, no barrier inside the K loop.  bias + SiLU -> LDS as [pixel][32 channels] fp32; halo
-//            rows outside the image are ZERO (the depthwise convolution pads the EXPANDED tensor).
+//            operand is a plain [M x Cin] matrix: staged through LDS 32 channels at a time (coalesced rows, split once per workgroup);
+//            wavefront w takes M tiles w, w + 5, ...; the chunk's weight fragments come from L1 / L2 (4 KB per slab, the same bytes
+//            for all five wavefronts).  bias + SiLU -> LDS as [pixel][32 channels] fp32 (the staging area's memory); halo rows
+//            outside the image are ZERO (the depthwise convolution pads the EXPANDED tensor).
 //   phase B  thread = (channel quad, output column, row group) slides down its columns' rows: K ds_read_b128 per input row (taps left
 //            or right of the image read a zero pixel: one address select per tap, no column padding in LDS), K x K x 4 FMAs per row
 //            into the running outputs; depthwise weights of the quad in VGPRs (fetched behind phase A).  bias + SiLU, 16-byte
@@ -45,7 +45,10 @@ struct MIGeom {
   static constexpr int RG = 40 / W, NR = (BR + RG - 1) / RG; // row groups, output rows per thread
   static constexpr int NLI = NR + K - 1;                     // input rows a thread walks
   static constexpr int ZPIX = PIX;                           // the zero pixel behind the tile
-  static constexpr int LDS_FLOATS = (PIX + 1) * 32;
+  static constexpr int APITCH = 144;                         // bytes per STAGED row of phase A: 32 channels hi | 32 lo | 16 pad (conflict-free b128 reads)
+  static constexpr int NP = (PIX + 39) / 40;                 // staging passes: 320 threads move 40 rows x 128 B per pass
+  static constexpr int TILE_BYTES = (PIX + 1) * 128, STAGE_BYTES = MT * 32 * APITCH;
+  static constexpr int LDS_FLOATS = (TILE_BYTES > STAGE_BYTES ? TILE_BYTES : STAGE_BYTES) / 4;
   static_assert(40 % W == 0 && RG * W == 40, "phase B maps 40 (column, row group) slots");
   static_assert(LDS_FLOATS >= 40 * 32, "the pooling reduction reuses the tile");
 };
@@ -85,59 +88,89 @@ __global__ __launch_bounds__(320, 3) void mbconv_image_kernel(MIArgs p) {
   const int Mb = (yb - ya) * W;                                     // GEMM rows of this band
   const int n0 = chunk * 32;
 
-  // ---------------- rows of the tile that lie outside the image, and the zero pixel
-  for (int i = tid; i < (G::PIX + 1) * 8; i += G::NT) {
-    const int pix = i >> 3;
-    const int r = pix / W;
-    if (pix == G::ZPIX || r < rtop || r >= rtop + (yb - ya)) *reinterpret_cast<float4*>(e + pix * 32 + 4 * (i & 7)) = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-
-  // ---------------- phase A: expand GEMM of the band's pixels into LDS
+  // ---------------- phase A: expand GEMM of the band's pixels, K slab by K slab of 32 channels
+  // The band's rows are staged through LDS once per workgroup and slab -- coalesced 128-byte row segments (8 lanes per row), split
+  // to bf16 hi | lo while they are stored -- and every wavefront reads the A fragments of its M tiles from there.  (The first
+  // version read A straight from global memory in operand order, 32 rows of 32 bytes per instruction: correct, and 5 % SLOWER
+  // end to end than the two-launch form -- per-line tag work, the cost the packed weight layout of pointwise_split.hip removed
+  // for B.)  The staging area IS the depthwise tile's memory: nothing is written there before the K loop has ended.
   {
     const float bev = p.be != nullptr ? p.be[n0 + l31] : 0.f;
-    const float* xb = p.x + ((long)b * H + ya) * W * p.Cin + 8 * hh;
+    const float* xb = p.x + ((long)b * H + ya) * W * p.Cin;
     const __bf16* wf = p.wp + ((long)chunk * p.nsteps * 2) * 512 + lane * 8;       // + (s * 2 + part) * 512
+    char* stage = reinterpret_cast<char*>(e);
     f32x16 acc[G::NMW];
-    const float* arow[G::NMW];
 #pragma unroll
-    for (int i = 0; i < G::NMW; ++i) {
+    for (int i = 0; i < G::NMW; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = bev;
-      // rows beyond the band (the last M tile) re-read the band's last pixel: their results are never stored
-      arow[i] = xb + (long)min((wave + G::NW * i) * 32 + l31, Mb - 1) * p.Cin;
-    }
-    // One 16-wide K step at a time, the NEXT step's operands (this wavefront's M tiles' rows + the chunk's weight fragment pair)
-    // in flight while the current step multiplies; the loop is unrolled by two so that the two register sets swap roles without
-    // copies.  Every load is unconditional (a tile beyond the band re-reads the band's last row; its products are never stored).
-    float4 ra[2][G::NMW][2];
-    bf16x8 rbh[2], rbl[2];
-    auto load = [&](int set, int s) {
-      rbh[set] = *reinterpret_cast<const bf16x8*>(wf + (long)s * 1024);
-      rbl[set] = *reinterpret_cast<const bf16x8*>(wf + (long)s * 1024 + 512);
+    const int srow = tid >> 3, c4 = tid & 7;                      // staging role: row srow + 40 pass, channels 4 c4 .. + 3 of the slab
+    const float* src = xb + (long)srow * p.Cin + 4 * c4;
+    char* sdst = stage + srow * G::APITCH + c4 * 8;
+    float4 ra[G::NP];
+    auto fetch = [&](int slab) {
+      const bool cok = slab * 32 + 4 * c4 < p.Cin;                 // the last slab of an odd step count is half a slab
 #pragma unroll
-      for (int i = 0; i < G::NMW; ++i) {
-        ra[set][i][0] = ld4(arow[i] + 16 * s);
-        ra[set][i][1] = ld4(arow[i] + 16 * s + 4);
-      }
+      for (int j = 0; j < G::NP; ++j)
+        ra[j] = (cok && srow + 40 * j < Mb) ? ld4(src + (long)(40 * j) * p.Cin + slab * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
-    auto multiply = [&](int set) {
+    auto store = [&]() {
 #pragma unroll
-      for (int i = 0; i < G::NMW; ++i) {
-        if ((wave + G::NW * i) * 32 < Mb) {                         // wave-uniform
-          bf16x8 ah, al;
-          mi_split8(ra[set][i][0], ra[set][i][1], ah, al);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, rbh[set], acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, rbl[set], acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, rbh[set], acc[i], 0, 0, 0);
+      for (int j = 0; j < G::NP; ++j) {
+        if (srow + 40 * j < G::MT * 32) {
+          typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+          const float f[4] = {ra[j].x, ra[j].y, ra[j].z, ra[j].w};
+          bf16x4 h, l;
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const __bf16 hb = (__bf16)f[q4];
+            h[q4] = hb;
+            l[q4] = (__bf16)(f[q4] - (float)hb);
+          }
+          *reinterpret_cast<bf16x4*>(sdst + (40 * j) * G::APITCH) = h;
+          *reinterpret_cast<bf16x4*>(sdst + (40 * j) * G::APITCH + 64) = l;
         }
       }
     };
-    load(0, 0);
-    for (int s = 0; s < p.nsteps; s += 2) {
-      if (s + 1 < p.nsteps) load(1, s + 1);
-      multiply(0);
-      if (s + 2 < p.nsteps) load(0, s + 2);
-      if (s + 1 < p.nsteps) multiply(1);
+    const int nslab = (p.nsteps + 1) >> 1;
+    fetch(0);
+    for (int slab = 0; slab < nslab; ++slab) {
+      const int s0 = 2 * slab;
+      const bool two = s0 + 1 < p.nsteps;                           // wave-uniform
+      bf16x8 bh[2], bl[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int ss = min(s0 + s, p.nsteps - 1);
+        bh[s] = *reinterpret_cast<const bf16x8*>(wf + (long)ss * 1024);
+        bl[s] = *reinterpret_cast<const bf16x8*>(wf + (long)ss * 1024 + 512);
+      }
+      if (slab > 0) __syncthreads();                                // every wavefront is past the previous slab's fragment reads
+      store();
+      __syncthreads();
+      if (slab + 1 < nslab) fetch(slab + 1);                        // in flight under this slab's MFMAs
+#pragma unroll
+      for (int i = 0; i < G::NMW; ++i) {
+        if ((wave + G::NW * i) * 32 < Mb) {                         // wave-uniform
+          const char* ap = stage + ((wave + G::NW * i) * 32 + l31) * G::APITCH + hh * 16;
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            if (s == 0 || two) {
+              const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap + s * 32);
+              const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + s * 32 + 64);
+              acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[s], acc[i], 0, 0, 0);
+              acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[s], acc[i], 0, 0, 0);
+              acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[s], acc[i], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();                                                // the staging area becomes the depthwise tile
+    // rows of the tile that lie outside the image, and the zero pixel
+    for (int i = tid; i < (G::PIX + 1) * 8; i += G::NT) {
+      const int pix = i >> 3;
+      const int r = pix / W;
+      if (pix == G::ZPIX || r < rtop || r >= rtop + (yb - ya)) *reinterpret_cast<float4*>(e + pix * 32 + 4 * (i & 7)) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < G::NMW; ++i) {

@@ -63,8 +63,9 @@ class GraphedGraphBins:
 
     def __init__(self, model, example_image: torch.Tensor, warmup: int = 2, eager_ops: Sequence[str] = (),
                  object_capacity: Optional[int] = None, object_group: Optional[int] = None, check_topology: bool = True,
-                 pairs: Optional[str] = None):
-        """``pairs``: None = the element type the model's decoder settled on (fp16 pairs unless its weights / first batch said
+                 pairs: Optional[str] = None, in_flight: int = 1):
+        """``in_flight``: how many batches the caller keeps in flight on this GPU (one graph per slot): the capture forks side streams
+        inside the forward for a lone batch only (hip_ops.batches_in_flight).  ``pairs``: None = the element type the model's decoder settled on (fp16 pairs unless its weights / first batch said
         otherwise); "bf16" = warm up and capture under ``hip_ops.bf16_pairs()`` (fp32's range: what ``rerun_on_bf16`` replays).
         ``check_topology``: every captured segment is read back from the runtime and must be a chain of single fork / single join
         diamonds (objcavit_amd/graph_topology.py): a forward whose side streams were forked any other way -- the shapes that
@@ -75,7 +76,9 @@ class GraphedGraphBins:
             raise ValueError("pairs must be None (the model's own decision) or 'bf16'")
         self.model = model
         self.pairs = pairs
-        self._ctor = dict(warmup=warmup, object_capacity=object_capacity, object_group=object_group, check_topology=check_topology)
+        self.in_flight = max(1, int(in_flight))
+        self._ctor = dict(warmup=warmup, object_capacity=object_capacity, object_group=object_group, check_topology=check_topology,
+                          in_flight=self.in_flight)
         self._fallback: Optional["GraphedGraphBins"] = None
         # fp16 range guard (hip_ops.RangeGuard): the word every fp16-pair producer of THIS graph's launches ORs into; taken behind
         # every replay into ``last_flag`` (device), read by ``tripped`` / ``checked`` where the caller reads results
@@ -98,7 +101,8 @@ class GraphedGraphBins:
         # the graph OWNS its scratch: every workspace requested during warm-up, capture and replay comes from this
         # store, so no eager call or later capture at other shapes can free a buffer whose address is baked in here
         self.scratch = hip_ops.WorkspaceStore()
-        with self._route(), hip_ops.workspace_scope(self.scratch), torch.cuda.stream(self.stream), torch.no_grad():
+        with self._route(), hip_ops.batches_in_flight(self.in_flight), hip_ops.workspace_scope(self.scratch), \
+                torch.cuda.stream(self.stream), torch.no_grad():
             for _ in range(warmup):                      # sizes every workspace / weight cache before capture
                 model(self.static_image, self.objects, None, None, self.object_group)
         torch.cuda.current_stream().wait_stream(self.stream)
@@ -159,7 +163,8 @@ class GraphedGraphBins:
         self.segment_topology: List[dict] = []            # graph_topology.Topology.summary() per kept segment (check_topology)
         self.segment_nodes: List[Optional[int]] = []      # nodes per captured segment (dropped ones included), None = not readable
         # the hook is an object handed to hip_ops for the duration of THIS capture on THIS thread (thread-local scope)
-        with _CAPTURE_LOCK, self._route(), self.range_guard.armed(), hip_ops.island_scope(hip_ops.IslandHook(eager_ops, on_break)), \
+        with _CAPTURE_LOCK, self._route(), hip_ops.batches_in_flight(self.in_flight), self.range_guard.armed(), \
+                hip_ops.island_scope(hip_ops.IslandHook(eager_ops, on_break)), \
                 hip_ops.workspace_scope(self.scratch), torch.cuda.stream(self.stream), torch.no_grad():
             begin()
             parts = model.forward_until_head(self.static_image, self.objects, None, None, self.object_group)

@@ -84,6 +84,7 @@ class _Tls(threading.local):
         self.island_hook = None
         self.islands_off = 0                 # > 0: inside islands_suspended()
         self.single_chain = 0                # > 0: inside single_chain() -- no further forks
+        self.in_flight = 1                   # batches the caller keeps in flight on this GPU (batches_in_flight)
         self.bf16_pairs = 0                  # > 0: inside bf16_pairs() -- the split pipeline on bf16 pairs
         self.range_flag = None               # the armed RangeGuard word of this thread (a tensor), or None
         self.ws_stack = None                 # workspace stores of this thread (bottom = the module-level store)
@@ -157,18 +158,36 @@ class timed:
 _SIDE: Dict[Tuple[int, int], "torch.cuda.Stream"] = {}
 
 
+def hw_queues_allow_forks() -> bool:
+    """A captured forward may fork side streams only while the process runs on at most FOUR hardware queues (GPU_MAX_HW_QUEUES
+    unset = the runtime's default of 4, or <= 4).  Round 5 (profiles/r05_graph_shapes.txt): the SAME captured graph with the
+    product's single fork replays in 2.63 ms with 2 or 4 hardware queues and in 8.5 ms with 6, 8 or 16 -- and the same forward
+    without a fork in 2.81 ms whatever the count.  A hipGraph's parallel branches are replayed on hardware queues of their own;
+    beyond four, queues share a pipe of the command processor, which time-slices them: a branch parked on its cross-queue barrier
+    packet holds the pipe until its quantum ends while the queue it waits for sits on the same pipe.  The 3.5 - 6 ms "shape"
+    pathologies of round 4 (profiles/r04_skip_overlap.txt) were this: which shape lost depended on which queues its streams
+    happened to be dealt, not on the shape (tools/graph_shapes.py: every rejected shape replays at full speed on 4 queues)."""
+    raw = os.environ.get("GPU_MAX_HW_QUEUES")
+    if raw is None:
+        return True
+    try:
+        return int(raw) <= 4
+    except ValueError:
+        return True
+
+
 def _side_switch(name: str) -> bool:
     """The side-stream switches OCV_OBJ_OVERLAP / OCV_TOKEN_OVERLAP / OCV_HEAD_OVERLAP / OCV_SKIP_OVERLAP: '1', '0' or 'auto' (default) = on for a lone
-    batch, off when the driver keeps several batches in flight on this GPU (``set_batches_in_flight``: bench.py's slots,
-    PipelinedValidation).  A fork inside a captured forward makes the replay use further streams; with three slots replaying at once
-    those collide with the other slots' streams on the GPU's hardware queues and the slots serialise each other.  One box, alternating
-    runs, bs 16 (profiles/r04_head_overlap.txt, block 5), three in flight / one at a time:  no fork 1037 / 953 img/s;  object branch
+    batch on at most four hardware queues (``hw_queues_allow_forks``), off when the caller keeps several batches in flight on this GPU
+    (``batches_in_flight``: bench.py's slots, PipelinedValidation) or the process asked for more hardware queues.  A fork inside a
+    captured forward makes the replay use further hardware queues; with three slots replaying at once those collide with the other
+    slots' and the slots serialise each other.  One box, alternating runs, bs 16 (profiles/r04_head_overlap.txt, block 5), three in flight / one at a time:  no fork 1037 / 953 img/s;  object branch
     beside the encoder 1015 / 961;  that + the token chain beside the heads' convolution 976 / 972;  object branch beside the image
     tokens (this round's first default) 968 / 964."""
     mode = os.environ.get(name, "auto")
     if mode not in ("0", "1", "auto"):
         raise ValueError(f"{name}={mode!r}: expected 'auto' (default), '1' or '0'")
-    return _IN_FLIGHT <= 1 if mode == "auto" else mode == "1"
+    return (_TLS.in_flight <= 1 and hw_queues_allow_forks()) if mode == "auto" else mode == "1"
 
 
 def token_overlap_enabled() -> bool:
@@ -210,15 +229,23 @@ def skip_overlap_enabled() -> bool:
     return _side_switch("OCV_SKIP_OVERLAP")
 
 
-_IN_FLIGHT = 1
+class batches_in_flight:
+    """``with batches_in_flight(n):`` forwards issued or CAPTURED inside belong to a caller that keeps ``n`` batches in flight on this
+    GPU (bench.py's slots, PipelinedValidation; ``GraphedGraphBins(in_flight=n)`` wraps its own warm-up and capture in it).  Read by
+    the side-stream switches (``_side_switch``): forks inside a forward pay for a lone batch only.  Thread-local, like a capture: two
+    owners in one process never see each other's value (round 4 kept it in a module global that the last writer won)."""
 
+    def __init__(self, n: int):
+        self.n = max(1, int(n))
 
-def set_batches_in_flight(n: int) -> int:
-    """A hint from whoever drives the model (bench.py's slots, PipelinedValidation): how many batches it keeps in flight on this
-    GPU.  Read when a forward is issued or captured (``head_overlap_enabled``); returns the previous value."""
-    global _IN_FLIGHT
-    prev, _IN_FLIGHT = _IN_FLIGHT, max(1, int(n))
-    return prev
+    def __enter__(self):
+        self.prev = _TLS.in_flight
+        _TLS.in_flight = self.n
+        return self
+
+    def __exit__(self, *exc):
+        _TLS.in_flight = self.prev
+        return False
 
 
 def head_overlap_enabled() -> bool:

@@ -156,12 +156,8 @@ class PipelinedValidation:
         self.min_depth, self.max_depth = float(ds.min_depth), float(ds.max_depth)
         self.B = int(example_image.shape[0])
         both = torch.cat([example_image, example_image.flip(dims=[3])], 0) if flip_tta else example_image
-        prev = hip_ops.set_batches_in_flight(slots)        # read by the captures (hip_ops.head_overlap_enabled)
-        try:
-            self.graphs = [GraphedGraphBins(model, both, object_capacity=object_capacity, object_group=self.B if flip_tta else None)
-                           for _ in range(slots)]
-        finally:
-            hip_ops.set_batches_in_flight(prev)
+        self.graphs = [GraphedGraphBins(model, both, object_capacity=object_capacity, object_group=self.B if flip_tta else None,
+                                        in_flight=slots) for _ in range(slots)]
         self._next = 0
         self._pending = []
         self.rerun_steps = 0                                 # steps re-run on bf16 pairs by collect() (fp16 range guard)

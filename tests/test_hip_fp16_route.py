@@ -276,33 +276,66 @@ def test_range_guard_word_is_set_by_every_fp16_pair_producer_and_only_by_them(op
     assert tripped(lambda: ops.conv3x3_winograd43_split(xs, u_hi, u_lo, fs, dev(bb), 0, out_fp32=False, out_split=True, cscale=cs))
 
 
-def _guard_model(H=352, W=384, seed=41):
+GUARD_GAINS = (("in_proj_weight", 2.0), ("conv_out", 2.0), ("conv3x3", 1.0), ("regressor.4", 2.0))      # a bin softmax that is not degenerate
+GUARD_SCALE = 12.0       # the batch that trips the guard = the calibration batch x 12 (see the docstring below for why not x 1e4)
+
+
+def _guard_model(H=352, W=384, seed=41, alpha=None):
+    """GraphBins whose DECODER carries a large intermediate when ``alpha`` is given: the third decoder stage's output scaled by alpha
+    in its BatchNorm, the fourth stage's first convolution by 1 / alpha on those input channels -- the same function (LeakyReLU is
+    positively homogeneous), an fp16-pair tensor alpha times larger between them."""
     from objcavit_amd.modules.GraphBins import GraphBins, SyntheticObjectProvider
     args = make_args(strategy="learned", language="clip", dimensions_train=[H, W], dimensions_test=[H, W])
     m = GraphBins(args, object_provider=SyntheticObjectProvider(12, "clip", seed=3)).eval()
-    sd = gen.load_into(m, seed, gen.PEAKY)
+    sd = gen.load_into(m, seed, GUARD_GAINS)
+    if alpha is not None:
+        sd = dict(sd)
+        pre = "dense_feature_extractor.decoder."
+        for k in (pre + "up3._net.4.weight", pre + "up3._net.4.bias"):
+            sd[k] = sd[k] * alpha
+        w = sd[pre + "up4._net.0.weight"].clone()
+        w[:, :256] = w[:, :256] / alpha                                   # the up-sampled half of cat([up(x), skip])
+        sd[pre + "up4._net.0.weight"] = w
+        m.load_state_dict(sd, strict=True)
     return m.cuda(), sd, args
 
 
-GUARD_SCALE = 1e4        # "replay a batch scaled x1e4 through the same captured graph"
+def _guard_alpha(ops, img, H, W):
+    """alpha that puts the largest entry of the third decoder stage's output at 3900 on ``img`` (below the calibration's 65504 / 16)."""
+    m, _, _ = _guard_model(H, W)
+    m.range_guard_sync = False
+    ops.range_check(True)
+    m(img.cuda())
+    seen = {k: v[0] for k, v in ops._Range.seen.items()}
+    ops.range_check(False)
+    amax = seen[f"conv3x3|{img.shape[0]},{H // 4},{W // 4},256,256"]
+    return 3900.0 / amax
 
 
 def test_range_guard_reruns_a_batch_beyond_fp16_range_on_bf16_pairs(ops):
-    """Calibrate on a tame batch, capture, replay a batch scaled x1e4 through the SAME captured graph: the guard trips, the batch is
-    re-run on the bf16-pair capture (captured lazily, once), the depth is finite and within 1e-3 of the CPU oracle, the route is
-    reported; the same graph then serves tame batches on fp16 pairs again, bit for bit.  The eager model guards itself the same way."""
+    """VERDICT r4 item 2.  Calibrate on a tame batch, capture, replay a LARGER batch through the SAME captured graph: the guard trips,
+    the batch is re-run on the bf16-pair capture (captured lazily, once), the depth is finite and within 1e-3 of the CPU oracle, the
+    route is reported; the same graph then serves tame batches on fp16 pairs again, bit for bit.  The eager model guards itself the
+    same way.
+    The larger batch is the calibration batch x 12 through a network whose decoder carries a large intermediate (``_guard_model``),
+    not the image x 1e4 the verdict names: every layer up to the bin softmax is positively homogeneous, so scaling the image scales
+    the logits, and ANY fp32-accurate implementation -- the exact-fp32 route included -- is already 1e-3 away from the CPU oracle at
+    x 30 and O(1) away at x 1e4 (profiles/r05_guard_scale.txt).  x 1e4 is replayed too: tripped, re-run, finite, equal to the bf16
+    route -- with no oracle claim, because there is no function left to agree on."""
     from objcavit_amd.graph import GraphedGraphBins
     H, W, B = 352, 384, 2
-    m, sd, args = _guard_model(H, W)
     img = gen.randn("img", (B, 3, H, W), 41)
+    alpha = _guard_alpha(ops, img, H, W)
+    m, sd, args = _guard_model(H, W, alpha=alpha)
     ops.ROUTE_REPORT.clear()
     tame = m(img.cuda()).depth_pred.clone()
-    assert m.dense_feature_extractor.decoder.settled_f16() is True and "range_guard" not in ops.ROUTE_REPORT
+    dec = m.dense_feature_extractor.decoder
+    assert dec.settled_f16() is True and "range_guard" not in ops.ROUTE_REPORT, (dec.__dict__.get("_f16_modes"), ops.ROUTE_REPORT)
     g = GraphedGraphBins(m, img.cuda())
     out = g.checked(img.cuda())
     assert g.trips == 0 and torch.equal(out.depth_pred, tame)
     big = img * GUARD_SCALE
-    raw = g(big.cuda())                                                    # what the fp16-pair capture alone makes of it: flagged
+    g(big.cuda())                                                          # what the fp16-pair capture alone makes of it: flagged
     assert g.tripped()
     out_big = g.checked(big.cuda())
     d_big, e_big = out_big.depth_pred.clone(), out_big.bin_edges.clone()
@@ -314,15 +347,20 @@ def test_range_guard_reruns_a_batch_beyond_fp16_range_on_bf16_pairs(ops):
     assert rel_dev(e_big, ref_e) < 1e-4 and max_rel(d_big, ref_d) < 1e-3, (rel_dev(e_big, ref_e), max_rel(d_big, ref_d))
     again = g.checked(img.cuda())                                          # the word was cleared by the take: fp16 pairs again
     assert g.trips == 1 and torch.equal(again.depth_pred, tame)
-    g.checked(big.cuda())
-    assert g.trips == 2                                                    # (the fallback graph is reused, not re-captured)
     # eager: GraphBins.forward arms its own word, reads it and re-runs on bf16 pairs
     ops.ROUTE_REPORT.clear()
     e = m(big.cuda())
-    assert "range_guard" in ops.ROUTE_REPORT and max_rel(e.depth_pred, ref_d) < 1e-3
+    assert "range_guard" in ops.ROUTE_REPORT and max_rel(e.depth_pred, ref_d) < 1e-3 and max_rel(e.depth_pred, d_big) < 1e-5
     assert torch.equal(m(img.cuda()).depth_pred, tame)
-    m.range_guard_sync = False                                             # switched off: the fp16 pairs' inf / NaN come through, loudly
-    assert not bool(torch.isfinite(m(big.cuda()).depth_pred).all()) or max_rel(m(big.cuda()).depth_pred, ref_d) > 1e-3
+    # the verdict's literal batch: x 1e4.  Tripped, re-run (the fallback graph is reused, not re-captured), finite, = the bf16 route.
+    huge = img * 1e4
+    out_h = g.checked(huge.cuda())
+    assert g.trips == 2 and bool(torch.isfinite(out_h.depth_pred).all())
+    with ops.bf16_pairs():
+        ref_h = m(huge.cuda()).depth_pred
+    assert max_rel(out_h.depth_pred, ref_h) < 1e-5
+    m.range_guard_sync = False                                             # guard off: the fp16 pairs' inf / NaN come through, loudly
+    assert not bool(torch.isfinite(m(huge.cuda()).depth_pred).all())
     m.range_guard_sync = True
 
 
@@ -331,7 +369,8 @@ def test_pipelined_validation_reruns_tripped_steps_at_collect(ops):
     batch exceeded the fp16 pairs' range is re-run on bf16 pairs there, its neighbours are untouched."""
     from objcavit_amd.validation import PipelinedValidation, ValidationStep
     H, W = 352, 384
-    m, sd, args = _guard_model(H, W, seed=43)
+    alpha = _guard_alpha(ops, gen.randn("im0", (1, 3, H, W), 400), H, W)
+    m, sd, args = _guard_model(H, W, alpha=alpha)
     imgs = [gen.randn(f"im{i}", (1, 3, H, W), 400 + i).cuda() for i in range(5)]
     imgs[2] = imgs[2] * GUARD_SCALE
     gts = [(torch.rand(1, 1, H, W, generator=torch.Generator().manual_seed(i)) * 9.0 + 0.5).cuda() for i in range(5)]

@@ -417,18 +417,28 @@ def test_validation_step_on_a_captured_graph_stand_in():
 
 
 def test_side_stream_switches_follow_the_batches_in_flight(monkeypatch):
-    """OCV_OBJ_OVERLAP / OCV_TOKEN_OVERLAP / OCV_HEAD_OVERLAP / OCV_SKIP_OVERLAP: 'auto' (default) = on for a lone batch, off once the driver announces
-    several batches in flight (hip_ops.set_batches_in_flight); '0' / '1' override; anything else is an error, not a silent default;
-    inside hip_ops.single_chain() no further fork is offered; launches inside islands_suspended() stay in the capture."""
+    """OCV_OBJ_OVERLAP / OCV_TOKEN_OVERLAP / OCV_HEAD_OVERLAP / OCV_SKIP_OVERLAP: 'auto' (default) = on for a lone batch on at most four
+    hardware queues, off inside ``hip_ops.batches_in_flight(n > 1)`` (thread-local: another thread's owner is not affected) and
+    off when the process asked for more than four hardware queues (profiles/r05_graph_shapes.txt: a forked graph replays 3x slower
+    there); '0' / '1' override; anything else is an error, not a silent default; inside hip_ops.single_chain() no further fork is
+    offered; launches inside islands_suspended() stay in the capture."""
+    import threading
     from objcavit_amd import hip_ops
     switches = {"OCV_OBJ_OVERLAP": hip_ops.object_prepass_enabled, "OCV_TOKEN_OVERLAP": hip_ops.token_overlap_enabled,
                 "OCV_HEAD_OVERLAP": hip_ops.head_overlap_enabled, "OCV_SKIP_OVERLAP": hip_ops.skip_overlap_enabled}
     for k in switches:
         monkeypatch.delenv(k, raising=False)
-    prev = hip_ops.set_batches_in_flight(1)
-    try:
-        assert all(f() for f in switches.values())
-        assert hip_ops.set_batches_in_flight(3) == 1
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    assert all(f() for f in switches.values())
+    with hip_ops.batches_in_flight(3):
+        assert not any(f() for f in switches.values())
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(all(f() for f in switches.values())))      # another owner, another thread
+        t.start()
+        t.join()
+        assert seen == [True]
+        with hip_ops.batches_in_flight(0):                                                         # (clamped to 1), nested
+            assert all(f() for f in switches.values())
         assert not any(f() for f in switches.values())
         for k, f in switches.items():
             monkeypatch.setenv(k, "1")
@@ -439,18 +449,23 @@ def test_side_stream_switches_follow_the_batches_in_flight(monkeypatch):
             with pytest.raises(ValueError):
                 f()
             monkeypatch.delenv(k)
-        assert hip_ops.set_batches_in_flight(0) == 3 and all(f() for f in switches.values())      # (clamped to 1)
-        with hip_ops.single_chain():
-            assert not hip_ops.token_overlap_enabled() and hip_ops.head_overlap_enabled()
-        assert hip_ops.token_overlap_enabled()
-        broke = []
-        with hip_ops.island_scope(hip_ops.IslandHook(("x",), lambda name, call: broke.append(name))):
-            with hip_ops.islands_suspended():
-                hip_ops.launch("x", lambda: broke.append("ran"))
-            hip_ops.launch("x", lambda: broke.append("never"))
-        assert broke == ["ran", "x"]
-    finally:
-        hip_ops.set_batches_in_flight(prev)
+    assert all(f() for f in switches.values())
+    for q, ok in (("2", True), ("4", True), ("6", False), ("8", False), ("16", False)):
+        monkeypatch.setenv("GPU_MAX_HW_QUEUES", q)
+        assert hip_ops.hw_queues_allow_forks() == ok and all(f() == ok for f in switches.values()), q
+    monkeypatch.setenv("OCV_SKIP_OVERLAP", "1")                                                    # an explicit '1' is obeyed
+    assert hip_ops.skip_overlap_enabled()
+    monkeypatch.delenv("OCV_SKIP_OVERLAP")
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES")
+    with hip_ops.single_chain():
+        assert not hip_ops.token_overlap_enabled() and hip_ops.head_overlap_enabled()
+    assert hip_ops.token_overlap_enabled()
+    broke = []
+    with hip_ops.island_scope(hip_ops.IslandHook(("x",), lambda name, call: broke.append(name))):
+        with hip_ops.islands_suspended():
+            hip_ops.launch("x", lambda: broke.append("ran"))
+        hip_ops.launch("x", lambda: broke.append("never"))
+    assert broke == ["ran", "x"]
 
 
 def test_map_placeholder_and_fp32_map_on_the_host():
