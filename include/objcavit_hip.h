@@ -42,7 +42,7 @@ const char* ocv_last_error(void);
  * (modules/DenseFeatureExtractor.py:37-47,104-118); the two-term fp16 split of the decoder's activations ends at +-65504.  Every
  * launcher that writes fp16 "hl32" pairs (ocv_conv_nhwc_split_x_fwd, ocv_conv3x3_winograd43_split_fwd,
  * ocv_upsample_concat_split_x_fwd, ocv_tap_interp_*_fwd) ORs 1 into the word the CALLING THREAD armed with ocv_range_flag_set when
- * a value it converts exceeds 32752 in magnitude (an atomic on that rare branch only; NULL = not armed, the default).  The word is
+ * a value it converts exceeds 65504 / 16 = 4094 in magnitude (the first-batch calibration's own limit) (an atomic on that rare branch only; NULL = not armed, the default).  The word is
  * device memory owned by the caller, sticky until the caller clears it; ocv_range_flag_take_fwd copies it to `out` and zeroes it
  * on the stream (one tiny launch: capturable).  The host reads `out` where it reads results and re-runs the batch on bf16 pairs
  * (objcavit_amd/hip_ops.py RangeGuard).  Both return 0 / -1. */
@@ -476,17 +476,6 @@ int ocv_mbconv_expand_dw_tiles(int Ho, int Wo, int k, int stride);
 int ocv_mbconv_expand_dw_fwd(const float* x, const void* w_packed, const float* bias_expand, const float* w_dw,
                              const float* bias_dw, float* y, float* part, int B, int H, int W, int Cin, int mid, int k,
                              int stride, int pad_t, int pad_l, int Ho, int Wo, ocv_stream_t stream);
-
-/* The same pair of layers for the LATE stages (round 5): stride 1, small maps, wide layers -- a workgroup owns (image, band of
- * rows, 32 expanded channels), the band's pixels are one GEMM with no halo recompute across columns, the expanded values live
- * in LDS only.  Built for 15 x 20 (one band) and 30 x 40 maps (4 bands of 8 rows): ocv_mbconv_image_tiles returns the
- * bands per image (= `tiles` of part [B][tiles][mid] for ocv_se_gate_partials_fwd) or 0 for a shape it does not cover.
- * x [B,H,W,Cin] NHWC fp32, Cin a multiple of 16; mid a multiple of 32; TF "SAME" padding of a stride-1 odd kernel ((k - 1) / 2 on
- * every side); operands and numerics otherwise as ocv_mbconv_expand_dw_fwd.  Replaces the same reference lines. */
-int ocv_mbconv_image_tiles(int H, int W, int k);
-int ocv_mbconv_image_fwd(const float* x, const void* w_packed, const float* bias_expand, const float* w_dw,
-                         const float* bias_dw, float* y, float* part, int B, int H, int W, int Cin, int mid, int k,
-                         ocv_stream_t stream);
 
 /* Split-bf16 activation layout "hl32" shared by ocv_upsample_concat_split_fwd and ocv_conv_nhwc_split_fwd: for a
  * logical NHWC activation [B,H,W,C] one bf16 buffer [B*H*W][2*Cp], Cp = C rounded up to 32, holding per pixel and per

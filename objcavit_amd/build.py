@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.environ.get("OCV_CSRC_DIR") or os.path.join(HERE, "csrc")      # env: patched copies for diagnostic builds (tools/build_variant.sh)
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libobjcavit_hip.so")
-SOURCES = ("capi.hip", "linear.hip", "attention.hip", "patch_embed.hip", "bin_head.hip", "depthwise.hip", "conv_igemm.hip", "encoder_nhwc.hip", "upsample.hip", "pointwise_split.hip", "stem.hip", "depthwise_se.hip", "metrics.hip", "mbconv_fused.hip", "mbconv_image.hip", "pos_sample.hip", "conv_exact.hip", "token_split3.hip", "tap_interp.hip", "pointwise_hl.hip", "xattn_h2.hip", "conv_few.hip", "token_h2.hip", "objects_pad.hip", "bin_edges.hip")
+SOURCES = ("capi.hip", "linear.hip", "attention.hip", "patch_embed.hip", "bin_head.hip", "depthwise.hip", "conv_igemm.hip", "encoder_nhwc.hip", "upsample.hip", "pointwise_split.hip", "stem.hip", "depthwise_se.hip", "metrics.hip", "mbconv_fused.hip", "pos_sample.hip", "conv_exact.hip", "token_split3.hip", "tap_interp.hip", "pointwise_hl.hip", "xattn_h2.hip", "conv_few.hip", "token_h2.hip", "objects_pad.hip", "bin_edges.hip")
 ARCH = "gfx950"
 
 

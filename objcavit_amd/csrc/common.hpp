@@ -64,9 +64,10 @@ __device__ __forceinline__ void ocv_split1(float v, unsigned short& hi, unsigned
 // or a replay of a captured graph, can exceed it.  So every kernel that writes fp16 pairs keeps the largest magnitude it converts
 // (one v_max per element pair) and, on the rare true branch only, ORs 1 into ONE device word (the guard the host armed for this
 // thread: ocv_range_flag_set; nullptr = not armed).  The word is sticky; the host reads it where it reads results and re-runs the
-// batch on bf16 pairs (objcavit_amd/hip_ops.py RangeGuard).  Half of fp16's largest value: a tripped batch is never wrong yet
-// un-tripped, and NaN inputs stay NaN (loud) without tripping -- bf16 pairs would not cure them.
-constexpr float OCV_F16_GUARD = 32752.f;
+// batch on bf16 pairs (objcavit_amd/hip_ops.py RangeGuard).  The limit is the calibration's own, 65504 / 16 (hip_ops.fp16_range_report):
+// a batch that leaves the envelope its model was calibrated for is re-run, long before a value can turn into inf.  NaN inputs stay
+// NaN (loud) without tripping -- bf16 pairs would not cure them.
+constexpr float OCV_F16_GUARD = 4094.f;
 __device__ __forceinline__ void ocv_range_note(unsigned* flag, float amax) {
   if (flag != nullptr && amax > OCV_F16_GUARD) atomicOr(flag, 1u);
 }

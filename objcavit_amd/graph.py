@@ -247,7 +247,7 @@ class GraphedGraphBins:
             cur.synchronize()                            # nothing of this graph is in flight while its sibling is captured
             self._fallback = GraphedGraphBins(self.model, self.static_image, pairs="bf16", **self._ctor)
         self.trips += 1
-        hip_ops.ROUTE_REPORT["range_guard"] = (f"{self.trips} batch(es) exceeded the fp16 pairs' guarded range (|x| > 32752 in a decoder "
+        hip_ops.ROUTE_REPORT["range_guard"] = (f"{self.trips} batch(es) exceeded the fp16 pairs' guarded range (|x| > 65504 / 16 in a decoder "
                                                "/ heads activation) under a captured graph and were re-run on the bf16-pair capture")
         return self._fallback(image, object_features, object_xywh_list)
 

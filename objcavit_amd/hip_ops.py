@@ -1116,7 +1116,7 @@ class bf16_pairs:
 
 
 class RangeGuard:
-    """One device word that every launch writing fp16 pairs ORs 1 into when a value it converts exceeds 32752 in magnitude
+    """One device word that every launch writing fp16 pairs ORs 1 into when a value it converts exceeds 65504 / 16 = 4094 in magnitude (the first-batch calibration's own limit)
     (include/objcavit_hip.h ``ocv_range_flag_set``; csrc/common.hpp ``ocv_range_note``).  The reference computes these layers in
     fp32 for any input (modules/DenseFeatureExtractor.py:37-47,104-118); the fp16-pair pipeline is calibrated on a model's FIRST
     batch only, and a captured graph cannot change its mind -- so the owner of a forward (GraphBins / AdaBins eagerly,
@@ -1160,7 +1160,7 @@ def guarded_forward(owner, decoder, device: torch.device, run):
         out = run()
     if RangeGuard.tripped(guard.take()):
         n = owner.__dict__["_range_trips"] = owner.__dict__.get("_range_trips", 0) + 1
-        ROUTE_REPORT["range_guard"] = (f"{n} batch(es) exceeded the fp16 pairs' guarded range (|x| > 32752 in a decoder / heads "
+        ROUTE_REPORT["range_guard"] = (f"{n} batch(es) exceeded the fp16 pairs' guarded range (|x| > 65504 / 16 in a decoder / heads "
                                        "activation) and were re-run on bf16 pairs")
         with bf16_pairs():
             out = run()
@@ -2060,58 +2060,6 @@ def expand_depthwise_se_gate(x: torch.Tensor, w_expand: "SplitWeight", b_expand:
                                            ph // 2, pw // 2, Ho, Wo, _stream()), "ocv_mbconv_expand_dw_fwd")
     with timed("se_gate"):
         check(lib.ocv_se_gate_partials_fwd(part.data_ptr(), tiles, Ho * Wo, w1.data_ptr(), b1.data_ptr(), w2t.data_ptr(),
-                                           b2.data_ptr(), gate.data_ptr(), hid.data_ptr(), B, mid, R, _stream()),
-              "ocv_se_gate_partials_fwd")
-    return out, gate
-
-
-def expand_depthwise_image_pays(B: int, cin: int, mid: int, H: int, W: int, k: int, stride: int, weight) -> bool:
-    """Whether a late MBConv block's expand + depthwise pair runs as ONE whole-image launch (csrc/mbconv_image.hip: stride 1, the
-    15 x 20 and 30 x 40 maps of B5's stages 4 - 7 at 480 x 640, Cin % 16 == 0, expanded channels % 32 == 0).  OCV_MBCONV_IMAGE=0
-    keeps the two-launch form (A/B)."""
-    mode = os.environ.get("OCV_MBCONV_IMAGE", "1")
-    if mode not in ("0", "1"):
-        raise ValueError(f"OCV_MBCONV_IMAGE={mode!r}: expected '1' (default) or '0'")
-    return (mode == "1" and stride == 1 and isinstance(weight, SplitWeight) and cin % 16 == 0 and mid % 32 == 0
-            and _lib.load().ocv_mbconv_image_tiles(int(H), int(W), int(k)) > 0)
-
-
-def expand_depthwise_image_se_gate(x: torch.Tensor, w_expand: "SplitWeight", b_expand: Optional[torch.Tensor], weight_kkc: torch.Tensor,
-                                   bias: Optional[torch.Tensor], k: int, w1: torch.Tensor, b1: torch.Tensor, w2t: torch.Tensor,
-                                   b2: torch.Tensor):
-    """silu(depthwise_kxk(silu(x @ We^T + be)) + bd), stride 1, of a channels_last tensor in ONE launch that owns whole images
-    (``expand_depthwise_image_pays``), and the squeeze-excite gate of that output from the launch's per-band pooling sums:
-    returns (y [B, mid, H, W] channels_last, gate [B, mid])."""
-    lib = _lib.load()
-    x = _nhwc(x, "x")
-    B, Cin, H, W = x.shape
-    if not isinstance(w_expand, SplitWeight) or w_expand.cin != Cin:
-        raise ValueError("expand_depthwise_image_se_gate: expand weight must be a SplitWeight matching x's channels")
-    _req(w_expand.packed, "w_expand.packed", torch.bfloat16)
-    mid = w_expand.cout
-    _req(weight_kkc, "weight")
-    if weight_kkc.shape != (k * k, mid):
-        raise ValueError(f"expand_depthwise_image_se_gate: depthwise weight {tuple(weight_kkc.shape)} does not match k={k}, C={mid}")
-    for n, t in (("b_expand", b_expand), ("bias", bias), ("w1", w1), ("b1", b1), ("w2t", w2t), ("b2", b2)):
-        if t is not None:
-            _req(t, n)
-    R = w1.shape[0]
-    if w1.shape != (R, mid) or w2t.shape != (R, mid) or b1.numel() != R or b2.numel() != mid:
-        raise ValueError("expand_depthwise_image_se_gate: squeeze-excite parameter shape mismatch")
-    if (b_expand is not None and b_expand.numel() != mid) or (bias is not None and bias.numel() != mid):
-        raise ValueError("expand_depthwise_image_se_gate: bias size mismatch")
-    tiles = lib.ocv_mbconv_image_tiles(H, W, k)
-    if tiles <= 0 or Cin % 16 or mid % 32:
-        raise ValueError(f"expand_depthwise_image_se_gate: unsupported shape {H}x{W} k={k} Cin={Cin} mid={mid}")
-    out = torch.empty(B, mid, H, W, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    part = workspace(B * tiles * mid * 4, x.device, "dw_part")
-    gate = torch.empty(B, mid, dtype=torch.float32, device=x.device)
-    hid = workspace(B * R * 4, x.device, "se_hidden")
-    with timed(f"expand_dw_image|{B},{H},{W},{Cin},{mid},k{k}"):
-        check(lib.ocv_mbconv_image_fwd(x.data_ptr(), w_expand.packed.data_ptr(), _ptr(b_expand), weight_kkc.data_ptr(), _ptr(bias),
-                                       out.data_ptr(), part.data_ptr(), B, H, W, Cin, mid, k, _stream()), "ocv_mbconv_image_fwd")
-    with timed("se_gate"):
-        check(lib.ocv_se_gate_partials_fwd(part.data_ptr(), tiles, H * W, w1.data_ptr(), b1.data_ptr(), w2t.data_ptr(),
                                            b2.data_ptr(), gate.data_ptr(), hid.data_ptr(), B, mid, R, _stream()),
               "ocv_se_gate_partials_fwd")
     return out, gate

@@ -216,12 +216,7 @@ class InvertedResidual(_FoldedMixin, nn.Module):
             # producer (hl32: the project epilogue of the block in front, the depthwise epilogue) and is read by LDS-DMA,
             # the gate is folded into per-image project weights (csrc/pointwise_hl.hip); hip_ops decides per layer
             emit_hl = split_w and hip_ops.pointwise_hl_expand_pays(B * Ho * Wo, cout, 6 * cout)      # for the block behind this one
-            if hip_ops.expand_depthwise_image_pays(B, cin, mid, H, W, k, stride, we):
-                # late stages, stride 1: ONE launch owns whole images -- the expanded tensor lives in LDS only, the squeeze-excite pool
-                # is complete per band (csrc/mbconv_image.hip); then the gate, then the project with the gate on its rows
-                y, g = hip_ops.expand_depthwise_image_se_gate(x, we, be, wd, bd, k, s1, sb1, s2, sb2)
-                out = hip_ops.pointwise_nhwc(y, wl, bl, hip_ops.ACT_NONE, gate=g, residual=res, out_split=emit_hl)
-            elif hip_ops.expand_depthwise_fusable(cin, we, k):
+            if hip_ops.expand_depthwise_fusable(cin, we, k):
                 # 3 launches: the expanded tensor stays in LDS (csrc/mbconv_fused.hip)
                 y, g = hip_ops.expand_depthwise_se_gate(x, we, be, wd, bd, k, stride, s1, sb1, s2, sb2)
                 out = hip_ops.pointwise_nhwc(y, wl, bl, hip_ops.ACT_NONE, gate=g, residual=res, out_split=emit_hl)

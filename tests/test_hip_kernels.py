@@ -1152,40 +1152,6 @@ def test_expand_depthwise_fused(ops, monkeypatch, tail, k, s, B, H, W, Cin, mid)
     assert torch.equal(y, y3) and torch.equal(g, g3)        # fixed-order pooling sums
 
 
-@pytest.mark.parametrize("k,H,W,B,Cin,mid", [(5, 15, 20, 2, 304, 1824), (3, 15, 20, 3, 512, 3072), (5, 30, 40, 2, 176, 1056),
-                                             (3, 30, 40, 1, 128, 768), (5, 15, 20, 1, 16, 32), (3, 30, 40, 2, 48, 96)])
-def test_expand_depthwise_whole_image(ops, monkeypatch, k, H, W, B, Cin, mid):
-    """the late stages' expand 1x1 + depthwise k x k (+ pooling sums) as ONE launch that owns whole images
-    (csrc/mbconv_image.hip; B5's stride-1 blocks of stages 4 - 7 at 480 x 640 and two small-channel shapes) against the fp64
-    formulation of the reference's layers (conv_pw + bn1 + act1 + conv_dw + bn2 + act2 + the pool of se: the hub backbone's
-    InvertedResidual, modules/DenseFeatureExtractor.py:18-27) and against the two-launch path: bands with halo rows above, below and
-    on both sides of the image, the last band shorter than the others, M tiles that end inside the band."""
-    assert ops.expand_depthwise_image_pays(B, Cin, mid, H, W, k, 1, ops.SplitWeight(dev(rnd("we", (mid, Cin), 2))))
-    R = max(1, Cin // 4)
-    x = rnd("x", (B, Cin, H, W), 1)
-    we, be = rnd("we", (mid, Cin), 2, 1 / math.sqrt(Cin)), rnd("be", (mid,), 3, 0.3)
-    wd, bd = rnd("wd", (mid, 1, k, k), 4, 0.3), rnd("bd", (mid,), 5, 0.2)
-    w1, b1 = rnd("w1", (R, mid), 6, 1 / math.sqrt(mid)), rnd("b1", (R,), 7, 0.3)
-    w2, b2 = rnd("w2", (mid, R), 8, 1 / math.sqrt(R)), rnd("b2", (mid,), 9, 0.3)
-    e = F.silu(F.conv2d(x.double(), we.double()[:, :, None, None], be.double())).float()
-    ref = F.silu(F.conv2d(_same_pad(e, k, 1), wd, bd, stride=1, groups=mid))
-    gref = torch.sigmoid(F.silu(ref.mean((2, 3)) @ w1.T + b1) @ w2.T + b2)
-    xg = dev(x).contiguous(memory_format=torch.channels_last)
-    wsp = ops.SplitWeight(dev(we))
-    se = (dev(w1), dev(b1), dev(w2).t().contiguous(), dev(b2))
-    wdk = dev(wd).flatten(1).t().contiguous()
-    y, g = ops.expand_depthwise_image_se_gate(xg, wsp, dev(be), wdk, dev(bd), k, *se)
-    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
-    assert rel_dev(y, ref) < SPLIT_TOL and rel_dev(g, gref) < SPLIT_TOL, (rel_dev(y, ref), rel_dev(g, gref))
-    y2, g2 = ops.depthwise_se_gate(ops.pointwise_nhwc(xg, wsp, dev(be), ops.ACT_SILU), wdk, dev(bd), k, 1, *se)
-    assert rel_dev(y, y2) < 1e-5 and rel_dev(g, g2) < 1e-5
-    y3, g3 = ops.expand_depthwise_image_se_gate(xg, wsp, dev(be), wdk, dev(bd), k, *se)
-    assert torch.equal(y, y3) and torch.equal(g, g3)        # fixed-order pooling sums, no atomics
-    assert not ops.expand_depthwise_image_pays(B, Cin, mid, H, W, k, 2, wsp) and not ops.expand_depthwise_image_pays(B, Cin, mid, 22, 76, k, 1, wsp)
-    monkeypatch.setenv("OCV_MBCONV_IMAGE", "0")
-    assert not ops.expand_depthwise_image_pays(B, Cin, mid, H, W, k, 1, wsp)
-
-
 @pytest.mark.parametrize("B,C,H,W,R", [(16, 144, 120, 160, 6), (2, 48, 240, 320, 12), (3, 3072, 15, 20, 128), (1, 8, 1, 3, 2)])
 def test_channel_mean_and_se_gate(ops, B, C, H, W, R):
     x = rnd("x", (B, C, H, W), 1)

@@ -1,4 +1,4 @@
-"""The late MBConv blocks' expand + depthwise (+ pooling) pair: ONE whole-image launch (csrc/mbconv_image.hip) against the two-launch
+"""(Needs tools/diag/mbconv_image.hip.txt wired back in: see the end of that file.)  The late MBConv blocks' expand + depthwise (+ pooling) pair: ONE whole-image launch against the two-launch
 form (pw_tile expand + dw_slide), per B5 shape at bs 16 and bs 1, HIP events, 30 launches per cell.  The squeeze-excite gate launch(es)
 behind either form are timed separately (tiles = bands per image vs the depthwise kernel's partial rows)."""
 import math, os, sys
@@ -23,9 +23,13 @@ def timeit(fn, n=30):
     return a.elapsed_time(b) / n * 1e3
 
 
-for B in (16, 1):
+ONLY = sys.argv[1] if len(sys.argv) > 1 else None          # e.g. "stage6 16": one shape at one batch (for counter passes)
+BS = (int(sys.argv[2]),) if len(sys.argv) > 2 else (16, 1)
+for B in BS:
     print(f"bs {B}:   shape                 fused_us   expand_us  dw_us  two_launch_us   se(fused tiles)_us  se(dw tiles)_us")
     for name, k, H, W, Cin, mid in SHAPES:
+        if ONLY and name != ONLY:
+            continue
         R = Cin // 4
         x = (torch.randn(B, Cin, H, W, device="cuda")).contiguous(memory_format=torch.channels_last)
         we = ops.SplitWeight(torch.randn(mid, Cin, device="cuda") / math.sqrt(Cin))
