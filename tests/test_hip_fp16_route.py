@@ -277,7 +277,7 @@ def test_range_guard_word_is_set_by_every_fp16_pair_producer_and_only_by_them(op
 
 
 GUARD_GAINS = (("in_proj_weight", 2.0), ("conv_out", 2.0), ("conv3x3", 1.0), ("regressor.4", 2.0))      # a bin softmax that is not degenerate
-GUARD_SCALE = 4.0        # the batch that trips the guard = the calibration batch x 4 (see the docstring below for why not x 1e4)
+GUARD_SCALE = 8.0        # the batch that trips the guard = the calibration batch x 8 (see the docstring below for why not x 1e4)
 
 
 def _guard_model(H=352, W=384, seed=41, alpha=None):
@@ -301,7 +301,8 @@ def _guard_model(H=352, W=384, seed=41, alpha=None):
 
 
 def _guard_alpha(ops, img, H, W):
-    """alpha that puts the largest entry of the third decoder stage's output at 2800 on ``img`` (inside the calibration's 65504 / 16)."""
+    """alpha that puts the largest entry of the third decoder stage's output at 3400 on ``img`` (inside the calibration's 65504 / 16 = 4094;
+    x 8 on the image takes it to ~5900: the decoder's activations grow far slower than the image, tools/exp_guard_growth.py)."""
     m, _, _ = _guard_model(H, W)
     m.range_guard_sync = False
     ops.range_check(True)
@@ -309,7 +310,7 @@ def _guard_alpha(ops, img, H, W):
     seen = {k: v[0] for k, v in ops._Range.seen.items()}
     ops.range_check(False)
     amax = seen[f"conv3x3|{img.shape[0]},{H // 4},{W // 4},256,256"]
-    return 2800.0 / amax
+    return 3400.0 / amax
 
 
 def test_range_guard_reruns_a_batch_beyond_fp16_range_on_bf16_pairs(ops):
@@ -317,7 +318,7 @@ def test_range_guard_reruns_a_batch_beyond_fp16_range_on_bf16_pairs(ops):
     the batch is re-run on the bf16-pair capture (captured lazily, once), the depth is finite and within 1e-3 of the CPU oracle, the
     route is reported; the same graph then serves tame batches on fp16 pairs again, bit for bit.  The eager model guards itself the
     same way.
-    The larger batch is the calibration batch x 4 through a network whose decoder carries a large intermediate (``_guard_model``),
+    The larger batch is the calibration batch x 8 through a network whose decoder carries a large intermediate (``_guard_model``),
     not the image x 1e4 the verdict names: every layer up to the bin softmax is positively homogeneous, so scaling the image scales
     the logits, and ANY fp32-accurate implementation -- the exact-fp32 route included -- is already 1e-3 away from the CPU oracle at
     x 30 and O(1) away at x 1e4 (profiles/r05_guard_scale.txt).  x 1e4 is replayed too: tripped, re-run, finite, equal to the bf16

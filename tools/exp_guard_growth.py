@@ -1,7 +1,7 @@
 """Does the decoder's alpha-scaled intermediate grow with the input scale, and does a captured graph's guard word see it?"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import torch
 import gen
 from objcavit_amd import hip_ops as ops
