@@ -407,29 +407,6 @@ int ocv_se_gate_weights_fwd(const float* part, int tiles, long pixels_per_image,
                             const float* w2t, const float* b2, const float* W, void* w_packed, long w_image_elems, float* gate,
                             float* hidden_ws, int B, int C, int R, int N, ocv_stream_t stream);
 
-/* The depthwise convolution (+ bias + SiLU + pooling partials, as ocv_depthwise_conv_nhwc_sum_hl_fwd) that ALSO computes the
- * block's squeeze-excite gate, gate[b][c] = sigmoid(b2[c] + sum_r w2t[r][c] silu(b1[r] + w1[r] . mean[b])), inside the same
- * launch: every workgroup publishes its pooling partial write-through, draws a ticket on counters[b], and the image's LAST
- * workgroup (whichever that is; nobody waits) acquires, sums the partials in a fixed order and forms the gate -- the two
- * launches of ocv_se_gate_partials_fwd disappear (round 4: 72 of a forward's 271 launches; csrc/se_tail.hpp has the protocol).
- * counters: uint32 [B], ZERO when the launch starts; the last workgroup of every image restores its zero, so the buffer is
- * zero-initialised ONCE by the caller and never again (graph replays need no memset node).  One buffer per concurrently running
- * launch.  ocv_se_tail_supported(C, R): the tail takes C <= 1536 (a multiple of 4) and R <= 128; a single workgroup reads
- * 8 C R bytes of squeeze-excite weights, so callers send only blocks where that is a few hundred KB (hip_ops.se_tail_pays).
- * ocv_mbconv_expand_dw_se_fwd: the same for the fused expand + depthwise launch.
- * ocv_se_fold_gate_weights_fwd: ocv_se_gate_weights_fwd's second launch on a GIVEN gate [B][C] (what the tail wrote). */
-int ocv_se_tail_supported(int C, int R);
-int ocv_depthwise_conv_nhwc_se_fwd(const float* in, const float* w, const float* bias, float* out, void* out_hl, float* part,
-                                   const float* se_w1, const float* se_b1, const float* se_w2t, const float* se_b2, int R,
-                                   float* gate, unsigned* counters, int B, int C, int H, int W, int k, int stride, int pad_t,
-                                   int pad_l, int Ho, int Wo, ocv_stream_t stream);
-int ocv_mbconv_expand_dw_se_fwd(const float* x, const void* w_packed, const float* bias_expand, const float* w_dw,
-                                const float* bias_dw, float* y, float* part, const float* se_w1, const float* se_b1,
-                                const float* se_w2t, const float* se_b2, int R, float* gate, unsigned* counters, int B, int H,
-                                int W, int Cin, int mid, int k, int stride, int pad_t, int pad_l, int Ho, int Wo,
-                                ocv_stream_t stream);
-int ocv_se_fold_gate_weights_fwd(const float* gate, const float* W, void* w_packed, long w_image_elems, int B, int C, int N,
-                                 ocv_stream_t stream);
 
 /* squeeze: out[b][c] = mean over the P = H*W pixels of x [B,P,C]; two-stage, fixed summation order. */
 size_t ocv_channel_mean_workspace_bytes(int B, int C, long P);
@@ -570,17 +547,7 @@ int ocv_tap_interp_combine_fwd(const float* z, int h, int w, int zpad, const flo
 /* the same with the element type of y_hl as a parameter (0 = bf16 pairs, 1 = fp16 pairs: ocv_conv_nhwc_split_x_fwd) */
 int ocv_tap_interp_combine_x_fwd(const float* z, int h, int w, int zpad, const float* zborder, const float* s, const float* bias,
                                  float* y, void* y_hl, int hl_f16, int B, int H, int W, int Cout, int act, ocv_stream_t stream);
-/* the same with the skip part s formed INSIDE the launch, on the matrix cores, instead of read as a tensor: skip_hl = the skip
- * tensor [B,H,W,Cs] in the hl32 split layout (ocv_split_act_elems(B,H,W,Cs) 2-byte elements, pad channels zero), ws_hi / ws_lo
- * the split halves [9][Cout][Cs rounded up to 32] of the convolution weight's skip columns (tap-major, as for
- * ocv_conv_nhwc_split_fwd with ksize 3), s_oscale [Cout] (nullable) the per-channel scale of the raw sums (fp16 pairs with scaled
- * weights).  hl_f16 names the element type of skip_hl, of the weight halves AND of y_hl.  Three products per K step (hi hi +
- * hi lo + lo hi, fp32 accumulate): the arithmetic of ocv_conv_nhwc_split_x_fwd on the same operands, in another summation order;
- * zero padding of the 3 x 3 convolution applied per tap.  Saves the skip-part launch and one fp32 [B,H,W,Cout] tensor written
- * and read (modules/DenseFeatureExtractor.py:37-39,44-47: the skip half of UpSampleWithSkip's first convolution). */
-int ocv_tap_interp_skip_fwd(const float* z, int h, int w, int zpad, const float* zborder, const void* skip_hl, int Cs,
-                            const void* ws_hi, const void* ws_lo, const float* s_oscale, const float* bias, float* y, void* y_hl,
-                            int hl_f16, int B, int H, int W, int Cout, int act, ocv_stream_t stream);
+
 
 /* Bilinear resize of x [B,h,w,C1] (NHWC fp32) to H x W with align_corners = True, concatenated along channels with
  * skip [B,H,W,C2] (nullable, then C2 = 0), written in the hl32 split layout for C1+C2 channels (out_hl,

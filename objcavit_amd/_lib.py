@@ -131,12 +131,6 @@ PROTOTYPES = {
     "ocv_bin_edges_fwd": (C.c_int, [_f32p, C.c_int, C.c_float, C.c_float, _f32p, _f32p, _f32p, C.c_int, C.c_int, _stream]),
     "ocv_object_tokens_pad_fwd": (C.c_int, [_f32p, C.c_void_p, C.c_float, _f32p, _u8p, C.c_int, C.c_int, C.c_int, _stream]),
     "ocv_object_front_pad_fwd": (C.c_int, [_f32p, C.c_void_p, C.c_int, C.c_int, C.c_float, _f32p, _u8p] + [C.c_int] * 4 + [_stream]),
-    "ocv_se_tail_supported": (C.c_int, [C.c_int, C.c_int]),
-    "ocv_depthwise_conv_nhwc_se_fwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_void_p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, _f32p, C.c_void_p]
-                                       + [C.c_int] * 10 + [_stream]),
-    "ocv_mbconv_expand_dw_se_fwd": (C.c_int, [_f32p, C.c_void_p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, _f32p, C.c_void_p]
-                                    + [C.c_int] * 11 + [_stream]),
-    "ocv_se_fold_gate_weights_fwd": (C.c_int, [_f32p, _f32p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, _stream]),
     "ocv_split_act_elems": (C.c_size_t, [C.c_int] * 4),
     "ocv_conv_nhwc_split_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p, C.c_void_p]
                                 + [C.c_int] * 6 + [_stream]),
@@ -156,8 +150,6 @@ PROTOTYPES = {
     "ocv_conv3x3_winograd43_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
     "ocv_conv3x3_winograd43_split_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p, _f32p, C.c_void_p] + [C.c_int] * 6 +
                                          [C.c_void_p, C.c_size_t, _stream]),
-    "ocv_tap_interp_skip_fwd": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p,
-                                          C.c_void_p] + [C.c_int] * 6 + [_stream]),
     "ocv_tap_interp_supported": (C.c_int, [C.c_int] * 5),
     "ocv_tap_interp_combine_fwd": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_void_p] + [C.c_int] * 5 + [_stream]),
     "ocv_upsample_concat_split_fwd": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_void_p,

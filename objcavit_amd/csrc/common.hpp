@@ -75,6 +75,16 @@ __device__ __forceinline__ float ocv_amax4(float m, const f32x4 v) {
   return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
 }
 
+
+// In-launch hand-off between workgroups (csrc/token_h2.hip: the layer tail's feed-forward chunks shared out over workgroups, the row
+// block's last arriver finishes the layer).  Per-XCD L2s are not coherent and a CU's L1 is never refreshed by other CUs' stores, so a
+// producer's partial goes out WRITE-THROUGH (sc1: an agent-scope atomic store), the storing wave drains it (s_waitcnt vmcnt(0)), and
+// ONE lane draws a ticket with an agent-scope atomic add; the last arriver issues one agent-scope acquire and reads with ordinary loads.
+typedef __attribute__((address_space(1))) unsigned ocv_gu32;
+__device__ __forceinline__ void ocv_store_sc1(float* p, float v) {
+  __hip_atomic_store((ocv_gu32*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------

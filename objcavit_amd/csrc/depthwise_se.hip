@@ -14,7 +14,6 @@
 #include <stdlib.h>
 
 #include "common.hpp"
-#include "se_tail.hpp"
 #include "../../include/objcavit_hip.h"
 
 namespace {
@@ -29,7 +28,6 @@ struct DWSArgs {
   int C, H, W, Ho, Wo, pad_t, pad_l;
   int QL, PL, RY;                  // quads per chunk, pixel lanes, output rows per work item
   int wox, nwork, tiles, chunks;   // x-blocks per output row, work items per image, workgroups per (image, chunk), chunks
-  SETail se;                       // se.cnt != nullptr: the image's last workgroup computes the squeeze-excite gate (se_tail.hpp)
 };
 
 // Sliding window: a work item = (x-block of PX output columns, run of RY output rows) of one channel quad.  The K input
@@ -39,15 +37,14 @@ struct DWSArgs {
 // 3x instead of 15x at k = 5 (PX = 2).  The L1 <- L2 path, not HBM, is what bounded the plain kernel (its 18 / 40
 // loads per x-block moved 6.5 TB/s out of L2 for 2.9 TB/s of useful traffic).
 // Weights: K = 3 in VGPRs (36); K = 5 in LDS (the 100 registers go to the window instead).
-// TAIL: the image's last workgroup forms the squeeze-excite gate (se_tail.hpp; opt-in, OCV_SE_TAIL=1).  A template parameter: compiled
-// into the one kernel, the tail's 32 loads in flight set the register count of every launch (k = 5: 9 spilled registers).
-template <int K, int S, int PX, bool TAIL>
+// (Round 4 built the squeeze-excite gate INTO this launch -- the image's last workgroup to arrive formed it: correct under load, 50
+// launches fewer, not faster (profiles/r04_se_tail.txt); removed in round 5, source in tools/diag/se_tail.patch.txt.)
+template <int K, int S, int PX>
 __global__ __launch_bounds__(256, 2) void dw_slide_kernel(DWSArgs p) {
   constexpr int NIN = (PX - 1) * S + K;
   constexpr bool WLDS = K > 3;
   __shared__ float4 red[256];
   __shared__ float4 wsh[WLDS ? K * K * 64 : 1];
-  __shared__ float se_sm[SE_TAIL_LDS_FLOATS];
   const int tid = threadIdx.x;
   const int q = tid % p.QL, pl = tid / p.QL;
   const int c4n = p.C >> 2;
@@ -183,16 +180,7 @@ __global__ __launch_bounds__(256, 2) void dw_slide_kernel(DWSArgs p) {
       t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
     }
     float* dst = p.part + ((b * p.tiles + tile) * (long)p.C) + c;
-    if constexpr (TAIL) {
-      se_store_sc1(dst, t);                                     // write-through: read by the image's last workgroup, on any XCD
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drained before this workgroup's ticket is drawn
-    } else {
-      *reinterpret_cast<float4*>(dst) = t;
-    }
-  }
-  if constexpr (TAIL) {
-    if (se_arrive(p.se, b, se_sm))
-      se_gate_from_partials(p.se, p.part + b * p.tiles * (long)p.C, p.tiles, p.C, b, se_sm);
+    *reinterpret_cast<float4*>(dst) = t;
   }
 }
 
@@ -430,7 +418,6 @@ __global__ __launch_bounds__(1024) void se_fused_small_kernel(const float* __res
 // re-split by every workgroup that touches them.  Grid (ceil(K / 64), B): a workgroup forms the gate of its 64 input
 // channels (same summation order as se_gate_hid_kernel) and scales / splits / packs their column block of W for all N
 // rows; thread = (octet of 8 inputs, one of 32 consecutive output rows): a wavefront half writes 512 contiguous bytes.
-// hid == nullptr: the gate itself is given (gate [B][C], written by the depthwise launch's last workgroups: se_tail.hpp).
 __global__ __launch_bounds__(256) void se_gate_weights_kernel(const float* __restrict__ hid, const float* __restrict__ w2t,
                                                               const float* __restrict__ b2, const float* __restrict__ W,
                                                               __bf16* __restrict__ wpk, long img_elems, float* __restrict__ gate,
@@ -440,14 +427,12 @@ __global__ __launch_bounds__(256) void se_gate_weights_kernel(const float* __res
   const long b = blockIdx.y;
   const int tid = threadIdx.x;
   const int k0 = blockIdx.x * 64;
-  if (hid != nullptr && tid < R) hs[tid] = hid[b * R + tid];
+  if (tid < R) hs[tid] = hid[b * R + tid];
   __syncthreads();
   if (tid < 64) {
     const int c = k0 + tid;
     float g = 0.f;                                   // inputs past C (K padded to 16): weight columns of zeros
-    if (c < C && hid == nullptr) {
-      g = gate[b * C + c];
-    } else if (c < C) {
+    if (c < C) {
       const float* w = w2t + c;
       float s0 = b2[c], s1 = 0.f, s2 = 0.f, s3 = 0.f;
       int r = 0;
@@ -512,10 +497,7 @@ __global__ __launch_bounds__(256) void se_gate_weights_kernel(const float* __res
 
 template <int K, int S, int PX>
 int launch_dws(const DWSArgs& a, const DWSGeom& g, int B, hipStream_t st) {
-  if (a.se.cnt != nullptr)
-    hipLaunchKernelGGL((dw_slide_kernel<K, S, PX, true>), dim3((unsigned)((long)g.tiles * g.chunks * B)), dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL((dw_slide_kernel<K, S, PX, false>), dim3((unsigned)((long)g.tiles * g.chunks * B)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((dw_slide_kernel<K, S, PX>), dim3((unsigned)((long)g.tiles * g.chunks * B)), dim3(256), 0, st, a);
   OCV_CHECK_LAUNCH("ocv_depthwise_conv_nhwc_sum_fwd");
   return 0;
 }
@@ -534,7 +516,7 @@ extern "C" int ocv_depthwise_conv_nhwc_sum_fwd(const float* in, const float* w, 
 }
 
 namespace {
-int dws_run(const float* in, const float* w, const float* bias, float* out, void* out_hl, float* part, const SETail* se,
+int dws_run(const float* in, const float* w, const float* bias, float* out, void* out_hl, float* part,
             int B, int C, int H, int W, int k, int stride, int pad_t, int pad_l, int Ho, int Wo, ocv_stream_t stream) {
   OCV_CHECK_ARG(in && w && (out || out_hl) && part, "ocv_depthwise_conv_nhwc_sum_fwd: null pointer");
   OCV_CHECK_ARG(out_hl == nullptr || (C % 32 == 0 && ocv_aligned16(out_hl)), "ocv_depthwise_conv_nhwc_sum_hl_fwd: the split output needs C to be a multiple of 32 (got %d) and 16-byte alignment", C);
@@ -545,12 +527,7 @@ int dws_run(const float* in, const float* w, const float* bias, float* out, void
   OCV_CHECK_ARG(ocv_aligned16(in) && ocv_aligned16(w) && ocv_aligned16(out) && ocv_aligned16(bias) && ocv_aligned16(part), "ocv_depthwise_conv_nhwc_sum_fwd: operands must be 16-byte aligned");
   const DWSGeom g = dws_geom(B, C, Ho, Wo, k, stride);
   OCV_CHECK_ARG((long)g.tiles * g.chunks * B < (1L << 31), "ocv_depthwise_conv_nhwc_sum_fwd: too many workgroups");
-  DWSArgs a{in, w, bias, out, part, (__bf16*)out_hl, C, H, W, Ho, Wo, pad_t, pad_l, g.QL, g.PL, g.RY, g.wox, g.nwork, g.tiles, g.chunks, SETail{}};
-  if (se != nullptr) {
-    a.se = *se;
-    a.se.total = g.tiles * g.chunks;
-    a.se.inv = 1.0f / (float)((long)Ho * Wo);
-  }
+  DWSArgs a{in, w, bias, out, part, (__bf16*)out_hl, C, H, W, Ho, Wo, pad_t, pad_l, g.QL, g.PL, g.RY, g.wox, g.nwork, g.tiles, g.chunks};
   hipStream_t st = (hipStream_t)stream;
   if (k == 3 && stride == 1) return launch_dws<3, 1, 4>(a, g, B, st);
   if (k == 3 && stride == 2) return launch_dws<3, 2, 2>(a, g, B, st);
@@ -562,37 +539,7 @@ int dws_run(const float* in, const float* w, const float* bias, float* out, void
 extern "C" int ocv_depthwise_conv_nhwc_sum_hl_fwd(const float* in, const float* w, const float* bias, float* out, void* out_hl,
                                                   float* part, int B, int C, int H, int W, int k, int stride, int pad_t,
                                                   int pad_l, int Ho, int Wo, ocv_stream_t stream) {
-  return dws_run(in, w, bias, out, out_hl, part, nullptr, B, C, H, W, k, stride, pad_t, pad_l, Ho, Wo, stream);
-}
-
-extern "C" int ocv_se_tail_supported(int C, int R) {
-  return C >= 4 && C % 4 == 0 && C <= SE_TAIL_MAX_C && R >= 1 && R <= SE_TAIL_MAX_R;
-}
-
-extern "C" int ocv_depthwise_conv_nhwc_se_fwd(const float* in, const float* w, const float* bias, float* out, void* out_hl,
-                                              float* part, const float* se_w1, const float* se_b1, const float* se_w2t,
-                                              const float* se_b2, int R, float* gate, unsigned* counters, int B, int C, int H,
-                                              int W, int k, int stride, int pad_t, int pad_l, int Ho, int Wo,
-                                              ocv_stream_t stream) {
-  OCV_CHECK_ARG(se_w1 && se_b1 && se_w2t && se_b2 && gate && counters, "ocv_depthwise_conv_nhwc_se_fwd: null pointer");
-  OCV_CHECK_ARG(ocv_se_tail_supported(C, R), "ocv_depthwise_conv_nhwc_se_fwd: the in-launch squeeze-excite tail takes C <= %d (a multiple of 4) and R <= %d (got C = %d, R = %d)",
-                SE_TAIL_MAX_C, SE_TAIL_MAX_R, C, R);
-  OCV_CHECK_ARG((reinterpret_cast<uintptr_t>(counters) & 3) == 0, "ocv_depthwise_conv_nhwc_se_fwd: counters must be 4-byte aligned");
-  const SETail se{se_w1, se_b1, se_w2t, se_b2, gate, counters, R, 0, 0.f};
-  return dws_run(in, w, bias, out, out_hl, part, &se, B, C, H, W, k, stride, pad_t, pad_l, Ho, Wo, stream);
-}
-
-extern "C" int ocv_se_fold_gate_weights_fwd(const float* gate, const float* W, void* w_packed, long w_image_elems, int B, int C,
-                                            int N, ocv_stream_t stream) {
-  OCV_CHECK_ARG(gate && W && w_packed, "ocv_se_fold_gate_weights_fwd: null pointer");
-  OCV_CHECK_ARG(B >= 1 && B <= 65535 && C >= 8 && C % 8 == 0 && N >= 1, "ocv_se_fold_gate_weights_fwd: bad sizes (C a multiple of 8)");
-  OCV_CHECK_ARG(w_image_elems >= (long)ocv_pointwise_packed_weight_elems(C, N) && (w_image_elems & 7) == 0 && ocv_aligned16(w_packed) && ocv_aligned16(W),
-                "ocv_se_fold_gate_weights_fwd: w_image_elems must hold one packed matrix (ocv_pointwise_packed_weight_elems) and keep 16-byte alignment");
-  const int Kp = (C + 15) / 16 * 16;
-  hipLaunchKernelGGL(se_gate_weights_kernel, dim3((Kp + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr,
-                     (const float*)nullptr, (const float*)nullptr, W, (__bf16*)w_packed, w_image_elems, const_cast<float*>(gate), C, 0, N);
-  OCV_CHECK_LAUNCH("ocv_se_fold_gate_weights_fwd");
-  return 0;
+  return dws_run(in, w, bias, out, out_hl, part, B, C, H, W, k, stride, pad_t, pad_l, Ho, Wo, stream);
 }
 
 extern "C" int ocv_se_gate_partials_fwd(const float* part, int tiles, long pixels_per_image, const float* w1,

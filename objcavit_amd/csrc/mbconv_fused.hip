@@ -25,7 +25,6 @@
 // Halo recompute of the GEMM: 340 / 256 pixels (k = 3), 432 / 256 (k = 5) -- the GEMM is a few percent of the block's
 // time at Cin <= 64, which is what this kernel is limited to (A fragments of a pixel tile fully in VGPRs).
 #include "common.hpp"
-#include "se_tail.hpp"
 #include "../../include/objcavit_hip.h"
 
 namespace {
@@ -38,7 +37,6 @@ struct FXArgs {
   float *y, *part;
   int Cin, mid, H, W, Ho, Wo, pad_t, pad_l;
   int tiles_x, tiles_per_image, nchunks;
-  SETail se;                        // se.cnt != nullptr: the image's last workgroup computes the squeeze-excite gate (se_tail.hpp)
 };
 
 template <int K, int S>
@@ -51,7 +49,6 @@ struct FXGeom {
   static constexpr int HALF = (IW + 1) / 2;
   static constexpr int NLI = (NR - 1) * S + K;         // halo rows a thread walks
   static constexpr int LDS_BYTES = MT * 32 * 32 * 4;
-  static_assert(LDS_BYTES >= SE_TAIL_LDS_FLOATS * 4, "the squeeze-excite tail reuses the staging array");
   // LDS slot of halo pixel (py, px)
   __device__ static __forceinline__ int slot(int py, int px) {
     return S == 1 ? py * IW + px : py * IW + (px >> 1) + (px & 1) * HALF;
@@ -73,10 +70,8 @@ __device__ __forceinline__ float4 fx_fma4(const float4 w, const float4 v, float4
   return a;
 }
 
-// TAIL: the image's last workgroup computes the squeeze-excite gate (se_tail.hpp; opt-in).  A template parameter because the tail's
-// 32 loads in flight set the register count of the WHOLE kernel: compiled in, the default launches paid for it in occupancy.
-template <int K, int S, int KS, bool TAIL>
-__global__ __launch_bounds__(256, K == 3 ? ((TAIL || S == 2) ? 2 : 3) : 1) void mbconv_expand_dw_kernel(FXArgs p) {
+template <int K, int S, int KS>
+__global__ __launch_bounds__(256, K == 3 ? (S == 2 ? 2 : 3) : 1) void mbconv_expand_dw_kernel(FXArgs p) {
   using G = FXGeom<K, S>;
   extern __shared__ __attribute__((aligned(16))) float e[];        // [MT * 32 pixels][32 channels]
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -229,18 +224,7 @@ __global__ __launch_bounds__(256, K == 3 ? ((TAIL || S == 2) ? 2 : 3) : 1) void 
     float s = 0.f;
 #pragma unroll 8
     for (int j = 0; j < 32; ++j) s += e[j * 32 + tid];
-    float* dst = p.part + ((long)b * p.tiles_per_image + t2) * p.mid + n0 + tid;
-    if constexpr (TAIL) {
-      se_store_sc1(dst, s);                                     // write-through: read by the image's last workgroup, on any XCD
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      *dst = s;
-    }
-  }
-  // (the staging array is free again behind se_arrive's first barrier: it needs SE_TAIL_LDS_FLOATS floats of it)
-  if constexpr (TAIL) {
-    if (se_arrive(p.se, b, e))
-      se_gate_from_partials(p.se, p.part + (long)b * p.tiles_per_image * p.mid, p.tiles_per_image, p.mid, b, e);
+    p.part[((long)b * p.tiles_per_image + t2) * p.mid + n0 + tid] = s;
   }
 }
 
@@ -249,15 +233,11 @@ int fx_launch(const FXArgs& a, int B, hipStream_t st) {
   using G = FXGeom<K, S>;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)mbconv_expand_dw_kernel<K, S, KS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)mbconv_expand_dw_kernel<K, S, KS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)mbconv_expand_dw_kernel<K, S, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     attr = true;
   }
   const long grid = (long)B * a.tiles_per_image * a.nchunks;
-  if (a.se.cnt != nullptr)
-    hipLaunchKernelGGL((mbconv_expand_dw_kernel<K, S, KS, true>), dim3((unsigned)grid), dim3(256), G::LDS_BYTES, st, a);
-  else
-    hipLaunchKernelGGL((mbconv_expand_dw_kernel<K, S, KS, false>), dim3((unsigned)grid), dim3(256), G::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((mbconv_expand_dw_kernel<K, S, KS>), dim3((unsigned)grid), dim3(256), G::LDS_BYTES, st, a);
   OCV_CHECK_LAUNCH("ocv_mbconv_expand_dw_fwd");
   return 0;
 }
@@ -279,7 +259,7 @@ extern "C" int ocv_mbconv_expand_dw_tiles(int Ho, int Wo, int k, int stride) {
 
 namespace {
 int fx_run(const float* x, const void* w_packed, const float* bias_expand, const float* w_dw, const float* bias_dw, float* y,
-           float* part, const SETail* se, int B, int H, int W, int Cin, int mid, int k, int stride, int pad_t, int pad_l,
+           float* part, int B, int H, int W, int Cin, int mid, int k, int stride, int pad_t, int pad_l,
            int Ho, int Wo, ocv_stream_t stream) {
   OCV_CHECK_ARG(x && w_packed && w_dw && y && part, "ocv_mbconv_expand_dw_fwd: null pointer");
   OCV_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && Ho >= 1 && Wo >= 1, "ocv_mbconv_expand_dw_fwd: bad sizes");
@@ -298,11 +278,6 @@ int fx_run(const float* x, const void* w_packed, const float* bias_expand, const
   a.tiles_per_image = ((Ho + 7) / 8) * a.tiles_x;
   a.nchunks = (mid + 31) / 32;
   OCV_CHECK_ARG((long)B * a.tiles_per_image * a.nchunks < (1L << 31), "ocv_mbconv_expand_dw_fwd: too many work items");
-  if (se != nullptr) {
-    a.se = *se;
-    a.se.total = a.tiles_per_image * a.nchunks;
-    a.se.inv = 1.0f / (float)((long)Ho * Wo);
-  }
   const int ks = (Cin + 15) / 16;
   hipStream_t st = (hipStream_t)stream;
   if (k == 3 && stride == 1) return fx_dispatch_ks<3, 1>(a, B, ks, st);
@@ -315,18 +290,5 @@ int fx_run(const float* x, const void* w_packed, const float* bias_expand, const
 extern "C" int ocv_mbconv_expand_dw_fwd(const float* x, const void* w_packed, const float* bias_expand, const float* w_dw,
                                         const float* bias_dw, float* y, float* part, int B, int H, int W, int Cin, int mid,
                                         int k, int stride, int pad_t, int pad_l, int Ho, int Wo, ocv_stream_t stream) {
-  return fx_run(x, w_packed, bias_expand, w_dw, bias_dw, y, part, nullptr, B, H, W, Cin, mid, k, stride, pad_t, pad_l, Ho, Wo, stream);
-}
-
-extern "C" int ocv_mbconv_expand_dw_se_fwd(const float* x, const void* w_packed, const float* bias_expand, const float* w_dw,
-                                           const float* bias_dw, float* y, float* part, const float* se_w1, const float* se_b1,
-                                           const float* se_w2t, const float* se_b2, int R, float* gate, unsigned* counters,
-                                           int B, int H, int W, int Cin, int mid, int k, int stride, int pad_t, int pad_l,
-                                           int Ho, int Wo, ocv_stream_t stream) {
-  OCV_CHECK_ARG(se_w1 && se_b1 && se_w2t && se_b2 && gate && counters, "ocv_mbconv_expand_dw_se_fwd: null pointer");
-  OCV_CHECK_ARG(ocv_se_tail_supported(mid, R), "ocv_mbconv_expand_dw_se_fwd: the in-launch squeeze-excite tail takes C <= %d (a multiple of 4) and R <= %d (got C = %d, R = %d)",
-                SE_TAIL_MAX_C, SE_TAIL_MAX_R, mid, R);
-  OCV_CHECK_ARG((reinterpret_cast<uintptr_t>(counters) & 3) == 0, "ocv_mbconv_expand_dw_se_fwd: counters must be 4-byte aligned");
-  const SETail se{se_w1, se_b1, se_w2t, se_b2, gate, counters, R, 0, 0.f};
-  return fx_run(x, w_packed, bias_expand, w_dw, bias_dw, y, part, &se, B, H, W, Cin, mid, k, stride, pad_t, pad_l, Ho, Wo, stream);
+  return fx_run(x, w_packed, bias_expand, w_dw, bias_dw, y, part, B, H, W, Cin, mid, k, stride, pad_t, pad_l, Ho, Wo, stream);
 }

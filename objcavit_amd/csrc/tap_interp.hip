@@ -26,9 +26,9 @@
 // neighbour is always read at +128 bytes: where ATen clamps it (last column) its weight is exactly 0 and the slot read holds
 // staged (finite) data.
 //
-// Round 4, OPT-IN (ocv_tap_interp_skip_fwd, template parameter SK; hip_ops.tap_skip_fused_pays): the skip part formed inside this
-// launch on the matrix cores instead of read as a tensor.  Correct, tested, and slower than the two launches -- the wavefront
-// tiles' operand traffic through L1 is what a GEMM with LDS tiles exists to avoid (profiles/r04_tap_skip.txt).
+// (Round 4 also formed the skip part INSIDE this launch, on the matrix cores: correct, tested, 8 % slower end to end -- a
+// wavefront-sized MFMA tile fed from L1 is what a GEMM with LDS tiles exists to avoid (profiles/r04_tap_skip.txt).  Removed in round
+// 5; source: tools/diag/tap_skip.patch.txt.)
 #include "common.hpp"
 #include "../../include/objcavit_hip.h"
 
@@ -54,12 +54,6 @@ struct TIArgs {
   int tiles_x, tiles_y;
   int fq_cap;            // pixels per staging buffer (multiple of 32: whole 256-lane rounds)
   int f16;               // element type of yhl
-  // fused skip part (SK != 0): conv3x3 over the skip tensor formed INSIDE this launch on the matrix cores (s is then null)
-  const void* shl;       // skip tensor, hl32 split layout [B][H][W][2 Cps] (element type = the kernel's SK)
-  const void* swhi;      // its weight halves [9][Cout][Cps] (2-byte elements; hip_ops.prep_conv_weight)
-  const void* swlo;
-  const float* sosc;     // [Cout] scale of the raw skip sums (fp16 pairs with per-channel weight scales), nullable
-  int Cps;               // skip channels rounded up to 32
   unsigned* range_flag;  // nullable: armed range-guard word, noted only where yhl holds fp16 pairs (common.hpp ocv_range_note)
 };
 
@@ -88,8 +82,7 @@ __device__ __forceinline__ void ti_wait_vm() {
 }
 
 // NJ = 256-chunk rounds (16 bytes per chunk) per tap: ceil((footprint + 1) x 8 / 256)
-// SK: 0 = the skip part comes as a tensor (p.s) or not at all; 1 / 2 = it is formed here from bf16 / fp16 pairs (below)
-template <int NJ, int SK>
+template <int NJ>
 __global__ __launch_bounds__(320, 4) void tap_interp_kernel(TIArgs p) {
   extern __shared__ __attribute__((aligned(16))) float zs[];          // [NBUF][fq_cap][CB]
   const int tid = threadIdx.x;
@@ -173,71 +166,11 @@ __global__ __launch_bounds__(320, 4) void tap_interp_kernel(TIArgs p) {
   }
 
   float4 acc[4], sv[4];                                // sv: the skip part of this item's pixels, requested before the taps
-  if constexpr (SK == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int Y = Y0 + (tid >> 7) + 2 * i, X = X0 + ((tid >> 3) & 15);
-      const bool ok = p.s != nullptr && Y < p.H && X < p.W && cb0 + cg < p.Cout;
-      sv[i] = ok ? ld4(p.s + (((long)b * p.H + Y) * p.W + X) * p.Cout + cb0 + cg) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  } else {
-    // The skip part on the matrix cores, while the first taps are in flight: wavefront cw's 32 x 32 tile = the 32 pixels its own
-    // lanes own (rows (cw >> 1) + 2 i, columns 8 (cw & 1) + 0..7: A row m = 8 i + column) x the block's 32 channels, K = 9 taps x
-    // Cps channels, three products per K step (hi hi + hi lo + lo hi, fp32 accumulate: the arithmetic of csrc/conv_igemm.hip).
-    // Operands straight from global memory in fragment order (a pixel's 32-channel block is one 128-byte line: [32 hi][32 lo];
-    // lane (m, kh) takes the 16 bytes of channels 16 ks + 8 kh ..+7 of both halves), padded taps / pixels past the image read a
-    // clamped address and are zeroed.  The tile goes through this wavefront's own 4 KB of LDS (tap 2's staging buffer + the spare
-    // region behind it: free until the producer issues tap 2, which is behind the barrier below) into the items' layout.
-    const int lane = tid & 63, cw = tid >> 6, m = lane & 31, kh = lane >> 5;
-    const int Yp = Y0 + (cw >> 1) + 2 * (m >> 3), Xp = X0 + 8 * (cw & 1) + (m & 7);
-    const int nB = min(cb0 + m, p.Cout - 1);                                      // B column = channel of this lane (tail: clamped, unused)
-    const char* xs = (const char*)p.shl + (long)b * p.H * p.W * 4 * p.Cps + kh * 16;
-    const char* wh = (const char*)p.swhi + ((long)nB * p.Cps + kh * 8) * 2;
-    const char* wl = (const char*)p.swlo + ((long)nB * p.Cps + kh * 8) * 2;
-    const int wtap = p.Cout * p.Cps * 2;                                          // bytes per tap of a weight half
-    const int ncb = p.Cps >> 5;
-    f32x16 sacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const ti_bf16x8 zero8 = __builtin_bit_cast(ti_bf16x8, make_uint4(0u, 0u, 0u, 0u));
-#pragma unroll 1
-    for (int t = 0; t < 9; ++t) {
-      const int yy = Yp + t / 3 - 1, xx = Xp + t % 3 - 1;
-      const bool ok = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-      const char* pa = xs + (min(max(yy, 0), p.H - 1) * p.W + min(max(xx, 0), p.W - 1)) * (4 * p.Cps);
-      const char* pbh = wh + t * wtap;
-      const char* pbl = wl + t * wtap;
-#pragma unroll 2
-      for (int c = 0; c < ncb; ++c) {
-        ti_bf16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          ah[ks] = *reinterpret_cast<const ti_bf16x8*>(pa + c * 128 + ks * 32);
-          al[ks] = *reinterpret_cast<const ti_bf16x8*>(pa + c * 128 + ks * 32 + 64);
-          bh[ks] = *reinterpret_cast<const ti_bf16x8*>(pbh + c * 64 + ks * 32);
-          bl[ks] = *reinterpret_cast<const ti_bf16x8*>(pbl + c * 64 + ks * 32);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const ti_bf16x8 a0 = ok ? ah[ks] : zero8, a1 = ok ? al[ks] : zero8;
-          if constexpr (SK == 2) {
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ti_h16x8, a0), __builtin_bit_cast(ti_h16x8, bh[ks]), sacc, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ti_h16x8, a0), __builtin_bit_cast(ti_h16x8, bl[ks]), sacc, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ti_h16x8, a1), __builtin_bit_cast(ti_h16x8, bh[ks]), sacc, 0, 0, 0);
-          } else {
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bh[ks], sacc, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bl[ks], sacc, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bh[ks], sacc, 0, 0, 0);
-          }
-        }
-      }
-    }
-    const float osc = p.sosc != nullptr ? p.sosc[nB] : 1.f;
-    float* sw = zs + 2 * bufstride + cw * (32 * CB);                               // this wavefront's 32 pixels x 32 channels
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sw[acc_row(r, kh) * CB + m] = sacc[r] * osc;      // accumulator row = pixel, lane column = channel
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                             // (same wavefront writes and reads: no barrier)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sv[i] = *reinterpret_cast<const float4*>(sw + (8 * i + (lane >> 3)) * CB + cg);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                             // read back before tap 2 may land in the buffer
+  for (int i = 0; i < 4; ++i) {
+    const int Y = Y0 + (tid >> 7) + 2 * i, X = X0 + ((tid >> 3) & 15);
+    const bool ok = p.s != nullptr && Y < p.H && X < p.W && cb0 + cg < p.Cout;
+    sv[i] = ok ? ld4(p.s + (((long)b * p.H + Y) * p.W + X) * p.Cout + cb0 + cg) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -367,10 +300,8 @@ extern "C" int ocv_tap_interp_combine_fwd(const float* z, int h, int w, int zpad
 }
 
 namespace {
-// checks + launch shared by the two entry points (skip part as a tensor / formed in the launch)
-int ti_launch(const char* who, const float* z, int h, int w, int zpad, const float* zborder, const float* s, const void* skip_hl, int Cs,
-              const void* ws_hi, const void* ws_lo, const float* s_oscale, const float* bias, float* y, void* y_hl, int hl_f16, int B,
-              int H, int W, int Cout, int act, ocv_stream_t stream) {
+int ti_launch(const char* who, const float* z, int h, int w, int zpad, const float* zborder, const float* s, const float* bias, float* y,
+              void* y_hl, int hl_f16, int B, int H, int W, int Cout, int act, ocv_stream_t stream) {
   OCV_CHECK_ARG(z && (y || y_hl), "%s: null pointer", who);
   OCV_CHECK_ARG(hl_f16 == 0 || hl_f16 == 1, "%s: hl_f16 must be 0 (bf16 pairs) or 1 (fp16 pairs)", who);
   OCV_CHECK_ARG((zpad == 0 && zborder == nullptr) || (zpad == 1 && zborder != nullptr && h >= 3 && w >= 3 && ocv_aligned16(zborder)),
@@ -384,17 +315,10 @@ int ti_launch(const char* who, const float* z, int h, int w, int zpad, const flo
                 "%s: operands must be 16-byte aligned", who);
   OCV_CHECK_ARG(ocv_tap_interp_supported(h, w, H, W, Cout), "%s: the low-resolution footprint of an output tile "
                 "exceeds the staging buffer (h=%d w=%d H=%d W=%d): not an up-sampling by ~2 or more", who, h, w, H, W);
-  const int Cps = (Cs + 31) / 32 * 32;
-  if (skip_hl != nullptr) {
-    OCV_CHECK_ARG(s == nullptr && ws_hi != nullptr && ws_lo != nullptr && Cs >= 1, "%s: the fused skip part needs its weight halves", who);
-    OCV_CHECK_ARG(ocv_aligned16(skip_hl) && ocv_aligned16(ws_hi) && ocv_aligned16(ws_lo), "%s: operands must be 16-byte aligned", who);
-    OCV_CHECK_ARG((long)H * W * 4 * Cps < (1L << 31) && (long)9 * Cout * Cps * 2 < (1L << 31),
-                  "%s: one image's skip tensor / the skip weight must stay below 2^31 bytes (32-bit offsets inside the kernel)", who);
-  }
   const int nj = ocv_cdiv(ti_footprint(h, w, H, W) + 1, 32);       // 1..6 staging rounds per tap (footprint + one spare slot)
   TIArgs a{z, zborder, s, bias, y, (__bf16*)y_hl, h, w, H, W, Cout, (Cout + 31) / 32 * 32, act, zpad,
            H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f,
-           ocv_cdiv(W, TX), ocv_cdiv(H, TY), nj * 32, hl_f16, skip_hl, ws_hi, ws_lo, s_oscale, Cps,
+           ocv_cdiv(W, TX), ocv_cdiv(H, TY), nj * 32, hl_f16,
            (hl_f16 && y_hl != nullptr) ? ocv_range_flag_current() : nullptr};
   const long nwg = (long)a.tiles_x * a.tiles_y * B;
   OCV_CHECK_ARG(nwg < (1L << 31) && ocv_cdiv(Cout, CB) <= 65535, "%s: grid too large", who);
@@ -404,26 +328,18 @@ int ti_launch(const char* who, const float* z, int h, int w, int zpad, const flo
   }
   const dim3 grid((unsigned)nwg, ocv_cdiv(Cout, CB));
   const size_t buf = (size_t)a.fq_cap * CB * sizeof(float);
-  size_t lds = NBUF * buf;
-  const int sk = skip_hl == nullptr ? 0 : 1 + hl_f16;
-  if (sk != 0 && lds < 2 * buf + (size_t)TY * TX * CB * sizeof(float))       // the skip tile starts in tap 2's buffer and may run past it
-    lds = 2 * buf + (size_t)TY * TX * CB * sizeof(float);
+  const size_t lds = NBUF * buf;
   const void* fn = nullptr;
-  switch (nj * 3 + sk) {
-#define OCV_TI_CASE(NJ, SK) case NJ * 3 + SK: fn = reinterpret_cast<const void*>(&tap_interp_kernel<NJ, SK>); \
-    hipLaunchKernelGGL((tap_interp_kernel<NJ, SK>), grid, dim3(320), lds, (hipStream_t)stream, a); break;
-#define OCV_TI_ROW(NJ) OCV_TI_CASE(NJ, 0) OCV_TI_CASE(NJ, 1) OCV_TI_CASE(NJ, 2)
-    OCV_TI_ROW(1) OCV_TI_ROW(2) OCV_TI_ROW(3) OCV_TI_ROW(4) OCV_TI_ROW(5)
-#undef OCV_TI_ROW
+  switch (nj) {
+#define OCV_TI_CASE(NJ) case NJ: fn = reinterpret_cast<const void*>(&tap_interp_kernel<NJ>); \
+    hipLaunchKernelGGL((tap_interp_kernel<NJ>), grid, dim3(320), lds, (hipStream_t)stream, a); break;
+    OCV_TI_CASE(1) OCV_TI_CASE(2) OCV_TI_CASE(3) OCV_TI_CASE(4) OCV_TI_CASE(5)
 #undef OCV_TI_CASE
     default: {                                                      // nj == 6: 72 KB of dynamic LDS, above the 64 KB default limit
-      fn = sk == 0 ? reinterpret_cast<const void*>(&tap_interp_kernel<6, 0>)
-                   : sk == 1 ? reinterpret_cast<const void*>(&tap_interp_kernel<6, 1>) : reinterpret_cast<const void*>(&tap_interp_kernel<6, 2>);
+      fn = reinterpret_cast<const void*>(&tap_interp_kernel<6>);
       const hipError_t attr = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       OCV_CHECK_ARG(attr == hipSuccess, "%s: hipFuncSetAttribute failed: %s", who, hipGetErrorString(attr));
-      if (sk == 0) hipLaunchKernelGGL((tap_interp_kernel<6, 0>), grid, dim3(320), lds, (hipStream_t)stream, a);
-      else if (sk == 1) hipLaunchKernelGGL((tap_interp_kernel<6, 1>), grid, dim3(320), lds, (hipStream_t)stream, a);
-      else hipLaunchKernelGGL((tap_interp_kernel<6, 2>), grid, dim3(320), lds, (hipStream_t)stream, a);
+      hipLaunchKernelGGL((tap_interp_kernel<6>), grid, dim3(320), lds, (hipStream_t)stream, a);
     }
   }
   (void)fn;
@@ -435,14 +351,5 @@ int ti_launch(const char* who, const float* z, int h, int w, int zpad, const flo
 extern "C" int ocv_tap_interp_combine_x_fwd(const float* z, int h, int w, int zpad, const float* zborder, const float* s,
                                             const float* bias, float* y, void* y_hl, int hl_f16, int B, int H, int W, int Cout,
                                             int act, ocv_stream_t stream) {
-  return ti_launch("ocv_tap_interp_combine_fwd", z, h, w, zpad, zborder, s, nullptr, 0, nullptr, nullptr, nullptr, bias, y, y_hl, hl_f16,
-                   B, H, W, Cout, act, stream);
-}
-
-extern "C" int ocv_tap_interp_skip_fwd(const float* z, int h, int w, int zpad, const float* zborder, const void* skip_hl, int Cs,
-                                       const void* ws_hi, const void* ws_lo, const float* s_oscale, const float* bias, float* y,
-                                       void* y_hl, int hl_f16, int B, int H, int W, int Cout, int act, ocv_stream_t stream) {
-  OCV_CHECK_ARG(skip_hl != nullptr, "ocv_tap_interp_skip_fwd: null skip tensor");
-  return ti_launch("ocv_tap_interp_skip_fwd", z, h, w, zpad, zborder, nullptr, skip_hl, Cs, ws_hi, ws_lo, s_oscale, bias, y, y_hl, hl_f16,
-                   B, H, W, Cout, act, stream);
+  return ti_launch("ocv_tap_interp_combine_fwd", z, h, w, zpad, zborder, s, bias, y, y_hl, hl_f16, B, H, W, Cout, act, stream);
 }

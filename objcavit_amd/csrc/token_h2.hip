@@ -15,7 +15,6 @@
 #include <stdlib.h>
 
 #include "common.hpp"
-#include "se_tail.hpp"             // sc1 stores / typed atomics of the in-launch hand-off
 #include "../../include/objcavit_hip.h"
 
 namespace {
@@ -144,7 +143,7 @@ struct TailArgs {
 // G > 1 (round 4, few tokens -- the reference's own batch of 1 - 2 images, 10 - 19 row blocks on 256 CUs): the launch is bound by
 // the 20-phase fragment stream of ONE workgroup (~50 us whatever the batch), so the eight feed-forward chunks of a row block go to
 // G workgroups (each repeats the output projection and LN1, walks nchunk / G chunks and leaves its raw partial sums write-through),
-// and the row block's LAST workgroup to arrive -- an agent-scope ticket, nobody waits (se_tail.hpp) -- adds the partials in the
+// and the row block's LAST workgroup to arrive -- an agent-scope ticket, nobody waits (common.hpp) -- adds the partials in the
 // fixed order 0 .. G - 1, does LN2 and the next layer's projection: 3 + 4 phases instead of 20.  G = 1 is the kernel of round 3,
 // instruction for instruction.
 template <int G>
@@ -225,16 +224,16 @@ __global__ __launch_bounds__(256, 1) void layer_tail_h2_kernel(TailArgs p) {
     // raw partial sums of this workgroup's chunks, write-through; then the ticket
     float* mine = p.part + ((long)(blk * G + g) * TM) * E128 + col;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) se_store_sc1(mine + acc_row(r, hh) * E128, acc1[r] + acc2[r] * LO_DOWN);
+    for (int r = 0; r < 16; ++r) ocv_store_sc1(mine + acc_row(r, hh) * E128, acc1[r] + acc2[r] * LO_DOWN);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-      const unsigned old = __hip_atomic_fetch_add((se_gu32*)(p.cnt + blk), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned old = __hip_atomic_fetch_add((ocv_gu32*)(p.cnt + blk), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const bool last = old == (unsigned)(G - 1);
       if (last) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store((se_gu32*)(p.cnt + blk), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // nobody else touches it any more
+        __hip_atomic_store((ocv_gu32*)(p.cnt + blk), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // nobody else touches it any more
       }
       last_flag = last ? 1u : 0u;
     }

@@ -1262,30 +1262,13 @@ def tap_interp_supported(h: int, w: int, H: int, W: int, Cout: int) -> bool:
     return bool(_lib.load().ocv_tap_interp_supported(int(h), int(w), int(H), int(W), int(Cout)))
 
 
-def tap_skip_fused_pays(Cs: int, Cout: int, H: int, W: int) -> bool:
-    """Whether the skip part of a low-resolution first convolution is formed inside the tap-interpolation launch
-    (``tap_interp_combine(..., skip=...)``) instead of by a convolution launch of its own.  **Opt-in** (OCV_TAP_SKIP=1, then for up to
-    OCV_TAP_SKIP_MAX_CP = 64 padded skip channels): built, correct (``test_tap_interp_with_the_skip_part_inside``) and SLOWER -- bs 16,
-    one box, alternating: 1050 -> 963 img/s three in flight, 991 -> 889 one at a time, bs 1 308 -> 292; the last stage alone 1057 -> 1030,
-    its fused launch 1.53 ms against 0.735 + 0.42 for the pair (profiles/r04_tap_skip.txt).
-    It saves the skip-part launches (0.42 + 0.30 + 0.16 ms) and 1.1 GB of fp32 written and read, but a 32-pixel x 32-channel
-    wavefront tile re-reads its operands from L1 for every tap: ~300 KB per workgroup through a texture path that the kernel's own
-    staging already uses (3 workgroups per CU, 160 KB of LDS: no room to stage the skip halo and the weights), and the launches take
-    1.3 ms longer per step than the two-launch form's GEMM with its 256 x 128 LDS tiles."""
-    mode = os.environ.get("OCV_TAP_SKIP", "0")
-    if mode not in ("0", "1"):
-        raise ValueError(f"OCV_TAP_SKIP={mode!r}: expected '0' (default) or '1'")
-    return mode == "1" and (Cs + 31) // 32 * 32 <= int(os.environ.get("OCV_TAP_SKIP_MAX_CP", "64"))
-
-
 def tap_interp_combine(z: torch.Tensor, s: Optional[torch.Tensor], bias: Optional[torch.Tensor], size: Tuple[int, int],
                        act: int = ACT_NONE, out_fp32: bool = True, out_split: bool = False,
-                       border: Optional[torch.Tensor] = None, split_f16: bool = False, skip=None):
+                       border: Optional[torch.Tensor] = None, split_f16: bool = False):
     """act(bias + s + sum over the 9 taps of the bilinear (align_corners) interpolation of z's tap products at the tap
     position): ocv_tap_interp_combine_fwd.  z [B, 9 Cout, h, w] channels_last (tap-major columns), s [B, Cout, H, W]
     channels_last or None.  ``border`` [9 Cout]: z is the interior of an (h+2) x (w+2) grid whose border ring holds this
-    vector (Decoder.conv2's padding).  ``skip`` = (SplitAct of the skip tensor, w_hi, w_lo, oscale or None) instead of ``s``: the
-    skip part is formed inside the launch (ocv_tap_interp_skip_fwd; the pairs' element type must be ``split_f16``'s).
+    vector (Decoder.conv2's padding).  ``split_f16``: element type of the split output.
     Returns fp32 tensor, SplitAct, or (fp32, SplitAct)."""
     lib = _lib.load()
     if not (out_fp32 or out_split):
@@ -1314,31 +1297,10 @@ def tap_interp_combine(z: torch.Tensor, s: Optional[torch.Tensor], bias: Optiona
         raise ValueError(f"tap_interp_combine: unsupported resize {h}x{w} -> {H}x{W} / channel count {Cout}")
     y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=z.device, memory_format=torch.channels_last) if out_fp32 else None
     ys = SplitAct.empty(B, Cout, H, W, z.device, f16=split_f16) if out_split else None
-    if skip is not None:
-        xs, w_hi, w_lo, osc = skip
-        if s is not None:
-            raise ValueError("tap_interp_combine: either the skip part (s) or the skip tensor and its weight (skip), not both")
-        Cs = xs.C
-        Cps = (Cs + 31) // 32 * 32
-        if tuple(xs.shape) != (B, Cs, H, W) or xs.f16 != bool(split_f16) or not xs.hl.is_contiguous():
-            raise ValueError(f"tap_interp_combine: skip must be a contiguous {(B, Cs, H, W)} SplitAct of the output's element type")
-        want = torch.float16 if split_f16 else torch.bfloat16
-        for t in (w_hi, w_lo):
-            if t.dtype != want or tuple(t.shape) != (9, Cout, Cps) or not t.is_contiguous() or t.device != z.device:
-                raise ValueError(f"tap_interp_combine: skip weight halves must be contiguous {(9, Cout, Cps)} {want}")
-        if osc is not None:
-            _req(osc, "oscale")
-            if osc.numel() != Cout:
-                raise ValueError("tap_interp_combine: oscale size mismatch")
-        with timed(f"tap_interp|{B},{H},{W},{Cout}"):
-            check(lib.ocv_tap_interp_skip_fwd(z.data_ptr(), h, w, zpad, _ptr(border), xs.hl.data_ptr(), Cs, w_hi.data_ptr(), w_lo.data_ptr(),
-                                              _ptr(osc), _ptr(bias), _ptr(y), ys.hl.data_ptr() if out_split else None,
-                                              int(bool(split_f16)), B, H, W, Cout, act, _stream()), "ocv_tap_interp_skip_fwd")
-    else:
-        with timed(f"tap_interp|{B},{H},{W},{Cout}"):
-            check(lib.ocv_tap_interp_combine_x_fwd(z.data_ptr(), h, w, zpad, _ptr(border), _ptr(s), _ptr(bias), _ptr(y),
-                                                   ys.hl.data_ptr() if out_split else None, int(bool(split_f16)), B, H, W, Cout, act,
-                                                   _stream()), "ocv_tap_interp_combine_fwd")
+    with timed(f"tap_interp|{B},{H},{W},{Cout}"):
+        check(lib.ocv_tap_interp_combine_x_fwd(z.data_ptr(), h, w, zpad, _ptr(border), _ptr(s), _ptr(bias), _ptr(y),
+                                               ys.hl.data_ptr() if out_split else None, int(bool(split_f16)), B, H, W, Cout, act,
+                                               _stream()), "ocv_tap_interp_combine_fwd")
     _note_range(f"tap_interp|{B},{H},{W},{Cout}", ys)
     if out_fp32 and out_split:
         return y, ys
@@ -1876,32 +1838,10 @@ def depthwise_nhwc_same(x: torch.Tensor, weight_kkc: torch.Tensor, bias: Optiona
     return out
 
 
-def se_tail_pays(C: int, R: int) -> bool:
-    """Whether a block's squeeze-excite gate is computed INSIDE the launch that produces the pooled tensor, by the image's last
-    workgroup to finish (csrc/se_tail.hpp), instead of by the two launches behind it.  OPT-IN (OCV_SE_TAIL=1): built for VERDICT
-    r3 item 1b, correct under load (tests), 50 launches fewer per forward (271 -> 221) -- and NOT faster, measured
-    (profiles/r04_se_tail.txt): every depthwise workgroup pays ~1 us for draining its stores and drawing its ticket, and the one
-    workgroup that does the tail reads the partials (written through to memory) and 8 C R bytes of weights at a single
-    workgroup's ~60 - 100 GB/s: +10 ... +24 us per depthwise launch against the 13 - 17 us of the two launches it replaces;
-    sum of the depthwise + squeeze-excite kernels 3.06 -> 3.19 ms per step at bs 16, 1.13 -> 1.14 at bs 1.
-    OCV_SE_TAIL_MAX_BYTES bounds the squeeze-excite weight bytes of the blocks that take it (default 400 000: B5's stages 1 - 5)."""
-    mode = os.environ.get("OCV_SE_TAIL", "0")
-    if mode not in ("0", "1"):
-        raise ValueError(f"OCV_SE_TAIL={mode!r}: expected '0' (default) or '1'")
-    return (mode == "1" and bool(_lib.load().ocv_se_tail_supported(int(C), int(R)))
-            and 8 * C * R <= int(os.environ.get("OCV_SE_TAIL_MAX_BYTES", "400000")))
-
-
-def _se_counters(B: int, device: torch.device) -> torch.Tensor:
-    """uint32 [B] arrival counters of the squeeze-excite tail: zero-filled when allocated, found zero and left zero by every
-    launch (one buffer per (device, stream): launches of one stream run one after the other)."""
-    return workspace(4 * B, device, "se_counters", zero=True)
-
-
 def depthwise_se_gate(x: torch.Tensor, weight_kkc: torch.Tensor, bias: Optional[torch.Tensor], k: int, stride: int,
                       w1: torch.Tensor, b1: torch.Tensor, w2t: torch.Tensor, b2: torch.Tensor):
     """silu(depthwise k x k (TF 'SAME') + bias) of a channels_last tensor AND the squeeze-excite gate of that output: three
-    launches (depthwise, hidden layer, gate), or ONE where ``se_tail_pays`` (opt-in: the image's last workgroup forms the gate).
+    launches (depthwise, hidden layer, gate; one for the last two where the squeeze-excite weights are small).
     Returns (y [B, C, Ho, Wo] channels_last, gate [B, C])."""
     lib = _lib.load()
     x = _nhwc(x, "x")
@@ -1924,14 +1864,6 @@ def depthwise_se_gate(x: torch.Tensor, weight_kkc: torch.Tensor, bias: Optional[
     out = torch.empty(B, Cc, Ho, Wo, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     part = workspace(B * tiles * Cc * 4, x.device, "dw_part")
     gate = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
-    if se_tail_pays(Cc, R):
-        cnt = _se_counters(B, x.device)
-        with timed(f"depthwise_se|{B},{H},{W},{Cc},k{k}s{stride}"):
-            check(lib.ocv_depthwise_conv_nhwc_se_fwd(x.data_ptr(), weight_kkc.data_ptr(), _ptr(bias), out.data_ptr(), None,
-                                                     part.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), R,
-                                                     gate.data_ptr(), cnt.data_ptr(), B, Cc, H, W, k, stride, ph // 2, pw // 2, Ho, Wo,
-                                                     _stream()), "ocv_depthwise_conv_nhwc_se_fwd")
-        return out, gate
     hid = workspace(B * R * 4, x.device, "se_hidden")
     with timed(f"depthwise|{B},{H},{W},{Cc},k{k}s{stride}"):
         check(lib.ocv_depthwise_conv_nhwc_sum_fwd(x.data_ptr(), weight_kkc.data_ptr(), _ptr(bias), out.data_ptr(),
@@ -1974,20 +1906,6 @@ def depthwise_se_gate_weights(x: torch.Tensor, weight_kkc: torch.Tensor, bias: O
     hid = workspace(B * R * 4, x.device, "se_hidden")
     img_elems = int(lib.ocv_pointwise_packed_weight_elems(Cc, N))
     wpk = torch.empty(B * img_elems, dtype=torch.bfloat16, device=x.device)
-    if se_tail_pays(Cc, R):
-        # two launches: the depthwise launch's last workgroups form the gate, the second folds it into the weights
-        gate = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
-        cnt = _se_counters(B, x.device)
-        with timed(f"depthwise_se|{B},{H},{W},{Cc},k{k}s{stride}"):
-            check(lib.ocv_depthwise_conv_nhwc_se_fwd(x.data_ptr(), weight_kkc.data_ptr(), _ptr(bias), None, ys.hl.data_ptr(),
-                                                     part.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), R,
-                                                     gate.data_ptr(), cnt.data_ptr(), B, Cc, H, W, k, stride, ph // 2, pw // 2, Ho, Wo,
-                                                     _stream()), "ocv_depthwise_conv_nhwc_se_fwd")
-        with timed("se_gate_weights"):
-            check(lib.ocv_se_fold_gate_weights_fwd(gate.data_ptr(), w_proj.data_ptr(), wpk.data_ptr(), img_elems, B, Cc, N, _stream()),
-                  "ocv_se_fold_gate_weights_fwd")
-        wg = PerImageSplitWeight(wpk, N, Cc, img_elems, B)
-        return (ys, wg, gate) if want_gate else (ys, wg)
     gate = torch.empty(B, Cc, dtype=torch.float32, device=x.device) if want_gate else None
     with timed(f"depthwise|{B},{H},{W},{Cc},k{k}s{stride}"):
         check(lib.ocv_depthwise_conv_nhwc_sum_hl_fwd(x.data_ptr(), weight_kkc.data_ptr(), _ptr(bias), None, ys.hl.data_ptr(),
@@ -2045,14 +1963,6 @@ def expand_depthwise_se_gate(x: torch.Tensor, w_expand: "SplitWeight", b_expand:
     out = torch.empty(B, mid, Ho, Wo, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     part = workspace(B * tiles * mid * 4, x.device, "dw_part")
     gate = torch.empty(B, mid, dtype=torch.float32, device=x.device)
-    if se_tail_pays(mid, R):
-        cnt = _se_counters(B, x.device)
-        with timed(f"expand_dw_se|{B},{H},{W},{Cin},{mid},k{k}s{stride}"):
-            check(lib.ocv_mbconv_expand_dw_se_fwd(x.data_ptr(), w_expand.packed.data_ptr(), _ptr(b_expand), weight_kkc.data_ptr(),
-                                                  _ptr(bias), out.data_ptr(), part.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2t.data_ptr(),
-                                                  b2.data_ptr(), R, gate.data_ptr(), cnt.data_ptr(), B, H, W, Cin, mid, k, stride,
-                                                  ph // 2, pw // 2, Ho, Wo, _stream()), "ocv_mbconv_expand_dw_se_fwd")
-        return out, gate
     hid = workspace(B * R * 4, x.device, "se_hidden")
     with timed(f"expand_dw|{B},{H},{W},{Cin},{mid},k{k}s{stride}"):
         check(lib.ocv_mbconv_expand_dw_fwd(x.data_ptr(), w_expand.packed.data_ptr(), _ptr(b_expand), weight_kkc.data_ptr(),

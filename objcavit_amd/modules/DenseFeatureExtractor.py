@@ -374,7 +374,7 @@ class UpSampleWithSkip(nn.Module):
                 xs = as_split(x)
                 wt = self._split1.upconv_weights(xs.shape[1], f16=f16)
                 z = hip_ops.conv_nhwc_split(xs, wt["a_hi"], wt["a_lo"], None, 1, hip_ops.ACT_NONE, out_fp32=True, oscale=wt["a_osc"])
-            sk = fused = None
+            sk = None
             if wt["s_hi"] is not None and wt["s_lo"] is None:
                 # <= 4 skip channels: 27 - 36 multiply-adds per output on the vector units, the image read in place
                 sk = hip_ops.conv3x3_few_channels(skip_features, wt["s_hi"])
@@ -383,16 +383,12 @@ class UpSampleWithSkip(nn.Module):
                 if c2 % 4 and getattr(skip_features, "_ocv_hl", None) is None:      # 3-channel image: one zero channel more (the weight's pad columns are zero too)
                     skip_features = F.pad(skip_features, (0, 0, 0, 0, 0, 4 - c2 % 4))
                     sk = self.skip_part(skip_features, wt, f16)
-                elif sk_pre is None and hip_ops.tap_skip_fused_pays(c2, self._net[0].out_channels, H, W):
-                    # opt-in (measured slower: hip_ops.tap_skip_fused_pays): the skip part formed INSIDE the tap-interpolation launch
-                    fused = (as_split(skip_features), wt["s_hi"], wt["s_lo"], wt["s_osc"])
-                    self.__dict__.pop("_skip_plan", None)
                 else:
                     # what a later forward may issue beside the encoder (SkipPrepass): this skip shape with this weight arrangement
                     self.__dict__["_skip_plan"] = (tuple(skip_features.shape), self._split1._w_up[0])
                     sk = sk_pre if sk_pre is not None else self.skip_part(skip_features, wt, f16)
             f = hip_ops.tap_interp_combine(z, sk, wt["bias"], (H, W), hip_ops.ACT_LEAKY_RELU, out_fp32=False, out_split=True,
-                                           border=wt["border"], split_f16=f16, skip=fused)
+                                           border=wt["border"], split_f16=f16)
         else:
             if isinstance(x, hip_ops.SplitAct):
                 x = x.float()

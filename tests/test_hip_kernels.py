@@ -980,13 +980,11 @@ def test_pointwise_hl(ops, cfg, B, H, W, Cin, Cout, act, use_res, outs):
 @pytest.mark.parametrize("cfg", [(0, 0), (1, 1), (2, 2), (4, 1)])
 @pytest.mark.parametrize("k,s,B,C,H,W,R,N", [(5, 1, 2, 1056, 30, 40, 44, 176), (3, 1, 3, 768, 9, 11, 32, 128),
                                              (5, 2, 2, 96, 13, 17, 4, 24), (3, 2, 16, 384, 15, 20, 16, 128)])
-@pytest.mark.parametrize("tail", ["0", "1"])
-def test_depthwise_hl_gate_weights_project(ops, monkeypatch, tail, cfg, k, s, B, C, H, W, R, N):
+def test_depthwise_hl_gate_weights_project(ops, monkeypatch, cfg, k, s, B, C, H, W, R, N):
     """The late-stage MBConv tail on the pre-split route: depthwise + SiLU written ONCE in the hl32 layout, the
     squeeze-excite gate folded into per-image packed project weights (ocv_se_gate_weights_fwd), the project 1x1 on the
     LDS-DMA kernel with tiles that never span images -- against the definition (gate applied to the rows) in float64, and
-    piece by piece against the fp32-row kernels.  tail = OCV_SE_TAIL: the gate by the hidden-layer launch / inside the depthwise launch."""
-    monkeypatch.setenv("OCV_SE_TAIL", tail)
+    piece by piece against the fp32-row kernels."""
     x, w, b = rnd("x", (B, C, H, W), 1), rnd("w", (C, 1, k, k), 2, 0.3), rnd("b", (C,), 3, 0.2)
     w1, b1 = rnd("w1", (R, C), 4, 1 / math.sqrt(C)), rnd("b1", (R,), 5, 0.3)
     w2, b2 = rnd("w2", (C, R), 6, 1 / math.sqrt(R)), rnd("b2", (C,), 7, 0.3)
@@ -1071,9 +1069,7 @@ def test_depthwise_nhwc_same(ops, k, s, B, C, H, W):
 @pytest.mark.parametrize("k,s", [(3, 1), (3, 2), (5, 1), (5, 2)])
 @pytest.mark.parametrize("B,C,H,W,R", [(2, 48, 60, 80, 12), (1, 8, 15, 20, 2), (3, 12, 33, 47, 4), (1, 4, 1, 1, 1),
                                        (2, 144, 30, 41, 6), (2, 1056, 9, 11, 44), (1, 3072, 4, 5, 128), (16, 240, 30, 40, 10)])
-@pytest.mark.parametrize("tail", ["0", "1"])          # OCV_SE_TAIL: the gate by two launches behind the depthwise one / inside it
-def test_depthwise_se_gate(ops, monkeypatch, tail, k, s, B, C, H, W, R):
-    monkeypatch.setenv("OCV_SE_TAIL", tail)
+def test_depthwise_se_gate(ops, k, s, B, C, H, W, R):
     x, w, b = rnd("x", (B, C, H, W), 1), rnd("w", (C, 1, k, k), 2, 0.3), rnd("b", (C,), 3, 0.2)
     w1, b1 = rnd("w1", (R, C), 4, 1 / math.sqrt(C)), rnd("b1", (R,), 5, 0.3)
     w2, b2 = rnd("w2", (C, R), 6, 1 / math.sqrt(R)), rnd("b2", (C,), 7, 0.3)
@@ -1088,48 +1084,13 @@ def test_depthwise_se_gate(ops, monkeypatch, tail, k, s, B, C, H, W, R):
     assert torch.equal(y, y2) and torch.equal(g, g2)        # fixed-order pooling sums
 
 
-@pytest.mark.parametrize("B,C,H,W,R,k,s", [(16, 240, 30, 40, 10, 5, 1), (1, 240, 60, 80, 10, 5, 2), (4, 1056, 30, 40, 44, 5, 1), (2, 48, 120, 160, 12, 3, 1)])
-def test_se_tail_handoff_under_load_against_the_two_launch_route(ops, monkeypatch, B, C, H, W, R, k, s):
-    """The in-launch squeeze-excite tail (csrc/se_tail.hpp: every depthwise workgroup publishes its pooling partial write-through,
-    the image's last workgroup acquires and forms the gate) against the two-launch route on the SAME inputs, forty times in a row
-    on new data while the partial buffer is recycled (the consumer's L1 / its XCD's L2 hold the PREVIOUS iteration's lines: a
-    missing release or acquire reads those) and while a second stream keeps the chip unevenly busy.  Both routes sum the partials
-    in fp32 in different orders: 1e-5.  The counters must read zero after every launch."""
-    monkeypatch.setenv("OCV_SE_TAIL", "1")
-    assert ops.se_tail_pays(C, R)
-    w, b = rnd("w", (C, 1, k, k), 2, 0.3), rnd("b", (C,), 3, 0.2)
-    w1, b1 = rnd("w1", (R, C), 4, 1 / math.sqrt(C)), rnd("b1", (R,), 5, 0.3)
-    w2, b2 = rnd("w2", (C, R), 6, 1 / math.sqrt(R)), rnd("b2", (C,), 7, 0.3)
-    par = (dev(w).flatten(1).t().contiguous(), dev(b), k, s, dev(w1), dev(b1), dev(w2).t().contiguous(), dev(b2))
-    side = torch.cuda.Stream()
-    load_x = torch.randn(8, 64, 120, 160, device="cuda").contiguous(memory_format=torch.channels_last)
-    load_w = torch.randn(25, 64, device="cuda") * 0.2
-    xs = [(torch.randn(B, C, H, W, device="cuda") * (0.2 + 0.1 * i)).contiguous(memory_format=torch.channels_last) for i in range(4)]
-    for it in range(40):
-        x = xs[it % 4] + 0.01 * it
-        if it % 3 != 2:                                          # uneven: two iterations out of three share the chip
-            with torch.cuda.stream(side):
-                ops.depthwise_nhwc_same(load_x, load_w, None, 5, 1, 3)
-        monkeypatch.setenv("OCV_SE_TAIL", "1")
-        y, g = ops.depthwise_se_gate(x, *par)
-        cnt = ops._se_counters(B, x.device)
-        monkeypatch.setenv("OCV_SE_TAIL", "0")
-        y0, g0 = ops.depthwise_se_gate(x, *par)
-        assert torch.equal(y, y0), it
-        assert rel_dev(g, g0) < 1e-5, (it, rel_dev(g, g0))
-        assert not bool(cnt.view(torch.int32)[:B].any()), it     # restored by the last workgroup of every image
-    torch.cuda.synchronize()
-
-
 @pytest.mark.parametrize("k,s", [(3, 1), (3, 2), (5, 1), (5, 2)])
 @pytest.mark.parametrize("B,H,W,Cin,mid", [(2, 17, 23, 24, 144), (1, 30, 40, 40, 240), (2, 33, 47, 64, 384), (1, 8, 32, 40, 48),
                                            (1, 3, 2, 24, 36), (3, 64, 70, 32, 100)])
-@pytest.mark.parametrize("tail", ["0", "1"])
-def test_expand_depthwise_fused(ops, monkeypatch, tail, k, s, B, H, W, Cin, mid):
+def test_expand_depthwise_fused(ops, k, s, B, H, W, Cin, mid):
     """Fused expand 1x1 + depthwise (+ squeeze-excite gate) against the fp32 formulation and against the two-launch
     path: image sizes that are not multiples of the 8 x 32 / 8 x 16 tiles, channel counts that do not fill the last
     32-channel chunk, images smaller than one tile, asymmetric 'SAME' padding at stride 2."""
-    monkeypatch.setenv("OCV_SE_TAIL", tail)
     R = max(1, Cin // 4)
     x = rnd("x", (B, Cin, H, W), 1)
     we, be = rnd("we", (mid, Cin), 2, 1 / math.sqrt(Cin)), rnd("be", (mid,), 3, 0.3)
@@ -1450,48 +1411,6 @@ def test_tap_interp_combine(ops, B, h, w, H, W, Cout, act):
                      (1, 1, 1, 1))[:, :, t // 3:t // 3 + H, t % 3:t % 3 + W] for t in range(9))
     assert rel_dev(y2, ref2) < TOL
     assert not ops.tap_interp_supported(64, 64, 32, 32, Cout)          # a down-scaling: the footprint does not fit
-
-
-@pytest.mark.parametrize("B,h,w,H,W,Cs,Cout,act,f16", [
-    (2, 15, 20, 30, 40, 24, 128, 2, True),       # the last decoder stage's shape class: 24 skip channels (one padded block)
-    (1, 15, 20, 30, 40, 40, 64, 2, False),       # two channel blocks, bf16 pairs
-    (1, 17, 22, 30, 40, 64, 72, 0, True),        # ragged resize, Cout % 32 != 0 (channel tail: clamped weight rows, pad channels zero)
-    (1, 5, 7, 11, 13, 8, 8, 3, True),            # tiles past the image on both axes, a quarter-filled channel block
-    (3, 30, 40, 60, 80, 100, 32, 2, False),      # four blocks deep
-    (1, 2, 3, 9, 23, 4, 40, 1, True),            # > 3x up-sampling (other staging round counts)
-    (1, 11, 38, 22, 76, 48, 32, 2, True)])       # KITTI's aspect
-def test_tap_interp_with_the_skip_part_inside(ops, B, h, w, H, W, Cs, Cout, act, f16):
-    """ocv_tap_interp_skip_fwd: the skip half of the stage's first convolution (conv3x3 over the skip tensor's split pairs, three
-    products per K step on the matrix cores) formed INSIDE the tap-interpolation launch -- against the definition in fp64 at the
-    split convolutions' bar, against the two-launch form (skip-part convolution + ocv_tap_interp_combine_fwd: the same products in
-    another order), and bitwise repeatable; zero padding per tap, ragged tiles, channel tails."""
-    z = rnd("z", (B, 9 * Cout, h, w), 1)
-    xs_, b = rnd("xs", (B, Cs, H, W), 2), rnd("b", (Cout,), 3, 0.3)
-    ws = rnd("ws", (Cout, Cs, 3, 3), 4, 1 / math.sqrt(9 * Cs))
-    if f16:
-        ws = ws * torch.logspace(-3, 2, Cout).view(-1, 1, 1, 1)              # per-channel scales: oscale is exercised
-    ref = F.conv2d(xs_.double(), ws.double(), padding=1) + b.double().view(1, -1, 1, 1)
-    for t in range(9):
-        up = F.interpolate(z[:, t * Cout:(t + 1) * Cout].double(), size=(H, W), mode="bilinear", align_corners=True)
-        dy, dx = t // 3 - 1, t % 3 - 1
-        ref = ref + F.pad(up, (1, 1, 1, 1))[:, :, 1 + dy:1 + dy + H, 1 + dx:1 + dx + W]
-    ref = [ref, torch.relu(ref), F.leaky_relu(ref, 0.01), F.silu(ref)][act]
-    cl = torch.channels_last
-    zg = dev(z).contiguous(memory_format=cl)
-    prep = ops.prep_conv_weight(dev(ws), f16=f16)
-    hi, lo, osc = prep if f16 else (prep[0], prep[1], None)
-    skip = ops.split_act(dev(xs_).contiguous(memory_format=cl), f16=f16)
-    y, ys = ops.tap_interp_combine(zg, None, dev(b), (H, W), act, out_fp32=True, out_split=True, split_f16=f16, skip=(skip, hi, lo, osc))
-    scale = ref.abs().max().item()
-    assert y.is_contiguous(memory_format=cl) and (y.cpu().double() - ref).abs().max().item() < SPLIT_TOL * scale
-    assert rel_dev(ys.float(), y) < 1e-5
-    sk = ops.conv_nhwc_split(skip, hi, lo, None, 3, 0, out_fp32=True, oscale=osc)
-    two = ops.tap_interp_combine(zg, sk, dev(b), (H, W), act, out_fp32=True, split_f16=f16)
-    assert (y - two).abs().max().item() < 4e-6 * scale                          # same products, another summation order
-    y_again = ops.tap_interp_combine(zg, None, dev(b), (H, W), act, out_fp32=True, split_f16=f16, skip=(skip, hi, lo, osc))
-    assert torch.equal(y, y_again)
-    with pytest.raises(ValueError):
-        ops.tap_interp_combine(zg, sk, dev(b), (H, W), act, skip=(skip, hi, lo, osc))
 
 
 @pytest.mark.parametrize("B,h,w,H,W,Cout,act", [(2, 15, 20, 30, 40, 64, 2), (1, 3, 4, 11, 13, 8, 0), (1, 1, 1, 7, 9, 40, 2),

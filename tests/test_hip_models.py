@@ -229,22 +229,6 @@ def test_side_streams_equal_the_single_stream(monkeypatch):
         assert (max(issued) == 3) if skip == "1" else not issued, (skip, issued)      # three stages' skip parts rode the side stream
         g = GraphedGraphBins(m, img)
         assert torch.equal(g(img).depth_pred, ref) and torch.equal(g(img).depth_pred, ref), (obj, tok, head, skip)
-    # opt-in OCV_TAP_SKIP=1: the last three stages' skip parts are formed inside their tap-interpolation launches
-    # (hip_ops.tap_skip_fused_pays), the fork carries the object branch alone -- same bits with and without the forks, and the
-    # two-launch form within rounding
-    monkeypatch.setenv("OCV_TAP_SKIP", "1")
-    switches("0", "0", "0", "0")
-    m(img)
-    ref_f = m(img).depth_pred.clone()
-    assert not torch.equal(ref_f, ref) and max_rel(ref_f, ref) < 1e-4
-    switches("1", "1", "1", "1")
-    del issued[:]
-    for _ in range(2):
-        assert torch.equal(m(img).depth_pred, ref_f)
-    assert max(issued) == 0
-    g = GraphedGraphBins(m, img)
-    assert torch.equal(g(img).depth_pred, ref_f)
-    monkeypatch.delenv("OCV_TAP_SKIP")
     # a forward without an object branch (AdaBins) on the same route
     from objcavit_amd.modules.AdaBins import AdaBins
     a = AdaBins(make_args(model="adabins", dimensions_train=[H, W], dimensions_test=[H, W])).eval()
