@@ -48,6 +48,10 @@ const char* ocv_last_error(void);
  * (objcavit_amd/hip_ops.py RangeGuard).  Both return 0 / -1. */
 int ocv_range_flag_set(unsigned* flag);
 int ocv_range_flag_take_fwd(unsigned* flag, unsigned* out, ocv_stream_t stream);
+/* on != 0: ocv_attention_fwd (and every composite built on it) issued by THIS THREAD takes the exact-fp32 core whatever
+ * OCV_ATTN_FORM says -- the two-term fp16 core converts projected queries / keys / values to fp16 and ends at +-65504 like the
+ * fp16 pairs; the range guard's fallback route (hip_ops.bf16_pairs) switches it together with them.  Returns 0. */
+int ocv_attention_set_fp32_range(int on);
 
 /* activation codes for ocv_linear_fwd */
 #define OCV_ACT_NONE 0
@@ -270,22 +274,23 @@ int ocv_pixel_dot_fwd(const float* feat, int channels_last, const float* queries
 size_t ocv_bin_head_workspace_bytes(int B, int n_bins, int C);
 /* The two stages of ocv_bin_head_fwd as separate calls (same arithmetic, lets a caller time the main kernel):
  *   ocv_bin_head_fold_fwd   Wf[b] = Wout (n_bins x Q) . queries[b] (Q x C)            -> Wf [B, n_bins, C]
- *   ocv_bin_head_folded_fwd depth[b][p] = sum_k softmax_k(bout + Wf[b] . feat[b][:, p]) * centers[b][k]  * channels_last: 0 = feat is NCHW, 1 = NHWC (both exact fp32 MFMA); 2 = NHWC with the logits on the bf16 matrix cores
- * in split form (hi*hi + hi*lo + lo*hi, fp32 accumulate: product error <= 2^-17; twice as fast, opt-in because a
- * near-one-hot softmax passes logit errors straight into depth); 3 = NHWC with the logits as a TWO-term fp16 split with a
- * scaled low term (v = hi + 2^-11 lo', hi = fp16(v), lo' = fp16((v - hi) 2^11): three v_mfma_f32_32x32x16_f16 per product
- * block, 22-bit products = the error of an fp32 FMA chain; both parts of Wf[b] fit the LDS, so one workgroup walks all
- * 256 bins and the map is read once -- the fastest faithful form; fp16's range: a map value or folded weight beyond
- * +-65504 turns the pixel's depth inf / NaN). */
+ *   ocv_bin_head_folded_fwd depth[b][p] = sum_k softmax_k(bout + Wf[b] . feat[b][:, p]) * centers[b][k]
+ * channels_last selects layout AND arithmetic: 0 = feat is NCHW, 1 = NHWC (both exact fp32 MFMA); 3 = NHWC with the logits as a
+ * TWO-term fp16 split with a scaled low term (v = hi + 2^-11 lo', hi = fp16(v), lo' = fp16((v - hi) 2^11): three
+ * v_mfma_f32_32x32x16_f16 per product block, 22-bit products = the error of an fp32 FMA chain; both parts of Wf[b] fit the LDS, so
+ * one workgroup walks all 256 bins and the map is read once -- the fastest faithful form; fp16's range: a map value or folded
+ * weight beyond +-65504 turns the pixel's depth inf / NaN); 2 = NHWC, three-term bf16 (fp32's range): ocv_bin_head_folded_ws_fwd
+ * only.  (Rounds 2 - 4 also carried a two-term bf16 form under code 2 -- 3x the depth error under near-one-hot softmaxes, opt-in,
+ * never a default: removed in round 5.) */
 int ocv_bin_head_fold_fwd(const float* queries, long q_bs, int q_ld, const float* Wout, float* Wf, int B, int C, int Q,
                           int n_bins, ocv_stream_t stream);
 int ocv_bin_head_folded_fwd(const float* feat, int channels_last, const float* Wf, const float* bout,
                             const float* centers, float* depth, int B, int C, int n_bins, int P, ocv_stream_t stream);
-/* The same with scratch for the per-half softmax states: for a channels_last map (channels_last == 1) the logits then run
+/* The same with scratch for the per-half softmax states: channels_last == 2 = an NHWC map whose logits run
  * as a THREE-term bf16 split (v = h + m + l, six matrix-core products per product, dropped terms <= 2^-24: fp32-faithful)
  * at 2.7x the matrix rate of the exact fp32 kernel -- 256 bins in two halves of 128 (three parts of a half's folded
  * matrix fill 96 KB of LDS), merged per pixel by a second launch.  partials: ocv_bin_head_partials_bytes(B, P) bytes,
- * 16-byte aligned (NULL, or OCV_BINHEAD=exact in the environment: the exact kernel of ocv_bin_head_folded_fwd). */
+ * 16-byte aligned.  Any other channels_last code is handed to ocv_bin_head_folded_fwd. */
 size_t ocv_bin_head_partials_bytes(int B, int P);
 int ocv_bin_head_folded_ws_fwd(const float* feat, int channels_last, const float* Wf, const float* bout, const float* centers,
                                float* depth, int B, int C, int n_bins, int P, void* partials, size_t partials_bytes,
@@ -494,23 +499,9 @@ int ocv_conv_nhwc_split_x_fwd(const void* x_hl, int Cin, const void* w_hi, const
                               const float* bias, const float* residual, float* y, void* y_hl, int B, int H, int W, int Cout,
                               int ksize, int act, void* workspace, size_t workspace_bytes, ocv_stream_t stream);
 
-/* The same 3 x 3 convolution (stride 1, zero padding 1) in Winograd F(2x2, 3x3) form, for shapes where the arithmetic
- * dominates the transforms' traffic (Cin, Cout in the thousands at <= ~30 x 40 pixels: the two deepest decoder stages):
- *   y = act( A^T [ U (.) (B^T d B) ] A + bias ),  U[xi][co][ci] = (G g G^T)[xi] for the 16 positions xi = 4 i + j
- * (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1], G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], A^T = [1 1 1 0; 0 1 -1 -1]).
- * x_hl: the input in the hl32 split layout (as ocv_conv_nhwc_split_fwd); u_hi / u_lo: the TRANSFORMED weights split in
- * bf16, [16][Cout][Cin rounded up to 32] (zero padded), built once per weight version by the caller; y (fp32 NHWC) and /
- * or y_hl (hl32) outputs; Cout a multiple of 8.  Input transform (exact re-join, fp32 four-term sums, re-split), 16
- * batched split-bf16 GEMMs on the matrix cores, output transform + bias + activation: three launches, 2.25x fewer
- * matrix-core operations than the direct form.  Scratch: ocv_conv3x3_winograd_workspace_bytes (256-byte aligned).
- * Replaces the same nn.Conv2d(k = 3) + BatchNorm2d + LeakyReLU of UpSampleWithSkip (modules/DenseFeatureExtractor.py:37-42). */
-size_t ocv_conv3x3_winograd_workspace_bytes(int B, int H, int W, int Cin, int Cout);
-int ocv_conv3x3_winograd_split_fwd(const void* x_hl, int Cin, const void* u_hi, const void* u_lo, const float* bias, float* y,
-                                   void* y_hl, int B, int H, int W, int Cout, int act, void* workspace,
-                                   size_t workspace_bytes, ocv_stream_t stream);
-/* The same convolution in Winograd F(4x4, 3x3) form on TWO-TERM FP16 splits (round 3): 4x fewer matrix-core operations than the
- * direct form (F(2x2, 3x3): 2.25x), a transformed input of 2.25x the activation instead of 4x.  Input and output are the bf16
- * hl32 split / fp32 tensors of ocv_conv3x3_winograd_split_fwd; inside, the transformed input and filter are fp16 (hi, lo) pairs
+/* The same 3 x 3 convolution (stride 1, zero padding 1) in Winograd F(4x4, 3x3) form on TWO-TERM FP16 splits (round 3), for shapes
+ * where the arithmetic dominates the transforms' traffic: 4x fewer matrix-core operations than the direct form, a transformed input
+ * of 2.25x the activation.  Input and output are the hl32 split / fp32 tensors of ocv_conv_nhwc_split_x_fwd; inside, the transformed input and filter are fp16 (hi, lo) pairs
  * (22-bit products: the transforms' ~100x error amplification stays at 2 - 3.5e-6 of max |y|, where two bf16 terms give 1e-4).
  *   u_hi, u_lo [36][Cout][Cp] fp16: U'[6 i + j][n][c] = (G g G^T)[i][j][n][c] * 2^k[6 i + j] * 2^-a[c] (fp64 transform; the
  *   power of two per POSITION puts the position's largest entry near 2^8, out of fp16's subnormals; the power of two per INPUT

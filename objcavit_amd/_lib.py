@@ -37,6 +37,7 @@ PROTOTYPES = {
     "ocv_last_error": (C.c_char_p, []),
     "ocv_range_flag_set": (C.c_int, [C.c_void_p]),
     "ocv_range_flag_take_fwd": (C.c_int, [C.c_void_p, C.c_void_p, _stream]),
+    "ocv_attention_set_fp32_range": (C.c_int, [C.c_int]),
     "ocv_linear_fwd": (C.c_int, [_f32p, C.c_int, C.c_long, _f32p, C.c_int, C.c_long, C.c_int, _f32p, _f32p, C.c_int,
                                  C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
     "ocv_linear_residual_layernorm_fwd": (C.c_int, [_f32p, C.c_int, _f32p, C.c_int, _f32p, _f32p, C.c_int, _f32p, _f32p,
@@ -144,9 +145,6 @@ PROTOTYPES = {
     "ocv_tap_interp_combine_x_fwd": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_void_p] + [C.c_int] * 6 + [_stream]),
     "ocv_pos_grid_sample_fwd": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                           C.c_int, _f32p, _f32p, _stream]),
-    "ocv_conv3x3_winograd_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
-    "ocv_conv3x3_winograd_split_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _f32p, _f32p, C.c_void_p] + [C.c_int] * 5 +
-                                       [C.c_void_p, C.c_size_t, _stream]),
     "ocv_conv3x3_winograd43_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
     "ocv_conv3x3_winograd43_split_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p, _f32p, C.c_void_p] + [C.c_int] * 6 +
                                          [C.c_void_p, C.c_size_t, _stream]),

@@ -356,6 +356,9 @@ __global__ __launch_bounds__(256) void attention_h2_kernel(AttnArgs p) {
   }
 }
 
+// != 0: this thread's attention cores take the exact-fp32 form whatever OCV_ATTN_FORM says (ocv_attention_set_fp32_range: the
+// fp16 range guard's fallback route, hip_ops.bf16_pairs -- the two-term fp16 core ends at +-65504 like the pairs it stands beside)
+thread_local int g_attn_fp32_range = 0;
 }  // namespace
 
 extern "C" int ocv_attention_fwd(const float* q, long q_bs, int q_ss, const float* k, long k_bs, int k_ss,
@@ -363,6 +366,11 @@ extern "C" int ocv_attention_fwd(const float* q, long q_bs, int q_ss, const floa
                                  long o_bs, int o_ss, int B, int H, int Sq, int Sk, float scale, ocv_stream_t stream) {
   return ocv_attention_launch(q, q_bs, q_ss, k, k_bs, k_ss, v, v_bs, v_ss, key_padding_mask, Sk, ctx, o_bs, o_ss, B, H,
                               Sq, Sk, scale, (hipStream_t)stream);
+}
+
+extern "C" int ocv_attention_set_fp32_range(int on) {
+  g_attn_fp32_range = on != 0;
+  return 0;
 }
 
 int ocv_attention_launch(const float* q, long q_bs, int q_ss, const float* k, long k_bs, int k_ss, const float* v,
@@ -382,7 +390,7 @@ int ocv_attention_launch(const float* q, long q_bs, int q_ss, const float* k, lo
   hipStream_t st = stream;
   const char* form = getenv("OCV_ATTN_FORM");               // read per call: h2 (default) | fp32
   OCV_CHECK_ARG(form == nullptr || strcmp(form, "h2") == 0 || strcmp(form, "fp32") == 0, "OCV_ATTN_FORM=%s: expected h2 or fp32", form);
-  if (form == nullptr || strcmp(form, "h2") == 0) {
+  if (g_attn_fp32_range == 0 && (form == nullptr || strcmp(form, "h2") == 0)) {
     static bool attr_h = false;
     if (!attr_h) {
       (void)hipFuncSetAttribute((const void*)attention_h2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -391,7 +399,7 @@ int ocv_attention_launch(const float* q, long q_bs, int q_ss, const float* k, lo
     }
     // smaller key chunks than the exact kernel: 33 KB of LDS per 128 keys = four workgroups per CU, one's softmax / split
     // arithmetic under another's MFMAs (512-key chunks -- one workgroup per CU -- measured 170 us at S = 1200, B = 16)
-    static const int kc_h2 = getenv("OCV_ATTN_KC") ? atoi(getenv("OCV_ATTN_KC")) : 128;
+    constexpr int kc_h2 = 128;                                 // keys per LDS chunk (64 / 256 measured no faster: profiles/r03_attention_h2.txt)
     if (a.kc > kc_h2 && kc_h2 >= 32 && kc_h2 % 32 == 0) a.kc = kc_h2;
     const size_t ldsh = (size_t)a.kc * (2 * 64 * sizeof(_Float16) + sizeof(float));
     if (vec)

@@ -133,117 +133,7 @@ __global__ __launch_bounds__(256) void bin_head_kernel(const float* __restrict__
   }
 }
 
-// ---------------------------------------------------------------------------
-// Split-bf16 bin head (NHWC feature map): the same computation with the 128 -> 256 logits on
-// v_mfma_f32_32x32x16_bf16, every product formed as hi*hi + hi*lo + lo*hi with fp32 accumulation (product error
-// <= 2^-17, as in the convolutions that produce the map).  24 MFMAs of 32 cycles per bin tile instead of 64 of 64:
-// the fp32 kernel above runs at 70 % of the fp32 matrix peak and is bound by it (0.75 ms at bs = 16); this one is
-// bound by streaming the map.  Wf[b] is split once per workgroup while it is staged, straight into MFMA A-operand
-// fragments (1 KB per (bin tile, K step, hi|lo): lane = 32 (k octet) + bin, read back with conflict-free linear
-// ds_read_b128); a pixel's 128 channels are split once per pixel tile and reused by all 8 bin tiles.
-// ---------------------------------------------------------------------------
 typedef __bf16 bh_bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ void bh_split8(const float4 u, const float4 v, bh_bf16x8& hi, bh_bf16x8& lo) {
-  const float f[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const __bf16 h = (__bf16)f[i];
-    hi[i] = h;
-    lo[i] = (__bf16)(f[i] - (float)h);
-  }
-}
-
-__global__ __launch_bounds__(256) void bin_head_split_kernel(const float* __restrict__ feat, const float* __restrict__ Wf,
-                                                             const float* __restrict__ bout,
-                                                             const float* __restrict__ centers, float* __restrict__ depth,
-                                                             long P, int ntiles) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  __bf16* wfrag = reinterpret_cast<__bf16*>(lds);           // [8 bin tiles][8 K steps][hi, lo][64 lanes][8]
-  float* bl = lds + (NB * CH * 2 * 2) / 4;                   // [256]
-  float* cl = bl + NB;                                       // [256]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, hh = lane >> 5;
-  const int b = blockIdx.y;
-  const float* fb = feat + (long)b * CH * P;
-  const float* wb = Wf + (long)b * NB * CH;
-
-  for (int idx = tid; idx < NB * CH / 8; idx += 256) {
-    const int k = idx >> 4, o = idx & 15;                    // bin, K octet
-    bh_bf16x8 hi, lo;
-    bh_split8(ld4(wb + (long)k * CH + 8 * o), ld4(wb + (long)k * CH + 8 * o + 4), hi, lo);
-    __bf16* d = wfrag + ((((k >> 5) * 8 + (o >> 1)) * 2) * 64 + (o & 1) * 32 + (k & 31)) * 8;
-    *reinterpret_cast<bh_bf16x8*>(d) = hi;
-    *reinterpret_cast<bh_bf16x8*>(d + 512) = lo;
-  }
-  bl[tid] = bout[tid];
-  cl[tid] = centers[(long)b * NB + tid];
-  __syncthreads();
-
-  float4 cur[16], nxt[16];
-  auto load_px = [&](float4 (&dst)[16], long pix) {
-    const bool ok = pix < P;
-    const float* src = fb + (ok ? pix : 0) * CH + 8 * hh;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      dst[2 * s] = ok ? ld4(src + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
-      dst[2 * s + 1] = ok ? ld4(src + 16 * s + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  int tile = blockIdx.x;
-  if (tile < ntiles) load_px(cur, (long)tile * TP + wave * 32 + l31);
-  for (; tile < ntiles; tile += gridDim.x) {
-    const long pix = (long)tile * TP + wave * 32 + l31;
-    const int tn = tile + gridDim.x;
-    if (tn < ntiles) load_px(nxt, (long)tn * TP + wave * 32 + l31);
-
-    bh_bf16x8 ph[8], pl[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) bh_split8(cur[2 * s], cur[2 * s + 1], ph[s], pl[s]);
-
-    float m_run = -__builtin_inff(), l_half = 0.f, d_half = 0.f;
-#pragma unroll 1
-    for (int t = 0; t < NB / 32; ++t) {
-      f32x16 acc = {0};
-      const __bf16* wf = wfrag + (t * 8 * 2) * 512 + lane * 8;
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const bh_bf16x8 ah = *reinterpret_cast<const bh_bf16x8*>(wf + s * 1024);
-        const bh_bf16x8 al = *reinterpret_cast<const bh_bf16x8*>(wf + s * 1024 + 512);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ph[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, pl[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ph[s], acc, 0, 0, 0);
-      }
-      float tmax = -__builtin_inff();
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        acc[r] += bl[t * 32 + acc_row(r, hh)];
-        tmax = fmaxf(tmax, acc[r]);
-      }
-      tmax = xor32_max(tmax);
-      const float m_new = fmaxf(m_run, tmax);
-      const float alpha = fast_exp(m_run - m_new);
-      float ps = 0.f, ds = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pr = fast_exp(acc[r] - m_new);
-        ps += pr;
-        ds += pr * cl[t * 32 + acc_row(r, hh)];
-      }
-      l_half = l_half * alpha + ps;
-      d_half = d_half * alpha + ds;
-      m_run = m_new;
-    }
-    const float l = xor32_sum(l_half), d = xor32_sum(d_half);
-    if (hh == 0 && pix < P) depth[(long)b * P + pix] = d / l;
-
-    if (tn < ntiles) {
-#pragma unroll
-      for (int s = 0; s < 16; ++s) cur[s] = nxt[s];
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------
 // THREE-term split bin head (NHWC map): fp32-faithful logits at the bf16 matrix rate.  Every operand is written as
@@ -566,100 +456,6 @@ __global__ __launch_bounds__(512, 2) void bin_head_h2_kernel(const float* __rest
   }
 }
 
-// (A/B only, OCV_BH_VARIANT=r3: the round-3 schedule)
-__global__ __launch_bounds__(512, 2) void bin_head_h2_r3_kernel(const float* __restrict__ feat, const float* __restrict__ Wf,
-                                                             const float* __restrict__ bout,
-                                                             const float* __restrict__ centers, float* __restrict__ depth,
-                                                             long P, int ntiles) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  _Float16* wfrag = reinterpret_cast<_Float16*>(lds);       // [8 bin tiles][8 K steps][hi, lo'][64 lanes][8]
-  float* bl = lds + (NB * CH * 2 * 2) / 4;                   // [256]
-  float* cl = bl + NB;                                       // [256]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, hh = lane >> 5;
-  const int b = blockIdx.y;
-  const float* fb = feat + (long)b * CH * P;
-  const float* wb = Wf + (long)b * NB * CH;
-
-  for (int idx = tid; idx < NB * CH / 8; idx += 512) {
-    const int k = idx >> 4, o = idx & 15;                    // bin, K octet
-    bh_h16x8 hi, lo;
-    bh_split8_h2(ld4(wb + (long)k * CH + 8 * o), ld4(wb + (long)k * CH + 8 * o + 4), hi, lo);
-    _Float16* d = wfrag + ((((k >> 5) * 8 + (o >> 1)) * 2) * 64 + (o & 1) * 32 + (k & 31)) * 8;
-    *reinterpret_cast<bh_h16x8*>(d) = hi;
-    *reinterpret_cast<bh_h16x8*>(d + 512) = lo;
-  }
-  if (tid < NB) {
-    bl[tid] = bout[tid];
-    cl[tid] = centers[(long)b * NB + tid];
-  }
-  __syncthreads();
-
-  float4 cur[16], nxt[16];
-  auto load_px = [&](float4 (&dst)[16], long pix) {
-    const bool ok = pix < P;
-    const float* src = fb + (ok ? pix : 0) * CH + 8 * hh;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      dst[2 * s] = ok ? ld4(src + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
-      dst[2 * s + 1] = ok ? ld4(src + 16 * s + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  int tile = blockIdx.x;
-  if (tile < ntiles) load_px(cur, (long)tile * TP3 + wave * 32 + l31);
-  for (; tile < ntiles; tile += gridDim.x) {
-    const long pix = (long)tile * TP3 + wave * 32 + l31;
-    const int tn = tile + gridDim.x;
-    if (tn < ntiles) load_px(nxt, (long)tn * TP3 + wave * 32 + l31);
-
-    bh_h16x8 ph[8], pl[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) bh_split8_h2(cur[2 * s], cur[2 * s + 1], ph[s], pl[s]);
-
-    float m_run = -__builtin_inff(), l_half = 0.f, d_half = 0.f;
-#pragma unroll 1
-    for (int t = 0; t < NB / 32; ++t) {
-      f32x16 acc1 = {0}, acc2 = {0};
-      const _Float16* wf = wfrag + (t * 8 * 2) * 512 + lane * 8;
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const bh_h16x8 ah = *reinterpret_cast<const bh_h16x8*>(wf + s * 1024);
-        const bh_h16x8 al = *reinterpret_cast<const bh_h16x8*>(wf + s * 1024 + 512);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, ph[s], acc2, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, pl[s], acc2, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ph[s], acc1, 0, 0, 0);
-      }
-      float tmax = -__builtin_inff();
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        acc1[r] = acc1[r] + acc2[r] * (1.0f / 2048.0f) + bl[t * 32 + acc_row(r, hh)];
-        tmax = fmaxf(tmax, acc1[r]);
-      }
-      tmax = xor32_max(tmax);
-      const float m_new = fmaxf(m_run, tmax);
-      const float alpha = fast_exp(m_run - m_new);
-      float ps = 0.f, ds = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pr = fast_exp(acc1[r] - m_new);
-        ps += pr;
-        ds += pr * cl[t * 32 + acc_row(r, hh)];
-      }
-      l_half = l_half * alpha + ps;
-      d_half = d_half * alpha + ds;
-      m_run = m_new;
-    }
-    const float l = xor32_sum(l_half), d = xor32_sum(d_half);
-    if (hh == 0 && pix < P) depth[(long)b * P + pix] = d / l;
-
-    if (tn < ntiles) {
-#pragma unroll
-      for (int s = 0; s < 16; ++s) cur[s] = nxt[s];
-    }
-  }
-}
-
 // depth = (d0 e0 + d1 e1) / (l0 e0 + l1 e1),  e_i = exp(m_i - max(m0, m1)): the online-softmax merge of the two halves
 __global__ __launch_bounds__(256) void bin_head_combine_kernel(const float* __restrict__ part, float* __restrict__ depth, long P,
                                                                long total) {
@@ -773,6 +569,7 @@ extern "C" int ocv_bin_head_folded_fwd(const float* feat, int channels_last, con
   OCV_CHECK_ARG(feat && Wf && bout && centers && depth, "ocv_bin_head_folded_fwd: null pointer");
   OCV_CHECK_ARG(C == CH && n_bins == NB, "ocv_bin_head_folded_fwd: needs C = %d, n_bins = %d", CH, NB);
   OCV_CHECK_ARG(B >= 1 && B <= 65535 && P >= 1 && ocv_aligned16(Wf), "ocv_bin_head_folded_fwd: bad sizes / alignment");
+  OCV_CHECK_ARG(channels_last == 0 || channels_last == 1 || channels_last == 3, "ocv_bin_head_folded_fwd: channels_last must be 0 (NCHW, exact fp32), 1 (NHWC, exact fp32) or 3 (NHWC, two-term fp16); 2 (three-term bf16) needs ocv_bin_head_folded_ws_fwd and its partials buffer");
   OCV_CHECK_ARG(!channels_last || ocv_aligned16(feat), "ocv_bin_head_folded_fwd: channels_last map must be 16-byte aligned");
   static bool attr = false;
   if (!attr) {
@@ -791,16 +588,6 @@ extern "C" int ocv_bin_head_folded_fwd(const float* feat, int channels_last, con
     if (perh > nt) perh = nt;
     if (perh < 1) perh = 1;
     const size_t ldsh = (size_t)NB * CH * 2 * 2 + 2 * NB * sizeof(float);
-    static const bool r3 = getenv("OCV_BH_VARIANT") != nullptr && strcmp(getenv("OCV_BH_VARIANT"), "r3") == 0;
-    if (r3) {
-      static bool attr4 = false;
-      if (!attr4) {
-        (void)hipFuncSetAttribute((const void*)bin_head_h2_r3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr4 = true;
-      }
-      hipLaunchKernelGGL(bin_head_h2_r3_kernel, dim3(perh, B), dim3(512), ldsh, (hipStream_t)stream, feat, Wf, bout, centers, depth,
-                         (long)P, nt);
-    } else
     hipLaunchKernelGGL(bin_head_h2_kernel, dim3(perh, B), dim3(512), ldsh, (hipStream_t)stream, feat, Wf, bout, centers, depth,
                        (long)P, nt);
     OCV_CHECK_LAUNCH("ocv_bin_head_folded_fwd(h2)");
@@ -809,22 +596,8 @@ extern "C" int ocv_bin_head_folded_fwd(const float* feat, int channels_last, con
   const int ntiles = ocv_cdiv(P, TP);
   const int per = blocks_per_image(B, ntiles);
   const size_t lds = (size_t)(NB * WLD + 2 * NB) * sizeof(float);
-  // NHWC maps: channels_last == 1 -> exact fp32 MFMA (default); == 2, or OCV_BINHEAD=split in the environment ->
-  // split-bf16 logits (2x faster; under the 6x-logit-gain stress weights of the tests its max depth error is
-  // 4e-4 .. 1.5e-3 against 7e-5 .. 5.5e-4 for the exact kernel, so it is opt-in)
-  const char* env = getenv("OCV_BINHEAD");                   // read per call: a latched copy once made A/B runs in one process lie
-  const bool want_split = env != nullptr && strcmp(env, "split") == 0;
-  const bool exact = !(channels_last == 2 || (channels_last == 1 && want_split));
-  if (channels_last && !exact) {
-    static bool attr2 = false;
-    if (!attr2) {
-      (void)hipFuncSetAttribute((const void*)bin_head_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr2 = true;
-    }
-    const size_t lds2 = (size_t)NB * CH * 2 * 2 + 2 * NB * sizeof(float);
-    hipLaunchKernelGGL(bin_head_split_kernel, dim3(per, B), dim3(256), lds2, (hipStream_t)stream, feat, Wf, bout, centers,
-                       depth, (long)P, ntiles);
-  } else if (channels_last)
+  // NHWC maps: channels_last == 1 -> exact fp32 MFMA; NCHW maps (0): the same kernel reading planes
+  if (channels_last)
     hipLaunchKernelGGL(bin_head_kernel<true>, dim3(per, B), dim3(256), lds, (hipStream_t)stream, feat, Wf, bout,
                        centers, depth, (long)P, ntiles);
   else
@@ -837,9 +610,7 @@ extern "C" int ocv_bin_head_folded_fwd(const float* feat, int channels_last, con
 extern "C" int ocv_bin_head_folded_ws_fwd(const float* feat, int channels_last, const float* Wf, const float* bout,
                                           const float* centers, float* depth, int B, int C, int n_bins, int P, void* partials,
                                           size_t partials_bytes, ocv_stream_t stream) {
-  const char* e = getenv("OCV_BINHEAD");                     // read per call (see ocv_bin_head_folded_fwd)
-  const int forced = e == nullptr ? 0 : (strcmp(e, "exact") == 0 ? 1 : (strcmp(e, "split") == 0 ? 2 : 0));
-  if (channels_last != 1 || forced != 0 || partials == nullptr)
+  if (channels_last != 2 || partials == nullptr)
     return ocv_bin_head_folded_fwd(feat, channels_last, Wf, bout, centers, depth, B, C, n_bins, P, stream);
   OCV_CHECK_ARG(feat && Wf && bout && centers && depth, "ocv_bin_head_folded_ws_fwd: null pointer");
   OCV_CHECK_ARG(C == CH && n_bins == NB, "ocv_bin_head_folded_ws_fwd: needs C = %d, n_bins = %d", CH, NB);

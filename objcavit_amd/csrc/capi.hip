@@ -101,12 +101,9 @@ extern "C" int ocv_mha_fwd(const float* q_src, const float* k_src, const float* 
   const int Se = (kv_limit > 0 && kv_limit < Sk) ? kv_limit : Sk;
   {
     // at most 32 live keys (the image <- object cross-attention): everything in one launch
-    static const bool unfused = getenv("OCV_MHA_UNFUSED") != nullptr;
-    if (!unfused) {
-      rc = ocv_cross_attn_fused_launch(q_src, k_src, v_src, key_padding_mask, Sk, in_proj_w, in_proj_b, out_w, out_b, out, B,
-                                       Sq, Sk, Se, E, H, (hipStream_t)stream);
-      if (rc != 1) return rc;
-    }
+    rc = ocv_cross_attn_fused_launch(q_src, k_src, v_src, key_padding_mask, Sk, in_proj_w, in_proj_b, out_w, out_b, out, B,
+                                     Sq, Sk, Se, E, H, (hipStream_t)stream);
+    if (rc != 1) return rc;
   }
   if ((rc = ocv_linear_fwd(q_src, E, 0, in_proj_w, E, 0, 0, in_proj_b, qp, E, 0, 1, B * Sq, E, E, OCV_ACT_NONE, stream))) return rc;
   if ((rc = ocv_linear_fwd(k_src, E, (long)Sk * E, in_proj_w + (size_t)E * E, E, 0, 0, in_proj_b + E, kp, E, (long)Se * E, B, Se, E, E, OCV_ACT_NONE, stream))) return rc;
@@ -135,12 +132,9 @@ extern "C" int ocv_mha_split3_fwd(const float* q_src, const float* k_src, const 
   char* ws = (char*)workspace;
   int rc;
   {
-    static const bool unfused = getenv("OCV_MHA_UNFUSED") != nullptr;
-    if (!unfused) {
-      rc = ocv_cross_attn_split3_launch(q_src, k_src, v_src, key_padding_mask, Sk, in_proj_p3, in_proj_b, out_proj_p3, out_b, out,
-                                        (float*)(ws + 2 * qb), B, Sq, Sk, Se, E, H, (hipStream_t)stream);
-      if (rc != 1) return rc;
-    }
+    rc = ocv_cross_attn_split3_launch(q_src, k_src, v_src, key_padding_mask, Sk, in_proj_p3, in_proj_b, out_proj_p3, out_b, out,
+                                      (float*)(ws + 2 * qb), B, Sq, Sk, Se, E, H, (hipStream_t)stream);
+    if (rc != 1) return rc;
   }
   float* qp = (float*)ws;
   float* ctx = (float*)(ws + qb);

@@ -780,8 +780,6 @@ namespace {
 // Split-K pays when the tile count leaves the last round of workgroups mostly empty: 600 tiles on 256 CUs run three
 // rounds for 2.34 rounds of work; as 1200 half-K workgroups they run five half-rounds = 2.5.  Returns 1 or 2.
 int conv_ksplit(long M, int Cout, int Cin, int ksize) {
-  static const int forced = getenv("OCV_CONV_KSPLIT") ? atoi(getenv("OCV_CONV_KSPLIT")) : 0;
-  if (forced == 1 || forced == 2) return (Cout & 7) == 0 ? forced : 1;
   const long tiles = (long)ocv_cdiv(M, CBM) * ocv_cdiv(Cout, CBN);
   const int nsteps = ksize * ksize * ((Cin + CBK - 1) / CBK);
   if ((Cout & 7) != 0 || nsteps < 128 || tiles <= 256) return 1;
@@ -907,208 +905,12 @@ extern "C" int ocv_conv_nhwc_fwd(const float* x1, int C1, const float* x2, int C
   return launch_conv(a, B, false, (hipStream_t)stream);
 }
 
-// =====================================================================================================================
-// Winograd F(2x2, 3x3) form of the 3x3 convolution for the deep decoder stages (row N1 of SURVEY.md section 8; reference
-// modules/DenseFeatureExtractor.py:37-42,104-116).
-//
-//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A        per 2 x 2 output tile, 4 x 4 input patch d, 3 x 3 filter g
-//
-// 16 multiplies per 4 outputs instead of 36: 2.25x fewer matrix-core operations, on a convolution kernel that runs at
-// the package power cap with its matrix pipe ~95 % busy, i.e. where nothing but fewer MFMAs helps.
-// The three stages:
-//   1. wino_input_kernel     V[xi][tile][c] = (B^T d B)[xi]: the split input is re-joined (hi + lo, exact), transformed
-//                            in fp32 (B has entries 0, +-1: four-term sums) and split again, one hl32 "image" of
-//                            T = B * ceil(H/2) * ceil(W/2) rows per position xi = 4 i + j;
-//   2. conv_split_dma_kernel as a BATCH of 16 independent 1 x 1 GEMMs (zbatch): M[xi] = V[xi] . U[xi]^T with
-//                            U[xi] = (G g G^T)[xi] transformed and split once on the host; raw fp32 slabs;
-//   3. wino_output_kernel    Y = A^T M A + bias, activation, fp32 and / or hl32 split stores.
-// V is 4x the activation and M 4x the output, so this pays only where both are small next to the arithmetic: the two
-// 30 x 40 stages (Cin 2224 / 1024, Cout 1024) -- measured 16 GEMMs 0.87 / 0.45 ms against 1.85 / 0.87 ms direct
-// (tools/exp_winograd_gemm.py); from 60 x 80 on the transforms' HBM traffic eats the gain and the direct kernel stays.
-// Numerics: the transforms are sums of at most four terms in fp32, the products keep the 2^-17 split-bf16 contract;
-// measured against fp64 the result is within 1.6x of the direct split-bf16 kernel's error (tests: 2e-5 of max |y|).
-// =====================================================================================================================
 namespace {
-
-struct WinoInArgs {
-  const __bf16* xhl;      // [B][H][W][2 Cp] hl32
-  __bf16* v;              // [16][T][2 Cp] hl32 rows
-  int B, H, W, Cp, th, tw;
-  long T, items;          // items = T * Cp / 8
-};
-
-// one thread = (tile, channel octet): 16 pixels x (8 hi + 8 lo) in, 16 positions x (8 hi + 8 lo) out
-__global__ __launch_bounds__(256) void wino_input_kernel(WinoInArgs p) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= p.items) return;
-  const int noct = p.Cp >> 3;
-  const long t = i / noct;
-  const int oc = (int)(i - t * noct);
-  const int c = oc * 8;
-  const int tx = (int)(t % p.tw);
-  const long r = t / p.tw;
-  const int ty = (int)(r % p.th), b = (int)(r / p.th);
-  const long coff = (long)(c >> 5) * 64 + (c & 31);                       // hi octet; lo octet at + 32
-  float d[4][4][8];
-#pragma unroll
-  for (int yy = 0; yy < 4; ++yy) {
-    const int y = 2 * ty - 1 + yy;
-#pragma unroll
-    for (int xx = 0; xx < 4; ++xx) {
-      const int x = 2 * tx - 1 + xx;
-      const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-      const __bf16* src = ok ? p.xhl + (((long)b * p.H + y) * p.W + x) * 2 * p.Cp + coff
-                             : reinterpret_cast<const __bf16*>(ocv_zero_page);
-      const bf16x8 h = *reinterpret_cast<const bf16x8*>(src);
-      const bf16x8 l = *reinterpret_cast<const bf16x8*>(src + (ok ? 32 : 8));
-#pragma unroll
-      for (int e = 0; e < 8; ++e) d[yy][xx][e] = (float)h[e] + (float)l[e];
-    }
-  }
-  // rows: B^T d   (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1])
-  float w[4][4][8];
-#pragma unroll
-  for (int xx = 0; xx < 4; ++xx)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      w[0][xx][e] = d[0][xx][e] - d[2][xx][e];
-      w[1][xx][e] = d[1][xx][e] + d[2][xx][e];
-      w[2][xx][e] = d[2][xx][e] - d[1][xx][e];
-      w[3][xx][e] = d[1][xx][e] - d[3][xx][e];
-    }
-  // columns: (B^T d) B, split, store position xi = 4 i + j
-#pragma unroll
-  for (int ii = 0; ii < 4; ++ii) {
-    float v4[4][8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      v4[0][e] = w[ii][0][e] - w[ii][2][e];
-      v4[1][e] = w[ii][1][e] + w[ii][2][e];
-      v4[2][e] = w[ii][2][e] - w[ii][1][e];
-      v4[3][e] = w[ii][1][e] - w[ii][3][e];
-    }
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      __bf16 hi[8], lo[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const __bf16 hb = (__bf16)v4[jj][e];
-        hi[e] = hb;
-        lo[e] = (__bf16)(v4[jj][e] - (float)hb);
-      }
-      __bf16* dst = p.v + (((long)(4 * ii + jj) * p.T + t) * 2 * p.Cp) + coff;
-      *reinterpret_cast<bf16x8*>(dst) = *reinterpret_cast<bf16x8*>(hi);
-      *reinterpret_cast<bf16x8*>(dst + 32) = *reinterpret_cast<bf16x8*>(lo);
-    }
-  }
-}
-
-struct WinoOutArgs {
-  const float* m;         // [16][T][Cout] raw GEMM results
-  const float* bias;
-  float* y;               // [B][H][W][Cout] fp32 (nullable)
-  __bf16* yhl;            // hl32 split copy (nullable)
-  int B, H, W, Cout, Cpo, th, tw, act;
-  long T, items;          // items = T * Cout / 4
-};
-
-// one thread = (tile, 4 channels): Y = A^T M A   (A^T = [1 1 1 0; 0 1 -1 -1]), bias, activation, up to 2 x 2 pixel stores
-__global__ __launch_bounds__(256) void wino_output_kernel(WinoOutArgs p) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= p.items) return;
-  const int nq = p.Cout >> 2;
-  const long t = i / nq;
-  const int n = (int)(i - t * nq) * 4;
-  const int tx = (int)(t % p.tw);
-  const long r = t / p.tw;
-  const int ty = (int)(r % p.th), b = (int)(r / p.th);
-  f32x4 m[4][4];
-#pragma unroll
-  for (int xi = 0; xi < 16; ++xi) m[xi >> 2][xi & 3] = *reinterpret_cast<const f32x4*>(p.m + ((long)xi * p.T + t) * p.Cout + n);
-  f32x4 s[2][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    s[0][j] = m[0][j] + m[1][j] + m[2][j];
-    s[1][j] = m[1][j] - m[2][j] - m[3][j];
-  }
-  const f32x4 bv = p.bias != nullptr ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int dy = 0; dy < 2; ++dy) {
-    const int y = 2 * ty + dy;
-    if (y >= p.H) continue;
-    f32x4 o[2];
-    o[0] = s[dy][0] + s[dy][1] + s[dy][2] + bv;
-    o[1] = s[dy][1] - s[dy][2] - s[dy][3] + bv;
-#pragma unroll
-    for (int dx = 0; dx < 2; ++dx) {
-      const int x = 2 * tx + dx;
-      if (x >= p.W) continue;
-      f32x4 v = o[dx];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = conv_act(v[e], p.act);
-      const long px = ((long)b * p.H + y) * p.W + x;
-      if (p.y != nullptr) *reinterpret_cast<f32x4*>(p.y + px * p.Cout + n) = v;
-      if (p.yhl != nullptr) {
-        __bf16 hi[4], lo[4];
-        split4(v, hi, lo);
-        const long oh = hl_index(px, n, p.Cpo);
-        *reinterpret_cast<uint2*>(p.yhl + oh) = *reinterpret_cast<uint2*>(hi);
-        *reinterpret_cast<uint2*>(p.yhl + oh + 32) = *reinterpret_cast<uint2*>(lo);
-      }
-    }
-  }
-}
-
 inline size_t wino_align(size_t v) { return (v + 255) & ~(size_t)255; }
-
 }  // namespace
 
-extern "C" size_t ocv_conv3x3_winograd_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
-  if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return 0;
-  const long T = (long)B * ((H + 1) / 2) * ((W + 1) / 2);
-  const int Cp = (Cin + 31) / 32 * 32;
-  return wino_align((size_t)16 * T * 2 * Cp * sizeof(__bf16)) + wino_align((size_t)16 * T * Cout * sizeof(float));
-}
-
-extern "C" int ocv_conv3x3_winograd_split_fwd(const void* x_hl, int Cin, const void* u_hi, const void* u_lo,
-                                              const float* bias, float* y, void* y_hl, int B, int H, int W, int Cout,
-                                              int act, void* workspace, size_t workspace_bytes, ocv_stream_t stream) {
-  OCV_CHECK_ARG(x_hl && u_hi && u_lo && (y || y_hl) && workspace, "ocv_conv3x3_winograd_split_fwd: null pointer");
-  OCV_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 8 && Cout % 8 == 0,
-                "ocv_conv3x3_winograd_split_fwd: bad sizes (Cout must be a multiple of 8, got %d)", Cout);
-  OCV_CHECK_ARG(act >= 0 && act <= 3, "ocv_conv3x3_winograd_split_fwd: unknown activation %d", act);
-  OCV_CHECK_ARG((reinterpret_cast<uintptr_t>(x_hl) & 127) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0 &&
-                    ocv_aligned16(u_hi) && ocv_aligned16(u_lo) && ocv_aligned16(y) && ocv_aligned16(y_hl) && ocv_aligned16(bias),
-                "ocv_conv3x3_winograd_split_fwd: x_hl must be 128-byte, workspace 256-byte, the rest 16-byte aligned");
-  OCV_CHECK_ARG(workspace_bytes >= ocv_conv3x3_winograd_workspace_bytes(B, H, W, Cin, Cout),
-                "ocv_conv3x3_winograd_split_fwd: workspace too small");
-  const int th = (H + 1) / 2, tw = (W + 1) / 2, Cp = (Cin + 31) / 32 * 32;
-  const long T = (long)B * th * tw;
-  OCV_CHECK_ARG(T * (Cin + 32) * 4 < (1L << 32) && (long)Cout * (Cin + 32) * 2 < (1L << 32),
-                "ocv_conv3x3_winograd_split_fwd: one transformed operand must stay below 4 GiB");
-  hipStream_t st = (hipStream_t)stream;
-  __bf16* v = (__bf16*)workspace;
-  float* m = (float*)((char*)workspace + wino_align((size_t)16 * T * 2 * Cp * sizeof(__bf16)));
-  if (y_hl != nullptr && Cout % 32 != 0) {
-    const int zrc = ocv_zero_async(y_hl, ocv_split_act_elems(B, H, W, Cout) * sizeof(__bf16), st);          // (a launch, not a memset node: common.hpp)
-    if (zrc != 0) return zrc;
-  }
-  WinoInArgs wi{(const __bf16*)x_hl, v, B, H, W, Cp, th, tw, T, T * (Cp / 8)};
-  hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((wi.items + 255) / 256)), dim3(256), 0, st, wi);
-  OCV_CHECK_LAUNCH("ocv_conv3x3_winograd_split_fwd(input transform)");
-  ConvArgs a{};
-  a.xhl = v; a.whi = (const __bf16*)u_hi; a.wlo = (const __bf16*)u_lo; a.y = m;
-  a.C1 = Cin; a.Cin = Cin; a.Cout = Cout; a.H = 1; a.W = (int)T; a.ks = 1; a.act = OCV_ACT_NONE; a.ksplit = 1;
-  a.zbatch = 16; a.xz_bytes = T * 2 * Cp * (long)sizeof(__bf16); a.wz_bytes = (long)Cout * Cp * (long)sizeof(__bf16);
-  a.Cpo = (Cout + 31) / 32 * 32;
-  const int rc = launch_conv(a, 1, true, st);
-  if (rc != 0) return rc;
-  WinoOutArgs wo{m, bias, y, (__bf16*)y_hl, B, H, W, Cout, a.Cpo, th, tw, act, T, T * (Cout / 4)};
-  hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)((wo.items + 255) / 256)), dim3(256), 0, st, wo);
-  OCV_CHECK_LAUNCH("ocv_conv3x3_winograd_split_fwd(output transform)");
-  return 0;
-}
-
+// (Round 2's Winograd F(2x2, 3x3) on bf16 pairs -- 2.25x fewer matrix operations, the 30 x 40 stage only -- was superseded by the
+// F(4x4, 3x3) form below in round 3 and left the product in round 5: tools/diag/winograd_f22.patch.txt.)
 
 // =====================================================================================================================
 // Winograd F(4x4, 3x3) on the two-term FP16 split (round 3).  36 multiplies per 16 outputs instead of 144: 4x fewer matrix-core
@@ -1498,8 +1300,6 @@ int patch_parts(int B, int C, int h, int w, int E) {
   const long M = (long)B * (h / 16) * (w / 16);
   const long tiles = (long)ocv_cdiv(M, CBM) * ocv_cdiv(E, CBN);
   const int S = 16 * (16 * C / CBK);
-  static const int forced = [] { const char* e = getenv("OCV_PATCH_PARTS"); return e ? atoi(e) : 0; }();   // A/B switch
-  if (forced >= 1 && forced <= 256 && S / forced >= 8) return forced;                                      // (A/B: down to 8 steps)
   int best = 1;
   double cost = 0.0;
   for (int n = 1; n <= 256 && S / n >= 16; ++n) {

@@ -591,11 +591,9 @@ extern "C" int ocv_ffn_residual_layernorm_fwd(const float* x, const float* w1, c
 // FFN with the hidden units of a row tile shared out over several workgroups (see ffn_fused_kernel); part: scratch of
 // ocv_ffn_split_count(M, FF) * M * 128 floats.  Same contract as ocv_ffn_residual_layernorm_fwd otherwise.
 int ocv_ffn_split_count(int M, int FF) {
-  static const int forced = getenv("OCV_FFN_SPLIT") ? atoi(getenv("OCV_FFN_SPLIT")) : 0;
   const int nchunk = FF / FKC, tiles = ocv_cdiv(M, FM);
   int ns = 1;
   while (2 * ns <= nchunk && nchunk % (2 * ns) == 0 && tiles * 2 * ns <= 256) ns *= 2;      // measured: 150 tiles x 2 lost 6 % (0.48 -> 0.51 ms for 4 layers), 16 tiles x 8 won 27 % (0.37 -> 0.27)
-  if (forced >= 1) { ns = 1; while (2 * ns <= forced && 2 * ns <= nchunk && nchunk % (2 * ns) == 0) ns *= 2; }
   return ns;
 }
 

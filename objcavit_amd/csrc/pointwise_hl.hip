@@ -303,12 +303,7 @@ int launch_ph(PHArgs a, hipStream_t st) {
 
 struct PhCfg { int rt = 0, tn = 0; };
 PhCfg& ph_cfg() {
-  static PhCfg c = [] {
-    PhCfg v;
-    const char* e = getenv("OCV_PWHL_CFG");                           // "rt,tn": diagnostic override of the tile choice
-    if (e != nullptr && sscanf(e, "%d,%d", &v.rt, &v.tn) != 2) v.rt = v.tn = 0;
-    return v;
-  }();
+  static PhCfg c;                                                     // (0, 0) = automatic; ocv_pointwise_hl_set_dispatch overrides (tests, tools)
   return c;
 }
 

@@ -453,10 +453,8 @@ __global__ __launch_bounds__(256) void pw_splitk_finish_kernel(PwFinArgs p) {
 // K slices per tile for a tile-kernel launch of `tiles` workgroups over Kp inputs: only where the launch would leave most of the
 // chip idle (fewer than 128 tiles on 256 CUs) and the chain is long (a batch of 1 - 2 in B5's stages 5 - 7).  1 = no split.
 int pw_ksplit(long tiles, int Kp, int Cout) {
-  static const int forced = getenv("OCV_PW_KSPLIT") ? atoi(getenv("OCV_PW_KSPLIT")) : 0;
   if ((Cout & 3) != 0) return 1;
   const int slabs = Kp / 128;                                  // the split launch runs two K groups per workgroup: 128-wide slabs
-  if (forced >= 1) return forced > slabs ? (slabs > 1 ? slabs : 1) : forced;
   if (tiles >= 128 || Kp < 1024) return 1;
   int ks = (int)(256 / tiles);
   if (ks > 8) ks = 8;
@@ -540,20 +538,10 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(PSArgs p) {
   for (int j = 0; j < NTL; ++j) store_tile_lds(p, acc[j], scratch, RES ? resq[j] : nullptr, m_base, 32 * j, lane);
 }
 
-// diagnostic override of the dispatch: OCV_PW_CFG = "rows" | "stream" | "tile" | "wn,wk" (tile kernel with that shape)
+// diagnostic override of the dispatch (ocv_pointwise_split_set_dispatch: tests, tools): family 1 = rows, 2 = stream, 3 = tile (with wn, wk)
 struct PwCfg { int wn = 0, wk = 0, family = 0; };
 PwCfg& pw_cfg() {
-  static PwCfg c = [] {
-    PwCfg v;
-    const char* e = getenv("OCV_PW_CFG");
-    if (e != nullptr) {
-      if (strcmp(e, "rows") == 0) v.family = 1;
-      else if (strcmp(e, "stream") == 0) v.family = 2;
-      else if (strcmp(e, "tile") == 0) v.family = 3;
-      else if (sscanf(e, "%d,%d", &v.wn, &v.wk) == 2) v.family = 3;
-    }
-    return v;
-  }();
+  static PwCfg c;
   return c;
 }
 

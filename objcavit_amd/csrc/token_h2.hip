@@ -315,10 +315,8 @@ extern "C" int ocv_layer_tail_h2_fwd(const float* ctx, const float* x, const ocv
 
 // Feed-forward chunks per row block over G workgroups: only where the launch leaves most of the chip idle (see the kernel)
 extern "C" int ocv_layer_tail_h2_groups(int M, int FF) {
-  static const int forced = [] { const char* e = getenv("OCV_TAIL_GROUPS"); return e ? atoi(e) : 0; }();      // A/B: 1, 2, 4 or 8
   const int nblk = ocv_cdiv(M, TM), nchunk = FF / KC;
   int G = nblk <= 24 ? 8 : nblk <= 56 ? 4 : 1;          // (2 groups at 75 - 105 row blocks measured neutral: 870 vs 870, 641 vs 640 img/s)
-  if (forced == 1 || forced == 2 || forced == 4 || forced == 8) G = forced;
   while (G > 1 && nchunk % G != 0) G >>= 1;
   return G;
 }

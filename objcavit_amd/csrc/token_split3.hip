@@ -746,9 +746,8 @@ int ocv_cross_attn_split3_launch(const float* q_src, const float* k_src, const f
   XA3Args a{q_src, mask, kv_ws, (const __bf16*)in_p3, (const __bf16*)out_p3, in_b, out_b, out, Sq, Se, mask_ld, 1.0f / sqrtf(32.0f)};
   // two sub-tiles per workgroup once the 64-query workgroups alone fill the chip several times over (256 CUs x 3 resident):
   // 110 against 117 us at bs 512, S = 300; slower below (bs 128: 44.9 against 41.8 us)
-  static const int forced = getenv("OCV_XATTN_NSUB") ? atoi(getenv("OCV_XATTN_NSUB")) : 0;
   const long wg64 = (long)ocv_cdiv(Sq, 2 * TM) * B;
-  const int nsub = forced == 1 || forced == 2 ? forced : (wg64 >= 2048 ? 2 : 1);
+  const int nsub = wg64 >= 2048 ? 2 : 1;
   if (nsub == 2)
     hipLaunchKernelGGL(xattn_main3_kernel<2>, dim3(ocv_cdiv(Sq, 2 * TM), B), dim3(256), 0, st, a);
   else

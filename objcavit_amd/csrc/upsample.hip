@@ -448,9 +448,7 @@ extern "C" int ocv_upsample_concat_split_x_fwd(const float* x, int h, int w, int
   UpArgs a{x, skip, (unsigned short*)out_hl, Cp, h, w, H, W, C1, C2,
            H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f,
            (long)B * H * W * (Cp / 4), f16 ? ocv_range_flag_current() : nullptr};
-  static const bool quad_only = getenv("OCV_UPSAMPLE_QUAD") != nullptr;
-  static const bool no_lds = getenv("OCV_UPSAMPLE_NOLDS") != nullptr;
-  if (C1 % ULC == 0 && C2 % 8 == 0 && a.sh <= 0.5f && a.sw <= 0.5f && !no_lds && getenv("OCV_UPSAMPLE_QUAD") == nullptr) {
+  if (C1 % ULC == 0 && C2 % 8 == 0 && a.sh <= 0.5f && a.sw <= 0.5f) {
     UpLArgs g{x, skip, (__bf16*)out_hl, Cp, h, w, H, W, C1, C2, a.sh, a.sw, (W + ULT_W - 1) / ULT_W, 0, C1 / ULC, a.range_flag};
     g.tiles_per_image = ((H + ULT_H - 1) / ULT_H) * g.tiles_x;
     const long nb = (long)B * g.tiles_per_image;
@@ -461,8 +459,7 @@ extern "C" int ocv_upsample_concat_split_x_fwd(const float* x, int h, int w, int
     OCV_CHECK_LAUNCH("ocv_upsample_concat_split_fwd");
     return 0;
   }
-  static const bool no_2x2 = getenv("OCV_UPSAMPLE_NO2X2") != nullptr;
-  if (C1 % 8 == 0 && C2 % 8 == 0 && Cp / 8 <= 256 && a.sh <= 1.0f && a.sw <= 1.0f && !quad_only && !no_2x2) {
+  if (C1 % 8 == 0 && C2 % 8 == 0 && Cp / 8 <= 256 && a.sh <= 1.0f && a.sw <= 1.0f) {
     UpBArgs g{x, skip, (__bf16*)out_hl, Cp, h, w, H, W, C1, C2, a.sh, a.sw, 0.f, Cp / 8, 1, (W + 1) / 2, (H + 1) / 2, 0, a.range_flag};
     g.inv_noct = 1.0f / (float)g.noct;
     g.nblk = (long)B * g.BH * g.BW;
@@ -477,7 +474,7 @@ extern "C" int ocv_upsample_concat_split_x_fwd(const float* x, int h, int w, int
     OCV_CHECK_LAUNCH("ocv_upsample_concat_split_fwd");
     return 0;
   }
-  if (C1 % 8 == 0 && C2 % 8 == 0 && Cp / 8 <= 256 * UP8_ITEMS && !quad_only) {
+  if (C1 % 8 == 0 && C2 % 8 == 0 && Cp / 8 <= 256 * UP8_ITEMS) {
     Up8Args g{x, skip, (__bf16*)out_hl, Cp, h, w, H, W, C1, C2, a.sh, a.sw, 0.f, Cp / 8, 1, (long)B * H * W, a.range_flag};
     g.inv_noct = 1.0f / (float)g.noct;
     g.PB = (256 * UP8_ITEMS) / g.noct;                           // a workgroup's items fit one pass of its threads

@@ -20,7 +20,7 @@
 // Range: fp16 tops out at 65504.  An ACTIVATION beyond that (token, projected query / key / value) converts to hi = inf and
 // the output row turns inf / NaN -- loud, not silently saturated; tokens, projected keys / values and softmax-weighted
 // contexts of this model are O(1) .. O(100).  The weight packer saturates at +-65504 (a static matrix: checked once, not
-// per element and launch).  OCV_XATTN_FORM=split3 (csrc/token_split3.hip) is the route with fp32's range.
+// per element and launch).  OCV_TOKENS=split3 (csrc/token_split3.hip) is the route with fp32's range.
 //
 //   xattn_kv_h2_kernel    K and V projected ONCE per image, one workgroup per image and operand, written pre-split in the
 //                         order the query tiles' lanes consume them: [B][2 operands][4 heads][64 lanes][2 steps][2 parts][8]
@@ -449,9 +449,8 @@ extern "C" int ocv_mha_few_keys_h2_fwd(const float* q_src, const float* k_src, c
   XAArgs a{q_src, key_padding_mask, (const _Float16*)workspace, (const _Float16*)in_proj_h2, (const _Float16*)out_proj_h2,
            in_proj_b, out_b, out, Sq, Se, Sk, 1.0f / sqrtf(32.0f), B, 0};
   // two sub-tiles per workgroup once the 64-query workgroups alone fill the chip several times over
-  static const int forced = getenv("OCV_XATTN_NSUB") ? atoi(getenv("OCV_XATTN_NSUB")) : 0;
   const long wg64 = (long)ocv_cdiv(Sq, 2 * TM) * B;
-  const int nsub = forced == 1 || forced == 2 ? forced : (wg64 >= 2048 ? 2 : 1);
+  const int nsub = wg64 >= 2048 ? 2 : 1;
   a.tiles = ocv_cdiv(Sq, nsub * TM);
   OCV_CHECK_ARG((long)a.tiles * B < (1L << 31), "ocv_mha_few_keys_h2_fwd: grid too large");
   if (nsub == 2)

@@ -468,7 +468,7 @@ def mha(q_src: torch.Tensor, k_src: torch.Tensor, v_src: torch.Tensor, in_proj_w
     kv_limit > 0: the caller guarantees every key j >= kv_limit is masked in every row, so those keys are skipped.
     ``packed``: the caller's cache of SplitWeight3 objects for this module (filled / refreshed here, keyed on the weights'
     identity and version) -> with at most 32 live keys every contraction runs as a two-term fp16 split with K / V projected once
-    per image (ocv_mha_few_keys_h2_fwd; OCV_XATTN_FORM selects the older forms), otherwise the projections run as three-term bf16
+    per image (ocv_mha_few_keys_h2_fwd; OCV_TOKENS=split3 | fp32 select the older forms), otherwise the projections run as three-term bf16
     splits (ocv_mha_split3_fwd); None, or OCV_TOKENS=fp32 -> the exact-fp32 kernels (ocv_mha_fwd)."""
     lib = _lib.load()
     for n, t in (("q_src", q_src), ("k_src", k_src), ("v_src", v_src), ("in_proj_weight", in_proj_w),
@@ -485,12 +485,10 @@ def mha(q_src: torch.Tensor, k_src: torch.Tensor, v_src: torch.Tensor, in_proj_w
     ws = workspace(nb, q_src.device)
     out = torch.empty(B, Sq, E, dtype=torch.float32, device=q_src.device)
     name = "mha_self" if q_src.data_ptr() == k_src.data_ptr() else ("mha_cross" if kv_limit else "mha_cross_full")
-    # few live keys (the image <- object cross-attention): OCV_XATTN_FORM = h2 (default: every contraction a two-term fp16 split,
-    # csrc/xattn_h2.hip) | split3 (three-term bf16 projections + exact-fp32 scores, fp32's range) | fp32 (round 2's single
-    # exact-fp32 launch); profiles/r03_cross_attention_roofline.txt has the three side by side at bs 16 ... 2048
-    form = os.environ.get("OCV_XATTN_FORM", "h2")
-    if form not in ("h2", "split3", "fp32"):
-        raise ValueError(f"OCV_XATTN_FORM={form!r}: expected h2, split3 or fp32")
+    # few live keys (the image <- object cross-attention), by OCV_TOKENS (``token_mode``): h2 (default: every contraction a two-term
+    # fp16 split, csrc/xattn_h2.hip) | split3 (three-term bf16 projections + exact-fp32 scores, fp32's range) | fp32 (round 2's
+    # single exact-fp32 launch); profiles/r03_cross_attention_roofline.txt has the three side by side at bs 16 ... 2048
+    form = token_mode()
     few = 0 < (kv_limit if 0 < kv_limit < Sk else Sk) <= 32 and (kv_limit == 0 or m is not None)
     small = few and form == "fp32"
     if packed is not None and token_split3_enabled() and E == 128 and n_heads == 4 and few and form == "h2" and B <= 65535:
@@ -617,7 +615,7 @@ def token_mode() -> str:
     mode = os.environ.get("OCV_TOKENS", "h2")
     if mode not in ("h2", "split3", "fp32"):
         raise ValueError(f"OCV_TOKENS={mode!r}: expected 'h2' (default), 'split3' or 'fp32'")
-    return mode
+    return "split3" if (mode == "h2" and _TLS.bf16_pairs) else mode          # (inside bf16_pairs(): the forms with fp32's range)
 
 
 def token_split3_enabled() -> bool:
@@ -912,19 +910,20 @@ def pixel_dot(feat: torch.Tensor, queries: torch.Tensor) -> torch.Tensor:
 
 
 def bin_head(feat: torch.Tensor, queries: torch.Tensor, w_out: torch.Tensor, b_out: torch.Tensor,
-             centers: torch.Tensor, split: bool = False, exact: bool = False) -> torch.Tensor:
+             centers: torch.Tensor, exact: bool = False) -> torch.Tensor:
     """depth [B,1,h,w] = sum_k softmax_k(conv1x1(pixel_dot(feat, queries)))_k * centers_k, fused.
     feat NCHW-contiguous: exact fp32 MFMA.  feat channels_last: logits as a TWO-term fp16 split with a scaled low term (22-bit
     products at the error of an fp32 FMA chain, three MFMAs per block, all 256 bins per workgroup: OCV_BINHEAD=h2, the default),
-    as a THREE-term bf16 split (OCV_BINHEAD=split3: six MFMAs, two bin halves + a merge launch; fp32's range), or on the exact
-    fp32 MFMA kernel with ``exact=True`` / OCV_BINHEAD=exact; ``split=True`` / OCV_BINHEAD=split computes them in the two-term
-    BF16 split -- ~3x the depth error under near-one-hot softmaxes (opt-in)."""
+    as a THREE-term bf16 split (OCV_BINHEAD=split3: six MFMAs, two bin halves + a merge launch; fp32's RANGE -- also what a
+    forward inside ``bf16_pairs()``, the range guard's fallback, takes), or on the exact fp32 MFMA kernel with ``exact=True`` /
+    OCV_BINHEAD=exact."""
     lib = _lib.load()
-    mode = os.environ.get("OCV_BINHEAD", "h2")              # read per call (the library's own getenv is latched once)
-    if mode not in ("h2", "split3", "exact", "split"):
-        raise ValueError(f"OCV_BINHEAD={mode!r}: expected 'h2' (default), 'split3', 'exact' or 'split'")
-    exact, split = exact or mode == "exact", split or mode == "split"
-    h2 = mode == "h2" and not exact and not split
+    mode = os.environ.get("OCV_BINHEAD", "h2")              # read per call
+    if mode not in ("h2", "split3", "exact"):
+        raise ValueError(f"OCV_BINHEAD={mode!r}: expected 'h2' (default), 'split3' or 'exact'")
+    if mode == "h2" and _TLS.bf16_pairs:
+        mode = "split3"                                     # a batch beyond the fp16 pairs' range: the head with fp32's range
+    exact = exact or mode == "exact"
     feat, cl = _map4(feat, "feat")
     _req(b_out, "b_out"); _req(centers, "centers")
     B, Cc, h, w = feat.shape
@@ -942,10 +941,11 @@ def bin_head(feat: torch.Tensor, queries: torch.Tensor, w_out: torch.Tensor, b_o
     wf = ws.view(torch.float32)
     check(lib.ocv_bin_head_fold_fwd(queries.data_ptr(), queries.stride(0), queries.stride(1), w2.data_ptr(), wf.data_ptr(), B,
                                     Cc, Q, nbins, _stream()), "ocv_bin_head_fold_fwd")
-    npart = int(lib.ocv_bin_head_partials_bytes(B, h * w)) if (cl and not exact and not split and not h2) else 0
+    route = 0 if not cl else (1 if exact else (3 if mode == "h2" else 2))          # include/objcavit_hip.h: ocv_bin_head_folded_fwd
+    npart = int(lib.ocv_bin_head_partials_bytes(B, h * w)) if route == 2 else 0
     part = workspace(npart, feat.device, "bin_head_partials") if npart else None
-    with timed("bin_head"):          # the logit / softmax / depth launch(es): split-3 halves + merge, or the exact kernel
-        check(lib.ocv_bin_head_folded_ws_fwd(feat.data_ptr(), (3 if h2 else 2 if split else 1) if cl else 0, wf.data_ptr(), b_out.data_ptr(),
+    with timed("bin_head"):          # the logit / softmax / depth launch(es): one, or the split-3 halves + merge
+        check(lib.ocv_bin_head_folded_ws_fwd(feat.data_ptr(), route, wf.data_ptr(), b_out.data_ptr(),
                                              centers.data_ptr(), depth.data_ptr(), B, Cc, nbins, h * w, _ptr(part), npart,
                                              _stream()), "ocv_bin_head_folded_ws_fwd")
     return depth
@@ -1102,16 +1102,22 @@ def conv_split_f16() -> bool:
 
 
 class bf16_pairs:
-    """``with bf16_pairs():`` forwards issued (or captured) inside run the decoder's / heads' split pipeline on bf16 pairs
-    whatever OCV_CONV_SPLIT says (thread-local): the handled fallback of a batch that tripped the fp16 range guard
-    (``RangeGuard``), and how its hipGraph is captured."""
+    """``with bf16_pairs():`` forwards issued (or captured) inside run on the forms with FP32'S RANGE (thread-local): the decoder's /
+    heads' split pipeline on bf16 pairs whatever OCV_CONV_SPLIT says, the token stacks' two-term fp16 layers as three-term bf16
+    (``token_mode``), the few-key cross-attention likewise, the attention cores on exact fp32 (``ocv_attention_set_fp32_range``),
+    the bin head as three-term bf16 (``bin_head``) -- rounds 1 - 3's arithmetic, parity-tested on its own.  It is the handled
+    fallback of a batch that tripped the fp16 range guard (``RangeGuard``), and how that fallback's hipGraph is captured."""
 
     def __enter__(self):
         _TLS.bf16_pairs += 1
+        if _TLS.bf16_pairs == 1 and torch.cuda.is_available():
+            check(_lib.load().ocv_attention_set_fp32_range(1), "ocv_attention_set_fp32_range")
         return self
 
     def __exit__(self, *exc):
         _TLS.bf16_pairs -= 1
+        if _TLS.bf16_pairs == 0 and torch.cuda.is_available():
+            check(_lib.load().ocv_attention_set_fp32_range(0), "ocv_attention_set_fp32_range")
         return False
 
 
@@ -1354,27 +1360,6 @@ def split_act(x: torch.Tensor, f16: bool = False) -> "SplitAct":
     return upsample_concat_split(x, None, tuple(x.shape[-2:]), f16=f16)
 
 
-_WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
-
-
-def prep_winograd_weight(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """[Cout, Cin, 3, 3] fp32 -> (u_hi, u_lo) bf16 [16, Cout, Cp]: the Winograd F(2x2, 3x3) filter transform
-    U[4 i + j] = (G g G^T)[i][j] (computed in fp64, rounded once to fp32), split like prep_conv_weight, Cp = Cin rounded
-    up to 32.  Done once per weight version by the callers (cached there)."""
-    Cout, Cin, kh, kw = weight.shape
-    if (kh, kw) != (3, 3):
-        raise ValueError("prep_winograd_weight: kernel must be 3x3")
-    G = torch.tensor(_WINO_G, dtype=torch.float64, device=weight.device)
-    u = torch.einsum("ia,ocab,jb->ijoc", G, weight.detach().double(), G).reshape(16, Cout, Cin).float()
-    Cp = (Cin + 31) // 32 * 32
-    if Cp != Cin:
-        u = torch.nn.functional.pad(u, (0, Cp - Cin))
-    hi = u.to(torch.bfloat16)
-    lo = (u - hi.float()).to(torch.bfloat16)
-    return hi.contiguous(), lo.contiguous()
-
-
-# F(4x4, 3x3) with the interpolation points 0, 1, -1, 2, -1/2, inf (csrc/conv_igemm.hip, w43_bt): G rows [1, a, a^2] / prod_{j != i}(a_i - a_j)
 _WINO43_G = ((1.0, 0.0, 0.0), (-1 / 3, -1 / 3, -1 / 3), (1 / 3, -1 / 3, 1 / 3), (1 / 15, 2 / 15, 4 / 15), (-16 / 15, 8 / 15, -4 / 15), (0.0, 0.0, 1.0))
 
 
@@ -1410,16 +1395,6 @@ def prep_winograd43_weight(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Te
     hi = u.to(torch.float16)
     lo = (u - hi.float()).to(torch.float16)
     return hi.contiguous(), lo.contiguous(), torch.exp2(-k).float().contiguous(), cscale.contiguous()
-
-
-def winograd_tile(B: int, H: int, W: int, Cin: int, Cout: int) -> int:
-    """Which Winograd form a 3x3 convolution that ``winograd_pays`` takes: 4 = F(4x4, 3x3) on two-term fp16 splits (default:
-    4x fewer matrix operations than direct, 36 GEMMs), 2 = F(2x2, 3x3) on two-term bf16 splits (round 2's: 2.25x, 16 GEMMs).
-    OCV_CONV_WINOGRAD_TILE=2|4 forces one."""
-    mode = os.environ.get("OCV_CONV_WINOGRAD_TILE", "4")
-    if mode not in ("2", "4"):
-        raise ValueError(f"OCV_CONV_WINOGRAD_TILE={mode!r}: expected 2 or 4")
-    return int(mode)
 
 
 def conv3x3_winograd43_split(x: "SplitAct", u_hi: torch.Tensor, u_lo: torch.Tensor, fscale: torch.Tensor, bias: Optional[torch.Tensor],
@@ -1465,58 +1440,11 @@ def conv3x3_winograd43_split(x: "SplitAct", u_hi: torch.Tensor, u_lo: torch.Tens
 
 
 def winograd_pays(B: int, H: int, W: int, Cin: int, Cout: int) -> bool:
-    """Where a Winograd form of a 3x3 convolution beats the direct split-bf16 kernel: the transformed input and the raw result go
-    through HBM, so the arithmetic must dominate.  F(4x4, 3x3) on two-term fp16 splits (the default form, ``winograd_tile``): the
-    decoder's 30 x 40 and 60 x 80 second convolutions (1024 -> 1024: 413 us against 1000 direct and 632 for F(2x2, 3x3); 512 -> 512:
-    557 against 882; 256 -> 256 at 120 x 160 is a tie and stays direct -- tools/run_wino43.py, profiles/r03_winograd43.txt).
-    F(2x2, 3x3) (OCV_CONV_WINOGRAD_TILE=2, round 2's): the 30 x 40 stage only (its 4x transformed input eats the gain at 60 x 80).
-    OCV_CONV_WINOGRAD=0 / =1 in the environment forces never / whenever the kernel supports the shape; OCV_WINO_MIN_CIN /
-    OCV_WINO_MIN_COUT / OCV_WINO_MAX_PIX move the thresholds."""
-    mode = os.environ.get("OCV_CONV_WINOGRAD", "auto")
-    if mode == "0" or Cout % 8 != 0:
-        return False
-    if mode == "1":
-        return True
-    f43 = winograd_tile(B, H, W, Cin, Cout) == 4
-    return Cin >= int(os.environ.get("OCV_WINO_MIN_CIN", "512" if f43 else "768")) \
-        and Cout >= int(os.environ.get("OCV_WINO_MIN_COUT", "512")) \
-        and B * H * W <= int(os.environ.get("OCV_WINO_MAX_PIX", "131072" if f43 else "32768"))
-
-
-def conv3x3_winograd_split(x: "SplitAct", u_hi: torch.Tensor, u_lo: torch.Tensor, bias: Optional[torch.Tensor],
-                           act: int = ACT_NONE, out_fp32: bool = True, out_split: bool = False):
-    """3x3 convolution (stride 1, padding 1) of a pre-split activation in Winograd F(2x2, 3x3) form
-    (ocv_conv3x3_winograd_split_fwd).  Returns fp32 tensor, SplitAct, or (fp32, SplitAct) like conv_nhwc_split."""
-    lib = _lib.load()
-    if not (out_fp32 or out_split):
-        raise ValueError("conv3x3_winograd_split: nothing to output")
-    _req(x.hl, "x.hl", torch.bfloat16)
-    B, Cin, H, W = x.shape
-    Cp = (Cin + 31) // 32 * 32
-    if x.hl.dim() != 4 or x.hl.shape[3] != 2 * Cp:
-        raise ValueError("conv3x3_winograd_split: x.hl must be [B, H, W, 2 * ceil32(C)] bf16")
-    for n, t in (("u_hi", u_hi), ("u_lo", u_lo)):
-        _req(t, n, torch.bfloat16)
-    if u_hi.dim() != 3 or u_hi.shape[0] != 16 or u_hi.shape[2] != Cp or u_lo.shape != u_hi.shape:
-        raise ValueError(f"conv3x3_winograd_split: transformed weights {tuple(u_hi.shape)} do not match {Cin} input channels")
-    Cout = u_hi.shape[1]
-    if Cout % 8 != 0:
-        raise ValueError("conv3x3_winograd_split: Cout must be a multiple of 8")
-    if bias is not None:
-        _req(bias, "bias")
-        if bias.numel() != Cout:
-            raise ValueError("conv3x3_winograd_split: bias size mismatch")
-    y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.hl.device, memory_format=torch.channels_last) if out_fp32 else None
-    ys = SplitAct.empty(B, Cout, H, W, x.hl.device) if out_split else None
-    nws = int(lib.ocv_conv3x3_winograd_workspace_bytes(B, H, W, Cin, Cout))
-    ws = workspace(nws, x.hl.device, "conv_winograd")
-    with timed(f"conv3x3w2|{B},{H},{W},{Cin},{Cout}"):
-        check(lib.ocv_conv3x3_winograd_split_fwd(x.hl.data_ptr(), Cin, u_hi.data_ptr(), u_lo.data_ptr(), _ptr(bias), _ptr(y),
-                                                 ys.hl.data_ptr() if out_split else None, B, H, W, Cout, act,
-                                                 ws.data_ptr(), ws.numel(), _stream()), "ocv_conv3x3_winograd_split_fwd")
-    if out_fp32 and out_split:
-        return y, ys
-    return y if out_fp32 else ys
+    """Where the Winograd F(4x4, 3x3) form of a 3x3 convolution (two-term fp16 splits inside, 36 GEMMs, 4x fewer matrix operations)
+    beats the direct kernel: the transformed input and the raw result go through HBM, so the arithmetic must dominate -- the
+    decoder's 30 x 40 and 60 x 80 second convolutions (1024 -> 1024: 413 us against 1000 direct; 512 -> 512: 557 against 882;
+    256 -> 256 at 120 x 160 is a tie and stays direct -- tools/run_wino43.py, profiles/r03_winograd43.txt)."""
+    return Cout % 8 == 0 and Cin >= 512 and Cout >= 512 and B * H * W <= 131072
 
 
 def _nhwc(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -1661,46 +1589,20 @@ class PerImageSplitWeight:
         self.packed, self.cout, self.cin, self.img_elems, self.images = packed, int(cout), int(cin), int(img_elems), int(images)
 
 
-def pointwise_hl_mode() -> str:
-    """OCV_PW_HL: '1' (default) = the late encoder stages take the pre-split 1x1 route where it pays END TO END
-    (pointwise_hl_project_pays / pointwise_hl_expand_pays), '0' = never (the fp32-row kernels of round 2: the A/B route)."""
-    mode = os.environ.get("OCV_PW_HL", "1")
-    if mode not in ("0", "1"):
-        raise ValueError(f"OCV_PW_HL={mode!r}: expected '1' (default) or '0'")
-    return mode
-
-
-def pointwise_hl_expand_pays(M: int, cin: int, cout: int) -> bool:
-    """Whether an expand 1x1 convolution (and the project in front of it, which then also writes the hl32 copy) should take
-    the pre-split route.  OPT-IN (OCV_PW_HL_EXPAND=1): layer by layer, launched back to back, the LDS-DMA kernel is 2 - 11 us
-    faster on every late expand layer (profiles/r03_pointwise_hl_sweep.txt), but in the real forward the route LOSES:
-    bench.py --inflight 1, same box, two rounds: 915.7 / 914.2 img/s without it, 896.5 / 894.9 with every late expand layer on
-    it, 907.8 / 907.2 with stages 6 - 7 only, 914.8 / 915.1 with 512 -> 3072 only.  The fp32 rows the round-2 kernel reads
-    were written by the launch in front of it and are still in L2 / Infinity Cache, while the hl32 copy is a second output
-    stream for every project layer; the isolated timing sees neither."""
-    if pointwise_hl_mode() == "0" or os.environ.get("OCV_PW_HL_EXPAND", "0") != "1" or cin % 8 != 0 or cout % 4 != 0:
-        return False
-    return M <= int(os.environ.get("OCV_PW_HL_MAX_ROWS", "32768")) and cin >= int(os.environ.get("OCV_PW_HL_MIN_CIN", "96"))
-
-
 def pointwise_hl_project_pays(B: int, rows_per_image: int, cin: int, cout: int) -> bool:
-    """Whether an MBConv project convolution should take the pre-split route with the squeeze-excite gate folded into
-    PER-IMAGE weights.  Measured at bs = 16 (profiles/r03_pointwise_hl_sweep.txt): the project GEMM itself gains on every
-    late layer with K >= 1056 (1056 -> 176: 57 -> 46 us, 1824 -> 304: 42 -> 30, 3072 -> 512: 86 -> 71), but writing and
-    re-reading B x Cout x Cin x 4 bytes of gated weights costs 6 us at 1200 rows per image (stage 5: 12 MB against 81 MB of
-    rows) and 10 - 18 us at 300 rows (stages 6, 7: as many bytes as the rows themselves), which eats the gain there; at
-    K = 768 (stage 4) the GEMM does not gain.  So: long K and weights well under the rows' own traffic -- stage 5's six
-    1056 -> 176 blocks.  End to end (bench.py --inflight 1, same box, two rounds): 919.7 / 918.0 img/s with this route
-    against 915.7 / 914.2 without; with the stage 6 - 7 layers as well 889.5 / 888.5."""
-    if pointwise_hl_mode() == "0" or cin % 32 != 0 or cout % 4 != 0:
+    """Whether an MBConv project convolution takes the pre-split route with the squeeze-excite gate folded into PER-IMAGE
+    weights.  Measured at bs = 16 (profiles/r03_pointwise_hl_sweep.txt): the project GEMM itself gains on every late layer with
+    K >= 1056 (1056 -> 176: 57 -> 46 us, 1824 -> 304: 42 -> 30, 3072 -> 512: 86 -> 71), but writing and re-reading
+    B x Cout x Cin x 4 bytes of gated weights costs 6 us at 1200 rows per image (stage 5: 12 MB against 81 MB of rows) and
+    10 - 18 us at 300 rows (stages 6, 7: as many bytes as the rows themselves), which eats the gain there; at K = 768 (stage 4) the
+    GEMM does not gain.  So: long K and weights well under the rows' own traffic -- stage 5's six 1056 -> 176 blocks.  End to end
+    (bench.py --inflight 1, same box, two rounds): 919.7 / 918.0 img/s with this route against 915.7 / 914.2 without; with the
+    stage 6 - 7 layers as well 889.5 / 888.5; the EXPAND layers on the pre-split route (hl32 copies written by the project in front)
+    lost end to end in every combination (896 - 915) and left the product in round 5.  A batch of 1 - 3: the fp32-row kernel with
+    its K slabs shared out over workgroups and the plain gate launch win (round 4)."""
+    if cin % 32 != 0 or cout % 4 != 0 or B < 4:
         return False
-    if B < int(os.environ.get("OCV_PW_HL_MIN_BATCH", "4")):
-        # a batch of 1 - 2 (round 4): the layer is ~40 tiles either way; the fp32-row kernel with its K slabs shared out over
-        # workgroups (ocv_pointwise_conv_nhwc_split_ws_fwd) and the plain gate launch beat folding the gate into per-image weights
-        return False
-    M = B * rows_per_image
-    return (M <= int(os.environ.get("OCV_PW_HL_MAX_ROWS", "32768")) and cin >= int(os.environ.get("OCV_PW_HL_PROJECT_MIN_CIN", "1024"))
-            and cout * int(os.environ.get("OCV_PW_HL_WEIGHT_RATIO", "4")) <= rows_per_image)
+    return B * rows_per_image <= 32768 and cin >= 1024 and 4 * cout <= rows_per_image
 
 
 def pointwise_hl(x: "SplitAct", weight, bias: Optional[torch.Tensor], act: int = ACT_NONE,

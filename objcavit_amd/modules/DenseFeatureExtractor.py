@@ -173,19 +173,14 @@ class SplitConv3x3:
         hi, lo, b, osc = self.prep_for(x.f16)
         B, Cin, H, W = x.shape
         if self.conv.kernel_size[0] == 3 and hip_ops.winograd_pays(B, H, W, Cin, self.conv.out_channels):
-            # the deep stages: Winograd F(4x4, 3x3) on fp16 pairs, 4x fewer matrix-core operations (csrc/conv_igemm.hip);
-            # F(2x2, 3x3) (OCV_CONV_WINOGRAD_TILE=2) exists for bf16 pairs only
-            tile = hip_ops.winograd_tile(B, H, W, Cin, self.conv.out_channels)
-            if tile == 4 or not x.f16:
-                if self._wino is None or self._wino[0] != tile:
-                    if torch.cuda.is_current_stream_capturing():
-                        raise RuntimeError("weight preparation during graph capture: run one eager warm-up call first")
-                    prep = hip_ops.prep_winograd43_weight if tile == 4 else hip_ops.prep_winograd_weight
-                    self._wino = (tile,) + tuple(prep(self._w_folded))
-                if tile == 4:
-                    return hip_ops.conv3x3_winograd43_split(x, self._wino[1], self._wino[2], self._wino[3], b, act, out_fp32=out_fp32,
-                                                            out_split=out_split, cscale=self._wino[4])
-                return hip_ops.conv3x3_winograd_split(x, self._wino[1], self._wino[2], b, act, out_fp32=out_fp32, out_split=out_split)
+            # the deep stages: Winograd F(4x4, 3x3), 4x fewer matrix-core operations; fp16 pairs inside whatever the input's
+            # element type (every tile scaled by a power of two from its own maximum: fp32's range) -- csrc/conv_igemm.hip
+            if self._wino is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("weight preparation during graph capture: run one eager warm-up call first")
+                self._wino = (4,) + tuple(hip_ops.prep_winograd43_weight(self._w_folded))
+            return hip_ops.conv3x3_winograd43_split(x, self._wino[1], self._wino[2], self._wino[3], b, act, out_fp32=out_fp32,
+                                                    out_split=out_split, cscale=self._wino[4])
         return hip_ops.conv_nhwc_split(x, hi, lo, b, self.conv.kernel_size[0], act, out_fp32=out_fp32, out_split=out_split, oscale=osc)
 
 # skip-connection table: encoder-name fragment -> (feature_select, skip channels 3..0)

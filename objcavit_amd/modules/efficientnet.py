@@ -212,32 +212,18 @@ class InvertedResidual(_FoldedMixin, nn.Module):
             Ho, Wo = -(-H // stride), -(-W // stride)
             split_w = isinstance(we, hip_ops.SplitWeight)
             res = x if self.has_residual else None
-            # LATE STAGES (few rows, wide layers): the row operand of both 1x1 convolutions arrives PRE-SPLIT from its
-            # producer (hl32: the project epilogue of the block in front, the depthwise epilogue) and is read by LDS-DMA,
-            # the gate is folded into per-image project weights (csrc/pointwise_hl.hip); hip_ops decides per layer
-            emit_hl = split_w and hip_ops.pointwise_hl_expand_pays(B * Ho * Wo, cout, 6 * cout)      # for the block behind this one
             if hip_ops.expand_depthwise_fusable(cin, we, k):
                 # 3 launches: the expanded tensor stays in LDS (csrc/mbconv_fused.hip)
                 y, g = hip_ops.expand_depthwise_se_gate(x, we, be, wd, bd, k, stride, s1, sb1, s2, sb2)
-                out = hip_ops.pointwise_nhwc(y, wl, bl, hip_ops.ACT_NONE, gate=g, residual=res, out_split=emit_hl)
-            else:
-                if split_w and hip_ops.pointwise_hl_expand_pays(B * H * W, cin, mid):
-                    x_hl = getattr(x, "_ocv_hl", None)
-                    if x_hl is None:
-                        x_hl = hip_ops.split_act(x)                     # first block of the region only
-                    y = hip_ops.pointwise_hl(x_hl, we, be, hip_ops.ACT_SILU)
-                else:
-                    y = hip_ops.pointwise_nhwc(x, we, be, hip_ops.ACT_SILU)
-                if split_w and hip_ops.pointwise_hl_project_pays(B, Ho * Wo, mid, cout):
-                    y_hl, wg = hip_ops.depthwise_se_gate_weights(y, wd, bd, k, stride, s1, sb1, s2, sb2, wl_f32)
-                    out = hip_ops.pointwise_hl(y_hl, wg, bl, hip_ops.ACT_NONE, residual=res, out_fp32=True, out_split=emit_hl)
-                else:
-                    y, g = hip_ops.depthwise_se_gate(y, wd, bd, k, stride, s1, sb1, s2, sb2)
-                    out = hip_ops.pointwise_nhwc(y, wl, bl, hip_ops.ACT_NONE, gate=g, residual=res, out_split=emit_hl)
-            if emit_hl:
-                out, out_hl = out
-                out._ocv_hl = out_hl              # rides along: the next block's expand / the decoder read it in place
-            return out
+                return hip_ops.pointwise_nhwc(y, wl, bl, hip_ops.ACT_NONE, gate=g, residual=res)
+            y = hip_ops.pointwise_nhwc(x, we, be, hip_ops.ACT_SILU)
+            if split_w and hip_ops.pointwise_hl_project_pays(B, Ho * Wo, mid, cout):
+                # stage 5's projects (long K, weights well under the rows' traffic): the depthwise output written ONCE, pre-split
+                # (hl32), read by LDS-DMA, the gate folded into per-image project weights (csrc/pointwise_hl.hip)
+                y_hl, wg = hip_ops.depthwise_se_gate_weights(y, wd, bd, k, stride, s1, sb1, s2, sb2, wl_f32)
+                return hip_ops.pointwise_hl(y_hl, wg, bl, hip_ops.ACT_NONE, residual=res, out_fp32=True)
+            y, g = hip_ops.depthwise_se_gate(y, wd, bd, k, stride, s1, sb1, s2, sb2)
+            return hip_ops.pointwise_nhwc(y, wl, bl, hip_ops.ACT_NONE, gate=g, residual=res)
         y = self.act1(self.bn1(self.conv_pw(x)))
         y = self.act2(self.bn2(self.conv_dw(y)))
         y = self.bn3(self.conv_pwl(self.se(y)))

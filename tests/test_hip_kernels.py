@@ -263,7 +263,7 @@ def test_mha_split3(ops, monkeypatch, Sq, Sk, counts, kv, form):
     ref = restate.multi_head_attention(qs, ks, vs, iw, ib, ow, ob, mask)
     args = (dev(qs), dev(ks), dev(vs), dev(iw), dev(ib), dev(ow), dev(ob), None if mask is None else dev(mask))
     cache = {}
-    monkeypatch.setenv("OCV_XATTN_FORM", form)
+    monkeypatch.setenv("OCV_TOKENS", form)                      # (the few-key cross-attention follows the token mode)
     got = ops.mha(*args, kv_limit=kv, packed=cache).cpu()
     few = (kv if 0 < kv < Sk else Sk) <= 32
     assert set(cache) == ({"in_proj_h2", "out_proj_h2"} if few and form == "h2" else {"in_proj_p3", "out_proj_p3"})
@@ -289,7 +289,7 @@ def test_mha_few_keys_large_launch(ops, monkeypatch, form):
     ow, ob = rnd("ow", (E, E), 6, 1 / math.sqrt(E)), rnd("ob", (E,), 7, 0.1)
     mask = torch.arange(Sk)[None, :] >= torch.tensor(counts)[:, None]
     args = (dev(qs), dev(ks), dev(vs), dev(iw), dev(ib), dev(ow), dev(ob), dev(mask))
-    monkeypatch.setenv("OCV_XATTN_FORM", form)
+    monkeypatch.setenv("OCV_TOKENS", form)                      # (the few-key cross-attention follows the token mode)
     got = ops.mha(*args, kv_limit=32, packed={}).cpu()
     exact = ops.mha(*args, kv_limit=32).cpu()
     nan = torch.isnan(exact)
@@ -661,12 +661,16 @@ def test_pixel_dot_and_bin_head_channels_last(ops, monkeypatch, B, h, w):
     # NCHW and NHWC paths agree to rounding
     got_nchw = ops.bin_head(dev(feat), qg, dev(wout), dev(bout), centers)
     assert float(((got - got_nchw).abs() / got_nchw).max()) < 1e-4      # different K order inside the MFMA chains
-    # opt-in path: logits in split bf16 (product error 2^-17).  This input is a stress case -- logit gain 6, a near
-    # one-hot softmax over 256 bins, so logit errors pass straight into depth -- and is held to the north-star bar
-    got_split = ops.bin_head(fg, qg, dev(wout), dev(bout), centers, split=True)
-    assert float(((got_split.cpu() - ref_depth).abs() / ref_depth).max()) < 1e-3
-    assert float(((got_split.cpu() - ref_depth).abs() / ref_depth).mean()) < 2e-5
-    assert torch.equal(got_split, ops.bin_head(fg, qg, dev(wout), dev(bout), centers, split=True))
+    # inside hip_ops.bf16_pairs() -- the fp16 range guard's fallback route -- the head takes the form with fp32's range (split3)
+    monkeypatch.setenv("OCV_BINHEAD", "split3")
+    want = ops.bin_head(fg, qg, dev(wout), dev(bout), centers)
+    monkeypatch.delenv("OCV_BINHEAD")
+    with ops.bf16_pairs():
+        assert torch.equal(ops.bin_head(fg, qg, dev(wout), dev(bout), centers), want)
+    big = (fg * 1e6).contiguous(memory_format=torch.channels_last)       # a map far beyond fp16's range, queries scaled the other way
+    with ops.bf16_pairs():
+        far = ops.bin_head(big, qg / 1e6, dev(wout), dev(bout), centers)
+    assert bool(torch.isfinite(far).all()) and float(((far - want).abs() / want).max()) < 1e-4
 
 
 @pytest.mark.parametrize("B,C,H,W,Cout,layout", [(2, 3, 33, 47, 128, "nchw"), (1, 3, 480, 640, 128, "nchw"), (2, 4, 16, 17, 8, "nhwc"),
@@ -1209,40 +1213,6 @@ def test_conv_nhwc_split_in_and_out(ops, B, H, W, Cin, Cout, k, act):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,act", [
-    (2, 30, 40, 96, 64, 2),        # even sizes, LeakyReLU
-    (1, 7, 9, 40, 72, 0),          # odd H and W (last tile row / column half outside), Cin % 32 != 0, Cout % 32 != 0
-    (3, 1, 1, 32, 8, 1),           # a single pixel: every tap but the centre is padding
-    (1, 2, 2, 8, 16, 3),           # one tile, SiLU
-    (1, 15, 20, 1024, 512, 2),     # long K: 32 channel chunks per position
-    (2, 13, 16, 300, 136, 2),      # ragged everything (300 rows of tiles are not a multiple of the 256-row GEMM tile)
-])
-def test_conv3x3_winograd_split(ops, B, H, W, Cin, Cout, act):
-    """ocv_conv3x3_winograd_split_fwd (input transform, 16 batched split-bf16 GEMMs, output transform) against an fp64
-    convolution at the SAME bar as the direct kernel (2e-5 of max |y|), and against the direct kernel itself."""
-    x = rnd("x", (B, Cin, H, W), 1)
-    w, b = rnd("w", (Cout, Cin, 3, 3), 3, 1 / math.sqrt(Cin * 9)), rnd("b", (Cout,), 4, 0.2)
-    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
-    ref = [ref, torch.relu(ref), F.leaky_relu(ref, 0.01), F.silu(ref)][act]
-    u_hi, u_lo = ops.prep_winograd_weight(dev(w))
-    assert tuple(u_hi.shape) == (16, Cout, (Cin + 31) // 32 * 32)
-    xs = ops.upsample_concat_split(dev(x), None, (H, W))
-    poison = [torch.full((1 << 22,), float("nan"), device="cuda") for _ in range(8)]
-    del poison                                                  # workspace and outputs come out of NaN-filled memory
-    y, ys = ops.conv3x3_winograd_split(xs, u_hi, u_lo, dev(b), act, out_fp32=True, out_split=True)
-    assert y.is_contiguous(memory_format=torch.channels_last)
-    assert rel_dev(y, ref) < SPLIT_TOL
-    assert rel_dev(ys.float(), y) < 1e-5
-    Cpo = (Cout + 31) // 32 * 32
-    blocks = ys.hl.view(B, H, W, Cpo // 32, 2, 32).permute(0, 1, 2, 4, 3, 5).reshape(B, H, W, 2, Cpo)
-    assert not bool(blocks[..., Cout:].any())                  # pad channels of the split output are zero
-    y2 = ops.conv3x3_winograd_split(xs, u_hi, u_lo, dev(b), act, out_fp32=True, out_split=False)
-    assert torch.equal(y, y2)
-    hi, lo = ops.prep_conv_weight(dev(w))
-    direct = ops.conv_nhwc_split(xs, hi, lo, dev(b), 3, act)
-    assert rel_dev(y, direct) < SPLIT_TOL
-
-
-@pytest.mark.parametrize("B,H,W,Cin,Cout,act", [
     (2, 30, 40, 96, 64, 2),        # H not a multiple of 4 (last tile row half outside), LeakyReLU
     (1, 7, 9, 40, 72, 0),          # odd H and W, Cin % 32 != 0, Cout % 32 != 0
     (3, 1, 1, 32, 8, 1),           # a single pixel: every tap but the centre is padding
@@ -1338,27 +1308,11 @@ def test_conv3x3_winograd43_keeps_fp32_range(ops, Cin):
         assert bool(torch.isfinite(y[1]).all())                            # and nowhere else: the other image is untouched
 
 
-def test_conv3x3_winograd_keeps_fp32_range_and_rejects_bad_operands(ops):
-    x = rnd("x", (1, 64, 12, 12), 1) * torch.logspace(-3, 3, 64).view(1, 64, 1, 1)
-    w = rnd("w", (32, 64, 3, 3), 2, 0.05) / torch.logspace(-3, 3, 64).view(1, 64, 1, 1)
-    ref = F.conv2d(x.double(), w.double(), padding=1)
-    u_hi, u_lo = ops.prep_winograd_weight(dev(w))
-    xs = ops.upsample_concat_split(dev(x), None, (12, 12))
-    assert rel_dev(ops.conv3x3_winograd_split(xs, u_hi, u_lo, None), ref) < SPLIT_TOL
-    with pytest.raises(ValueError):
-        ops.conv3x3_winograd_split(xs, u_hi[:, :, :32].contiguous(), u_lo[:, :, :32].contiguous(), None)     # wrong Cin
-    with pytest.raises(ValueError):
-        ops.prep_winograd_weight(dev(rnd("w1", (8, 8, 1, 1), 1)))
+def test_winograd_dispatch_policy(ops):
+    """hip_ops.winograd_pays: F(4x4, 3x3) takes the decoder's 30 x 40 and 60 x 80 second convolutions, nothing shallower or larger."""
     assert ops.winograd_pays(16, 30, 40, 2224, 1024) and ops.winograd_pays(16, 30, 40, 1024, 1024)
-    assert ops.winograd_tile(16, 30, 40, 1024, 1024) == 4                 # default form: F(4x4, 3x3) on two-term fp16 splits ...
-    assert ops.winograd_pays(16, 60, 80, 512, 512) and not ops.winograd_pays(16, 120, 160, 256, 256)     # ... which also takes 60 x 80
-    assert not ops.winograd_pays(16, 240, 320, 280, 128)
-    import os
-    os.environ["OCV_CONV_WINOGRAD_TILE"] = "2"                            # round 2's F(2x2, 3x3): the 30 x 40 stage only
-    try:
-        assert ops.winograd_pays(16, 30, 40, 1024, 1024) and not ops.winograd_pays(16, 60, 80, 1088, 512)
-    finally:
-        del os.environ["OCV_CONV_WINOGRAD_TILE"]
+    assert ops.winograd_pays(16, 60, 80, 512, 512) and not ops.winograd_pays(16, 120, 160, 256, 256)
+    assert not ops.winograd_pays(16, 240, 320, 280, 128) and not ops.winograd_pays(16, 30, 40, 1024, 36)
 
 
 @pytest.mark.parametrize("B,H,W,C1,C2,Cout,k,act", [

@@ -394,17 +394,17 @@ def test_encoder_fast_path_vs_oracle(monkeypatch):
     assert rel_dev(separate, ref_out) < 1e-4 and not torch.equal(separate, whole)
 
 
-@pytest.mark.parametrize("env", [{"OCV_PW_HL": "0"}, {"OCV_PW_HL_EXPAND": "1"},
-                                 {"OCV_PW_HL_EXPAND": "1", "OCV_PW_HL_PROJECT_MIN_CIN": "256", "OCV_PW_HL_WEIGHT_RATIO": "0"}])
-def test_encoder_pre_split_pointwise_routes_vs_oracle(monkeypatch, env):
-    """The late MBConv stages on each 1x1 route: round 2's fp32-row kernels (OCV_PW_HL=0), the opt-in pre-split expand layers
-    (hl32 copies riding along between blocks, split_act of the region's first input), and every project layer with the
-    gate folded into per-image weights -- the five skip activations and the extractor's output against the oracle, at a
-    batch whose late stages have ragged row counts (7 x 9 and 4 x 5 pixels per image)."""
+@pytest.mark.parametrize("every_project", [False, True])
+def test_encoder_pre_split_pointwise_routes_vs_oracle(monkeypatch, every_project):
+    """The late MBConv stages on their 1x1 routes: the fp32-row kernels and, where hip_ops.pointwise_hl_project_pays says so (or,
+    with the policy patched, on EVERY late project layer), the depthwise output written pre-split with the gate folded into
+    per-image weights -- the five skip activations and the extractor's output against the oracle, at a batch whose late stages
+    have ragged row counts (7 x 9 and 4 x 5 pixels per image)."""
     from oracle import effnet_ref
+    from objcavit_amd import hip_ops
     from objcavit_amd.modules.DenseFeatureExtractor import DenseFeatureExtractor
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    if every_project:
+        monkeypatch.setattr(hip_ops, "pointwise_hl_project_pays", lambda B, rows, cin, cout: cin % 32 == 0 and cout % 4 == 0 and cin >= 256)
     m = DenseFeatureExtractor(make_args()).eval()
     sd = gen.load_into(m, 9)
     img = gen.randn("img", (3, 3, 224, 288), 9)
