@@ -709,8 +709,8 @@ def main():
                 sustained_ips = n_sus * B / sustained_s
                 log(f"sustained leg: {n_sus} steps in {sustained_s:.2f} s = {sustained_ips:.1f} img/s")
                 # per-kernel table: one stream (a launch bracketed while a side stream shares the chip would time the sharing)
-                saved = {k: os.environ.get(k) for k in ("OCV_HEAD_OVERLAP", "OCV_TOKEN_OVERLAP", "OCV_OBJ_OVERLAP", "OCV_SKIP_OVERLAP")}
-                os.environ.update(OCV_HEAD_OVERLAP="0", OCV_TOKEN_OVERLAP="0", OCV_OBJ_OVERLAP="0", OCV_SKIP_OVERLAP="0")
+                saved = {"OCV_FORKS": os.environ.get("OCV_FORKS")}
+                os.environ["OCV_FORKS"] = "0"
                 try:
                     for _ in range(2):
                         model(img)                       # (scratch of the one-stream order: allocated outside the timed pass)

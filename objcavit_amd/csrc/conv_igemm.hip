@@ -793,11 +793,9 @@ int launch_conv(ConvArgs& a, int B, bool in_split, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  static const bool use_dma = getenv("OCV_CONV_NO_DMA") == nullptr;
-  if (in_split && use_dma) {
+  if (in_split) {
     static bool attr2 = false;
     if (!attr2) {
       (void)hipFuncSetAttribute((const void*)conv_split_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -811,8 +809,7 @@ int launch_conv(ConvArgs& a, int B, bool in_split, hipStream_t st) {
       hipLaunchKernelGGL(conv_split_dma_kernel<true>, dim3(a.mtiles * a.ntiles * parts), dim3(512), DNBUF * DBUF, st, a);
     else
       hipLaunchKernelGGL(conv_split_dma_kernel<false>, dim3(a.mtiles * a.ntiles * parts), dim3(512), DNBUF * DBUF, st, a);
-  } else if (in_split) hipLaunchKernelGGL(conv_igemm_kernel<true>, dim3(a.mtiles * a.ntiles), dim3(512), 2 * BUF_BYTES, st, a);
-  else hipLaunchKernelGGL(conv_igemm_kernel<false>, dim3(a.mtiles * a.ntiles), dim3(512), 2 * BUF_BYTES, st, a);
+  } else hipLaunchKernelGGL(conv_igemm_kernel<false>, dim3(a.mtiles * a.ntiles), dim3(512), 2 * BUF_BYTES, st, a);
   OCV_CHECK_LAUNCH("ocv_conv_nhwc");
   return 0;
 }
@@ -854,9 +851,7 @@ extern "C" int ocv_conv_nhwc_split_x_fwd(const void* x_hl, int Cin, const void* 
   }
   const long M = (long)B * H * W;
   const int ks = conv_ksplit(M, Cout, Cin, ksize);
-  static const bool use_dma = getenv("OCV_CONV_NO_DMA") == nullptr;
-  OCV_CHECK_ARG(use_dma || f16 == 0, "ocv_conv_nhwc_split_fwd: OCV_CONV_NO_DMA (the register-staged diagnostic kernel) takes bf16 pairs only");
-  if (ks > 1 && use_dma && workspace != nullptr && workspace_bytes >= (size_t)ks * M * Cout * sizeof(float)) {
+  if (ks > 1 && workspace != nullptr && workspace_bytes >= (size_t)ks * M * Cout * sizeof(float)) {
     // two workgroups per tile, each over half of the channel chunks -> raw partial sums -> finish pass
     ConvArgs h = a;
     h.bias = nullptr; h.res = nullptr; h.yhl = nullptr; h.act = OCV_ACT_NONE; h.y = (float*)workspace; h.ksplit = ks; h.oscale = nullptr;

@@ -85,6 +85,7 @@ class _Tls(threading.local):
         self.islands_off = 0                 # > 0: inside islands_suspended()
         self.single_chain = 0                # > 0: inside single_chain() -- no further forks
         self.in_flight = 1                   # batches the caller keeps in flight on this GPU (batches_in_flight)
+        self.fork_override = {}              # fork name -> forced on / off (forks())
         self.bf16_pairs = 0                  # > 0: inside bf16_pairs() -- the split pipeline on bf16 pairs
         self.range_flag = None               # the armed RangeGuard word of this thread (a tensor), or None
         self.ws_stack = None                 # workspace stores of this thread (bottom = the module-level store)
@@ -177,25 +178,50 @@ def hw_queues_allow_forks() -> bool:
 
 
 def _side_switch(name: str) -> bool:
-    """The side-stream switches OCV_OBJ_OVERLAP / OCV_TOKEN_OVERLAP / OCV_HEAD_OVERLAP / OCV_SKIP_OVERLAP: '1', '0' or 'auto' (default) = on for a lone
-    batch on at most four hardware queues (``hw_queues_allow_forks``), off when the caller keeps several batches in flight on this GPU
-    (``batches_in_flight``: bench.py's slots, PipelinedValidation) or the process asked for more hardware queues.  A fork inside a
-    captured forward makes the replay use further hardware queues; with three slots replaying at once those collide with the other
-    slots' and the slots serialise each other.  One box, alternating runs, bs 16 (profiles/r04_head_overlap.txt, block 5), three in flight / one at a time:  no fork 1037 / 953 img/s;  object branch
-    beside the encoder 1015 / 961;  that + the token chain beside the heads' convolution 976 / 972;  object branch beside the image
-    tokens (this round's first default) 968 / 964."""
-    mode = os.environ.get(name, "auto")
+    """The four forks of a forward -- "obj" (object branch beside the encoder), "skip" (the decoder's skip-part convolutions beside
+    the encoder's late stages, sharing that fork), "token" (object branch beside the image tokens), "head" (token chain beside the
+    heads' convolution) -- under ONE switch, OCV_FORKS = 'auto' (default) | '0' | '1': auto = on for a lone batch on at most four
+    hardware queues (``hw_queues_allow_forks``), off when the caller keeps several batches in flight on this GPU
+    (``batches_in_flight``: bench.py's slots, PipelinedValidation).  A fork inside a captured forward makes the replay use further
+    hardware queues; with three slots replaying at once those collide with the other slots' and the slots serialise each other.
+    One box, alternating runs, bs 16 (profiles/r04_head_overlap.txt, block 5), three in flight / one at a time:  no fork 1037 / 953
+    img/s;  obj 1015 / 961;  obj + head 976 / 972;  token alone 968 / 964.  Single forks can be forced on or off for tests and A/B
+    tools with ``with hip_ops.forks(obj=..., token=..., head=..., skip=...)`` (thread-local), which wins over the environment."""
+    forced = _TLS.fork_override.get(name)
+    if forced is not None:
+        return forced
+    mode = os.environ.get("OCV_FORKS", "auto")
     if mode not in ("0", "1", "auto"):
-        raise ValueError(f"{name}={mode!r}: expected 'auto' (default), '1' or '0'")
+        raise ValueError(f"OCV_FORKS={mode!r}: expected 'auto' (default), '1' or '0'")
     return (_TLS.in_flight <= 1 and hw_queues_allow_forks()) if mode == "auto" else mode == "1"
 
 
+class forks:
+    """``with forks(obj=False, head=True):`` forces single forks of the forward on or off on this thread (see ``_side_switch``)."""
+    NAMES = ("obj", "token", "head", "skip")
+
+    def __init__(self, **kw):
+        bad = set(kw) - set(self.NAMES)
+        if bad:
+            raise ValueError(f"forks: unknown fork name(s) {sorted(bad)}; expected some of {self.NAMES}")
+        self.kw = {k: bool(v) for k, v in kw.items() if v is not None}
+
+    def __enter__(self):
+        self.prev = dict(_TLS.fork_override)
+        _TLS.fork_override.update(self.kw)
+        return self
+
+    def __exit__(self, *exc):
+        _TLS.fork_override = self.prev
+        return False
+
+
 def token_overlap_enabled() -> bool:
-    """OCV_TOKEN_OVERLAP (``_side_switch``): the object branch of the SA/CA stack (embedding, positional MLP, object self-attention:
+    """Fork "token" (``_side_switch``): the object branch of the SA/CA stack (embedding, positional MLP, object self-attention:
     ~20 launches of a few workgroups each) on a side stream beside the image branch (patch embedding + image self-attention: equally
     latency-bound, small grids), joined in front of the cross-attention -- where the branch could not already be issued beside the
     encoder (``object_prepass_enabled``).  Lone batch: +3 % at bs 1 - 2, +0.9 % at bs 16."""
-    return _side_switch("OCV_TOKEN_OVERLAP") and not _TLS.single_chain
+    return _side_switch("token") and not _TLS.single_chain
 
 
 class single_chain:
@@ -214,19 +240,19 @@ class single_chain:
 
 
 def object_prepass_enabled() -> bool:
-    """OCV_OBJ_OVERLAP (``_side_switch``): where the object branch does not read the image features (the MLP positional strategies) it
+    """Fork "obj" (``_side_switch``): where the object branch does not read the image features (the MLP positional strategies) it
     is issued at the top of the forward, on a side stream beside the encoder (GraphBins.forward_until_head), instead of behind the
     decoder.  On its own worth little (lone batch 953 -> 961 img/s); it leaves ONE side chain behind the decoder, which is what
     ``head_overlap_enabled`` needs."""
-    return _side_switch("OCV_OBJ_OVERLAP")
+    return _side_switch("obj")
 
 
 def skip_overlap_enabled() -> bool:
-    """OCV_SKIP_OVERLAP (``_side_switch``): the skip-part convolutions of the decoder's last three stages (short-K GEMMs over encoder
+    """Fork "skip" (``_side_switch``): the skip-part convolutions of the decoder's last three stages (short-K GEMMs over encoder
     activations of stages 2 - 4, ~0.9 ms at bs 16) are issued on side stream 0 behind the encoder's fourth stage, beside its late
     stages, together with the object branch -- one fork, one join (modules/DenseFeatureExtractor.py ``SkipPrepass``).  Lone batch:
     +1.6 % at bs 16, +4.4 % at bs 1."""
-    return _side_switch("OCV_SKIP_OVERLAP")
+    return _side_switch("skip")
 
 
 class batches_in_flight:
@@ -249,7 +275,7 @@ class batches_in_flight:
 
 
 def head_overlap_enabled() -> bool:
-    """OCV_HEAD_OVERLAP (``_side_switch``): the heads' 3x3 convolution over the decoder's map (4800 workgroups, ~0.93 ms at bs 16) is
+    """Fork "head" (``_side_switch``): the heads' 3x3 convolution over the decoder's map (4800 workgroups, ~0.93 ms at bs 16) is
     issued on the main stream while the image-token chain -- patch embedding, self-attention stack, cross-attention, bin regressor:
     ~25 launches of 2 - 300 workgroups, ~0.6 ms of mostly idle chip -- runs on a second side stream; joined in front of the bin head,
     the first consumer of both.  Lone batch at bs 16: 961 -> 972 img/s.
@@ -259,7 +285,7 @@ def head_overlap_enabled() -> bool:
     hipStreamEndCapture, so that shape is never built.  The token kernels hold 52 KB of LDS per workgroup and cannot share a CU
     with the convolution's 144 KB: beside it they run ~2x slower and the convolution 1.18 instead of 0.93 ms -- which is why the
     gain is a third of the chain's length."""
-    return _side_switch("OCV_HEAD_OVERLAP")
+    return _side_switch("head")
 
 
 def side_stream(device: torch.device, which: int = 0) -> "torch.cuda.Stream":
@@ -281,7 +307,7 @@ class WorkspaceStore(dict):
     (``with workspace_scope(store)`` around its warm-up, capture and replays): nothing outside can grow -- i.e. free --
     scratch that the graph still writes on every replay, and ``freeze()`` turns a later growth request inside the
     scope into an error instead of a silent re-allocation.  Buffers are keyed by stream as well as tag: two streams of
-    one forward (OCV_OBJ_OVERLAP) never share scratch."""
+    one forward (its forks: ``_side_switch``) never share scratch."""
 
     def __init__(self):
         super().__init__()
@@ -1826,11 +1852,8 @@ def expand_depthwise_fusable(cin: int, weight, k: int = 3) -> bool:
     24 <= Cin <= 64 and a 3 x 3 depthwise kernel (measured at B = 16: 40 -> 240 at 120 x 160 181 us fused against 123 + 150
     as two launches, 24 -> 144 stride 2 at 240 x 320 239 against 202 + 203; the 5 x 5 blocks -- 25 FMAs per output and
     1.7x halo recompute of the expand SiLU -- are VALU-bound fused and stay on the two-launch path: 64 -> 384 at 60 x 80
-    219 us fused against 42 + 71).  OCV_MBCONV_FUSED=0 / =all in the environment forces never / whenever supported."""
-    mode = os.environ.get("OCV_MBCONV_FUSED", "1")
-    if mode == "0" or not isinstance(weight, SplitWeight) or not (24 <= cin <= 64 and cin % 8 == 0):
-        return False
-    return k == 3 or mode == "all"
+    219 us fused against 42 + 71)."""
+    return isinstance(weight, SplitWeight) and 24 <= cin <= 64 and cin % 8 == 0 and k == 3
 
 
 def expand_depthwise_se_gate(x: torch.Tensor, w_expand: "SplitWeight", b_expand: Optional[torch.Tensor], weight_kkc: torch.Tensor,

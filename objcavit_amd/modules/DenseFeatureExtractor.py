@@ -332,8 +332,6 @@ class UpSampleWithSkip(nn.Module):
         if os.environ.get("OCV_UPCONV", "lowres") == "direct":
             return False
         c1, cout = x.shape[1], self._net[0].out_channels
-        if cout < int(os.environ.get("OCV_UPCONV_MIN_COUT", "0")):
-            return False
         return (c1 % 32 == 0 and cout % 8 == 0 and x.shape[2] < skip_features.shape[2] and x.shape[3] < skip_features.shape[3]
                 and hip_ops.tap_interp_supported(x.shape[2], x.shape[3], skip_features.shape[2], skip_features.shape[3], cout))
 
@@ -461,7 +459,7 @@ class SkipPrepass:
       * one fork behind stage 4 for the three, the object branch still forked at the top (= a side branch with TWO incoming edges
         from the main chain): 21.1 vs 16.6 ms, 8.2 vs 3.4 ms -- on this ROCm a graph branch may depend on the main chain ONCE;
       * this shape: **bs 16 984.6 -> 1000.0 img/s (+1.6 %), bs 1 296.4 -> 309.6 (+4.4 %)**; with two / one of the three
-        convolutions (forks behind stage 3 / 2: OCV_SKIP_STAGES) 992 / 988 and 304 / 303 (tools/ab_skip_stages.sh)."""
+        convolutions (forks behind stage 3 / 2) 992 / 988 and 304 / 303 (tools/ab_skip_stages.sh)."""
 
     def __init__(self, decoder: "Decoder", device: torch.device, extra=None):
         self.extra, self.extra_result = extra, None      # further image-independent work for the same fork (GraphBins: the object branch)
@@ -469,9 +467,7 @@ class SkipPrepass:
         self.side = hip_ops.side_stream(device, 0)
         self.f16 = decoder.settled_f16()
         sel = decoder.feature_select
-        import os
-        n = min(3, max(1, int(os.environ.get("OCV_SKIP_STAGES", "3"))))       # (A/B switch: tools/ab_skip_stages.sh)
-        stages = [(sel[0], decoder.up4), (sel[1], decoder.up3), (sel[2], decoder.up2)][:n]
+        stages = [(sel[0], decoder.up4), (sel[1], decoder.up3), (sel[2], decoder.up2)]
         self.stage_of = {} if self.f16 is None else dict(stages)
         self.trigger = stages[-1][0]                     # the last of the activations to appear
         self.pending = []                                # (stage, activation, weight dict)

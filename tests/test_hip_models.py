@@ -184,8 +184,8 @@ def test_graphbins_with_table_object_provider():
 
 
 def test_side_streams_equal_the_single_stream(monkeypatch):
-    """The forward's side streams -- OCV_OBJ_OVERLAP (object branch beside the encoder), OCV_TOKEN_OVERLAP (object branch beside the
-    image tokens), OCV_HEAD_OVERLAP (token chain beside the heads' 3x3 convolution), OCV_SKIP_OVERLAP (the decoder's skip-part
+    """The forward's four forks (hip_ops.forks) -- obj (object branch beside the encoder), token (object branch beside the
+    image tokens), head (token chain beside the heads' 3x3 convolution), skip (the decoder's skip-part
     convolutions beside the encoder) -- in every combination, eager and captured: the same kernels on the same operands, so the same
     bits as the single-stream forward, ragged object counts included.  The skip-part convolutions really are issued on the side
     stream (counted), and an AdaBins forward (no object branch) takes the same route."""
@@ -201,11 +201,10 @@ def test_side_streams_equal_the_single_stream(monkeypatch):
     feats = [gen.randn("f0", (5, 512), 1).cuda(), gen.randn("f1", (2, 512), 2).cuda()]
     boxes = [torch.rand(5, 4, device="cuda") * 100 + 10, torch.rand(2, 4, device="cuda") * 100 + 10]
 
+    from objcavit_amd import hip_ops as _ops
+
     def switches(obj, tok, head, skip):
-        monkeypatch.setenv("OCV_OBJ_OVERLAP", obj)
-        monkeypatch.setenv("OCV_TOKEN_OVERLAP", tok)
-        monkeypatch.setenv("OCV_HEAD_OVERLAP", head)
-        monkeypatch.setenv("OCV_SKIP_OVERLAP", skip)
+        monkeypatch.setattr(_ops._TLS, "fork_override", {"obj": obj == "1", "token": tok == "1", "head": head == "1", "skip": skip == "1"})
 
     from objcavit_amd.modules import DenseFeatureExtractor as dfe
     issued = []
@@ -281,9 +280,9 @@ def test_graph_replay_with_eager_island_equals_eager_dispatch(monkeypatch, head_
     """GraphedGraphBins: graph segments + an eager island + the eager head give bit-identical depth to plain dispatch,
     for the captured image and for new contents of the static input.  With the token chain on a side stream beside the heads'
     3x3 convolution (the default) that launch stays inside the capture -- a capture cannot be cut while a fork is open."""
-    monkeypatch.setenv("OCV_HEAD_OVERLAP", head_overlap)
     n_isl = 2 if head_overlap == "1" else 3
     from objcavit_amd import hip_ops
+    monkeypatch.setattr(hip_ops._TLS, "fork_override", {"head": head_overlap == "1"})
     from objcavit_amd.graph import GraphedGraphBins
     from objcavit_amd.modules.GraphBins import GraphBins, SyntheticObjectProvider
     H, W = 352, 384

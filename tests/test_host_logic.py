@@ -417,17 +417,17 @@ def test_validation_step_on_a_captured_graph_stand_in():
 
 
 def test_side_stream_switches_follow_the_batches_in_flight(monkeypatch):
-    """OCV_OBJ_OVERLAP / OCV_TOKEN_OVERLAP / OCV_HEAD_OVERLAP / OCV_SKIP_OVERLAP: 'auto' (default) = on for a lone batch on at most four
-    hardware queues, off inside ``hip_ops.batches_in_flight(n > 1)`` (thread-local: another thread's owner is not affected) and
-    off when the process asked for more than four hardware queues (profiles/r05_graph_shapes.txt: a forked graph replays 3x slower
-    there); '0' / '1' override; anything else is an error, not a silent default; inside hip_ops.single_chain() no further fork is
-    offered; launches inside islands_suspended() stay in the capture."""
+    """The forward's four forks under ONE switch, OCV_FORKS: 'auto' (default) = on for a lone batch on at most four hardware queues,
+    off inside ``hip_ops.batches_in_flight(n > 1)`` (thread-local: another thread's owner is not affected) and off when the process
+    asked for more than four hardware queues (profiles/r05_graph_shapes.txt: a forked graph replays 3x slower there); '0' / '1'
+    override; anything else is an error, not a silent default; ``hip_ops.forks(name=...)`` forces single forks (thread-local) and
+    wins over the environment; inside hip_ops.single_chain() no further fork is offered; launches inside islands_suspended() stay in
+    the capture."""
     import threading
     from objcavit_amd import hip_ops
-    switches = {"OCV_OBJ_OVERLAP": hip_ops.object_prepass_enabled, "OCV_TOKEN_OVERLAP": hip_ops.token_overlap_enabled,
-                "OCV_HEAD_OVERLAP": hip_ops.head_overlap_enabled, "OCV_SKIP_OVERLAP": hip_ops.skip_overlap_enabled}
-    for k in switches:
-        monkeypatch.delenv(k, raising=False)
+    switches = {"obj": hip_ops.object_prepass_enabled, "token": hip_ops.token_overlap_enabled,
+                "head": hip_ops.head_overlap_enabled, "skip": hip_ops.skip_overlap_enabled}
+    monkeypatch.delenv("OCV_FORKS", raising=False)
     monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
     assert all(f() for f in switches.values())
     with hip_ops.batches_in_flight(3):
@@ -440,22 +440,31 @@ def test_side_stream_switches_follow_the_batches_in_flight(monkeypatch):
         with hip_ops.batches_in_flight(0):                                                         # (clamped to 1), nested
             assert all(f() for f in switches.values())
         assert not any(f() for f in switches.values())
-        for k, f in switches.items():
-            monkeypatch.setenv(k, "1")
-            assert f()
-            monkeypatch.setenv(k, "0")
-            assert not f()
-            monkeypatch.setenv(k, "yes")
+        monkeypatch.setenv("OCV_FORKS", "1")
+        assert all(f() for f in switches.values())
+        monkeypatch.setenv("OCV_FORKS", "0")
+        assert not any(f() for f in switches.values())
+        monkeypatch.setenv("OCV_FORKS", "yes")
+        for f in switches.values():
             with pytest.raises(ValueError):
                 f()
-            monkeypatch.delenv(k)
+        monkeypatch.delenv("OCV_FORKS")
+        for k, f in switches.items():                                                              # one fork forced, the others follow 'auto'
+            with hip_ops.forks(**{k: True}):
+                assert f() and sum(g() for g in switches.values()) == 1
     assert all(f() for f in switches.values())
+    with hip_ops.forks(head=False, skip=False):
+        assert hip_ops.object_prepass_enabled() and not hip_ops.head_overlap_enabled() and not hip_ops.skip_overlap_enabled()
+        with hip_ops.forks(head=True):
+            assert hip_ops.head_overlap_enabled() and not hip_ops.skip_overlap_enabled()
+        assert not hip_ops.head_overlap_enabled()
+    with pytest.raises(ValueError):
+        hip_ops.forks(decoder=True)
     for q, ok in (("2", True), ("4", True), ("6", False), ("8", False), ("16", False)):
         monkeypatch.setenv("GPU_MAX_HW_QUEUES", q)
         assert hip_ops.hw_queues_allow_forks() == ok and all(f() == ok for f in switches.values()), q
-    monkeypatch.setenv("OCV_SKIP_OVERLAP", "1")                                                    # an explicit '1' is obeyed
-    assert hip_ops.skip_overlap_enabled()
-    monkeypatch.delenv("OCV_SKIP_OVERLAP")
+    with hip_ops.forks(skip=True):                                                                 # an explicit request is obeyed
+        assert hip_ops.skip_overlap_enabled()
     monkeypatch.delenv("GPU_MAX_HW_QUEUES")
     with hip_ops.single_chain():
         assert not hip_ops.token_overlap_enabled() and hip_ops.head_overlap_enabled()
