@@ -485,10 +485,11 @@ def side_leg(device, wl, model, nslot, seconds, seed=42):
     dt = time.perf_counter() - t0
     tripped = sum(int(g.tripped()) for g in slots)
     nodes = [sum(x for x in g.segment_nodes if x) for g in slots][0]
+    forks = sum(t.get("forks", 0) for t in slots[0].segment_topology)      # side-stream forks inside the captured forward (0 = single chain)
     del slots
     torch.cuda.empty_cache()
     return {"images_per_s": round(n * B / dt, 1), "ms_per_step": round(dt / n * 1e3, 3), "batch": B, "inflight": nslot, "steps": n,
-            "seconds": round(dt, 2), "graph_nodes": nodes, "capture_s": round(t_build, 2), "fp16_range_guard_tripped": tripped,
+            "seconds": round(dt, 2), "graph_nodes": nodes, "graph_forks": forks, "capture_s": round(t_build, 2), "fp16_range_guard_tripped": tripped,
             "workload": f"BASELINE configs[{wl.idx}] {wl.H}x{wl.W}, {wl.n_obj} objs/img, {wl.kw}"}
 
 

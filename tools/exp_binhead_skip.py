@@ -1,0 +1,38 @@
+"""would a two-level bin head skip anything on the benchmark workload?
+
+The kernel the verdict proposes forms coarse logits (hi * hi, one MFMA per block) for all 256 bins and the two correction MFMAs only
+for (32-pixel x 32-bin) tiles in which SOME pixel's logit lies within T of that pixel's maximum (a bin further than T below the
+maximum contributes < e^-T to the softmax: with T = 14, < 1e-6, so its logit does not need 22 bits).  A tile is the MFMA's unit: the
+corrections can be skipped only when ALL 32 pixels of the tile have ALL 32 bins more than T below their maxima.  This script forms
+the exact logits of BASELINE configs[2] (the bench's weights, images and objects) in fp32 torch and counts such tiles -- for the
+pixel order of the kernel (32 consecutive pixels of a row) and for T = 14 and T = 10 -- i.e. the fraction of the two correction
+products (2 / 3 of the kernel's matrix work) the data would let it drop."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+torch.set_grad_enabled(False)
+wl = bench.Workload(2, 4)
+dev = torch.device("cuda")
+model, sd, args = bench.build_model(dev, wl)
+img = bench.synthetic_images(wl.batch, 42, wl.H, wl.W).to(dev)
+model(img)
+feat, queries, centers, edges, _ = model.forward_until_head(img)
+from objcavit_amd import hip_ops
+f = hip_ops.fp32_map(feat).float()                           # [B, 128, h, w]
+B, Cc, h, w = f.shape
+conv = model.conv_out[0]
+Wf = conv.weight.view(256, 128) @ queries                    # [B, 256, 128]   (queries [B, 128, 128]: rows = query channels)
+logits = torch.einsum("bkc,bcp->bkp", Wf, f.reshape(B, Cc, h * w)) + conv.bias.view(1, 256, 1)       # [B, 256, P]
+mx = logits.amax(dim=1, keepdim=True)
+print(f"logits: std {float(logits.std()):.2f}, max - mean per pixel {float((mx - logits.mean(1, keepdim=True)).mean()):.2f}, "
+      f"softmax max prob mean {float(torch.softmax(logits, 1).amax(1).mean()):.3f}")
+P = h * w
+Pp = P // 32 * 32
+for T in (14.0, 10.0, 6.0):
+    near = (logits[:, :, :Pp] > mx[:, :, :Pp] - T)                                   # [B, 256, Pp]
+    frac_bins = float(near.float().mean())
+    tiles = near.view(B, 8, 32, Pp // 32, 32).any(dim=4).any(dim=2)                   # [B, 8 bin tiles, pixel tiles]
+    print(f"T = {T:4.1f}: {100 * frac_bins:5.1f} % of (pixel, bin) pairs within T of the pixel's maximum; "
+          f"{100 * float(tiles.float().mean()):5.1f} % of 32 x 32 tiles need their correction products "
+          f"(-> matrix work {100 * (1 + 2 * float(tiles.float().mean())) / 3:5.1f} % of today's three products)")
