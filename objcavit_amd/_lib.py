@@ -53,6 +53,7 @@ PROTOTYPES = {
     "ocv_split_h2_packed_elems": (C.c_size_t, [C.c_int, C.c_int]),
     "ocv_pack_split_h2_fwd": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, C.c_void_p, _stream]),
     "ocv_mha_few_keys_h2_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "ocv_mha_few_keys_h2_set_dispatch": (C.c_int, [C.c_int]),
     "ocv_mha_few_keys_h2_fwd": (C.c_int, [_f32p, _f32p, _f32p, _u8p, C.c_void_p, _f32p, C.c_void_p, _f32p, _f32p, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, _stream]),
     "ocv_ffn_residual_layernorm_fwd": (C.c_int, [_f32p] * 7 + [C.c_float, _u8p, _f32p, C.c_int, C.c_int, C.c_int, _stream]),

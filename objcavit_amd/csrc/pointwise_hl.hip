@@ -340,7 +340,7 @@ extern "C" int ocv_pointwise_hl_fwd(const void* x_hl, int Cin, const void* w_pac
   a.rows_per_image = w_image_elems ? rows_per_image : (int)M;
   OCV_CHECK_ARG(w_image_elems != 0 || M < (1L << 31), "ocv_pointwise_hl_fwd: M too large");
   hipStream_t st = (hipStream_t)stream;
-  // Tile choice (measured on MI355X at bs = 16, tools/run_pw_hl.py -> profiles/r03_pointwise_hl_sweep.txt; OCV_PWHL_CFG /
+  // Tile choice (measured on MI355X at bs = 16, tools/history/run_pw_hl.py -> profiles/r03_pointwise_hl_sweep.txt;
   // ocv_pointwise_hl_set_dispatch force one): long K (the project layers, 512 -> 3072) 64 rows per wavefront, two channel
   // blocks when the output is wide as well; short K (the expand layers, K <= 304: 2 - 5 slabs) the smallest tile -- those
   // launches are bound by the latency of a workgroup's single pass load -> multiply -> store, and the most workgroups in

@@ -607,7 +607,7 @@ extern "C" int ocv_pointwise_conv_nhwc_split_ws_fwd(const float* x, const float*
   PSArgs a{x, gate, bias, residual, (const __bf16*)w_packed, y, M, Cin, Kp, Cout,
            rows_per_image > 0 ? rows_per_image : 1, act, (__bf16*)y_hl, (Cout + 31) / 32 * 32};
   hipStream_t st = (hipStream_t)stream;
-  // Dispatch (measured on MI355X, bs = 16 encoder shapes, tools/run_pw.py):
+  // Dispatch (measured on MI355X, bs = 16 encoder shapes, tools/history/run_pw.py):
   //   rows   : Cin <= 128 and >= 2 10^5 rows (the stage 1-2 expand layers: one pass over the rows, channels walked)
   //   stream : <= 32 output channels and many rows (stage-1 project layers: pure row stream)
   //   tile   : everything else; 32 rows x 128 (64) channels per workgroup -- the smallest tile won on every late-stage

@@ -255,7 +255,8 @@ __global__ __launch_bounds__(256, 3) void xattn_kv_h2_kernel(XKVArgs p, int B) {
 struct XAArgs {
   const float* q_src;                  // [B][Sq][128]
   const uint8_t* mask;                 // [B][mask_ld] (nullable)
-  const _Float16* kv;                  // from xattn_kv_h2_kernel
+  const _Float16* kv;                  // from xattn_kv_h2_kernel (the two-launch form)
+  const float *k_src, *v_src;          // [B][mask_ld][128]: the one-launch form projects them itself
   const _Float16 *in_h2, *out_h2;
   const float *in_b, *out_b;
   float* out;                          // [B][Sq][128]
@@ -264,9 +265,13 @@ struct XAArgs {
   int B, tiles;                        // images, query tiles (of 32 NSUB queries) per image
 };
 
-template <int NSUB>
-__global__ __launch_bounds__(256, 3) void xattn_main_h2_kernel(XAArgs p) {
-  __shared__ __attribute__((aligned(16))) _Float16 planes[NSUB * 2 * PLANE];      // query rows, later the context rows
+// OWNKV: the ONE-LAUNCH form of small calls (every workgroup resident at once, the call a latency chain): each query tile
+// projects its image's K and V itself -- the same MFMAs on the same operands in the same order as xattn_kv_h2_kernel, the packed
+// accumulators kept in the registers the record would have been loaded into, so the two forms agree bit for bit --, which
+// trades the K / V launch and its record's round trip through L2 for two more projections per workgroup.
+template <int NSUB, bool OWNKV = false>
+__global__ __launch_bounds__(256, OWNKV ? 2 : 3) void xattn_main_h2_kernel(XAArgs p) {
+  __shared__ __attribute__((aligned(16))) _Float16 planes[(NSUB + (OWNKV ? 2 : 0)) * 2 * PLANE];   // query rows, later the context rows (+ key and value rows)
   __shared__ float Ms[32];
   const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
@@ -292,17 +297,24 @@ __global__ __launch_bounds__(256, 3) void xattn_main_h2_kernel(XAArgs p) {
   constexpr float NEG_INF = -__builtin_inff();
 
   WFragH fq;
-  load_wh(fq, p.in_h2 + ((long)h * NS * 2) * 512 + lane * 8);                      // Wq rows of head h
+  if (OWNKV) load_wh(fq, p.in_h2 + ((long)(4 + h) * NS * 2) * 512 + lane * 8);     // Wk rows of head h first
+  else load_wh(fq, p.in_h2 + ((long)h * NS * 2) * 512 + lane * 8);                 // Wq rows of head h
+  if (OWNKV) {
+    stage_rows_h2(planes + NSUB * 2 * PLANE, p.k_src + b * p.mask_ld * E128, 0, p.Se, tid);
+    stage_rows_h2(planes + (NSUB + 1) * 2 * PLANE, p.v_src + b * p.mask_ld * E128, 0, p.Se, tid);
+  }
 #pragma unroll
   for (int u = 0; u < NSUB; ++u) stage_rows_h2(planes + u * 2 * PLANE, p.q_src + b * p.Sq * E128, q0 + u * TM, p.Sq, tid);
   if (tid < 32) Ms[tid] = (tid >= p.Se || (p.mask != nullptr && p.mask[b * p.mask_ld + tid] != 0)) ? NEG_INF : 0.f;
   // this lane's K and V operands of the image's record (L2): [step][part][8] fp16 each, in flight under the Q projection
-  const _Float16* kf = p.kv + ((b * 2 * 4 + h) * 64 + lane) * 32;
+  const _Float16* kf = OWNKV ? nullptr : p.kv + ((b * 2 * 4 + h) * 64 + lane) * 32;
   h16x8 kh[2], kl[2], vh[2], vl[2];
+  if (!OWNKV) {
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    kh[t] = *reinterpret_cast<const h16x8*>(kf + 16 * t);
-    kl[t] = *reinterpret_cast<const h16x8*>(kf + 16 * t + 8);
+    for (int t = 0; t < 2; ++t) {
+      kh[t] = *reinterpret_cast<const h16x8*>(kf + 16 * t);
+      kl[t] = *reinterpret_cast<const h16x8*>(kf + 16 * t + 8);
+    }
   }
   // Q is scaled by log2(e) / sqrt(32): the scores come out in the log2 domain and the softmax is a bare v_exp_f32 (exp2)
   const float qs1 = p.scale * 1.44269504088896340736f, qs2 = qs1 * LO_DOWN;
@@ -313,6 +325,34 @@ __global__ __launch_bounds__(256, 3) void xattn_main_h2_kernel(XAArgs p) {
     bq[4 * g] = t.x * qs1; bq[4 * g + 1] = t.y * qs1; bq[4 * g + 2] = t.z * qs1; bq[4 * g + 3] = t.w * qs1;
   }
   __syncthreads();
+
+  if (OWNKV) {
+    // K^T (rows d, columns keys), then V (rows keys, columns d): xattn_kv_h2_kernel's arithmetic, the results kept in registers
+    {
+      f32x16 a1 = {0}, a2 = {0}, a;
+      project_t<true>(fq, planes + NSUB * 2 * PLANE, l31, hh, a1, a2);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a[r] = a1[r] + a2[r] * LO_DOWN + p.in_b[E128 + h * 32 + acc_row(r, hh)];
+      pack_steps(a, kh, kl);
+    }
+    load_wh(fq, p.in_h2 + ((long)(8 + h) * NS * 2) * 512 + lane * 8);              // Wv rows of head h
+    {
+      f32x16 a1 = {0}, a2 = {0}, a;
+      const _Float16* pa = planes + (NSUB + 1) * 2 * PLANE + l31 * PROW + 8 * hh;
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        const h16x8 xh = *reinterpret_cast<const h16x8*>(pa + 16 * st);
+        const h16x8 xl = *reinterpret_cast<const h16x8*>(pa + 16 * st + PLANE);
+        mfma3(xh, xl, fq.w[st][0], fq.w[st][1], a1, a2);
+        if (st & 1) __builtin_amdgcn_sched_barrier(0);
+      }
+      const float bv = p.in_b[2 * E128 + h * 32 + l31];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a[r] = a1[r] + a2[r] * LO_DOWN + bv;
+      pack_steps(a, vh, vl);
+    }
+    load_wh(fq, p.in_h2 + ((long)h * NS * 2) * 512 + lane * 8);                    // Wq rows of head h
+  }
 
   // Q^T of head h, straight into the B-operand form of the score MFMAs
   h16x8 qh[NSUB][2], ql[NSUB][2];
@@ -326,10 +366,12 @@ __global__ __launch_bounds__(256, 3) void xattn_main_h2_kernel(XAArgs p) {
   }
   WFragH fo;
   if (NSUB == 1) load_wh(fo, p.out_h2 + ((long)h * NS * 2) * 512 + lane * 8);      // Wo rows 32 h ..: in flight from here on
+  if (!OWNKV) {
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    vh[t] = *reinterpret_cast<const h16x8*>(kf + 4 * 64 * 32 + 16 * t);
-    vl[t] = *reinterpret_cast<const h16x8*>(kf + 4 * 64 * 32 + 16 * t + 8);
+    for (int t = 0; t < 2; ++t) {
+      vh[t] = *reinterpret_cast<const h16x8*>(kf + 4 * 64 * 32 + 16 * t);
+      vl[t] = *reinterpret_cast<const h16x8*>(kf + 4 * 64 * 32 + 16 * t + 8);
+    }
   }
   __syncthreads();                                   // every wavefront has read the query planes: they may take the context
 
@@ -403,7 +445,14 @@ __global__ __launch_bounds__(256, 3) void xattn_main_h2_kernel(XAArgs p) {
   }
 }
 
+int g_one_launch_wgs = 512;          // one launch while every query tile's workgroup is resident at once (2 per CU)
+
 }  // namespace
+
+extern "C" int ocv_mha_few_keys_h2_set_dispatch(int one_launch_max_workgroups) {
+  g_one_launch_wgs = one_launch_max_workgroups < 0 ? 512 : one_launch_max_workgroups;
+  return 0;
+}
 
 extern "C" size_t ocv_split_h2_packed_elems(int N, int K) {
   if (N < 1 || K < 1) return 0;
@@ -441,13 +490,19 @@ extern "C" int ocv_mha_few_keys_h2_fwd(const float* q_src, const float* k_src, c
                     ocv_aligned16(out),
                 "ocv_mha_few_keys_h2_fwd: every pointer must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
+  XAArgs a{q_src, key_padding_mask, (const _Float16*)workspace, k_src, v_src, (const _Float16*)in_proj_h2,
+           (const _Float16*)out_proj_h2, in_proj_b, out_b, out, Sq, Se, Sk, 1.0f / sqrtf(32.0f), B, 0};
+  if ((long)ocv_cdiv(Sq, TM) * B <= g_one_launch_wgs) {      // small call: ONE launch, K / V projected by every query tile
+    a.tiles = ocv_cdiv(Sq, TM);
+    hipLaunchKernelGGL((xattn_main_h2_kernel<1, true>), dim3((unsigned)((long)a.tiles * B)), dim3(256), 0, st, a);
+    OCV_CHECK_LAUNCH("ocv_mha_few_keys_h2_fwd(one launch)");
+    return 0;
+  }
   XKVArgs ka{k_src, v_src, (const _Float16*)in_proj_h2, in_proj_b, (_Float16*)workspace, Sk, Se};
   // one image per workgroup while they are all resident at once, several per workgroup beyond
   const int per_wg = ocv_cdiv(B, 256);               // images per workgroup, evenly: bs 300 -> 150 workgroups x 2 (384 per operand measured no faster)
   hipLaunchKernelGGL(xattn_kv_h2_kernel, dim3(ocv_cdiv(B, per_wg), 2), dim3(256), 0, st, ka, B);
   OCV_CHECK_LAUNCH("ocv_mha_few_keys_h2_fwd(K / V projection)");
-  XAArgs a{q_src, key_padding_mask, (const _Float16*)workspace, (const _Float16*)in_proj_h2, (const _Float16*)out_proj_h2,
-           in_proj_b, out_b, out, Sq, Se, Sk, 1.0f / sqrtf(32.0f), B, 0};
   // two sub-tiles per workgroup once the 64-query workgroups alone fill the chip several times over
   const long wg64 = (long)ocv_cdiv(Sq, 2 * TM) * B;
   const int nsub = wg64 >= 2048 ? 2 : 1;

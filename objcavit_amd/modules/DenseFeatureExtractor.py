@@ -452,14 +452,14 @@ class SkipPrepass:
     decoder's element type is settled (never during the calibrating first call).
     ONE fork and ONE join, on the object branch's side stream (hip_ops.side_stream 0), shared with that branch (``extra``:
     GraphBins hands its object pre-pass over instead of forking it at the top of the forward).  Measured shapes
-    (tools/ab_skip_overlap.sh, one batch at a time, captured forward, alternating runs on one box):
+    (tools/history/ab_skip_overlap.sh, one batch at a time, captured forward, alternating runs on one box):
       * each convolution issued when its own activation appeared and joined where it was read (four forks, four joins between two
         streams): every replay 3.5 ms SLOWER at every batch size (bs 16: 20.6 vs 16.9 ms; bs 1: 6.9 vs 3.4), one replay crashed
         (hipGraphLaunch);
       * one fork behind stage 4 for the three, the object branch still forked at the top (= a side branch with TWO incoming edges
         from the main chain): 21.1 vs 16.6 ms, 8.2 vs 3.4 ms -- on this ROCm a graph branch may depend on the main chain ONCE;
       * this shape: **bs 16 984.6 -> 1000.0 img/s (+1.6 %), bs 1 296.4 -> 309.6 (+4.4 %)**; with two / one of the three
-        convolutions (forks behind stage 3 / 2) 992 / 988 and 304 / 303 (tools/ab_skip_stages.sh)."""
+        convolutions (forks behind stage 3 / 2) 992 / 988 and 304 / 303 (tools/history/ab_skip_stages.sh)."""
 
     def __init__(self, decoder: "Decoder", device: torch.device, extra=None):
         self.extra, self.extra_result = extra, None      # further image-independent work for the same fork (GraphBins: the object branch)

@@ -334,6 +334,34 @@ def test_mha_few_keys_h2_random_shapes(ops):
         assert rel_dev(z(got), z(exact)) < TOL, (case, B, Sq, Sk, counts, kv)
 
 
+def test_mha_few_keys_h2_one_launch_equals_two_launches(ops):
+    """Small calls (every query tile's workgroup resident at once) run as ONE launch whose tiles project K / V themselves; larger
+    ones as the K / V launch + the tiles.  Same MFMAs on the same operands in the same order: the two forms agree BIT FOR BIT,
+    ragged object counts, an image without a live key (NaN rows) and a separate value tensor included."""
+    from objcavit_amd import _lib
+    lib = _lib.load()
+    E = 128
+    iw, ib = rnd("iw", (3 * E, E), 4, 2 / math.sqrt(E)), rnd("ib", (3 * E,), 5, 0.1)
+    ow, ob = rnd("ow", (E, E), 6, 1 / math.sqrt(E)), rnd("ob", (E,), 7, 0.1)
+    par = (dev(iw), dev(ib), dev(ow), dev(ob))
+    try:
+        for case, (B, Sq, Sk, live) in enumerate([(16, 300, 16, 16), (2, 300, 16, 16), (5, 77, 40, 32), (1, 1, 1, 1), (32, 300, 24, 20)]):
+            counts = [(live - (7 * i) % (live + 1)) for i in range(B)]
+            counts[0] = live
+            qs, ks, vs = rnd("q", (B, Sq, E), 10 + case), rnd("k", (B, Sk, E), 20 + case), rnd("v", (B, Sk, E), 30 + case)
+            mask = torch.arange(Sk)[None, :] >= torch.tensor(counts)[:, None]
+            args = (dev(qs), dev(ks), dev(vs if case % 2 else ks)) + par + (dev(mask),)
+            outs = []
+            for limit in (1 << 30, 0):                                  # one launch whatever the size / always two launches
+                assert lib.ocv_mha_few_keys_h2_set_dispatch(limit) == 0
+                outs.append(ops.mha(*args, kv_limit=live if live < Sk else 0, packed={}).cpu())
+            nan = torch.isnan(outs[0])
+            assert torch.equal(nan, torch.isnan(outs[1])) and bool(nan.any()) == (0 in counts), (case, counts)
+            assert torch.equal(torch.nan_to_num(outs[0]), torch.nan_to_num(outs[1])), (case, B, Sq, Sk)
+    finally:
+        lib.ocv_mha_few_keys_h2_set_dispatch(-1)
+
+
 @pytest.mark.parametrize("scale", [1e-4, 1e-2, 1.0, 300.0])
 def test_two_term_fp16_kernels_hold_their_relative_error_at_any_magnitude(ops, scale):
     """The scaled low term keeps the two-term fp16 split out of fp16's subnormals and v_mfma_f32_32x32x16_f16 honours the
