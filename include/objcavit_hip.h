@@ -283,8 +283,11 @@ size_t ocv_bin_head_workspace_bytes(int B, int n_bins, int C);
  * TWO-term fp16 split with a scaled low term (v = hi + 2^-11 lo', hi = fp16(v), lo' = fp16((v - hi) 2^11): three
  * v_mfma_f32_32x32x16_f16 per product block, 22-bit products = the error of an fp32 FMA chain; both parts of Wf[b] fit the LDS, so
  * one workgroup walks all 256 bins and the map is read once -- the fastest faithful form; fp16's range: a map value or folded
- * weight beyond +-65504 turns the pixel's depth inf / NaN); 2 = NHWC, three-term bf16 (fp32's range): ocv_bin_head_folded_ws_fwd
- * only.  (Rounds 2 - 4 also carried a two-term bf16 form under code 2 -- 3x the depth error under near-one-hot softmaxes, opt-in,
+ * weight beyond +-65504 turns the pixel's depth inf / NaN); 4 = 3 with TWO-LEVEL logits: every bin coarsely first (the hi hi
+ * product alone), the three-product logits and the softmax arithmetic only for the 32-bin tiles in which some pixel of the
+ * wavefront's 32 has a bin within T = 24 (+ twice the coarse product's proven error bound) of its largest coarse logit -- the
+ * bins left out weigh <= 224 e^-24 of a pixel's softmax; cost 64 + 24 n MFMAs per 32 pixels, n = tiles kept, against 192;
+ * 2 = NHWC, three-term bf16 (fp32's range): ocv_bin_head_folded_ws_fwd only.  (Rounds 2 - 4 also carried a two-term bf16 form under code 2 -- 3x the depth error under near-one-hot softmaxes, opt-in,
  * never a default: removed in round 5.) */
 int ocv_bin_head_fold_fwd(const float* queries, long q_bs, int q_ld, const float* Wout, float* Wf, int B, int C, int Q,
                           int n_bins, ocv_stream_t stream);

@@ -300,8 +300,26 @@ __device__ __forceinline__ void bh_split8_h2(const float4 u, const float4 v, bh_
 // by raw s_barriers, weights one step ahead (0.346 ms: with ONE wavefront per SIMD in its MFMA phase the LDS latency is exposed
 // in every K step); the same stagger by one s_sleep with the weights two steps ahead (0.255 ms; MFMA / VALU co-execution 7 M
 // cycles against 71 M before: the groups fall back in step).
+//
+// TWO-LEVEL logits (round 5, TWO_LEVEL = true, the default).  A bin whose logit lies T below the pixel's largest carries e^-T of the
+// softmax: it needs no 22-bit logit -- it needs no exponential at all.  So the eight bin tiles are first formed COARSELY, the hi hi
+// product alone (8 MFMAs a tile instead of 24, an 11-bit product: |coarse - exact| <= 2^-10 |w_k| |f_p| by Cauchy-Schwarz, with
+// |w_k| <= the largest row norm of Wf[b], found while the weights are staged, and |f_p| the pixel's own norm, one dot product per
+// lane), each lane keeps the largest coarse logit of its 16 bins per tile, and a tile gets its full three-product logits and its
+// softmax arithmetic only if SOME lane of the wavefront has a bin within T_p = T + 2 eps_p of its pixel's coarse maximum (eps_p the
+// bound above): then every skipped bin is provably >= T below the exact maximum, the skipped bins of a pixel together weigh
+// <= 224 e^-T of its largest bin (T = 24: 8.5e-9), and the tile that holds a pixel's maximum is always kept.  A non-finite pixel
+// or weight makes the test true for every tile (the comparison is written to fail on NaN): inf / NaN reach the output as in the
+// one-level kernel.  Matrix work: 64 + 24 n MFMAs per 32 pixels, n = tiles kept (1 .. 8), against 192: on the benchmark's maps
+// n = 1 (tools/exp_binhead_skip.py: one tile of eight per 32 pixels at T = 6 .. 14 alike) -- 46 %; every tile kept (a flat
+// distribution over the bins): 133 %.  The coarse pass is as much LDS as matrix work (one 1 KB fragment read per MFMA = the LDS
+// pipe's 128 B / clk when four SIMDs do it); it is not software-pipelined by hand: the compiler has two accumulator sets to
+// alternate and only 8 v_max3 per tile to place.  OCV_BINHEAD=h2dense keeps the one-level kernel.
 typedef float bh_f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 bh_h16x2 __attribute__((ext_vector_type(2)));
+constexpr float BH_SKIP_T = 24.0f * 1.44269504088896340736f;     // T in the kernel's base-2 logits
 
+template <bool TWO_LEVEL>
 __global__ __launch_bounds__(512, 2) void bin_head_h2_kernel(const float* __restrict__ feat, const float* __restrict__ Wf,
                                                              const float* __restrict__ bout,
                                                              const float* __restrict__ centers, float* __restrict__ depth,
@@ -318,12 +336,23 @@ __global__ __launch_bounds__(512, 2) void bin_head_h2_kernel(const float* __rest
   const float* fb = feat + (long)b * CH * P;
   const float* wb = Wf + (long)b * NB * CH;
 
+  unsigned* wn2 = reinterpret_cast<unsigned*>(cl + NB);     // [1] the largest squared row norm of Wf[b] log2(e), as bits (TWO_LEVEL)
+  if (TWO_LEVEL) {
+    if (tid == 0) *wn2 = 0u;
+    __syncthreads();
+  }
   for (int idx = tid; idx < NB * CH / 8; idx += 512) {
     const int k = idx >> 4, o = idx & 15;                    // bin, K octet
     bh_h16x8 hi, lo;
     float4 u = ld4(wb + (long)k * CH + 8 * o), v = ld4(wb + (long)k * CH + 8 * o + 4);
     u.x *= LOG2E; u.y *= LOG2E; u.z *= LOG2E; u.w *= LOG2E;
     v.x *= LOG2E; v.y *= LOG2E; v.z *= LOG2E; v.w *= LOG2E;
+    if (TWO_LEVEL) {                                         // 16 consecutive lanes hold one row: its squared norm, then the maximum
+      float q = u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w + v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+      for (int d_ = 8; d_ > 0; d_ >>= 1) q += __shfl_xor(q, d_, 64);
+      if (o == 0) atomicMax(wn2, __float_as_uint(q));        // (non-negative floats order as their bits; a NaN sits above them all)
+    }
     bh_split8_h2(u, v, hi, lo);
     _Float16* d = wfrag + ((((k >> 5) * 8 + (o >> 1)) * 2) * 64 + (o & 1) * 32 + (k & 31)) * 8;
     *reinterpret_cast<bh_h16x8*>(d) = hi;
@@ -361,6 +390,9 @@ __global__ __launch_bounds__(512, 2) void bin_head_h2_kernel(const float* __rest
       const _Float16* wf = wfrag + ((t * 8 + s_) * 2) * 512 + lane * 8;
       wh[s_ % 3] = *reinterpret_cast<const bh_h16x8*>(wf);
       wl[s_ % 3] = *reinterpret_cast<const bh_h16x8*>(wf + 512);
+    };
+    auto fetch_w_hi = [&](int t, int s_) {
+      wh[s_ % 3] = *reinterpret_cast<const bh_h16x8*>(wfrag + ((t * 8 + s_) * 2) * 512 + lane * 8);
     };
     auto fetch_bias = [&](int t, f32x16& a1) {               // accumulator register r = bin acc_row(r, hh): four runs of four
       const float* bp = bl + t * 32 + 4 * hh;
@@ -424,6 +456,68 @@ __global__ __launch_bounds__(512, 2) void bin_head_h2_kernel(const float* __rest
     __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                    \
   }
     f32x16 A1, A2, B1, B2;
+    if constexpr (TWO_LEVEL) {
+      // the pixel's squared norm (this lane's 64 channels, the other 64 in lane ^ 32) from the hi parts: inf / NaN if any is
+      float fn2 = 0.f;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bh_h16x2 h2v = {ph[s][2 * e], ph[s][2 * e + 1]};
+          fn2 = __builtin_amdgcn_fdot2(h2v, h2v, fn2, false);
+        }
+      }
+      fn2 += __shfl_xor(fn2, 32, 64);
+      // coarse logits: a1 (bias) += hi hi, the lane's largest of each tile is all that is kept.  The 64 MFMAs of the eight tiles are
+      // ONE stream: their hi fragments come SIX steps ahead through six rotating registers (the one-level loop's hi and lo' sets)
+      // -- one 1 KB LDS read per MFMA saturates the LDS pipe, and its queueing latency is what a wavefront would wait for
+      auto lane_max = [&](const f32x16& a1) {
+        float m = fmaxf(a1[0], a1[1]);
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) m = fmaxf(fmaxf(m, a1[r]), a1[r + 1]);
+        return m;
+      };
+      bh_h16x8 wq[6];
+      auto fetch_q = [&](int j) { wq[j % 6] = *reinterpret_cast<const bh_h16x8*>(wfrag + (j * 2) * 512 + lane * 8); };
+      float tmx[NB / 32];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) fetch_q(j);
+      fetch_bias(0, A1);
+#pragma unroll
+      for (int t = 0; t < NB / 32; ++t) {
+        f32x16& acc = (t & 1) ? B1 : A1;
+        f32x16& oth = (t & 1) ? A1 : B1;
+        if (t + 1 < NB / 32) fetch_bias(t + 1, oth);
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+          const int j = t * 8 + s_;
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[j % 6], ph[s_], acc, 0, 0, 0);
+          if (j + 6 < NB / 32 * 8) fetch_q(j + 6);
+        }
+        tmx[t] = lane_max(acc);
+      }
+      float pmax = tmx[0];
+#pragma unroll
+      for (int t = 1; t < NB / 32; ++t) pmax = fmaxf(pmax, tmx[t]);
+      pmax = xor32_max(pmax);
+      // T_p = T + 2 eps_p, eps_p = 2^-10 |w|max |f_p| (+ 1 % and 2^-6 for the roundings of the bound itself and of the accumulation)
+      const float wn = __uint_as_float(*wn2);
+      const float eps = __builtin_sqrtf(wn * fn2) * (1.01f / 1024.0f) + 0.015625f;
+      const float floor_ = pmax - (BH_SKIP_T + 2.0f * eps);
+      unsigned keep = 0;
+#pragma unroll
+      for (int t = 0; t < NB / 32; ++t)
+        keep |= (__builtin_amdgcn_ballot_w64(!(tmx[t] <= floor_)) != 0ull ? 1u : 0u) << t;
+      keep = __builtin_amdgcn_readfirstlane(keep);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+      for (int t = 0; t < NB / 32; ++t) {
+        if (!((keep >> t) & 1u)) continue;
+        fetch_bias(t, A1);
+        mma_tile(t, A1, A2);
+        softmax_tile(t, A1, A2, t);
+      }
+    } else {
     fetch_bias(0, A1);
     fetch_bias(1, B1);
     mma_tile(0, A1, A2);
@@ -445,6 +539,7 @@ __global__ __launch_bounds__(512, 2) void bin_head_h2_kernel(const float* __rest
     __builtin_amdgcn_sched_barrier(0);
     softmax_tile(NB / 32 - 1, B1, B2, 1);
     __builtin_amdgcn_sched_barrier(0);
+    }
 #undef BH_INTERLEAVE
     const float l = xor32_sum(l2.x + l2.y), d = xor32_sum(d2.x + d2.y);
     if (hh == 0 && pix < P) depth[(long)b * P + pix] = d / l;
@@ -569,7 +664,7 @@ extern "C" int ocv_bin_head_folded_fwd(const float* feat, int channels_last, con
   OCV_CHECK_ARG(feat && Wf && bout && centers && depth, "ocv_bin_head_folded_fwd: null pointer");
   OCV_CHECK_ARG(C == CH && n_bins == NB, "ocv_bin_head_folded_fwd: needs C = %d, n_bins = %d", CH, NB);
   OCV_CHECK_ARG(B >= 1 && B <= 65535 && P >= 1 && ocv_aligned16(Wf), "ocv_bin_head_folded_fwd: bad sizes / alignment");
-  OCV_CHECK_ARG(channels_last == 0 || channels_last == 1 || channels_last == 3, "ocv_bin_head_folded_fwd: channels_last must be 0 (NCHW, exact fp32), 1 (NHWC, exact fp32) or 3 (NHWC, two-term fp16); 2 (three-term bf16) needs ocv_bin_head_folded_ws_fwd and its partials buffer");
+  OCV_CHECK_ARG(channels_last == 0 || channels_last == 1 || channels_last == 3 || channels_last == 4, "ocv_bin_head_folded_fwd: channels_last must be 0 (NCHW, exact fp32), 1 (NHWC, exact fp32), 3 (NHWC, two-term fp16) or 4 (the same with two-level logits); 2 (three-term bf16) needs ocv_bin_head_folded_ws_fwd and its partials buffer");
   OCV_CHECK_ARG(!channels_last || ocv_aligned16(feat), "ocv_bin_head_folded_fwd: channels_last map must be 16-byte aligned");
   static bool attr = false;
   if (!attr) {
@@ -577,19 +672,24 @@ extern "C" int ocv_bin_head_folded_fwd(const float* feat, int channels_last, con
     (void)hipFuncSetAttribute((const void*)bin_head_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  if (channels_last == 3) {                                  // two-term fp16 split, all 256 bins per workgroup (the default route)
+  if (channels_last == 3 || channels_last == 4) {            // two-term fp16 split, all 256 bins per workgroup; 4 = two-level logits (the default route)
     static bool attr3 = false;
     if (!attr3) {
-      (void)hipFuncSetAttribute((const void*)bin_head_h2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)bin_head_h2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)bin_head_h2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr3 = true;
     }
     const int nt = ocv_cdiv(P, TP3);
     int perh = (256 + B - 1) / B;                            // persistent grid: about one workgroup per CU over the images
     if (perh > nt) perh = nt;
     if (perh < 1) perh = 1;
-    const size_t ldsh = (size_t)NB * CH * 2 * 2 + 2 * NB * sizeof(float);
-    hipLaunchKernelGGL(bin_head_h2_kernel, dim3(perh, B), dim3(512), ldsh, (hipStream_t)stream, feat, Wf, bout, centers, depth,
-                       (long)P, nt);
+    const size_t ldsh = (size_t)NB * CH * 2 * 2 + 2 * NB * sizeof(float) + 16;
+    if (channels_last == 4)
+      hipLaunchKernelGGL(bin_head_h2_kernel<true>, dim3(perh, B), dim3(512), ldsh, (hipStream_t)stream, feat, Wf, bout, centers,
+                         depth, (long)P, nt);
+    else
+      hipLaunchKernelGGL(bin_head_h2_kernel<false>, dim3(perh, B), dim3(512), ldsh, (hipStream_t)stream, feat, Wf, bout, centers,
+                         depth, (long)P, nt);
     OCV_CHECK_LAUNCH("ocv_bin_head_folded_fwd(h2)");
     return 0;
   }

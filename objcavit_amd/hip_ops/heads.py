@@ -234,15 +234,17 @@ def bin_head(feat: torch.Tensor, queries: torch.Tensor, w_out: torch.Tensor, b_o
              centers: torch.Tensor, exact: bool = False) -> torch.Tensor:
     """depth [B,1,h,w] = sum_k softmax_k(conv1x1(pixel_dot(feat, queries)))_k * centers_k, fused.
     feat NCHW-contiguous: exact fp32 MFMA.  feat channels_last: logits as a TWO-term fp16 split with a scaled low term (22-bit
-    products at the error of an fp32 FMA chain, three MFMAs per block, all 256 bins per workgroup: OCV_BINHEAD=h2, the default),
+    products at the error of an fp32 FMA chain, three MFMAs per block, all 256 bins per workgroup) formed on TWO LEVELS -- every bin
+    coarsely (one MFMA per block), the full logits and the softmax arithmetic only for the 32-bin tiles that hold a bin within
+    e^-24 of a pixel's largest (csrc/bin_head.hip: OCV_BINHEAD=h2, the default; h2dense = every tile in full, round 4's kernel),
     as a THREE-term bf16 split (OCV_BINHEAD=split3: six MFMAs, two bin halves + a merge launch; fp32's RANGE -- also what a
     forward inside ``bf16_pairs()``, the range guard's fallback, takes), or on the exact fp32 MFMA kernel with ``exact=True`` /
     OCV_BINHEAD=exact."""
     lib = _lib.load()
     mode = os.environ.get("OCV_BINHEAD", "h2")              # read per call
-    if mode not in ("h2", "split3", "exact"):
-        raise ValueError(f"OCV_BINHEAD={mode!r}: expected 'h2' (default), 'split3' or 'exact'")
-    if mode == "h2" and _TLS.bf16_pairs:
+    if mode not in ("h2", "h2dense", "split3", "exact"):
+        raise ValueError(f"OCV_BINHEAD={mode!r}: expected 'h2' (default), 'h2dense', 'split3' or 'exact'")
+    if mode in ("h2", "h2dense") and _TLS.bf16_pairs:
         mode = "split3"                                     # a batch beyond the fp16 pairs' range: the head with fp32's range
     exact = exact or mode == "exact"
     feat, cl = _map4(feat, "feat")
@@ -262,7 +264,7 @@ def bin_head(feat: torch.Tensor, queries: torch.Tensor, w_out: torch.Tensor, b_o
     wf = ws.view(torch.float32)
     check(lib.ocv_bin_head_fold_fwd(queries.data_ptr(), queries.stride(0), queries.stride(1), w2.data_ptr(), wf.data_ptr(), B,
                                     Cc, Q, nbins, _stream()), "ocv_bin_head_fold_fwd")
-    route = 0 if not cl else (1 if exact else (3 if mode == "h2" else 2))          # include/objcavit_hip.h: ocv_bin_head_folded_fwd
+    route = 0 if not cl else (1 if exact else ({"h2": 4, "h2dense": 3}.get(mode, 2)))          # include/objcavit_hip.h: ocv_bin_head_folded_fwd
     npart = int(lib.ocv_bin_head_partials_bytes(B, h * w)) if route == 2 else 0
     part = workspace(npart, feat.device, "bin_head_partials") if npart else None
     with timed("bin_head"):          # the logit / softmax / depth launch(es): one, or the split-3 halves + merge

@@ -677,7 +677,7 @@ def test_pixel_dot_and_bin_head_channels_last(ops, monkeypatch, B, h, w):
                               wout.double(), bout.double(), 0.001, 10.0)
     exact = ops.bin_head(fg, qg, dev(wout), dev(bout), centers, exact=True)
     ex = float(((exact.cpu().double() - d64).abs() / d64).max())
-    for mode in ("split3", "h2"):
+    for mode in ("split3", "h2dense", "h2"):
         monkeypatch.setenv("OCV_BINHEAD", mode)
         got = ops.bin_head(fg, qg, dev(wout), dev(bout), centers)
         assert float(((got.cpu() - ref_depth).abs() / ref_depth).max()) < 1e-4, mode
@@ -739,6 +739,43 @@ def test_bin_head_h2_on_scaled_maps(ops, monkeypatch, scale):
     monkeypatch.setenv("OCV_BINHEAD", "h2")
     got = ops.bin_head((fg * scale).contiguous(memory_format=torch.channels_last), dev(q) / scale, dev(wout), dev(bout), centers)
     assert float(((got - ref).abs() / ref).max()) < 5e-5
+
+
+@pytest.mark.parametrize("gain", [0.02, 0.6, 6.0, 40.0])
+def test_bin_head_two_level_logits_against_every_tile_in_full(ops, monkeypatch, gain):
+    """The default bin head forms every bin coarsely and only the 32-bin tiles near a pixel's maximum in full (csrc/bin_head.hip).
+    Flat softmaxes (small logit gain): every tile is kept; peaked ones (gain 6, 40): most are dropped, and the dropped bins weigh
+    <= 224 e^-24.  What differs from the one-level kernel is the path of the online softmax's running maximum, i.e. rounding: the
+    two-level depth is held to the same bound as every faithful form -- against an fp64 evaluation of the same folded logits,
+    within 2x of the exact-fp32 MFMA kernel's own error (tools/exp_binhead_two_level.py prints the three side by side).  A NaN /
+    inf / beyond-fp16 map value reaches its pixel's depth in both kernels alike (a non-finite pixel keeps every tile), and its
+    neighbours in the same 32-pixel group stay as they were."""
+    from objcavit_amd.modules.AdaBins import bin_edges_and_centers
+    B, h, w = 2, 37, 53                                                  # ragged: the last 32-pixel groups are partly beyond the map
+    feat, q = rnd("f", (B, 128, h, w), 11), rnd("q", (B, 128, 128), 12, 0.5)
+    wout, bout = rnd("wo", (256, 128, 1, 1), 13, gain / math.sqrt(128)), rnd("bo", (256,), 14, 0.5)
+    widths = torch.rand(B, 256, generator=torch.Generator().manual_seed(15)) + 0.1
+    widths = widths / widths.sum(1, keepdim=True)
+    _, centers = bin_edges_and_centers(dev(widths), 0.001, 10.0)
+    fg = dev(feat).contiguous(memory_format=torch.channels_last)
+    run = lambda m, f=fg: (monkeypatch.setenv("OCV_BINHEAD", m), ops.bin_head(f, dev(q), dev(wout), dev(bout), centers))[1]   # noqa: E731
+    dense, two, exact = run("h2dense"), run("h2"), run("exact")
+    d64, _ = restate.bin_head(widths.double(), restate.pixel_wise_dot_product(feat.double(), q.double()), wout.double(), bout.double(),
+                              0.001, 10.0)
+    err = lambda t: float(((t.cpu().double() - d64).abs() / d64).max())   # noqa: E731
+    ex = err(exact)
+    assert err(two) <= 2.0 * ex + 2e-6 and err(dense) <= 2.0 * ex + 2e-6, (err(two), err(dense), ex)
+    assert float(((two - dense).abs() / dense).max()) <= 2.0 * ex + 2e-6
+    bad = fg.clone()
+    bad[0, 5, 3, 7] = float("nan")
+    bad[1, 9, 20, 40] = float("inf")
+    bad[1, 100, 36, 52] = 1e6                                            # beyond fp16: hi = inf
+    d2, t2 = run("h2dense", bad), run("h2", bad)
+    for (b, y, x) in ((0, 3, 7), (1, 20, 40), (1, 36, 52)):
+        assert not bool(torch.isfinite(d2[b, 0, y, x])) and not bool(torch.isfinite(t2[b, 0, y, x]))
+    ok = torch.isfinite(d2)
+    assert torch.equal(ok, torch.isfinite(t2)) and int((~ok).sum()) == 3
+    assert float(((t2[ok] - d2[ok]).abs() / d2[ok]).max()) <= 2.0 * ex + 2e-6
 
 
 # ------------------------------------------------------------------ depthwise convolution

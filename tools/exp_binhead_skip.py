@@ -36,3 +36,18 @@ for T in (14.0, 10.0, 6.0):
     print(f"T = {T:4.1f}: {100 * frac_bins:5.1f} % of (pixel, bin) pairs within T of the pixel's maximum; "
           f"{100 * float(tiles.float().mean()):5.1f} % of 32 x 32 tiles need their correction products "
           f"(-> matrix work {100 * (1 + 2 * float(tiles.float().mean())) / 3:5.1f} % of today's three products)")
+
+# the two kernels on exactly these inputs (HIP-event time of the main launch)
+for mode in ("h2dense", "h2", "h2dense", "h2"):
+    os.environ["OCV_BINHEAD"] = mode
+    for _ in range(3):
+        d = model.head(feat, queries, centers)
+    torch.cuda.synchronize()
+    hip_ops.enable_timing(True)
+    for _ in range(20):
+        d = model.head(feat, queries, centers)
+    us = hip_ops.timing_results()["bin_head"][1] * 1e3
+    hip_ops.enable_timing(False)
+    if mode == "h2dense":
+        ref = d
+    print(f"OCV_BINHEAD={mode:8s} {us:7.1f} us   max rel dev from h2dense {float(((d - ref).abs() / ref).max()):.1e}")
