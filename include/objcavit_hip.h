@@ -137,7 +137,7 @@ int ocv_mha_split3_fwd(const float* q_src, const float* k_src, const float* v_sr
  *   ocv_pack_split_h2_fwd: W [N][K] fp32 -> ocv_split_h2_packed_elems(N, K) fp16, 16-byte aligned, laid out
  *     packed[((jt * nsteps + s) * 2 + part) * 512 + lane * 8 + e] = part(W[32 jt + (lane & 31)][16 s + 8 (lane >> 5) + e]).
  *   in_proj_h2 / out_proj_h2 = packed in_proj_weight [3E, E] / out_proj.weight [E, E]; workspace: the K / V record,
- *   ocv_mha_few_keys_h2_workspace_bytes(B); every pointer 16-byte aligned.  ONE launch while every 32-query tile's workgroup is
+ *   ocv_mha_few_keys_h2_workspace_bytes(B); every pointer 16-byte aligned.  ONE launch while the call is
  *   small (ceil(Sq / 32) B <= 320 workgroups: each tile projects its image's K / V itself -- same arithmetic, bit-identical
  *   results, the record unused), two launches beyond (K / V once per image, then the tiles).
  *   ocv_mha_few_keys_h2_set_dispatch(n): one launch up to n workgroups (0 = always two launches, < 0 = the default 320). */
