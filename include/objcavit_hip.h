@@ -33,7 +33,10 @@ extern "C" {
 
 typedef void* ocv_stream_t;
 
-#define OCV_ABI_VERSION 3 /* 2: ocv_encoder_layer_params starts with struct_size (round 3); 3: ocv_patch_embed_split_fwd and
+#define OCV_ABI_VERSION 4 /* 4: round 5 REMOVED the opt-in entry points that lost their A/Bs (ocv_tap_interp_skip_fwd, the squeeze-excite tail
+ * family ocv_*_se_fwd / ocv_se_fold_gate_weights_fwd / ocv_se_tail_supported, ocv_conv3x3_winograd_split_fwd F(2x2)) and added the range
+ * guard (ocv_range_flag_set, ocv_range_flag_take_fwd, ocv_attention_set_fp32_range), bin head route 4, ocv_mha_few_keys_h2_set_dispatch;
+ * 2: ocv_encoder_layer_params starts with struct_size (round 3); 3: ocv_patch_embed_split_fwd and
                            ocv_conv3x3_winograd43_split_fwd take the split operands' element type (+ cscale / oscale), round 4 */
 int ocv_abi_version(void);
 const char* ocv_last_error(void);
