@@ -74,6 +74,20 @@ class SyntheticObjectProvider:
         return self._cache[key]
 
 
+def _record_on(result, stream) -> None:
+    """``record_stream`` for every tensor of a (nested) result produced on another stream: without it the caching allocator hands a
+    freed block back to ITS stream's next allocation while this stream's launches may still be reading it."""
+    if isinstance(result, torch.Tensor):
+        if result.is_cuda:
+            result.record_stream(stream)
+    elif isinstance(result, PaddedObjects):
+        for t in (result.features, result.xywh, result.counts):
+            _record_on(t, stream)
+    elif isinstance(result, (tuple, list)):
+        for t in result:
+            _record_on(t, stream)
+
+
 class GraphBins(nn.Module):
     images_are_independent = True      # an image's result does not depend on its batch mates (per object group: SURVEY.md Q3)
 
@@ -160,6 +174,7 @@ class GraphBins(nn.Module):
             if skip_pre is not None:
                 skip_pre.joined = True             # (same side stream: the wait above is its join too)
                 pre = skip_pre.extra_result
+            _record_on(pre, main)                  # allocated on the side stream, read on this one: the allocator must know
             dense_features = dfe.decoder(encoded, _split_only=not torch.is_grad_enabled() and not self.training, _skip_pre=skip_pre)
         else:
             dense_features = self.dense_feature_extractor(image, _split_only=True)   # (the heads read the split copy: hip_ops.map_placeholder)
