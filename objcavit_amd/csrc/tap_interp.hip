@@ -203,11 +203,14 @@ __global__ __launch_bounds__(320, 4) void tap_interp_kernel(TIArgs p) {
         const float4 v01 = *reinterpret_cast<const float4*>(r0p + CB);
         const float4 v10 = *reinterpret_cast<const float4*>(r1p);
         const float4 v11 = *reinterpret_cast<const float4*>(r1p + CB);
+        // four fused multiply-adds per channel INTO the accumulator (two channels per v_pk_fma_f32): the sum-then-add form cost
+        // a v_pk_mul + a v_pk_add more per channel pair, a fifth of the loop's vector instructions in a kernel whose consumers are
+        // bound by them (profiles/r05_sq.json: 1024 per wavefront item, vector pipe ~50 % busy beside HBM at ~55 %)
         const float a = hy0[i] * wx0[dx], bq = hy0[i] * wx1[dx], c = hy1[i] * wx0[dx], d = hy1[i] * wx1[dx];
-        acc[i].x += a * v00.x + bq * v01.x + c * v10.x + d * v11.x;
-        acc[i].y += a * v00.y + bq * v01.y + c * v10.y + d * v11.y;
-        acc[i].z += a * v00.z + bq * v01.z + c * v10.z + d * v11.z;
-        acc[i].w += a * v00.w + bq * v01.w + c * v10.w + d * v11.w;
+        acc[i].x = fmaf(d, v11.x, fmaf(c, v10.x, fmaf(bq, v01.x, fmaf(a, v00.x, acc[i].x))));
+        acc[i].y = fmaf(d, v11.y, fmaf(c, v10.y, fmaf(bq, v01.y, fmaf(a, v00.y, acc[i].y))));
+        acc[i].z = fmaf(d, v11.z, fmaf(c, v10.z, fmaf(bq, v01.z, fmaf(a, v00.z, acc[i].z))));
+        acc[i].w = fmaf(d, v11.w, fmaf(c, v10.w, fmaf(bq, v01.w, fmaf(a, v00.w, acc[i].w))));
       }
       __builtin_amdgcn_sched_barrier(0);               // keep each tap's arithmetic with its LDS reads
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this tap's LDS reads are done before the buffer is handed back
