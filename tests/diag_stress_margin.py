@@ -1,5 +1,5 @@
 """Diagnostic (run by hand on the GPU box; lives under tests/ because it calls the oracle): the stress-case error that
-tests/test_hip_models.py::test_config2_full_size_properties pins below 6e-4 -- N(0,1) "images", 6x logit gain, fp32 rounding
+tests/test_hip_models.py::test_config2_full_size_properties pins below 2e-4 -- N(0,1) "images", 6x logit gain, fp32 rounding
 amplified ~2000x -- under the arithmetic routes of the rounds.  python tests/diag_stress_margin.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,7 +13,7 @@ from objcavit_amd.modules.GraphBins import GraphBins, SyntheticObjectProvider
 ROUTES = {
     "round 4 default (decoder / heads convolutions on two-term FP16 splits, weights scaled per output channel)": {},
     "round 3 default (the same convolutions on two-term BF16 splits; fp16 two-term attention / bin head / layer tails, Winograd F(4,3))": {"OCV_CONV_SPLIT": "bf16"},
-    "fp16 pairs, no Winograd": {"OCV_CONV_WINOGRAD": "0"},
+    "fp16 pairs, no Winograd": {"_no_winograd": "1"},
     "fp16 pairs + the encoder's 1x1 convolutions on exact fp32 (OCV_PW=fp32)": {"OCV_PW": "fp32"},
     "exact-fp32 convolutions, default tokens / heads": {"OCV_CONV": "exact"},
 }
@@ -21,6 +21,11 @@ torch.set_grad_enabled(False)
 img = gen.randn("img", (8, 3, 480, 640), 5)
 ref = None
 for name, env in ROUTES.items():
+    env = dict(env)
+    from objcavit_amd import hip_ops
+    pays = hip_ops.winograd_pays
+    if env.pop("_no_winograd", None):                        # (the dispatch rule is a function, no switch: replace it for this route)
+        hip_ops.winograd_pays = hip_ops.conv.winograd_pays = lambda *a: False
     saved = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
@@ -36,6 +41,7 @@ for name, env in ROUTES.items():
         e = ((d[3:4].cpu() - ref).abs() / ref.abs())
         print(f"{name}: max-rel {float(e.max()):.2e}  mean-rel {float(e.mean()):.2e}", flush=True)
     finally:
+        hip_ops.winograd_pays = hip_ops.conv.winograd_pays = pays
         for k, v in saved.items():
             if v is None:
                 os.environ.pop(k, None)
