@@ -550,7 +550,7 @@ extern "C" int ocv_se_gate_partials_fwd(const float* part, int tiles, long pixel
   OCV_CHECK_ARG(C <= 8192 && C % 4 == 0, "ocv_se_gate_partials_fwd: C must be a multiple of 4, at most 8192 (got %d)", C);
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = (size_t)(C + (C >= 4096 ? C : 4096)) * sizeof(float);      // mean[C] | red[TG][C], TG * C <= 4096
-  // (A/B: OCV_SE_FUSED_MAXC / MAXR = 1824 / 76 and 3072 / 128 take stages 6 and 7 in -- measured SLOWER there, every workgroup of an
+  // (A/B, round 4: limits of 1824 / 76 and 3072 / 128 instead of the two below take stages 6 and 7 in -- measured SLOWER there, every workgroup of an
   //  image re-reading 0.55 / 1.5 MB of W1: bs 16 1000 -> 996 -> 994 img/s one at a time, bs 1 293 -> 286 -> 284)
   constexpr int max_c = 1536, max_r = 64;
   if (C <= max_c && R <= max_r && R <= 128) {                       // small squeeze-excite weights: ONE launch
