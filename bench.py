@@ -594,15 +594,17 @@ def main():
                 # they are timed live (with several batches in flight no side stream is forked, so the heads' convolution
                 # can be an island too: the log line below lists all three).
                 n = max(1, a.inflight)
-                slots = [GraphedGraphBins(model, img, eager_ops=(island,), in_flight=n) for _ in range(n)]
+                # (only slot 0 carries the islands: the event-timed steps run on it; the other slots replay the forward as a
+                #  caller captures it, whole)
+                slots = [GraphedGraphBins(model, img, eager_ops=(island,) if k == 0 else (), in_flight=n) for k in range(n)]
                 # a slot is replayed on the stream it was captured on: creating further streams can put two slots on
                 # the same hardware queue (ROCm maps streams round-robin onto GPU_MAX_HW_QUEUES = 4 queues), which
                 # serialises them -- measured: 781 instead of 840 img/s with the same code, depending on creation order
                 streams = [g.stream for g in slots]
                 run = slots[0]
                 launch_mode = (f"hipGraph replay in {len(run.segments) - len(run.islands)} segments + {len(run.islands) + 1} eager, "
-                               "event-timed launches (roofline convolutions, bin head) per step"
-                               + (f"; {n} batches in flight (one graph instance + stream per slot, steps round-robin; the first "
+                               "event-timed launches (roofline convolutions, bin head) per step on slot 0"
+                               + (f", the whole forward as captured on the other slots; {n} batches in flight (one graph instance + stream per slot, steps round-robin; the first "
                                   f"ROOFLINE_STEPS steps of the timed region run alone, which is where the event timings come from)"
                                   if n > 1 else ""))
                 log(f"forward captured into {len(run.segments) - len(run.islands)} hipGraph segments x {n} slots "
@@ -688,7 +690,7 @@ def main():
             seq_step = lambda: step(0, 0)
             if nslot > 1:
                 from objcavit_amd.graph import GraphedGraphBins
-                lone = GraphedGraphBins(model, img, eager_ops=(island,), in_flight=1)
+                lone = GraphedGraphBins(model, img, in_flight=1)
 
                 def seq_step():
                     with torch.cuda.stream(lone.stream):
