@@ -36,7 +36,7 @@ __device__ __forceinline__ float tap(const MetArgs& p, const float* pb, const fl
 }
 
 __global__ __launch_bounds__(256) void depth_metrics_partial_kernel(MetArgs p) {
-  __shared__ double red[NSUM][256];
+  __shared__ double red[NSUM][4];
   const int tid = threadIdx.x, tile = blockIdx.x;
   const long b = blockIdx.y;
   const long P = (long)p.H * p.W;
@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void depth_metrics_partial_kernel(MetArgs p) {
 #pragma unroll
   for (int i = 0; i < NSUM; ++i) acc[i] = 0.0;
   int pending = 0;
+#pragma unroll 4
   for (long pix = lo + tid; pix < hi; pix += 256) {
     const float g = gb[pix];
     const int Y = (int)(pix / p.W), X = (int)(pix - (long)Y * p.W);
@@ -88,14 +89,18 @@ __global__ __launch_bounds__(256) void depth_metrics_partial_kernel(MetArgs p) {
       }
     }
   }
+  // workgroup totals: a fixed xor-tree over each wavefront's 64 lanes, then the four wavefronts in order (one thread walking 256 LDS
+  // doubles per sum was a third of the launch)
+  const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-  for (int i = 0; i < NSUM; ++i) red[i][tid] = acc[i] + (double)s[i];
-  __syncthreads();
-  if (tid < NSUM) {
-    double t = 0.0;
-    for (int k = 0; k < 256; ++k) t += red[tid][k];
-    p.part[((b * p.tiles) + tile) * NSUM + tid] = t;
+  for (int i = 0; i < NSUM; ++i) {
+    double t = acc[i] + (double)s[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    if (lane == 0) red[i][wave] = t;
   }
+  __syncthreads();
+  if (tid < NSUM) p.part[((b * p.tiles) + tile) * NSUM + tid] = ((red[tid][0] + red[tid][1]) + red[tid][2]) + red[tid][3];
 }
 
 // one workgroup per image, one wavefront per sum: lanes stride over the tiles, then a fixed xor-tree adds the 64 lanes
