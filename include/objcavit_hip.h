@@ -585,6 +585,14 @@ int ocv_depth_metrics_fwd(const float* pred, const float* pred_mirror, int h, in
 #define OCV_BINNORM_NONE 2
 int ocv_bin_edges_fwd(const float* raw, int mode, float min_depth, float max_depth, float* widths_normed, float* edges,
                       float* centers, int B, int n_bins, ocv_stream_t stream);
+/* The bin regressor and ocv_bin_edges_fwd in ONE launch (modules/miniViT.py:33-42 == modules/ObjCAViT.py:373-388): per image,
+ * row x + b * x_stride (E floats: token 0) -> Linear(E, H1) + LeakyReLU(leaky_slope) -> Linear(H1, H2) + LeakyReLU -> Linear(H2, n_bins) ->
+ * normalisation `mode` -> widths, edges, centres as above.  Weights row-major [out][in], 16-byte aligned; E, H1, H2 multiples of 4, <= 1024.
+ * Plain fp32 FMA chains in k order (the three GEMM launches it replaces summed in MFMA order: results agree to fp32 rounding). */
+int ocv_regressor_bins_fwd(const float* x, long x_stride, const float* w1, const float* b1, const float* w2, const float* b2,
+                           const float* w3, const float* b3, int E, int H1, int H2, int n_bins, float leaky_slope, int mode,
+                           float min_depth, float max_depth, float* widths_normed, float* edges, float* centers, int B,
+                           ocv_stream_t stream);
 
 /* Ragged object lists with the per-image COUNT in device memory (shape-static: a captured graph serves any object set up to its
  * capacity; replaces pad_sequence / F.pad / mask building of SelfAttnCrossAttn.forward, modules/ObjCAViT.py:180-183,192-194).

@@ -130,6 +130,8 @@ PROTOTYPES = {
     "ocv_conv_nhwc_exact_fwd": (C.c_int, [_f32p, C.c_int, _f32p, C.c_int, _f32p, _f32p, _f32p, _f32p] + [C.c_int] * 6 + [_stream]),
     "ocv_mbconv_expand_dw_tiles": (C.c_int, [C.c_int] * 4),
     "ocv_mbconv_expand_dw_fwd": (C.c_int, [_f32p, C.c_void_p, _f32p, _f32p, _f32p, _f32p, _f32p] + [C.c_int] * 11 + [_stream]),
+    "ocv_regressor_bins_fwd": (C.c_int, [_f32p, C.c_long, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                         C.c_int, C.c_float, C.c_float, _f32p, _f32p, _f32p, C.c_int, _stream]),
     "ocv_bin_edges_fwd": (C.c_int, [_f32p, C.c_int, C.c_float, C.c_float, _f32p, _f32p, _f32p, C.c_int, C.c_int, _stream]),
     "ocv_object_tokens_pad_fwd": (C.c_int, [_f32p, C.c_void_p, C.c_float, _f32p, _u8p, C.c_int, C.c_int, C.c_int, _stream]),
     "ocv_object_front_pad_fwd": (C.c_int, [_f32p, C.c_void_p, C.c_int, C.c_int, C.c_float, _f32p, _u8p] + [C.c_int] * 4 + [_stream]),

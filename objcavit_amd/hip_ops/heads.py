@@ -296,6 +296,32 @@ def bin_edges(raw: torch.Tensor, norm: str, min_depth: float, max_depth: float) 
     return w, e, c
 
 
+def regressor_bins(head: torch.Tensor, w1, b1, w2, b2, w3, b3, norm: str, min_depth: float, max_depth: float,
+                   leaky_slope: float = 0.01) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """The bin regressor (Linear + LeakyReLU, Linear + LeakyReLU, Linear) on one row per image + ``bin_edges`` in ONE launch.
+    head [B, E]: rows may be strided (``tokens[:, 0, :]``), each row contiguous.  -> (bin_widths_normed, bin_edges, centers)."""
+    lib = _lib.load()
+    if norm not in BINNORM:
+        raise ValueError("regressor_bins: norm must be one of " + ", ".join(BINNORM))
+    _req(head, "head", contiguous=False)
+    if head.dim() != 2 or head.stride(1) != 1:
+        raise ValueError("regressor_bins: head must be [B, E] with contiguous rows")
+    for nme, t in (("w1", w1), ("b1", b1), ("w2", w2), ("b2", b2), ("w3", w3), ("b3", b3)):
+        _req(t, nme)
+    B, E = head.shape
+    H1, H2, n = w1.shape[0], w2.shape[0], w3.shape[0]
+    if w1.shape != (H1, E) or w2.shape != (H2, H1) or w3.shape != (n, H2) or b1.numel() != H1 or b2.numel() != H2 or b3.numel() != n:
+        raise ValueError("regressor_bins: parameter shape mismatch")
+    w = torch.empty(B, n, dtype=torch.float32, device=head.device)
+    e = torch.empty(B, n + 1, dtype=torch.float32, device=head.device)
+    c = torch.empty_like(w)
+    with timed("regressor_bins"):
+        check(lib.ocv_regressor_bins_fwd(head.data_ptr(), head.stride(0), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                         w3.data_ptr(), b3.data_ptr(), E, H1, H2, n, float(leaky_slope), BINNORM[norm], float(min_depth),
+                                         float(max_depth), w.data_ptr(), e.data_ptr(), c.data_ptr(), B, _stream()), "ocv_regressor_bins_fwd")
+    return w, e, c
+
+
 # ---------------------------------------------------------------------------
 # ragged object lists with device-resident counts (csrc/objects_pad.hip)
 # ---------------------------------------------------------------------------

@@ -21,6 +21,16 @@ def regress_bin_widths(regressor: nn.Sequential, head: torch.Tensor, norm: str, 
     (reference modules/miniViT.py:33-42 == modules/ObjCAViT.py:378-388).  ``depth_range`` = (min_depth, max_depth): the
     normalisation, the bin edges and the bin centres come out of ONE launch (csrc/bin_edges.hip); edges and centres ride along
     on the returned tensor for ``AdaBins.bin_edges_and_centers`` (reference modules/AdaBins.py:79-83)."""
+    fits = all(isinstance(regressor[i], nn.Linear) and regressor[i].bias is not None and regressor[i].in_features % 4 == 0
+               and regressor[i].in_features <= 1024 for i in (0, 2, 4)) and regressor[4].out_features <= 4096
+    if depth_range is not None and norm != "softmax" and head.is_cuda and head.dim() == 2 and head.stride(1) == 1 and fits:
+        # ONE launch for the three layers, the normalisation, the edges and the centres (csrc/bin_edges.hip: regressor_bins_kernel)
+        lo, hi = float(depth_range[0]), float(depth_range[1])
+        par = [t.detach() for i in (0, 2, 4) for t in (regressor[i].weight, regressor[i].bias)]
+        w, edges, centers = hip_ops.regressor_bins(head, *par, "linear" if norm == "linear" else "sigmoid", lo, hi,
+                                                   leaky_slope=regressor[1].negative_slope)
+        w._ocv_bins = ((lo, hi), edges, centers)
+        return w
     y = hip_ops.linear(head.contiguous(), regressor[0].weight.detach(), regressor[0].bias.detach(), hip_ops.ACT_LEAKY_RELU)
     y = hip_ops.linear(y, regressor[2].weight.detach(), regressor[2].bias.detach(), hip_ops.ACT_LEAKY_RELU)
     y = hip_ops.linear(y, regressor[4].weight.detach(), regressor[4].bias.detach(), hip_ops.ACT_NONE)

@@ -741,6 +741,35 @@ def test_bin_head_h2_on_scaled_maps(ops, monkeypatch, scale):
     assert float(((got - ref).abs() / ref).max()) < 5e-5
 
 
+@pytest.mark.parametrize("norm", ["linear", "sigmoid"])
+@pytest.mark.parametrize("B,E,H1,H2,n", [(16, 128, 256, 256, 256), (1, 128, 256, 256, 256), (3, 64, 100, 36, 80), (2, 128, 256, 256, 1000)])
+def test_regressor_bins_one_launch(ops, norm, B, E, H1, H2, n):
+    """ocv_regressor_bins_fwd (the bin regressor's three layers + normalisation + edges + centres in one launch, one workgroup per
+    image) against the reference's formulation in fp64 (modules/miniViT.py:33-42, AdaBins.py:79-83) and against the launches it
+    replaces (three ocv_linear_fwd + ocv_bin_edges_fwd); the head rows are a strided view of a token tensor, as in the model."""
+    tok = rnd("tok", (B, 7, E), 1)
+    par = [rnd("w1", (H1, E), 2, 1 / math.sqrt(E)), rnd("b1", (H1,), 3, 0.2), rnd("w2", (H2, H1), 4, 1 / math.sqrt(H1)), rnd("b2", (H2,), 5, 0.2),
+           rnd("w3", (n, H2), 6, 2 / math.sqrt(H2)), rnd("b3", (n,), 7, 0.2)]
+    head = dev(tok)[:, 0, :]
+    assert not head.is_contiguous() or B == 1
+    w, e, c = ops.regressor_bins(head, *[dev(t) for t in par], norm, 0.001, 10.0)
+    x = tok[:, 0, :].double()
+    y = F.leaky_relu(x @ par[0].double().T + par[1].double(), 0.01)
+    y = F.leaky_relu(y @ par[2].double().T + par[3].double(), 0.01)
+    y = y @ par[4].double().T + par[5].double()
+    y = torch.relu(y) + 0.1 if norm == "linear" else torch.sigmoid(y)
+    wr = y / y.sum(1, keepdim=True)
+    er = torch.cumsum(F.pad((10.0 - 0.001) * wr, (1, 0), value=0.001), 1)
+    cr = 0.5 * (er[:, :-1] + er[:, 1:])
+    assert rel_dev(w, wr.float()) < 2e-6 and rel_dev(e, er.float()) < 2e-6 and rel_dev(c, cr.float()) < 2e-6
+    g = [dev(t) for t in par]
+    y3 = ops.linear(ops.linear(ops.linear(head.contiguous(), g[0], g[1], ops.ACT_LEAKY_RELU), g[2], g[3], ops.ACT_LEAKY_RELU), g[4], g[5],
+                    ops.ACT_NONE)
+    w3, e3, c3 = ops.bin_edges(y3, norm, 0.001, 10.0)
+    assert rel_dev(w, w3.cpu()) < 2e-6 and rel_dev(e, e3.cpu()) < 2e-6 and rel_dev(c, c3.cpu()) < 2e-6
+    assert torch.equal(w, ops.regressor_bins(head, *g, norm, 0.001, 10.0)[0])
+
+
 @pytest.mark.parametrize("gain", [0.02, 0.6, 6.0, 40.0])
 def test_bin_head_two_level_logits_against_every_tile_in_full(ops, monkeypatch, gain):
     """The default bin head forms every bin coarsely and only the 32-bin tiles near a pixel's maximum in full (csrc/bin_head.hip).
