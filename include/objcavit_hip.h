@@ -508,15 +508,6 @@ int ocv_conv_nhwc_split_ws_fwd(const void* x_hl, int Cin, const void* w_hi, cons
 int ocv_conv_nhwc_split_x_fwd(const void* x_hl, int Cin, const void* w_hi, const void* w_lo, const float* oscale, int f16,
                               const float* bias, const float* residual, float* y, void* y_hl, int B, int H, int W, int Cout,
                               int ksize, int act, void* workspace, size_t workspace_bytes, ocv_stream_t stream);
-/* Route of the pre-split convolution / GEMM kernel behind ocv_conv_nhwc_split_*_fwd and ocv_conv3x3_winograd43_split_fwd's GEMM
- * batch (round 6).  Two forms of one kernel: the parked epilogue, one (pixel tile, channel tile) per workgroup (rounds 2 - 5), and
- * the DIRECT form -- MFMA operands swapped so that a lane holds four consecutive channels of a pixel, epilogue in registers, stores
- * straight from the accumulators, a workgroup walking npn channel tiles of its pixel tile on one prologue (Cout % 4 == 0).
- * direct = 1, npn = 0 (default): the direct form where 2 or 3 tiles per workgroup are modelled to pay (the decoder's tap GEMMs at
- * 15 x 20 ... 60 x 80, the Winograd batches, the 176 -> 1024 skip part), the parked form elsewhere; direct = 1, npn = k: the direct
- * form with min(k, channel tiles) per workgroup wherever it applies; direct = 0: never.  Both forms give the same bits (the K loop of
- * a tile is the same sequence of products and sums).  Process-wide; diagnostics / tests / A-B tools only.  Returns 0 / -1. */
-int ocv_conv_split_set_dispatch(int direct, int npn);
 
 /* The same 3 x 3 convolution (stride 1, zero padding 1) in Winograd F(4x4, 3x3) form on TWO-TERM FP16 splits (round 3), for shapes
  * where the arithmetic dominates the transforms' traffic: 4x fewer matrix-core operations than the direct form, a transformed input

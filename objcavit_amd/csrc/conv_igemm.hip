@@ -81,8 +81,6 @@ struct ConvArgs {
   unsigned rowpitch;                    // conv_split_dma_kernel: bytes between consecutive rows of the (B H) x W pixel grid of the
                                         // split input when they are not dense (0 = dense, W * 4 Cp); the patch embedding reads
                                         // every 16th image row of the feature map as one GEMM row grid this way
-  int npn;                              // conv_split_dma_kernel<.., true>: channel tiles one workgroup walks for its pixel tile (>= 1),
-  int ngroups;                          // and ceil(ntiles / npn): the DMA ring runs on across them, one prologue per workgroup
 };
 
 // 16-byte global load (compiler-visible: hipcc tracks it and inserts the s_waitcnt before the first use).
@@ -727,290 +725,6 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
 }
 
 
-// ---------------------------------------------------------------------------
-// DIRECT form of the same kernel (round 6): a workgroup walks `npn` channel tiles of its pixel tile with the DMA ring running on
-// across the tile boundary -- ONE prologue (row addresses, first loads from beyond L2) per workgroup and fewer, longer workgroups.
-// For that nothing of a tile's epilogue may stand between two K loops:
-//   * the MFMA operands are SWAPPED (weights as the A operand, pixels as B: the fragment reads are the same, the arguments trade
-//     places), so register r of lane l of accumulator (i, j) is output PIXEL 16 i + (l & 15), CHANNEL 16 j + 4 (l >> 4) + r: a lane
-//     holds four consecutive channels of one pixel (csrc/stem.hip writes its output the same way since round 4);
-//   * bias / scale / activation / residual / the (hi, lo) split are applied in registers and the tile leaves as 16-byte (fp32) or
-//     8-byte (pairs) stores straight from the accumulators -- no LDS park, no barrier, and nobody waits for the stores (the K
-//     loop's barrier is a raw s_barrier behind lgkmcnt(0): __syncthreads() would drain vmcnt, which counts stores on gfx950).
-// Same bits as the parked form (the same products summed in the same order).  Where it pays and where it does not: launch_conv.
-// Everything else -- LDS image, swizzle, producers' piece map, counted vmcnt -- is conv_split_dma_kernel's.
-// ---------------------------------------------------------------------------
-template <bool F16, int ACT>
-__device__ __forceinline__ void conv_direct_store(const ConvArgs& p, const f32x4 (&acc)[8][4], long mrow0, int ncol0, long yoff) {
-  // mrow0 = first pixel of this lane (+ 16 i), ncol0 = first channel of this lane (+ 16 j); Cout % 4 == 0
-  float amax = 0.f;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n = ncol0 + 16 * j;
-    if (n < p.Cout) {
-      f32x4 bv, sv;                                                        // (element loads: the vectors' alignment is the caller's)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        bv[e] = p.bias != nullptr ? p.bias[n + e] : 0.f;
-        sv[e] = p.oscale != nullptr ? p.oscale[n + e] : 1.f;
-      }
-      const long hoff = (long)(n >> 5) * 64 + (n & 31);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const long m = mrow0 + 16 * i;
-        if (m < p.M) {
-          f32x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float t = fmaf(acc[i][j][e], sv[e], bv[e]);                     // (sv = 1, bv = 0: exact)
-            if constexpr (ACT == OCV_ACT_LEAKY_RELU) t = t > 0.f ? t : 0.01f * t;
-            else if constexpr (ACT == OCV_ACT_RELU) t = fmaxf(t, 0.f);
-            else if constexpr (ACT == OCV_ACT_SILU) t = fast_silu(t);
-            v[e] = t;
-          }
-          const long o = m * p.Cout + n;
-          if (p.res != nullptr) v += *reinterpret_cast<const f32x4*>(p.res + o);
-          if (p.y != nullptr) *reinterpret_cast<f32x4*>(p.y + yoff + o) = v;
-          if (p.yhl != nullptr) {
-            __attribute__((aligned(8))) unsigned short hi[4], lo[4];
-            split4_bits<F16>(v, hi, lo);
-            if constexpr (F16) amax = ocv_amax4(amax, v);
-            __bf16* d = p.yhl + m * 2 * p.Cpo + hoff;
-            *reinterpret_cast<uint2*>(d) = *reinterpret_cast<const uint2*>(hi);
-            *reinterpret_cast<uint2*>(d + 32) = *reinterpret_cast<const uint2*>(lo);
-          }
-        }
-      }
-    }
-  }
-  if constexpr (F16) ocv_range_note(p.yhl != nullptr ? p.range_flag : nullptr, amax);
-}
-
-// raw fp32 result (no bias / scale / activation / residual / split copy): the tap GEMMs, the Winograd batch, split-K parts
-__device__ __forceinline__ void conv_direct_store_raw(const ConvArgs& p, const f32x4 (&acc)[8][4], long mrow0, int ncol0, long yoff) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const long m = mrow0 + 16 * i;
-    if (m < p.M) {
-      float* dst = p.y + yoff + m * p.Cout + ncol0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (ncol0 + 16 * j < p.Cout) *reinterpret_cast<f32x4*>(dst + 16 * j) = acc[i][j];
-    }
-  }
-}
-
-template <bool F16>
-__global__ __launch_bounds__(512) void conv_split_direct_kernel(ConvArgs p) {
-  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-  const int ntile = p.mtiles * p.ngroups, nwg = ntile * (p.zflat > 0 ? p.zflat : p.ksplit * p.zbatch);
-  int wg = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int kz = wg / ntile;                                     // (GEMM of the batch, K part) of this workgroup
-  wg -= kz * ntile;
-  const int taps = p.ks * p.ks, pad = p.ks >> 1;
-  const int nchunk = p.Cp / CBK;
-  int zb, ch0, nsteps;
-  if (p.zflat > 0) {                                             // steps [s0, s1) of the zbatch GEMMs' chunks laid end to end
-    const int S = p.zbatch * nchunk;
-    const int s0 = (int)((long)S * kz / p.zflat), s1 = (int)((long)S * (kz + 1) / p.zflat);
-    zb = s0 / nchunk;
-    ch0 = s0 - zb * nchunk;
-    nsteps = s1 - s0;
-  } else {
-    zb = kz / p.ksplit;                                          // zb: 0 unless zbatch > 1
-    const int kh = kz - zb * p.ksplit;                           // kh: 0 unless ksplit == 2
-    ch0 = nchunk * kh / p.ksplit;                                // channel chunks [ch0, ch1)
-    nsteps = taps * (nchunk * (kh + 1) / p.ksplit - ch0);
-  }
-  const int mt = wg / p.ngroups, ng = wg - mt * p.ngroups;
-  const long m0 = (long)mt * CBM;
-  const int nt0 = ng * p.npn;                                    // channel tiles [nt0, nt0 + ntl) of this workgroup
-  const int ntl = min(p.npn, p.ntiles - nt0);
-  const long yoff = (long)kz * p.M * p.Cout;
-
-  if (wave < 4) {
-    // =========================== CONSUMERS, v_mfma_f32_16x16x32, weights as the A operand ===========================
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l15 = lane & 15, q4 = lane >> 4;
-    const int co = ((q4 ^ ((l15 >> 1) & 3)) * 16);
-    const long mrow0 = m0 + wm * 128 + l15;
-    const bool raw = p.bias == nullptr && p.oscale == nullptr && p.res == nullptr && p.yhl == nullptr && p.act == OCV_ACT_NONE;
-    int buf = 0;                                                   // ring slot of the step being multiplied
-
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                  // step 0 has landed (the producers waited for it)
-    asm volatile("" ::: "memory");
-    for (int it = 0; it < ntl; ++it) {
-      f32x4 acc[8][4];
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int step = 0; step < nsteps; ++step) {
-        const unsigned char* base = lds + buf * DBUF;
-        buf = buf == DNBUF - 1 ? 0 : buf + 1;
-        const unsigned char* pa = base + (wm * 128 + l15) * DROW + co;
-        const unsigned char* pb = base + 2 * DA + (wn * 64 + l15) * DROW + co;
-        bf16x8 ah[8], al[8], bh[4], bl[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          bh[j] = *reinterpret_cast<const bf16x8*>(pb + j * 16 * DROW);
-          bl[j] = *reinterpret_cast<const bf16x8*>(pb + DB + j * 16 * DROW);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          ah[i] = *reinterpret_cast<const bf16x8*>(pa + i * 16 * DROW);
-          al[i] = *reinterpret_cast<const bf16x8*>(pa + DA + i * 16 * DROW);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if constexpr (F16) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cv_h16x8, bh[j]), __builtin_bit_cast(cv_h16x8, ah[i]), acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cv_h16x8, bl[j]), __builtin_bit_cast(cv_h16x8, ah[i]), acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cv_h16x8, bh[j]), __builtin_bit_cast(cv_h16x8, al[i]), acc[i][j], 0, 0, 0);
-            } else {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
-            }
-          }
-        // this wavefront's fragment reads have returned (the MFMAs took them); the slot may be refilled after the barrier.  A raw
-        // barrier: __syncthreads() would also wait for the previous tile's stores (vmcnt counts stores on gfx950).
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-      }
-      const int ncol0 = (nt0 + it) * CBN + wn * 64 + 4 * q4;
-      if (raw) conv_direct_store_raw(p, acc, mrow0, ncol0, yoff);
-      else if (p.act == OCV_ACT_LEAKY_RELU) conv_direct_store<F16, OCV_ACT_LEAKY_RELU>(p, acc, mrow0, ncol0, yoff);
-      else if (p.act == OCV_ACT_NONE) conv_direct_store<F16, OCV_ACT_NONE>(p, acc, mrow0, ncol0, yoff);
-      else if (p.act == OCV_ACT_RELU) conv_direct_store<F16, OCV_ACT_RELU>(p, acc, mrow0, ncol0, yoff);
-      else conv_direct_store<F16, OCV_ACT_SILU>(p, acc, mrow0, ncol0, yoff);
-    }
-    return;
-  }
-
-  // =========================== PRODUCERS (LDS-DMA issuers) ===========================
-  const int pw = wave - 4;
-  const int lrow = lane >> 2;
-  const int lchunk = (lane & 3) ^ ((lane >> 3) & 3);               // logical 16-byte chunk (8 channels) this lane fetches
-  unsigned rbA[4], tapmask[4];
-  if (p.ks == 1 && p.rowpitch == 0) {                               // a plain GEMM: no pixel coordinates, one tap
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const unsigned am = (unsigned)m0 + 64 * pw + 16 * i + lrow;
-      const bool valid = am < (unsigned)p.M;
-      tapmask[i] = valid ? 1u : 0u;
-      rbA[i] = (valid ? am : 0u) * (unsigned)(4 * p.Cp) + (unsigned)(lchunk * 16);
-    }
-  } else {
-    const unsigned hw = (unsigned)(p.H * p.W);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const unsigned am = (unsigned)m0 + 64 * pw + 16 * i + lrow;           // M < 2^30 (4 GiB operand limit)
-      const bool valid = am < (unsigned)p.M;
-      const unsigned img = valid ? am / hw : 0u;
-      const unsigned rem = valid ? am - img * hw : 0u;
-      const int y = (int)(rem / (unsigned)p.W), x = (int)(rem - (unsigned)y * (unsigned)p.W);
-      unsigned mask = 0;
-      int t = 0;
-      for (int dy = -pad; dy <= pad; ++dy)
-        for (int dx = -pad; dx <= pad; ++dx, ++t)
-          if (valid && (unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W) mask |= 1u << t;
-      tapmask[i] = mask;
-      rbA[i] = (p.rowpitch == 0 ? (valid ? am : 0u) * (unsigned)(4 * p.Cp)
-                                : (img * (unsigned)p.H + (unsigned)y) * p.rowpitch + (unsigned)x * (unsigned)(4 * p.Cp)) +
-               (unsigned)(lchunk * 16);
-    }
-  }
-  const unsigned wtap = (unsigned)((long)p.Cout * p.Cp * 2);
-  const char* xz = (const char*)p.xhl + (long)zb * p.xz_bytes;     // (advanced in zflat mode)
-  const char* whz = (const char*)p.whi + (long)zb * p.wz_bytes;
-  const char* wlz = (const char*)p.wlo + (long)zb * p.wz_bytes;
-  unsigned rbB[2];
-  auto set_rows_b = [&](int n0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int bn = min(n0 + 32 * pw + 16 * i + lrow, p.Cout - 1);
-      rbB[i] = (unsigned)(((long)bn * p.Cp + lchunk * 8) * 2);
-    }
-  };
-  int nx_n0 = nt0 * CBN;
-  set_rows_b(nx_n0);
-
-  int nx_tap = 0, nx_c0 = ch0 * CBK, nx_ky = 0, nx_kx = 0, nx_s = 0;
-  auto issue_dma = [&](int buf) {
-    const int tap = nx_tap, c0 = nx_c0, ky = nx_ky, kx = nx_kx;
-    const char* const xz_ = xz;
-    const char* const whz_ = whz;
-    const char* const wlz_ = wlz;
-    const int soff = (((ky - pad) * p.W + (kx - pad)) * 2 * p.Cp + 2 * c0) * 2;       // hl32: chunk c0 starts at 2 c0
-    unsigned char* base = lds + buf * DBUF;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool ok = ((tapmask[i] >> tap) & 1u);               // pad channels are zeros in memory: no channel check
-      const unsigned off = rbA[i] + (unsigned)soff;
-      const void* sh = ok ? (const void*)(xz_ + off) : (const void*)ocv_zero_page;
-      const void* sl = ok ? (const void*)(xz_ + off + 64) : (const void*)ocv_zero_page;   // same 128-B line
-      unsigned char* dst = base + (64 * pw + 16 * i) * DROW;
-      __builtin_amdgcn_global_load_lds((gptr_t)sh, (lptr_t)dst, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)sl, (lptr_t)(dst + DA), 16, 0, 0);
-    }
-    const unsigned woff = (unsigned)tap * wtap + (unsigned)c0 * 2;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      unsigned char* dst = base + 2 * DA + (32 * pw + 16 * i) * DROW;
-      __builtin_amdgcn_global_load_lds((gptr_t)(whz_ + woff + rbB[i]), (lptr_t)dst, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(wlz_ + woff + rbB[i]), (lptr_t)(dst + DB), 16, 0, 0);
-    }
-    // the step after this one
-    if (++nx_kx == p.ks) { nx_kx = 0; ++nx_ky; }
-    if (++nx_tap == taps) { nx_tap = 0; nx_ky = 0; nx_c0 += CBK; }
-    if (p.zflat > 0 && nx_c0 == p.Cp) {                          // first chunk of the next GEMM of the batch (zflat: npn = 1)
-      nx_c0 = 0;
-      xz += p.xz_bytes; whz += p.wz_bytes; wlz += p.wz_bytes;
-    }
-    if (++nx_s == nsteps) {                                      // first step of the next channel tile: same rows, next weights
-      nx_s = 0; nx_tap = 0; nx_ky = 0; nx_kx = 0; nx_c0 = ch0 * CBK;
-      nx_n0 += CBN;
-      set_rows_b(nx_n0);
-    }
-  };
-
-#define OCV_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
-  const int total = ntl * nsteps;
-  issue_dma(0);
-  if (total > 1) {
-    issue_dma(1);
-    OCV_WAIT_VM(12);
-  } else {
-    OCV_WAIT_VM(0);
-  }
-  __builtin_amdgcn_s_barrier();
-  int nb = 2;                                                      // ring slot of the next step to issue
-  for (int t = 0; t < total; ++t) {
-    if (t + 2 < total) {
-      issue_dma(nb);
-      nb = nb == DNBUF - 1 ? 0 : nb + 1;
-      OCV_WAIT_VM(12);                                 // step t+1 has landed, step t+2 may still be in flight
-    } else {
-      OCV_WAIT_VM(0);
-    }
-    __builtin_amdgcn_s_barrier();
-  }
-#undef OCV_WAIT_VM
-}
-
-
 // Second pass of a split-K convolution: y = act(part0 + part1 + bias) (+ residual), fp32 and / or hl32 split output.
 // One thread per (pixel, channel octet); fixed summation order.
 struct FinArgs {
@@ -1072,40 +786,10 @@ int conv_ksplit(long M, int Cout, int Cin, int ksize) {
   const double c1 = (double)((tiles + 255) / 256), c2 = (double)((2 * tiles + 255) / 256) / 2.0;
   return c2 <= 0.9 * c1 ? 2 : 1;
 }
-// Route of the pre-split kernel (round 6; tools/ab_conv_direct.py -> profiles/r06_conv_direct.txt).  The DIRECT form
-// (conv_split_direct_kernel) is taken where a workgroup walking 2 or 3 channel tiles is modelled to pay; everything else keeps the
-// parked epilogue.  What the A/B says: (i) stores straight from the accumulators are NOT faster than the parked epilogue -- on a par
-// as 16-byte fp32 stores (tap GEMMs: -1.5 ... +1.5 us per tile), 4.8 us per tile SLOWER as 8-byte stores of (hi, lo) pairs (32-byte
-// runs from four wavefronts against 64-byte runs from eight); (ii) one prologue for several channel tiles is worth 3 - 12 us per
-// workgroup, and fewer, longer workgroups often fill the last round of 256 CUs better; (iii) a workgroup that walks MANY tiles
-// loses the L2 sharing of its pixel tile with its neighbours (nine tiles at 120 x 160: 1.25x slower).  Hence: n <= 3, launches of
-// at most 600 pixel tiles, and only where the model below predicts >= 3 %.  Model (fits the A/B's 30 cells to ~5 %):
-// rounds of 256 workgroups x (10 us per workgroup + n x (2.3 us + 1.35 us per K step)).
-// ocv_conv_split_set_dispatch overrides (tests, A/B tools): direct = 0 never, direct = 1 with npn = 0 this rule, npn = k forces
-// the direct form with min(k, ntiles) tiles per workgroup wherever it applies (Cout % 4 == 0, not the patch embedding's flat K).
-struct ConvCfg { int direct = 1, npn = 0; };
-ConvCfg& conv_cfg() {
-  static ConvCfg c;
-  return c;
-}
-int conv_npn(long mtiles, int ntiles, int parts, int nsteps) {
-  if (ntiles < 2 || mtiles > 600) return 1;
-  const double tile = 2.3 + 1.35 * nsteps;
-  double c1 = 0.0, cost = 0.0;
-  int best = 1;
-  for (int n = 1; n <= 3 && n <= ntiles; ++n) {
-    const long wgs = mtiles * ((ntiles + n - 1) / n) * parts;
-    const double c = (double)((wgs + 255) / 256) * (10.0 + n * tile);
-    if (n == 1) c1 = cost = c;
-    else if (c < cost) { cost = c; best = n; }
-  }
-  return cost <= 0.97 * c1 ? best : 1;
-}
 int launch_conv(ConvArgs& a, int B, bool in_split, hipStream_t st) {
   a.Cp = (a.Cin + CBK - 1) / CBK * CBK;
   a.M = (long)B * a.H * a.W;
   a.mtiles = ocv_cdiv(a.M, CBM); a.ntiles = ocv_cdiv(a.Cout, CBN);
-  a.npn = 1; a.ngroups = a.ntiles;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1116,25 +800,12 @@ int launch_conv(ConvArgs& a, int B, bool in_split, hipStream_t st) {
     if (!attr2) {
       (void)hipFuncSetAttribute((const void*)conv_split_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)hipFuncSetAttribute((const void*)conv_split_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)conv_split_direct_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)conv_split_direct_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr2 = true;
     }
     if (a.ksplit < 1) a.ksplit = 1;
     if (a.zbatch < 1) a.zbatch = 1;
     const unsigned parts = a.zflat > 0 ? a.zflat : a.ksplit * a.zbatch;
-    bool direct = false;
-    if (conv_cfg().direct && (a.Cout & 3) == 0 && a.zflat == 0) {
-      const int nsteps = a.ks * a.ks * (a.Cp / CBK) / a.ksplit;
-      a.npn = conv_cfg().npn > 0 ? (conv_cfg().npn < a.ntiles ? conv_cfg().npn : a.ntiles) : conv_npn(a.mtiles, a.ntiles, (int)parts, nsteps);
-      a.ngroups = ocv_cdiv(a.ntiles, a.npn);
-      direct = conv_cfg().npn > 0 || a.npn > 1;
-    }
-    if (direct) {
-      const unsigned grid = (unsigned)(a.mtiles * a.ngroups) * parts;
-      if (a.f16) hipLaunchKernelGGL(conv_split_direct_kernel<true>, dim3(grid), dim3(512), DNBUF * DBUF, st, a);
-      else hipLaunchKernelGGL(conv_split_direct_kernel<false>, dim3(grid), dim3(512), DNBUF * DBUF, st, a);
-    } else if (a.f16)
+    if (a.f16)
       hipLaunchKernelGGL(conv_split_dma_kernel<true>, dim3(a.mtiles * a.ntiles * parts), dim3(512), DNBUF * DBUF, st, a);
     else
       hipLaunchKernelGGL(conv_split_dma_kernel<false>, dim3(a.mtiles * a.ntiles * parts), dim3(512), DNBUF * DBUF, st, a);
@@ -1143,14 +814,6 @@ int launch_conv(ConvArgs& a, int B, bool in_split, hipStream_t st) {
   return 0;
 }
 }  // namespace
-
-extern "C" int ocv_conv_split_set_dispatch(int direct, int npn) {
-  OCV_CHECK_ARG((direct == 0 || direct == 1) && npn >= 0 && npn <= 4096,
-                "ocv_conv_split_set_dispatch: direct must be 0 or 1, npn (channel tiles per workgroup) 0 = automatic or 1 .. 4096");
-  conv_cfg().direct = direct;
-  conv_cfg().npn = npn;
-  return 0;
-}
 
 extern "C" size_t ocv_split_act_elems(int B, int H, int W, int C) {
   if (B < 1 || H < 1 || W < 1 || C < 1) return 0;

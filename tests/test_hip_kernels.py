@@ -1559,49 +1559,6 @@ def test_conv_nhwc_split_many_tiles(ops, B, H, W, Cin, Cout, k, act):
     assert rel_dev(y, y3) < 1e-5
 
 
-@pytest.mark.parametrize("f16", [False, True])
-@pytest.mark.parametrize("B,H,W,Cin,Cout,k,act", [
-    (2, 30, 40, 256, 1152, 1, 0),       # a tap GEMM: nine channel tiles per pixel tile, raw fp32 result
-    (3, 37, 41, 64, 520, 3, 2),         # ragged rows (4551 pixels), five channel tiles with a ragged last one (520 = 4 x 128 + 8)
-    (1, 60, 80, 40, 256, 3, 0),         # a skip-part convolution: K padded 40 -> 64, two channel tiles
-    (2, 17, 23, 96, 12, 3, 3),          # Cout % 8 != 0 but % 4 == 0: below one tile, SiLU
-    (4, 60, 80, 464, 512, 3, 2),        # the split-K shape (300 pixel tiles x 4): raw halves + finish pass
-])
-def test_conv_split_direct_route_equals_parked_route(ops, f16, B, H, W, Cin, Cout, k, act):
-    """Round 6: the pre-split kernel's DIRECT route (operands swapped, epilogue from the accumulators, a workgroup walking several
-    channel tiles: the default) against the parked-epilogue route of rounds 2 - 5 and an fp64 convolution; every forced tile count
-    must give the automatic one's result bit for bit (the K loop of a tile does not depend on which workgroup runs it)."""
-    from objcavit_amd import _lib
-    lib = _lib.load()
-    x = rnd("x", (B, Cin, H, W), 1)
-    w, b = rnd("w", (Cout, Cin, k, k), 3, 1 / math.sqrt(Cin * k * k)), rnd("b", (Cout,), 4, 0.2)
-    ref = F.conv2d(x.double(), w.double(), b.double(), padding=k // 2).float()
-    ref = [ref, torch.relu(ref), F.leaky_relu(ref, 0.01), F.silu(ref)][act]
-    prep = ops.prep_conv_weight(dev(w), f16=f16)
-    hi, lo, osc = (prep + (None,))[:3]
-    xs = ops.upsample_concat_split(dev(x), None, (H, W), f16=f16)
-    run = lambda: ops.conv_nhwc_split(xs, hi, lo, dev(b), k, act, out_fp32=True, out_split=True, oscale=osc)
-    try:
-        assert lib.ocv_conv_split_set_dispatch(0, 0) == 0
-        y0, s0 = run()
-        assert lib.ocv_conv_split_set_dispatch(1, 0) == 0
-        y1, s1 = run()
-        assert rel_dev(y1, ref) < SPLIT_TOL and rel_dev(y0, ref) < SPLIT_TOL
-        assert rel_dev(y1, y0) < 1e-6 and rel_dev(s1.float(), s0.float()) < 1e-6
-        assert rel_dev(s1.float(), y1) < (1e-6 if f16 else 1e-5)
-        for npn in (1, 2, 3, 64):
-            assert lib.ocv_conv_split_set_dispatch(1, npn) == 0
-            y2, s2 = run()
-            assert torch.equal(y2, y1) and torch.equal(s2.hl, s1.hl), npn
-        if Cout % 32:                                               # pad channels of the split copy stay zero on the direct route
-            Cp = (Cout + 31) // 32 * 32
-            pads = s1.hl.view(B, H, W, Cp // 32, 2, 32).permute(0, 1, 2, 4, 3, 5).reshape(B, H, W, 2, Cp)[..., Cout:]
-            assert not bool(pads.any())
-    finally:
-        lib.ocv_conv_split_set_dispatch(1, 0)
-    assert lib.ocv_conv_split_set_dispatch(2, 0) == -1 and lib.ocv_conv_split_set_dispatch(1, -1) == -1
-
-
 # ------------------------------------------------------------------ positional-embedding samplers
 def test_pos_grid_sample_roi_vs_hand_computed_boxes(ops):
     """ocv_pos_grid_sample_fwd, RoI mode, against the hand-computed boxes of tests/roi_cases.py (box inside one cell,

@@ -1,4 +1,5 @@
-"""Round 6: the pre-split convolution / GEMM kernel's two routes on the decoder's launches, same process, alternating.
+"""(needs tools/diag/conv_direct.patch.txt applied: the direct form is not in the product -- profiles/r06_conv_direct.txt)
+Round 6: the pre-split convolution / GEMM kernel's two routes on the decoder's launches, same process, alternating.
   route 0  conv_split_dma_kernel: accumulators parked in LDS, all eight wavefronts store, one tile per workgroup (rounds 2 - 5)
   route 1  the shipped rule (csrc/conv_igemm.hip launch_conv): conv_split_direct_kernel -- operands swapped, in-register epilogue, a
            workgroup walks npn = 2 or 3 channel tiles -- where that is modelled to pay, route 0 elsewhere; npnK = direct form forced
