@@ -476,10 +476,13 @@ def side_leg(device, wl, model, nslot, seconds, seed=42):
     slots = [GraphedGraphBins(model, img, in_flight=nslot) for _ in range(nslot)]
     t_build = time.perf_counter() - t_build
 
+    flags = []                                               # every step's taken range-guard word (device, 4 bytes each): read once, below
+
     def step(k):
         g = slots[k % nslot]
         with torch.cuda.stream(g.stream):
             out = g(img)
+            flags.append(g.last_flag)
             hip_ops.depth_metrics(out.depth_pred, gt, wl.min_depth, wl.max_depth, crop=box, first_image_id=0)
 
     for k in range(2 * nslot):
@@ -497,7 +500,8 @@ def side_leg(device, wl, model, nslot, seconds, seed=42):
         torch.cuda.synchronize()
         n += per_round
     dt = time.perf_counter() - t0
-    tripped = sum(int(g.tripped()) for g in slots)
+    taken = [f for f in flags if f is not None]               # ALL steps of the leg, not the last replay of each slot
+    tripped = int(torch.cat(taken).ne(0).sum()) if taken else 0
     nodes = [sum(x for x in g.segment_nodes if x) for g in slots][0]
     forks = sum(t.get("forks", 0) for t in slots[0].segment_topology)      # side-stream forks inside the captured forward (0 = single chain)
     del slots
@@ -505,6 +509,48 @@ def side_leg(device, wl, model, nslot, seconds, seed=42):
     return {"images_per_s": round(n * B / dt, 1), "ms_per_step": round(dt / n * 1e3, 3), "batch": B, "inflight": nslot, "steps": n,
             "seconds": round(dt, 2), "graph_nodes": nodes, "graph_forks": forks, "capture_s": round(t_build, 2), "fp16_range_guard_tripped": tripped,
             "workload": f"BASELINE configs[{wl.idx}] {wl.H}x{wl.W}, {wl.n_obj} objs/img, {wl.kw}"}
+
+
+def pipelined_validation_leg(device, wl, model, nslot, seconds, seed=42):
+    """The reference's validation loop as the product serves it: ``validation.PipelinedValidation`` -- one step =
+    the ``wl.batch`` images AND their mirrors as one joint forward (modules/GraphBinsLM.py:159,173) + the fused metric kernel, ``nslot``
+    steps in flight, records collected per round -- for ~``seconds`` on the driver's clock.  ``images_per_s`` counts VALIDATED images
+    (each costs two forwards: ``forwards_per_s``).  -> dict for the JSON line."""
+    import torch
+    from objcavit_amd import hip_ops
+    from objcavit_amd.validation import PipelinedValidation
+    B = wl.batch
+    img = synthetic_images(B, seed, wl.H, wl.W).to(device)
+    gt = (torch.rand(B, 1, wl.H, wl.W, generator=torch.Generator().manual_seed(7)) * (0.9 * wl.max_depth) + 0.05 * wl.max_depth).to(device)
+    t_build = time.perf_counter()
+    model(torch.cat([img, img.flip(dims=[3])], 0))           # calibrating first call at the joint shape
+    pv = PipelinedValidation(model, model.args, img, slots=nslot)
+    t_build = time.perf_counter() - t_build
+    for k in range(2 * nslot):
+        pv.submit(img, gt, first_image_id=k * B)
+    pv.collect()
+    t0 = time.perf_counter()
+    for k in range(nslot):
+        pv.submit(img, gt, first_image_id=k * B)
+    pv.collect()
+    per_round = max(nslot, int(0.2 / max((time.perf_counter() - t0) / nslot, 1e-4)) // nslot * nslot)
+    n, rows, t0 = 0, 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for k in range(per_round):
+            pv.submit(img, gt, first_image_id=(n + k) * B)
+        rows += int(pv.collect().shape[0])                   # one synchronisation + one host read of the round's range-guard words
+        n += per_round
+    dt = time.perf_counter() - t0
+    nodes = sum(x for x in pv.graphs[0].segment_nodes if x)
+    out = {"images_per_s": round(n * B / dt, 1), "forwards_per_s": round(2 * n * B / dt, 1), "ms_per_step": round(dt / n * 1e3, 3),
+           "batch": B, "slots": nslot, "steps": n, "records": rows, "seconds": round(dt, 2), "graph_nodes_joint_2b": nodes,
+           "capture_s": round(t_build, 2), "steps_rerun_on_bf16_pairs": pv.rerun_steps,
+           "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "unset (runtime default 4)"),
+           "hw_queue_note": hip_ops.ROUTE_REPORT.get("PipelinedValidation"),
+           "workload": f"PipelinedValidation(slots={nslot}): image + mirror per step, BASELINE configs[{wl.idx}] {wl.H}x{wl.W}, {wl.n_obj} objs/img"}
+    del pv
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -615,9 +661,12 @@ def main():
                 a.eager, run, slots, streams = True, model, [model], [torch.cuda.current_stream(device)]
                 torch.cuda.synchronize()
 
+        step_flags = []                                    # every step's taken range-guard word (device, 4 bytes): read once behind the timed region
+
         def step(first_id, slot=0):
             with torch.cuda.stream(streams[slot]):
                 out = slots[slot](img)
+                step_flags.append(getattr(slots[slot], "last_flag", None))
                 return out.depth_pred, hip_ops.depth_metrics(out.depth_pred, gt, wl.min_depth, wl.max_depth, crop=box,
                                                              first_image_id=first_id)
 
@@ -676,7 +725,10 @@ def main():
         timing = hip_ops.timing_results()          # graph mode: only the eager islands + bin head carry events here
         # fp16 range guard: every replay took its word into the slot's last_flag on the device (one one-thread launch per step inside
         # the timed region); read here, behind it.  A tripped synthetic batch would mean the timed steps need the bf16 re-run.
-        guard_tripped = sum(int(g.tripped()) for g in slots if hasattr(g, "tripped"))
+        # EVERY timed step's word (take() zeroes the sticky flag per replay: the slots' last words alone would miss earlier trips)
+        taken = [f for f in step_flags[-a.steps:] if f is not None]
+        guard_tripped = int(torch.cat(taken).ne(0).sum()) if taken else 0
+        del step_flags[:]
         log(f"timed region done: {dt / a.steps * 1e3:.1f} ms/step")
         default_depth = depth.clone()              # slot outputs are overwritten by the legs below
         if not a.eager:
@@ -778,6 +830,14 @@ def main():
             for b in (1, 2, 16):
                 legs["small_batch"][f"bs{b}_one_at_a_time"] = side_leg(device, Workload(2, b), model, 1, a.leg_seconds)
                 log(f"configs[2] bs {b} one at a time: {legs['small_batch'][f'bs{b}_one_at_a_time']['images_per_s']} img/s")
+            # ... and with four steps in flight, the form that hides the launch latency of the reference's bs-1 loop: plain forwards
+            # (bs 1 / bs 2 = image + mirror, four graph slots), then the product's own driver of that loop, PipelinedValidation
+            for b in (1, 2):
+                legs["small_batch"][f"bs{b}_inflight4"] = side_leg(device, Workload(2, b), model, 4, a.leg_seconds)
+                log(f"configs[2] bs {b}, four in flight: {legs['small_batch'][f'bs{b}_inflight4']['images_per_s']} img/s")
+            legs["small_batch"]["pipelined_validation_bs1_slots4"] = pipelined_validation_leg(device, Workload(2, 1), model, 4, a.leg_seconds)
+            log(f"PipelinedValidation bs 1 (image + mirror per step), four slots: "
+                f"{legs['small_batch']['pipelined_validation_bs1_slots4']['images_per_s']} validated img/s")
         depth = default_depth
 
     # max over ranks of the job time; ranks RCCL / gloo actually saw; per-rank rates
@@ -859,7 +919,7 @@ def main():
                                  "fp16_range_first_batch": (fmode[2] if fmode and len(fmode) > 2 else None),
                                  "route_report": dict(_ops.ROUTE_REPORT),
                                  # sticky device word ORed by every fp16-pair producer, taken per replay (hip_ops.RangeGuard)
-                                 "fp16_range_guard_tripped_slots": guard_tripped}
+                                 "fp16_range_guard_tripped_steps": guard_tripped}
             res.update(kernel_report(timing, a, B, wl, split_f16))
             if legs is not None:
                 res.update(legs)

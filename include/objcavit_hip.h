@@ -16,10 +16,16 @@
  *     scratch memory is supplied by the caller (`*_workspace_bytes`);
  *   - return 0 on success, a hipError_t (> 0) if a launch failed, -1 for a
  *     rejected argument; ocv_last_error() returns the message (thread-local).
- *   - results are fp32.  Contractions run on v_mfma_f32_32x32x2_f32 (exact fp32) or, where an entry point says so
- *     (3x3 / 1x1 convolutions, the opt-in bin-head mode), in SPLIT bf16: every operand v = hi + lo with
- *     hi = bf16(v), lo = bf16(v - hi), every product formed as hi*hi + hi*lo + lo*hi on the bf16 matrix cores with
- *     fp32 accumulation (relative error of a product <= 2^-17).
+ *   - results are fp32, and so are storage and accumulation.  A contraction runs in one of four forms, named by its entry point:
+ *       exact fp32     v_mfma_f32_32x32x2_f32 (the *_exact_* / unsuffixed token entry points, OCV_* = exact / fp32 routes);
+ *       fp16 pairs     every operand v = hi + lo with hi = fp16(v), lo = fp16(v - hi) (or lo' = fp16((v - hi) 2^11) for the token
+ *                      kernels), every product hi*hi + hi*lo + lo*hi on v_mfma_f32_*_f16 with fp32 accumulation: relative error
+ *                      of a product <= 2^-22, range +-65504 (range guard below).  THE DEFAULT of the decoder's and heads' 3x3 / 1x1
+ *                      convolutions (f16 = 1 of the *_x_fwd entry points), the token stacks' layer tails, the self-attention core,
+ *                      the few-key cross-attention and the bin head;
+ *       bf16 pairs     the same with bf16 terms: <= 2^-17 per product, fp32's range.  The encoder's 1x1 layers, and the route every
+ *                      fp16-pair kernel falls back to when the range guard trips (f16 = 0);
+ *       bf16 triples   three terms, six products ("split3"): 2^-24, fp32's range: the token linears that need both.
  */
 #ifndef OBJCAVIT_HIP_H
 #define OBJCAVIT_HIP_H
@@ -48,13 +54,18 @@ const char* ocv_last_error(void);
  * a value it converts exceeds 65504 / 16 = 4094 in magnitude (the first-batch calibration's own limit) (an atomic on that rare branch only; NULL = not armed, the default).  The word is
  * device memory owned by the caller, sticky until the caller clears it; ocv_range_flag_take_fwd copies it to `out` and zeroes it
  * on the stream (one tiny launch: capturable).  The host reads `out` where it reads results and re-runs the batch on bf16 pairs
- * (objcavit_amd/hip_ops.py RangeGuard).  Both return 0 / -1. */
+ * (objcavit_amd/hip_ops/_core.py: RangeGuard, guarded_forward, bf16_pairs; objcavit_amd/graph.py GraphedGraphBins.checked).  Both
+ * return 0 / -1. */
 int ocv_range_flag_set(unsigned* flag);
 int ocv_range_flag_take_fwd(unsigned* flag, unsigned* out, ocv_stream_t stream);
 /* on != 0: ocv_attention_fwd (and every composite built on it) issued by THIS THREAD takes the exact-fp32 core whatever
- * OCV_ATTN_FORM says -- the two-term fp16 core converts projected queries / keys / values to fp16 and ends at +-65504 like the
+ * ocv_attention_set_dispatch says -- the two-term fp16 core converts projected queries / keys / values to fp16 and ends at +-65504 like the
  * fp16 pairs; the range guard's fallback route (hip_ops.bf16_pairs) switches it together with them.  Returns 0. */
 int ocv_attention_set_fp32_range(int on);
+/* Core of ocv_attention_fwd and of every composite built on it (ocv_mha_fwd, ocv_mha_split3_fwd beyond 32 keys, ocv_encoder_layer_fwd,
+ * ocv_encoder_stack_fwd): form 0 = two-term fp16 products on v_mfma_f32_32x32x16_f16 (default), 1 = exact fp32 MFMA (the A/B numerics
+ * route).  Process-wide, like the other *_set_dispatch entry points; the library reads no environment variable.  Returns 0 / -1. */
+int ocv_attention_set_dispatch(int form);
 
 /* activation codes for ocv_linear_fwd */
 #define OCV_ACT_NONE 0

@@ -38,6 +38,7 @@ PROTOTYPES = {
     "ocv_range_flag_set": (C.c_int, [C.c_void_p]),
     "ocv_range_flag_take_fwd": (C.c_int, [C.c_void_p, C.c_void_p, _stream]),
     "ocv_attention_set_fp32_range": (C.c_int, [C.c_int]),
+    "ocv_attention_set_dispatch": (C.c_int, [C.c_int]),
     "ocv_linear_fwd": (C.c_int, [_f32p, C.c_int, C.c_long, _f32p, C.c_int, C.c_long, C.c_int, _f32p, _f32p, C.c_int,
                                  C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
     "ocv_linear_residual_layernorm_fwd": (C.c_int, [_f32p, C.c_int, _f32p, C.c_int, _f32p, _f32p, C.c_int, _f32p, _f32p,

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
 //      which are packed from their accumulator straight into the B operand, as before)
 // The scores are formed in the log2 domain (Q scaled by log2(e) / sqrt(d)): the softmax is a bare v_exp_f32; the running
 // output pair is rescaled only in the tiles where some query's running maximum moved (wavefront-uniform test).
-// fp16's range applies to q / sqrt(d), k and v (beyond +-65504 the affected rows turn inf / NaN); OCV_ATTN_FORM=fp32
+// fp16's range applies to q / sqrt(d), k and v (beyond +-65504 the affected rows turn inf / NaN); ocv_attention_set_dispatch(1)
 // selects the exact kernel above.
 // ---------------------------------------------------------------------------
 typedef _Float16 at_h16x8 __attribute__((ext_vector_type(8)));
@@ -356,9 +356,12 @@ __global__ __launch_bounds__(256) void attention_h2_kernel(AttnArgs p) {
   }
 }
 
-// != 0: this thread's attention cores take the exact-fp32 form whatever OCV_ATTN_FORM says (ocv_attention_set_fp32_range: the
+// != 0: this thread's attention cores take the exact-fp32 form whatever ocv_attention_set_dispatch says (ocv_attention_set_fp32_range: the
 // fp16 range guard's fallback route, hip_ops.bf16_pairs -- the two-term fp16 core ends at +-65504 like the pairs it stands beside)
 thread_local int g_attn_fp32_range = 0;
+// 0 = the two-term fp16 core (default), 1 = exact fp32: ocv_attention_set_dispatch (process-wide; the A/B numerics route of tests, tools
+// and bench.py's exact-fp32 leg -- set from OCV_ATTN_FORM by the Python side, objcavit_amd/hip_ops/tokens.py attention_form_sync)
+int g_attn_form = 0;
 }  // namespace
 
 extern "C" int ocv_attention_fwd(const float* q, long q_bs, int q_ss, const float* k, long k_bs, int k_ss,
@@ -370,6 +373,12 @@ extern "C" int ocv_attention_fwd(const float* q, long q_bs, int q_ss, const floa
 
 extern "C" int ocv_attention_set_fp32_range(int on) {
   g_attn_fp32_range = on != 0;
+  return 0;
+}
+
+extern "C" int ocv_attention_set_dispatch(int form) {
+  OCV_CHECK_ARG(form == 0 || form == 1, "ocv_attention_set_dispatch: form must be 0 (two-term fp16 core) or 1 (exact fp32 core), got %d", form);
+  g_attn_form = form;
   return 0;
 }
 
@@ -388,9 +397,7 @@ int ocv_attention_launch(const float* q, long q_bs, int q_ss, const float* k, lo
                    (o_ss % 4 == 0);
   dim3 grid(ocv_cdiv(Sq, 128), H, B), block(256);
   hipStream_t st = stream;
-  const char* form = getenv("OCV_ATTN_FORM");               // read per call: h2 (default) | fp32
-  OCV_CHECK_ARG(form == nullptr || strcmp(form, "h2") == 0 || strcmp(form, "fp32") == 0, "OCV_ATTN_FORM=%s: expected h2 or fp32", form);
-  if (g_attn_fp32_range == 0 && (form == nullptr || strcmp(form, "h2") == 0)) {
+  if (g_attn_fp32_range == 0 && g_attn_form == 0) {
     static bool attr_h = false;
     if (!attr_h) {
       (void)hipFuncSetAttribute((const void*)attention_h2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

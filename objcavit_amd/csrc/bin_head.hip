@@ -391,9 +391,6 @@ __global__ __launch_bounds__(512, 2) void bin_head_h2_kernel(const float* __rest
       wh[s_ % 3] = *reinterpret_cast<const bh_h16x8*>(wf);
       wl[s_ % 3] = *reinterpret_cast<const bh_h16x8*>(wf + 512);
     };
-    auto fetch_w_hi = [&](int t, int s_) {
-      wh[s_ % 3] = *reinterpret_cast<const bh_h16x8*>(wfrag + ((t * 8 + s_) * 2) * 512 + lane * 8);
-    };
     auto fetch_bias = [&](int t, f32x16& a1) {               // accumulator register r = bin acc_row(r, hh): four runs of four
       const float* bp = bl + t * 32 + 4 * hh;
 #pragma unroll
@@ -507,7 +504,9 @@ __global__ __launch_bounds__(512, 2) void bin_head_h2_kernel(const float* __rest
       unsigned keep = 0;
 #pragma unroll
       for (int t = 0; t < NB / 32; ++t)
-        keep |= (__builtin_amdgcn_ballot_w64(!(tmx[t] <= floor_)) != 0ull ? 1u : 0u) << t;
+        // (a lane maximum of -inf: fmaxf dropped NaN logits -- an inf feature times a zero weight beside -inf ones -- and such a tile
+        //  must reach the exact pass like in the one-level kernel, where the NaN poisons the pixel's sums: keep it)
+        keep |= (__builtin_amdgcn_ballot_w64(!(tmx[t] <= floor_) || tmx[t] == -__builtin_inff()) != 0ull ? 1u : 0u) << t;
       keep = __builtin_amdgcn_readfirstlane(keep);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1

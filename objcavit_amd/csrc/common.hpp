@@ -64,7 +64,7 @@ __device__ __forceinline__ void ocv_split1(float v, unsigned short& hi, unsigned
 // or a replay of a captured graph, can exceed it.  So every kernel that writes fp16 pairs keeps the largest magnitude it converts
 // (one v_max per element pair) and, on the rare true branch only, ORs 1 into ONE device word (the guard the host armed for this
 // thread: ocv_range_flag_set; nullptr = not armed).  The word is sticky; the host reads it where it reads results and re-runs the
-// batch on bf16 pairs (objcavit_amd/hip_ops.py RangeGuard).  The limit is the calibration's own, 65504 / 16 (hip_ops.fp16_range_report):
+// batch on bf16 pairs (objcavit_amd/hip_ops/_core.py RangeGuard).  The limit is the calibration's own, 65504 / 16 (hip_ops.fp16_range_report):
 // a batch that leaves the envelope its model was calibrated for is re-run, long before a value can turn into inf.  NaN inputs stay
 // NaN (loud) without tripping -- bf16 pairs would not cure them.
 constexpr float OCV_F16_GUARD = 4094.f;

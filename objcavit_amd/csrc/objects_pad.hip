@@ -24,9 +24,12 @@ __global__ __launch_bounds__(256) void object_tokens_pad_kernel(const float* __r
   if (i >= (long)B * cap * E4) return;
   const long row = i / E4;
   const int b = (int)(row / cap), j = (int)(row - (long)b * cap);
-  const bool live = j < min(max(counts[b], 1), cap);            // counts are device data nobody has checked: [1, cap] by force, so an
+  const int cnt = counts[b];
+  const bool live = j < min(max(cnt, 1), cap);                  // counts are device data nobody has checked: [1, cap] by force, so an
                                                                // image always keeps one live key (a count of 0 = fully masked softmax = NaN)
-  const float4 v = live ? ld4(tok + 4 * i) : make_float4(pad, pad, pad, pad);
+  // ... and a count below 1 makes that one key the PAD row, not whatever the caller's buffer holds in row 0: defined and
+  // deterministic (the reference's own padded rows, modules/ObjCAViT.py:180-183), never a plausible-looking stray object
+  const float4 v = (live && cnt >= 1) ? ld4(tok + 4 * i) : make_float4(pad, pad, pad, pad);
   *reinterpret_cast<float4*>(out + 4 * i) = v;
   if (i - row * E4 == 0) mask[row] = live ? 0 : 1;
 }

@@ -124,10 +124,27 @@ def _mask_u8(mask: Optional[torch.Tensor], B: int, Sk: int) -> Optional[torch.Te
     return mask.contiguous()
 
 
+_ATTN_FORMS = {"h2": 0, "fp32": 1}
+_attn_form_set = [None]
+
+
+def attention_form_sync() -> None:
+    """OCV_ATTN_FORM = h2 (default: the self-attention core on two-term fp16 products) | fp32 (exact-fp32 MFMA, the A/B numerics route)
+    handed to the library (ocv_attention_set_dispatch) whenever it changed: the C side reads no environment.  Called by every
+    function below that reaches the attention core."""
+    form = os.environ.get("OCV_ATTN_FORM", "h2")
+    if form != _attn_form_set[0]:
+        if form not in _ATTN_FORMS:
+            raise ValueError(f"OCV_ATTN_FORM={form!r}: expected 'h2' (default) or 'fp32'")
+        check(_lib.load().ocv_attention_set_dispatch(_ATTN_FORMS[form]), "ocv_attention_set_dispatch")
+        _attn_form_set[0] = form
+
+
 def attention_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, key_padding_mask: Optional[torch.Tensor],
                    n_heads: int) -> torch.Tensor:
     """softmax(q k^T / sqrt(32) + mask) v per head; q [B,Sq,E], k / v [B,Sk,E] (last-dim-contiguous views allowed)."""
     lib = _lib.load()
+    attention_form_sync()
     for n, t in (("q", q), ("k", k), ("v", v)):
         _req(t, n, contiguous=False)
         if t.dim() != 3 or t.stride(2) != 1:
@@ -154,6 +171,7 @@ def mha(q_src: torch.Tensor, k_src: torch.Tensor, v_src: torch.Tensor, in_proj_w
     per image (ocv_mha_few_keys_h2_fwd; OCV_TOKENS=split3 | fp32 select the older forms), otherwise the projections run as three-term bf16
     splits (ocv_mha_split3_fwd); None, or OCV_TOKENS=fp32 -> the exact-fp32 kernels (ocv_mha_fwd)."""
     lib = _lib.load()
+    attention_form_sync()
     for n, t in (("q_src", q_src), ("k_src", k_src), ("v_src", v_src), ("in_proj_weight", in_proj_w),
                  ("in_proj_bias", in_proj_b), ("out_proj.weight", out_w), ("out_proj.bias", out_b)):
         _req(t, n)
@@ -344,6 +362,7 @@ def encoder_layer(x: torch.Tensor, params: EncoderLayerParams, key_padding_mask:
                   zero_padded_rows: bool = False, n_heads: int = 4, dim_ff: int = 1024, eps: float = 1e-5,
                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = _lib.load()
+    attention_form_sync()
     _req(x, "x")
     if x.dim() != 3:
         raise ValueError("encoder_layer: x must be [B, S, E]")
@@ -364,6 +383,7 @@ def encoder_stack(x: torch.Tensor, params: Sequence[EncoderLayerParams], key_pad
     """A whole nn.TransformerEncoder in 1 + 2 L launches (ocv_encoder_stack_fwd); every layer's params must carry the
     packed split3 weights (layer_params(layer, packed_cache))."""
     lib = _lib.load()
+    attention_form_sync()
     _req(x, "x")
     if x.dim() != 3:
         raise ValueError("encoder_stack: x must be [B, S, E]")

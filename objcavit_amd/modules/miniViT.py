@@ -21,8 +21,16 @@ def regress_bin_widths(regressor: nn.Sequential, head: torch.Tensor, norm: str, 
     (reference modules/miniViT.py:33-42 == modules/ObjCAViT.py:378-388).  ``depth_range`` = (min_depth, max_depth): the
     normalisation, the bin edges and the bin centres come out of ONE launch (csrc/bin_edges.hip); edges and centres ride along
     on the returned tensor for ``AdaBins.bin_edges_and_centers`` (reference modules/AdaBins.py:79-83)."""
-    fits = all(isinstance(regressor[i], nn.Linear) and regressor[i].bias is not None and regressor[i].in_features % 4 == 0
-               and regressor[i].in_features <= 1024 for i in (0, 2, 4)) and regressor[4].out_features <= 4096
+    # the one-launch form takes exactly the reference's stack: Linear, LeakyReLU, Linear, LeakyReLU (the same slope), Linear, with
+    # contiguous fp32 parameters; anything else (another activation, a bias-free or strided layer) goes layer by layer below
+    fits = (len(regressor) == 5
+            and all(isinstance(regressor[i], nn.Linear) and regressor[i].bias is not None and regressor[i].in_features % 4 == 0
+                    and regressor[i].in_features <= 1024
+                    and all(t.dtype == torch.float32 and t.is_contiguous() for t in (regressor[i].weight, regressor[i].bias))
+                    for i in (0, 2, 4))
+            and regressor[4].out_features <= 4096
+            and all(isinstance(regressor[i], nn.LeakyReLU) for i in (1, 3))
+            and regressor[1].negative_slope == regressor[3].negative_slope)
     if depth_range is not None and norm != "softmax" and head.is_cuda and head.dim() == 2 and head.stride(1) == 1 and fits:
         # ONE launch for the three layers, the normalisation, the edges and the centres (csrc/bin_edges.hip: regressor_bins_kernel)
         lo, hi = float(depth_range[0]), float(depth_range[1])
@@ -31,6 +39,10 @@ def regress_bin_widths(regressor: nn.Sequential, head: torch.Tensor, norm: str, 
                                                    leaky_slope=regressor[1].negative_slope)
         w._ocv_bins = ((lo, hi), edges, centers)
         return w
+    for i in (1, 3):                                          # (hip_ops.linear's LeakyReLU is the reference's: slope 0.01)
+        if not isinstance(regressor[i], nn.LeakyReLU) or regressor[i].negative_slope != 0.01:
+            raise NotImplementedError(f"regressor[{i}] = {regressor[i]!r}: the HIP path implements the reference's LeakyReLU(0.01) "
+                                      "(modules/miniViT.py:17-19, modules/ObjCAViT.py:299-303)")
     y = hip_ops.linear(head.contiguous(), regressor[0].weight.detach(), regressor[0].bias.detach(), hip_ops.ACT_LEAKY_RELU)
     y = hip_ops.linear(y, regressor[2].weight.detach(), regressor[2].bias.detach(), hip_ops.ACT_LEAKY_RELU)
     y = hip_ops.linear(y, regressor[4].weight.detach(), regressor[4].bias.detach(), hip_ops.ACT_NONE)

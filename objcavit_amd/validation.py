@@ -130,10 +130,12 @@ class PipelinedValidation:
     (bench.py --batch 1: the same slot mechanism) 288 img/s one after the other, 609 with three in flight, **685 - 692 with
     four** (the default; five and more collapse to 420 - 530 whatever GPU_MAX_HW_QUEUES says: the slots then share hardware queues);
     bs 2 (= image + mirror) 461 -> 817 -> 872.  Results are those of ``ValidationStep(joint=True)``: same kernels, same order per step.
-    REQUIRES ``GPU_MAX_HW_QUEUES >= slots`` in the environment BEFORE the HIP runtime initialises (the runtime's default is 4 and
-    gives only the first streams queues of their own: slots that share a hardware queue run one after the other, measured 781
-    instead of 840 img/s; ``OCV_SET_HW_QUEUES=8`` before ``import objcavit_amd`` sets it).  A smaller or unset value is accepted
-    but WARNED about and recorded in ``hip_ops.ROUTE_REPORT["PipelinedValidation"]``.
+    WANTS ``GPU_MAX_HW_QUEUES=4`` (= the default ``slots``) in the environment BEFORE the HIP runtime initialises: set explicitly the
+    runtime deals every slot stream a hardware queue of its own (unset, its default of 4 gives only the first streams one: slots
+    that share a queue run one after the other, measured 781 instead of 840 img/s); ``OCV_SET_HW_QUEUES=4`` before ``import
+    objcavit_amd`` sets it, bench.py and tests/conftest.py do the same.  NOT more than 4: on 6+ queues a captured forward that forks
+    side streams replays 3x slower (hip_ops.hw_queues_allow_forks), so the package then captures lone batches without forks,
+    process-wide.  A smaller or unset value is accepted but WARNED about and recorded in ``hip_ops.ROUTE_REPORT["PipelinedValidation"]``.
 
         pv = PipelinedValidation(model, args, example_image)
         for i, (image, depth_gt) in enumerate(loader):      # bs 1, as the reference

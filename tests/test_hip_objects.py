@@ -53,6 +53,23 @@ def test_object_pad_kernels_vs_reference_formulation(ops, counts, cap, S, group,
         ops.object_front_pad(enc.cuda(), cnt, cap - 1, PAD)             # more object rows than image tokens
 
 
+def test_object_pad_stray_counts_keep_one_defined_key(ops):
+    """device counts nobody validated.  A count of 0 (or below) keeps ONE live key so that no image's softmax is fully
+    masked -- and that key is the PAD row, not whatever row 0 of the caller's buffer holds; a count beyond the capacity is the
+    capacity.  (Host-side lists are validated before they reach the device: PaddedObjects.from_lists rejects empty lists.)"""
+    B, cap, E, S = 4, 6, 128, 20
+    tok = gen.randn("tok", (B, cap, E), 9)
+    cnt = torch.tensor([0, -3, 99, 2], dtype=torch.int32).cuda()
+    out, mask = ops.object_tokens_pad(tok.cuda(), cnt, PAD)
+    out, mask = out.cpu(), mask.cpu().bool()
+    for b in (0, 1):
+        assert bool((out[b] == PAD).all()) and mask[b].tolist() == [False] + [True] * (cap - 1)
+    assert torch.equal(out[2], tok[2]) and not bool(mask[2].any())
+    assert torch.equal(out[3, :2], tok[3, :2]) and bool((out[3, 2:] == PAD).all()) and mask[3].tolist() == [False, False] + [True] * (cap - 2)
+    keys, kpm = ops.object_front_pad(tok.cuda(), cnt, S, PAD)
+    assert kpm.cpu().bool()[0].tolist() == [False] + [True] * (S - 1) and not bool(kpm.cpu().bool()[2, :cap].any())
+
+
 @pytest.mark.parametrize("B,n,norm", [(1, 256, "linear"), (16, 256, "linear"), (3, 100, "sigmoid"), (2, 1000, "linear"), (2, 7, "none")])
 def test_bin_edges_kernel_vs_torch(ops, B, n, norm):
     raw = gen.randn("raw", (B, n), 3, 2.0)

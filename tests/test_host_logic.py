@@ -35,6 +35,11 @@ def test_library_loads_and_exports_every_symbol():
     assert lib.ocv_bin_head_workspace_bytes(2, 256, 128) == 2 * 256 * 128 * 4
     rc = lib.ocv_linear_fwd(None, 4, 0, None, 4, 0, 0, None, None, 4, 0, 1, 1, 1, 4, 0, None)
     assert rc == -1 and b"null pointer" in lib.ocv_last_error()
+    # dispatch switches are entry points, not environment reads inside the library
+    assert lib.ocv_attention_set_dispatch(2) == -1 and b"form must be 0" in lib.ocv_last_error()
+    assert lib.ocv_attention_set_dispatch(1) == 0 and lib.ocv_attention_set_dispatch(0) == 0
+    csrc = os.path.join(ROOT, "objcavit_amd", "csrc")
+    assert not any("getenv" in open(os.path.join(csrc, f)).read() for f in os.listdir(csrc)), "the C side reads no environment variable"
 
 
 def test_missing_library_fails_loudly(tmp_path):
