@@ -240,8 +240,9 @@ def kernel_report(timing, a, B, wl, split_f16=True):
     km = kernel_model(B, wl)
     kernels, convs = {}, []
     for name, (cnt, ms) in timing.items():
-        if name.startswith(("conv3x3|", "conv1x1|", "conv3x3w4|")):
+        if name.startswith(("conv3x3|", "conv1x1|", "conv3x3w4|", "conv3x3p|")):
             k = 1 if name.startswith("conv1x1") else 3
+            packed = name.startswith("conv3x3p|")                    # packed taps: K = the nine taps' real 8-channel granules (round 6)
             # Winograd launches (the timing name says so): F(4x4,3x3) = 36 multiplies per 16 outputs on two-term fp16 splits; direct = 9 per output
             wino = 4 if name.startswith("conv3x3w4|") else 0
             per_out = {0: 1.0, 4: 36.0 / 144.0}[wino]
@@ -249,9 +250,12 @@ def kernel_report(timing, a, B, wl, split_f16=True):
             b_, h_, w_, ci, co = (int(v) for v in name.split("|")[1].split(","))
             m_ = b_ * h_ * w_
             flops = 2.0 * m_ * co * ci * k * k                      # algorithmic (fp32-equivalent, direct-form) FLOPs
-            issued = 3 * flops * per_out                             # 2-byte matrix-core FLOPs the launch(es) actually issue (3 MFMAs per product)
+            # 2-byte matrix-core FLOPs the launch(es) actually issue (3 MFMAs per product) over the K the kernel walks: every tap padded
+            # to a multiple of 32 channels (tap-major), or ceil(9 ceil(Cin / 8) / 4) steps of 32 (packed taps)
+            k_walked = ((9 * ((ci + 7) // 8) + 3) // 4 * 32) if packed else k * k * ((ci + 31) // 32 * 32)
+            issued = 3 * 2.0 * m_ * co * k_walked * per_out
             byts = m_ * ci * 4 + m_ * co * 4 + k * k * co * ci * 4   # read input once, write output once, weights
-            form = {0: "direct", 4: "winograd F(4x4,3x3), 3 launches"}[wino]
+            form = "direct, packed taps" if packed else {0: "direct", 4: "winograd F(4x4,3x3), 3 launches"}[wino]
             convs.append(dict(shape=f"B{b_} {h_}x{w_} {ci}->{co} k{k}", form=form, mfma_dtype=mfma_dtype,
                               launches_per_step=cnt / a.steps, ms=round(ms, 4),
                               alg_GFLOP=round(flops / 1e9, 1), alg_MB=round(byts / 1e6, 1),
@@ -259,6 +263,7 @@ def kernel_report(timing, a, B, wl, split_f16=True):
                               issued_mfma_TFLOPs=round(issued / (ms * 1e-3) / 1e12, 1),
                               frac_mfma_algorithmic=round(flops / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
                               frac_mfma_issued=round(issued / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+                              k_walked=k_walked, k_real=k * k * ci,
                               GBps=round(byts / (ms * 1e-3) / 1e9, 1)))
             continue
         if name.startswith("tap_interp|"):

@@ -520,6 +520,19 @@ int ocv_conv_nhwc_split_x_fwd(const void* x_hl, int Cin, const void* w_hi, const
                               const float* bias, const float* residual, float* y, void* y_hl, int B, int H, int W, int Cout,
                               int ksize, int act, void* workspace, size_t workspace_bytes, ocv_stream_t stream);
 
+/* The same 3 x 3 convolution (stride 1, zero padding 1) with PACKED TAPS (round 6): the K axis of the implicit GEMM is the nine taps'
+ * REAL 8-channel granules laid end to end instead of nine chunks of ceil32(Cin) channels, so the matrix cores do not multiply the
+ * zero pad channels of every tap -- 24 input channels: 7 K steps of 32 instead of 9; 40: 12 instead of 18 (the skip parts of the
+ * decoder's first convolutions, modules/DenseFeatureExtractor.py:44-47 on the encoder's 24- and 40-channel features).  x_hl, outputs,
+ * oscale, f16, bias, residual, act: as ocv_conv_nhwc_split_x_fwd (Cin % 8 == 0).  w_hi / w_lo: ONE [Cout][Kp] matrix each,
+ * Kp = ocv_conv3x3_packed_taps_k(Cin) = ceil(9 (Cin / 8) / 4) * 32, element (co, 8 ((Cin / 8) t + g) + e) = weight[co][8 g + e] of
+ * tap t = 3 ky + kx, zeros beyond the ninth tap.  Same products, same fp32 accumulation; the K order differs from the tap-major form,
+ * so results agree to rounding, not bit for bit. */
+int ocv_conv3x3_packed_taps_k(int Cin);
+int ocv_conv3x3_split_packed_taps_fwd(const void* x_hl, int Cin, const void* w_hi, const void* w_lo, const float* oscale, int f16,
+                                      const float* bias, const float* residual, float* y, void* y_hl, int B, int H, int W, int Cout,
+                                      int act, ocv_stream_t stream);
+
 /* The same 3 x 3 convolution (stride 1, zero padding 1) in Winograd F(4x4, 3x3) form on TWO-TERM FP16 splits (round 3), for shapes
  * where the arithmetic dominates the transforms' traffic: 4x fewer matrix-core operations than the direct form, a transformed input
  * of 2.25x the activation.  Input and output are the hl32 split / fp32 tensors of ocv_conv_nhwc_split_x_fwd; inside, the transformed input and filter are fp16 (hi, lo) pairs

@@ -144,6 +144,9 @@ PROTOTYPES = {
                                    + [C.c_int] * 6 + [C.c_void_p, C.c_size_t, _stream]),
     "ocv_conv_nhwc_split_x_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _f32p, C.c_int, _f32p, _f32p, _f32p, C.c_void_p]
                                   + [C.c_int] * 6 + [C.c_void_p, C.c_size_t, _stream]),
+    "ocv_conv3x3_packed_taps_k": (C.c_int, [C.c_int]),
+    "ocv_conv3x3_split_packed_taps_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _f32p, C.c_int, _f32p, _f32p, _f32p, C.c_void_p]
+                                          + [C.c_int] * 5 + [_stream]),
     "ocv_upsample_concat_split_x_fwd": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_void_p, C.c_int,
                                                   C.c_int, C.c_int, C.c_int, _stream]),
     "ocv_tap_interp_combine_x_fwd": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_void_p] + [C.c_int] * 6 + [_stream]),

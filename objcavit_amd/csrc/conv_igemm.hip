@@ -81,6 +81,13 @@ struct ConvArgs {
   unsigned rowpitch;                    // conv_split_dma_kernel: bytes between consecutive rows of the (B H) x W pixel grid of the
                                         // split input when they are not dense (0 = dense, W * 4 Cp); the patch embedding reads
                                         // every 16th image row of the feature map as one GEMM row grid this way
+  int gpt, gpt_inv;                     // conv_split_dma_kernel, 3 x 3 only: > 0 = PACKED TAPS (round 6).  The K axis is the nine taps'
+  int Kp;                               // REAL channel granules (8 channels = 16 bytes of hi, 16 of lo) laid end to end, gpt = ceil(Cin / 8)
+                                        // per tap, instead of nine chunks of Cp channels: a 32-channel K step holds four granules that may
+                                        // belong to two taps (two pixels).  24 input channels: 27 granules = 7 steps instead of 9; 40: 45
+                                        // granules = 12 steps instead of 18 (their Cp = 32 / 64 multiply 25 % / 37 % zeros).  The weights
+                                        // are ONE [Cout][Kp] matrix in the same granule order, Kp = steps x 32; gpt_inv = a 16.16
+                                        // reciprocal of gpt, exact for every granule index of the launch (checked on the host).
 };
 
 // 16-byte global load (compiler-visible: hipcc tracks it and inserts the s_waitcnt before the first use).
@@ -506,7 +513,7 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
     zb = kz / p.ksplit;                                          // zb: 0 unless zbatch > 1
     const int kh = kz - zb * p.ksplit;                           // kh: 0 unless ksplit == 2
     ch0 = nchunk * kh / p.ksplit;                                // channel chunks [ch0, ch1)
-    nsteps = taps * (nchunk * (kh + 1) / p.ksplit - ch0);
+    nsteps = p.gpt > 0 ? p.Kp / CBK : taps * (nchunk * (kh + 1) / p.ksplit - ch0);
   }
   const char* xz = (const char*)p.xhl + (long)zb * p.xz_bytes;   // (advanced by the producers in zflat mode)
   const char* whz = (const char*)p.whi + (long)zb * p.wz_bytes;
@@ -656,12 +663,47 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int bn = min(n0 + 32 * pw + 16 * i + lrow, p.Cout - 1);
-    rbB[i] = (unsigned)(((long)bn * p.Cp + lchunk * 8) * 2);
+    rbB[i] = (unsigned)(((long)bn * (p.gpt > 0 ? p.Kp : p.Cp) + lchunk * 8) * 2);
   }
   const unsigned wtap = (unsigned)((long)p.Cout * p.Cp * 2);
 
+  // PACKED TAPS: this lane's granule of step s is G = 4 s + lchunk = (tap, granule cg of the tap's pixel); tap and cg differ between
+  // the four lanes of a row, so the tap shift and the in-image test are per lane (a dozen VALU instructions per step on wavefronts
+  // that otherwise only issue DMA).  Granules beyond the ninth tap (the K padding of the last step) read the zero page; the
+  // weights hold zeros there.
+  int nx_pk = 0;
+  auto issue_dma_packed = [&](int buf) {
+    const int G = 4 * nx_pk + lchunk;
+    const int tap_raw = (int)(((unsigned)G * (unsigned)p.gpt_inv) >> 16);
+    const int cg = G - tap_raw * p.gpt;
+    const bool in_k = tap_raw < 9;
+    const int tap = in_k ? tap_raw : 8;
+    const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;                  // tap / 3 for tap <= 8
+    // rbA carries lchunk * 16 (the dense layout's granule of this lane): replaced by the packed granule's place in its pixel
+    const int soff = ((ky - 1) * p.W + (kx - 1)) * 4 * p.Cp + (cg >> 2) * 128 + (cg & 3) * 16 - lchunk * 16;
+    unsigned char* base = lds + buf * DBUF;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = in_k && ((tapmask[i] >> tap) & 1u);
+      const unsigned off = rbA[i] + (unsigned)soff;
+      const void* sh = ok ? (const void*)(xz + off) : (const void*)ocv_zero_page;
+      const void* sl = ok ? (const void*)(xz + off + 64) : (const void*)ocv_zero_page;
+      unsigned char* dst = base + (64 * pw + 16 * i) * DROW;
+      __builtin_amdgcn_global_load_lds((gptr_t)sh, (lptr_t)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)sl, (lptr_t)(dst + DA), 16, 0, 0);
+    }
+    const unsigned woff = (unsigned)nx_pk * (CBK * 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      unsigned char* dst = base + 2 * DA + (32 * pw + 16 * i) * DROW;
+      __builtin_amdgcn_global_load_lds((gptr_t)(whz + woff + rbB[i]), (lptr_t)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(wlz + woff + rbB[i]), (lptr_t)(dst + DB), 16, 0, 0);
+    }
+    ++nx_pk;
+  };
+
   int nx_tap = 0, nx_c0 = ch0 * CBK, nx_ky = 0, nx_kx = 0;
-  auto issue_dma = [&](int buf) {
+  auto issue_dma_dense = [&](int buf) {
     const int tap = nx_tap, c0 = nx_c0, ky = nx_ky, kx = nx_kx;
     const char* const xz_ = xz;
     const char* const whz_ = whz;
@@ -691,6 +733,11 @@ __global__ __launch_bounds__(512) void conv_split_dma_kernel(ConvArgs p) {
       __builtin_amdgcn_global_load_lds((gptr_t)(whz_ + woff + rbB[i]), (lptr_t)dst, 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)(wlz_ + woff + rbB[i]), (lptr_t)(dst + DB), 16, 0, 0);
     }
+  };
+
+  auto issue_dma = [&](int buf) {
+    if (p.gpt > 0) issue_dma_packed(buf);                         // (uniform: a scalar branch)
+    else issue_dma_dense(buf);
   };
 
   // Three LDS buffers, DMA two K steps ahead: in interval t (consumers on buffer t % 3) the producers issue step t+2
@@ -861,6 +908,48 @@ extern "C" int ocv_conv_nhwc_split_x_fwd(const void* x_hl, int Cin, const void* 
     hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)((f.items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, f);
     OCV_CHECK_LAUNCH("ocv_conv_nhwc_split_fwd(finish)");
     return 0;
+  }
+  return launch_conv(a, B, true, (hipStream_t)stream);
+}
+
+// PACKED TAPS (round 6; ConvArgs::gpt): the same 3 x 3 convolution with the K axis = the nine taps' REAL 8-channel granules laid end
+// to end.  Pays where Cin is far from a multiple of 32 -- the decoder's skip parts over 24 and 40 encoder channels (7 K steps instead
+// of 9, 12 instead of 18): the matrix cores no longer multiply the zero pad channels of every tap.  w_hi / w_lo: ONE [Cout][Kp]
+// matrix each, Kp = ocv_conv3x3_packed_taps_k(Cin), element (co, 8 (gpt t + g) + e) = weight[co][8 g + e][tap t] (zero where
+// 8 g + e >= Cin, and beyond the ninth tap), split into pairs like the tap-major weights (hip_ops.prep_conv_weight_packed_taps).
+extern "C" int ocv_conv3x3_packed_taps_k(int Cin) {
+  if (Cin < 1 || Cin > 2040) return 0;
+  const int gpt = (Cin + 7) / 8;
+  return (9 * gpt + 3) / 4 * CBK;
+}
+
+extern "C" int ocv_conv3x3_split_packed_taps_fwd(const void* x_hl, int Cin, const void* w_hi, const void* w_lo, const float* oscale,
+                                                 int f16, const float* bias, const float* residual, float* y, void* y_hl, int B,
+                                                 int H, int W, int Cout, int act, ocv_stream_t stream) {
+  OCV_CHECK_ARG(x_hl && w_hi && w_lo && (y || y_hl), "ocv_conv3x3_split_packed_taps_fwd: null pointer");
+  OCV_CHECK_ARG(ocv_aligned16(y) && ocv_aligned16(y_hl) && ocv_aligned16(residual), "ocv_conv3x3_split_packed_taps_fwd: outputs and residual must be 16-byte aligned");
+  OCV_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && Cout >= 1 && Cin >= 8 && Cin % 8 == 0 && Cin <= 2040,
+                "ocv_conv3x3_split_packed_taps_fwd: bad sizes (Cin must be a multiple of 8 in [8, 2040], got %d)", Cin);
+  OCV_CHECK_ARG(act >= 0 && act <= 3, "ocv_conv3x3_split_packed_taps_fwd: unknown activation %d", act);
+  OCV_CHECK_ARG(f16 == 0 || f16 == 1, "ocv_conv3x3_split_packed_taps_fwd: f16 must be 0 (bf16 pairs) or 1 (fp16 pairs)");
+  OCV_CHECK_ARG((reinterpret_cast<uintptr_t>(x_hl) & 127) == 0 && ocv_aligned16(w_hi) && ocv_aligned16(w_lo),
+                "ocv_conv3x3_split_packed_taps_fwd: x_hl must be 128-byte aligned, weights 16-byte aligned");
+  const int Kp = ocv_conv3x3_packed_taps_k(Cin), gpt = Cin / 8;
+  OCV_CHECK_ARG((long)B * H * W * (Cin + 32) * 4 < (1L << 32) && (long)Cout * Kp * 2 < (1L << 32),
+                "ocv_conv3x3_split_packed_taps_fwd: each operand must be smaller than 4 GiB");
+  const int inv = (65536 + gpt - 1) / gpt;
+  for (int G = 0; G < Kp / 8; ++G)
+    OCV_CHECK_ARG((int)(((unsigned)G * (unsigned)inv) >> 16) == G / gpt, "ocv_conv3x3_split_packed_taps_fwd: internal (reciprocal of %d inexact at %d)", gpt, G);
+  ConvArgs a{};
+  a.xhl = (const __bf16*)x_hl; a.yhl = (__bf16*)y_hl; a.Cpo = (Cout + 31) / 32 * 32;
+  a.whi = (const __bf16*)w_hi; a.wlo = (const __bf16*)w_lo; a.bias = bias; a.res = residual; a.y = y;
+  a.C1 = Cin; a.C2 = 0; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.ks = 3; a.act = act; a.ksplit = 1;
+  a.f16 = f16; a.oscale = oscale;
+  a.gpt = gpt; a.gpt_inv = inv; a.Kp = Kp;
+  a.range_flag = (f16 && y_hl != nullptr) ? ocv_range_flag_current() : nullptr;
+  if (y_hl != nullptr && Cout % 32 != 0) {       // the kernels write channels < Cout only: pad channels must read as zero
+    const int zrc = ocv_zero_async(y_hl, ocv_split_act_elems(B, H, W, Cout) * sizeof(__bf16), (hipStream_t)stream);
+    if (zrc != 0) return zrc;
   }
   return launch_conv(a, B, true, (hipStream_t)stream);
 }

@@ -175,6 +175,77 @@ def prep_conv_weight(weight: torch.Tensor, f16: bool = False):
     return hi.contiguous(), lo.contiguous(), torch.exp2(-k).float().contiguous()
 
 
+def packed_taps_pay(Cin: int) -> bool:
+    """Whether a 3x3 convolution over ``Cin`` channels runs as PACKED TAPS (ocv_conv3x3_split_packed_taps_fwd: the nine taps' real
+    8-channel granules laid end to end along K) rather than tap-major with every tap padded to a multiple of 32 channels: where
+    that saves at least a sixth of the K steps -- 24 channels (7 steps instead of 9), 40 (12 instead of 18), 8 / 16 (3 / 5 instead
+    of 9); 64, 128, 176 ... do not (the decoder's other skip parts, every full-width convolution)."""
+    if Cin < 8 or Cin % 8 != 0:
+        return False
+    packed = (9 * (Cin // 8) + 3) // 4
+    dense = 9 * ((Cin + 31) // 32)
+    return 6 * packed <= 5 * dense
+
+
+def prep_conv_weight_packed_taps(weight: torch.Tensor, f16: bool = False):
+    """[Cout, Cin, 3, 3] fp32 (Cin % 8 == 0) -> the two-term split of ONE [1, Cout, Kp] matrix in packed-tap order (include/
+    objcavit_hip.h, ocv_conv3x3_split_packed_taps_fwd): column 8 ((Cin / 8) t + g) + e = weight[:, 8 g + e] of tap t = 3 ky + kx,
+    zeros behind the ninth tap up to Kp = ocv_conv3x3_packed_taps_k(Cin).  Pairs and per-row scales as ``prep_conv_weight``
+    (f16: (hi, lo, oscale); else (hi, lo))."""
+    Cout, Cin, kh, kw = weight.shape
+    if (kh, kw) != (3, 3) or Cin % 8 != 0:
+        raise ValueError("prep_conv_weight_packed_taps: needs a 3x3 kernel over a multiple of 8 input channels")
+    Kp = int(_lib.load().ocv_conv3x3_packed_taps_k(Cin))
+    w = weight.detach().float().permute(0, 2, 3, 1).reshape(Cout, 9 * Cin)            # [co][tap][c]: tap-major granules of 8
+    w = torch.nn.functional.pad(w, (0, Kp - 9 * Cin)).reshape(1, Cout, Kp)
+    if not f16:
+        hi = w.to(torch.bfloat16)
+        lo = (w - hi.float()).to(torch.bfloat16)
+        return hi.contiguous(), lo.contiguous()
+    amax = w.abs().amax(dim=(0, 2))
+    k = torch.where(amax > 0, torch.round(8.0 - torch.log2(amax.clamp_min(1e-30))), torch.zeros_like(amax)).clamp(-100.0, 100.0)
+    w = w * torch.exp2(k)[None, :, None]
+    hi = w.to(torch.float16)
+    lo = (w - hi.float()).to(torch.float16)
+    return hi.contiguous(), lo.contiguous(), torch.exp2(-k).float().contiguous()
+
+
+def conv3x3_split_packed_taps(x: SplitAct, w_hi: torch.Tensor, w_lo: torch.Tensor, bias: Optional[torch.Tensor], act: int = ACT_NONE,
+                              out_fp32: bool = True, out_split: bool = False, oscale: Optional[torch.Tensor] = None):
+    """3x3 convolution (stride 1, padding 1) of a pre-split activation on packed-tap weights (``prep_conv_weight_packed_taps``):
+    ocv_conv3x3_split_packed_taps_fwd.  Returns fp32 tensor, SplitAct, or (fp32, SplitAct) like ``conv_nhwc_split``."""
+    lib = _lib.load()
+    if not (out_fp32 or out_split):
+        raise ValueError("conv3x3_split_packed_taps: nothing to output")
+    dt = x.hl.dtype
+    _req(x.hl, "x.hl", dt)
+    B, Cin, H, W = x.shape
+    if x.hl.dim() != 4 or x.hl.shape[3] != 2 * ((Cin + 31) // 32 * 32):
+        raise ValueError("conv3x3_split_packed_taps: x.hl must be [B, H, W, 2 * ceil32(C)]")
+    for n, t in (("w_hi", w_hi), ("w_lo", w_lo)):
+        _req(t, n, dt)
+    Kp = int(lib.ocv_conv3x3_packed_taps_k(Cin))
+    if Cin % 8 != 0 or Kp == 0 or w_hi.dim() != 3 or w_hi.shape[0] != 1 or w_hi.shape[2] != Kp or w_lo.shape != w_hi.shape:
+        raise ValueError(f"conv3x3_split_packed_taps: weights {tuple(w_hi.shape)} do not match {Cin} input channels (Kp = {Kp})")
+    Cout = w_hi.shape[1]
+    for n, t in (("bias", bias), ("oscale", oscale)):
+        if t is not None:
+            _req(t, n)
+            if t.numel() != Cout:
+                raise ValueError(f"conv3x3_split_packed_taps: {n} size mismatch")
+    y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.hl.device, memory_format=torch.channels_last) if out_fp32 else None
+    ys = SplitAct.empty(B, Cout, H, W, x.hl.device, f16=x.f16) if out_split else None
+    ptrs = (x.hl.data_ptr(), Cin, w_hi.data_ptr(), w_lo.data_ptr(), _ptr(oscale), int(x.f16), _ptr(bias), None, _ptr(y),
+            ys.hl.data_ptr() if out_split else None, B, H, W, Cout, act)
+    keep = (x, w_hi, w_lo, oscale, bias, y, ys)          # an eager island re-issues this launch on every replay
+    launch(f"conv3x3p|{B},{H},{W},{Cin},{Cout}",
+           lambda: (keep, check(lib.ocv_conv3x3_split_packed_taps_fwd(*ptrs, _stream()), "ocv_conv3x3_split_packed_taps_fwd"))[1])
+    _note_range(f"conv3x3p|{B},{H},{W},{Cin},{Cout}", ys)
+    if out_fp32 and out_split:
+        return y, ys
+    return y if out_fp32 else ys
+
+
 def conv_nhwc_exact(x1: torch.Tensor, x2: Optional[torch.Tensor], w_tap_major: torch.Tensor, bias: Optional[torch.Tensor],
                     ksize: int, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """act(conv_kxk(cat([x1, x2], 1)) + bias) (+ residual) in exact fp32 (ocv_conv_nhwc_exact_fwd); logical shapes

@@ -162,7 +162,9 @@ class SplitConv3x3:
                 ws = w[:, c1:].contiguous()
                 if f16 and not hip_ops.fp16_weight_safe(ws.flatten(1)):
                     raise Fp16Unsafe(f"{self.conv} (skip part): column spread beyond 2^17")
-                ps = hip_ops.prep_conv_weight(ws, f16=f16)
+                # few skip channels (24, 40: the two high-resolution stages): packed taps -- 7 / 12 K steps instead of 9 / 18
+                d["s_packed"] = hip_ops.packed_taps_pay(cin - c1)
+                ps = (hip_ops.prep_conv_weight_packed_taps if d["s_packed"] else hip_ops.prep_conv_weight)(ws, f16=f16)
                 d.update(s_hi=ps[0], s_lo=ps[1], s_osc=ps[2] if f16 else None)
             self._w_up = self._w_up_all[(c1, ckey, bool(f16))] = ((c1, ckey, bool(f16)), d)
         return dict(self._w_up[1], bias=self._prep[2])
@@ -398,6 +400,8 @@ class UpSampleWithSkip(nn.Module):
         else:
             ride = getattr(skip_features, "_ocv_hl", None)      # (an encoder block of the late stages may leave its split copy beside it)
             xs = ride if ride is not None and ride.f16 == f16 else hip_ops.split_act(skip_features, f16=f16)
+        if wt.get("s_packed"):
+            return hip_ops.conv3x3_split_packed_taps(xs, wt["s_hi"], wt["s_lo"], None, hip_ops.ACT_NONE, out_fp32=True, oscale=wt["s_osc"])
         return hip_ops.conv_nhwc_split(xs, wt["s_hi"], wt["s_lo"], None, 3, hip_ops.ACT_NONE, out_fp32=True, oscale=wt["s_osc"])
 
     def split_ready(self, x, skip_features) -> bool:

@@ -1559,6 +1559,44 @@ def test_conv_nhwc_split_many_tiles(ops, B, H, W, Cin, Cout, k, act):
     assert rel_dev(y, y3) < 1e-5
 
 
+@pytest.mark.parametrize("f16", [False, True])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,act", [
+    (2, 30, 40, 24, 128, 0),           # 27 granules = 7 K steps (the last one: 3 real granules + 1 of padding); a skip part's shape
+    (1, 61, 83, 40, 256, 2),           # 45 granules = 12 steps, granules of one step from two taps; ragged rows, two channel tiles
+    (3, 9, 11, 8, 40, 3),              # one granule per tap: a step holds FOUR taps; Cout % 32 != 0 with a split copy
+    (1, 17, 23, 176, 72, 1),           # 22 granules per tap (198 -> 50 steps): granule index / 22 up to 199
+    (2, 1, 1, 16, 16, 0),              # a single pixel: every tap but the centre is padding
+])
+def test_conv3x3_packed_taps(ops, f16, B, H, W, Cin, Cout, act):
+    """Round 6: ocv_conv3x3_split_packed_taps_fwd -- the 3x3 implicit GEMM with the nine taps' real 8-channel granules laid end to end
+    along K (no zero pad channels per tap) -- against an fp64 convolution at the tap-major kernel's bar and against the tap-major
+    kernel itself (same products, another summation order)."""
+    x = rnd("x", (B, Cin, H, W), 1)
+    w, b = rnd("w", (Cout, Cin, 3, 3), 3, 1 / math.sqrt(Cin * 9)), rnd("b", (Cout,), 4, 0.2)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1).float()
+    ref = [ref, torch.relu(ref), F.leaky_relu(ref, 0.01), F.silu(ref)][act]
+    xs = ops.upsample_concat_split(dev(x), None, (H, W), f16=f16)
+    prep = ops.prep_conv_weight_packed_taps(dev(w), f16=f16)
+    hi, lo, osc = (prep + (None,))[:3]
+    Kp = (9 * (Cin // 8) + 3) // 4 * 32
+    assert tuple(hi.shape) == (1, Cout, Kp) and ops._lib.load().ocv_conv3x3_packed_taps_k(Cin) == Kp
+    y, ys = ops.conv3x3_split_packed_taps(xs, hi, lo, dev(b), act, out_fp32=True, out_split=True, oscale=osc)
+    assert rel_dev(y, ref) < SPLIT_TOL
+    assert rel_dev(ys.float(), y) < (1e-6 if f16 else 1e-5)
+    d = ops.prep_conv_weight(dev(w), f16=f16)
+    yd = ops.conv_nhwc_split(xs, d[0], d[1], dev(b), 3, act, out_fp32=True, oscale=(d + (None,))[2])
+    assert rel_dev(y, yd) < 2e-6
+    assert torch.equal(y, ops.conv3x3_split_packed_taps(xs, hi, lo, dev(b), act, out_fp32=True, oscale=osc))      # deterministic
+    if Cout % 32:
+        Cp = (Cout + 31) // 32 * 32
+        pads = ys.hl.view(B, H, W, Cp // 32, 2, 32).permute(0, 1, 2, 4, 3, 5).reshape(B, H, W, 2, Cp)[..., Cout:]
+        assert not bool(pads.any())
+    with pytest.raises(ValueError):
+        ops.conv3x3_split_packed_taps(xs, d[0], d[1], dev(b), act)                      # tap-major weights are not packed-tap weights
+    assert ops.packed_taps_pay(24) and ops.packed_taps_pay(40) and not ops.packed_taps_pay(64) and not ops.packed_taps_pay(176)
+    assert not ops.packed_taps_pay(128) and not ops.packed_taps_pay(12)
+
+
 # ------------------------------------------------------------------ positional-embedding samplers
 def test_pos_grid_sample_roi_vs_hand_computed_boxes(ops):
     """ocv_pos_grid_sample_fwd, RoI mode, against the hand-computed boxes of tests/roi_cases.py (box inside one cell,
