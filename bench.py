@@ -832,6 +832,15 @@ def main():
                     del m_c
                     torch.cuda.empty_cache()
                 log(f"configs[{c}]: {legs['configs_all'][f'configs[{c}]']['images_per_s']} img/s")
+            # the reference's do_final_upscale models (51 of its 108 params files; modules/GraphBins.py:45, modules/AdaBins.py:43): features,
+            # tokens and depth at FULL resolution -- configs[2] with that one switch, same objects, same weights' seed
+            wl_f = Workload(2)
+            wl_f.kw = dict(wl_f.kw, do_final_upscale=True)
+            m_f = build_model(device, wl_f)[0]
+            legs["configs_all"]["configs[2] + do_final_upscale"] = side_leg(device, wl_f, m_f, max(1, a.inflight), a.leg_seconds)
+            log(f"configs[2] + do_final_upscale: {legs['configs_all']['configs[2] + do_final_upscale']['images_per_s']} img/s")
+            del m_f
+            torch.cuda.empty_cache()
             for b in (1, 2, 16):
                 legs["small_batch"][f"bs{b}_one_at_a_time"] = side_leg(device, Workload(2, b), model, 1, a.leg_seconds)
                 log(f"configs[2] bs {b} one at a time: {legs['small_batch'][f'bs{b}_one_at_a_time']['images_per_s']} img/s")
