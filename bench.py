@@ -478,7 +478,8 @@ def side_leg(device, wl, model, nslot, seconds, seed=42):
     box = crop_box(model.args, wl.H, wl.W)
     t_build = time.perf_counter()
     model(img)                                               # calibrating first call of this model / shape
-    slots = [GraphedGraphBins(model, img, in_flight=nslot) for _ in range(nslot)]
+    sts = hip_ops.independent_streams(nslot, device) if nslot > 1 else [None]      # (slots on hardware queues of their own: checked)
+    slots = [GraphedGraphBins(model, img, in_flight=nslot, stream=sts[k]) for k in range(nslot)]
     t_build = time.perf_counter() - t_build
 
     flags = []                                               # every step's taken range-guard word (device, 4 bytes each): read once, below
@@ -647,7 +648,10 @@ def main():
                 n = max(1, a.inflight)
                 # (only slot 0 carries the islands: the event-timed steps run on it; the other slots replay the forward as a
                 #  caller captures it, whole)
-                slots = [GraphedGraphBins(model, img, eager_ops=(island,) if k == 0 else (), in_flight=n) for k in range(n)]
+                # slot streams that do not share a hardware queue -- checked, not assumed (hip_ops.independent_streams: the runtime's
+                # dealing of its GPU_MAX_HW_QUEUES queues put two of four consecutive streams on one: profiles/r06_stream_queues.txt)
+                sts = hip_ops.independent_streams(n, device) if n > 1 else [None]
+                slots = [GraphedGraphBins(model, img, eager_ops=(island,) if k == 0 else (), in_flight=n, stream=sts[k]) for k in range(n)]
                 # a slot is replayed on the stream it was captured on: creating further streams can put two slots on
                 # the same hardware queue (ROCm maps streams round-robin onto GPU_MAX_HW_QUEUES = 4 queues), which
                 # serialises them -- measured: 781 instead of 840 img/s with the same code, depending on creation order

@@ -63,8 +63,10 @@ class GraphedGraphBins:
 
     def __init__(self, model, example_image: torch.Tensor, warmup: int = 2, eager_ops: Sequence[str] = (),
                  object_capacity: Optional[int] = None, object_group: Optional[int] = None, check_topology: bool = True,
-                 pairs: Optional[str] = None, in_flight: int = 1):
-        """``in_flight``: how many batches the caller keeps in flight on this GPU (one graph per slot): the capture forks side streams
+                 pairs: Optional[str] = None, in_flight: int = 1, stream: Optional["torch.cuda.Stream"] = None):
+        """``stream``: the stream to capture on and replay on (default: a new one).  Callers that keep several graphs in flight pass
+        streams from ``hip_ops.independent_streams`` -- two slots whose streams share a hardware queue serialise.
+        ``in_flight``: how many batches the caller keeps in flight on this GPU (one graph per slot): the capture forks side streams
         inside the forward for a lone batch only (hip_ops.batches_in_flight).  ``pairs``: None = the element type the model's decoder settled on (fp16 pairs unless its weights / first batch said
         otherwise); "bf16" = warm up and capture under ``hip_ops.bf16_pairs()`` (fp32's range: what ``rerun_on_bf16`` replays).
         ``check_topology``: every captured segment is read back from the runtime and compared with the only shape the product's
@@ -99,7 +101,7 @@ class GraphedGraphBins:
             self.objects = PaddedObjects(torch.zeros(B, cap, fdim, device=dev), torch.full((B, cap, 4), -1.0, device=dev),
                                          torch.ones(B, dtype=torch.int32, device=dev))
             self.load_objects(None, None)          # the provider's objects for the example image: warm-up on real values
-        self.stream = torch.cuda.Stream()
+        self.stream = stream if stream is not None else torch.cuda.Stream()
         self.stream.wait_stream(torch.cuda.current_stream())
         # the graph OWNS its scratch: every workspace requested during warm-up, capture and replay comes from this
         # store, so no eager call or later capture at other shapes can free a buffer whose address is baked in here

@@ -295,6 +295,64 @@ def side_stream(device: torch.device, which: int = 0) -> "torch.cuda.Stream":
     return st
 
 
+_PROBE: Dict[int, "torch.Tensor"] = {}
+
+
+def streams_share_a_queue(a: "torch.cuda.Stream", b: "torch.cuda.Stream", sleep_cycles: int = 400_000) -> bool:
+    """Whether work on stream ``b`` waits for work on stream ``a`` although nothing orders them: a long, empty kernel on ``a``, then a
+    tiny one on ``b``; if the tiny one ends only with the long one the two streams sit on ONE hardware queue.  ROCm deals its
+    GPU_MAX_HW_QUEUES hardware queues to streams by a rule of its own, at a stream's first use (tools/exp_stream_queues.py) -- the only
+    way to know is to look.  The tiny kernel writes a scratch word allocated beforehand (an allocation inside the probe would itself
+    wait for the device).  ~1 ms; synchronises the device."""
+    dev = a.device
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    scratch = _PROBE.get(idx)
+    if scratch is None:
+        scratch = _PROBE[idx] = torch.zeros(64, device=dev)
+    for st in (a, b):                                     # first use of a stream = its hardware queue is dealt: not inside the timed part
+        with torch.cuda.stream(st):
+            scratch.zero_()
+    torch.cuda.synchronize(dev)
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    with torch.cuda.stream(a):
+        e0.record()
+        torch.cuda._sleep(sleep_cycles)
+        e1.record()
+    with torch.cuda.stream(b):
+        scratch.zero_()
+        e2.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e2) > 0.5 * e0.elapsed_time(e1)
+
+
+def independent_streams(n: int, device: torch.device, candidates: int = 16) -> list:
+    """``n`` new streams of ``device`` no two of which share a hardware queue (checked pairwise, both directions:
+    ``streams_share_a_queue``), for callers that keep several captured forwards in flight -- two slots on one queue run one after the
+    other (round 4: 781 instead of 840 img/s at bs 16; round 6: 500 instead of 739 at bs 1, profiles/r06_stream_queues.txt).  Up to
+    ``candidates`` streams are created; rejected ones are dropped.  If the runtime has fewer than ``n`` independent queues to give
+    (GPU_MAX_HW_QUEUES < n) the best set found is returned, completed with colliding streams, and the shortfall is recorded in
+    ``ROUTE_REPORT["independent_streams"]``.  Not capturable; call it before any capture.  ~1 ms per pair tested."""
+    if device.type != "cuda":
+        raise _lib.HipLibraryError("independent_streams needs a GPU device")
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    chosen, spare = [], []
+    for _ in range(max(n, candidates)):
+        if len(chosen) == n:
+            break
+        st = torch.cuda.Stream(device=idx)
+        if all(not streams_share_a_queue(c, st) and not streams_share_a_queue(st, c) for c in chosen):
+            chosen.append(st)
+        else:
+            spare.append(st)
+    if len(chosen) < n:
+        ROUTE_REPORT["independent_streams"] = (f"only {len(chosen)} of {n} requested streams got a hardware queue of their own "
+                                               f"(GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', 'unset')}): the others share one and serialise")
+        chosen += spare[:n - len(chosen)]
+        while len(chosen) < n:
+            chosen.append(torch.cuda.Stream(device=idx))
+    return chosen
+
+
 # ---------------------------------------------------------------------------
 # workspace: one growing byte buffer per (device, stream, tag), held in a STORE
 # ---------------------------------------------------------------------------

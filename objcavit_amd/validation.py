@@ -158,8 +158,11 @@ class PipelinedValidation:
         self.min_depth, self.max_depth = float(ds.min_depth), float(ds.max_depth)
         self.B = int(example_image.shape[0])
         both = torch.cat([example_image, example_image.flip(dims=[3])], 0) if flip_tta else example_image
+        # slot streams that do NOT share a hardware queue (checked: hip_ops.independent_streams; the runtime's own dealing put two of
+        # four consecutive streams on one queue -- 349 instead of 441 validated img/s at bs 1, profiles/r06_stream_queues.txt)
+        streams = hip_ops.independent_streams(slots, example_image.device) if slots > 1 else [None]
         self.graphs = [GraphedGraphBins(model, both, object_capacity=object_capacity, object_group=self.B if flip_tta else None,
-                                        in_flight=slots) for _ in range(slots)]
+                                        in_flight=slots, stream=streams[k]) for k in range(slots)]
         self._next = 0
         self._pending = []
         self.rerun_steps = 0                                 # steps re-run on bf16 pairs by collect() (fp16 range guard)

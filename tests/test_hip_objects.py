@@ -243,6 +243,22 @@ def test_baseline_config_at_the_reference_validation_batch(B):
     assert torch.equal(g(img).depth_pred, d)
 
 
+def test_independent_streams_do_not_share_a_hardware_queue():
+    """Round 6: slots in flight need streams on hardware queues of their own, and the runtime's own dealing does not give that (of the
+    streams created in a row, the third and the fourth shared a queue: profiles/r06_stream_queues.txt).  hip_ops.independent_streams
+    checks pairwise with a long empty kernel on one stream and a tiny one on the other."""
+    from objcavit_amd import hip_ops
+    dev = torch.device("cuda:0")
+    sts = hip_ops.independent_streams(4, dev)
+    assert len(sts) == 4 and len({s.cuda_stream for s in sts}) == 4
+    assert hip_ops.ROUTE_REPORT.get("independent_streams") is None          # tests/conftest.py: GPU_MAX_HW_QUEUES = 4
+    for i in range(4):
+        for j in range(4):
+            if i != j:
+                assert not hip_ops.streams_share_a_queue(sts[i], sts[j]), (i, j)
+    assert hip_ops.streams_share_a_queue(sts[0], sts[0])                    # (the probe sees what it should: one stream is one queue)
+
+
 def test_pipelined_validation_equals_the_sequential_step():
     """PipelinedValidation: the reference's bs-1 validation loop with four steps in flight (the default: one captured joint image +
     mirror graph per slot, own stream each) gives the records of ValidationStep(joint=True) issued one after the other -- nine images,
