@@ -698,7 +698,9 @@ def main():
     # With several batches in flight the first ROOFLINE_STEPS steps of the timed region run ALONE on slot 0 (the other
     # slots wait for them): their event pairs are the live kernel timings of the JSON; the remaining steps are pipelined
     # and carry no events (a launch bracketed on one stream while another stream shares the chip would time the sharing).
-    ROOFLINE_STEPS = max(1, min(2, a.steps // 10))     # one step = two event-timed launches of the roofline convolution + one bin head
+    ROOFLINE_STEPS = 1                                 # one step = three event-timed launches of the roofline convolution + one bin head
+                                                       # (rounds 3 - 5 took two of twenty: every step that runs alone is 5 % slower than
+                                                       # a pipelined one, and `value` is the whole timed region)
     if not a.stub_cpu:
         hip_ops.enable_timing(True)
     records = []
