@@ -39,7 +39,9 @@ extern "C" {
 
 typedef void* ocv_stream_t;
 
-#define OCV_ABI_VERSION 4 /* 4: round 5 REMOVED the opt-in entry points that lost their A/Bs (ocv_tap_interp_skip_fwd, the squeeze-excite tail
+#define OCV_ABI_VERSION 5 /* 5: round 6 ADDED ocv_attention_set_dispatch (the library reads no environment variable any more),
+ * ocv_conv3x3_packed_taps_k / ocv_conv3x3_split_packed_taps_fwd; nothing removed or changed: a caller built against 4 keeps working;
+ * 4: round 5 REMOVED the opt-in entry points that lost their A/Bs (ocv_tap_interp_skip_fwd, the squeeze-excite tail
  * family ocv_*_se_fwd / ocv_se_fold_gate_weights_fwd / ocv_se_tail_supported, ocv_conv3x3_winograd_split_fwd F(2x2)) and added the range
  * guard (ocv_range_flag_set, ocv_range_flag_take_fwd, ocv_attention_set_fp32_range), bin head route 4, ocv_mha_few_keys_h2_set_dispatch;
  * 2: ocv_encoder_layer_params starts with struct_size (round 3); 3: ocv_patch_embed_split_fwd and

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("OCV_LIB_PATH") or os.path.join(_HERE, "lib", "libobjc
 _f32p = C.c_void_p      # device pointers travel as integers
 _u8p = C.c_void_p
 _stream = C.c_void_p
-ABI_VERSION = 4          # include/objcavit_hip.h: OCV_ABI_VERSION
+ABI_VERSION = 5          # include/objcavit_hip.h: OCV_ABI_VERSION
 
 
 class EncoderLayerParams(C.Structure):

@@ -28,7 +28,7 @@ def test_library_loads_and_exports_every_symbol():
     lib = _lib.load()
     for name in _lib.PROTOTYPES:
         assert hasattr(lib, name), name
-    assert lib.ocv_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.ocv_abi_version() == _lib.ABI_VERSION == 5
     # argument validation runs on the host before any launch
     assert lib.ocv_patch_embed_workspace_bytes(16, 128, 240, 320, 128) == 16 * 4800 * 128 * 4      # 16 K slices x [M, E] fp32
     assert lib.ocv_patch_embed_workspace_bytes(1, 128, 240, 320, 64) == 0
