@@ -335,6 +335,9 @@ def independent_streams(n: int, device: torch.device, candidates: int = 16) -> l
     if device.type != "cuda":
         raise _lib.HipLibraryError("independent_streams needs a GPU device")
     idx = device.index if device.index is not None else torch.cuda.current_device()
+    if not hasattr(torch.cuda, "_sleep"):                  # (the probe's long kernel: a private torch helper -- without it, streams as dealt)
+        ROUTE_REPORT["independent_streams"] = "torch.cuda._sleep is missing: slot streams were not checked for shared hardware queues"
+        return [torch.cuda.Stream(device=idx) for _ in range(n)]
     chosen, spare = [], []
     for _ in range(max(n, candidates)):
         if len(chosen) == n:
