@@ -2,7 +2,7 @@
 # rocm-smi power / sclk samples while bench.py runs with 1 and with 3 batches in flight (is the whole step at the power cap?)
 mkdir -p gpurun_out/power
 for n in 1 3; do
-  python3 bench.py --steps 1500 --warmup 3 --inflight $n --no-cpu-baseline > gpurun_out/power/b_$n.log 2>&1 &
+  python3 bench.py --steps 1500 --warmup 3 --inflight $n --no-cpu-baseline --no-extras > gpurun_out/power/b_$n.log 2>&1 &
   BP=$!
   sleep 25
   for i in $(seq 1 25); do rocm-smi --showpower --showclocks 2>&1 | grep -i "power (W)\|sclk" ; sleep 0.2; done > gpurun_out/power/smi_$n.txt
